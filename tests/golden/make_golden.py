@@ -1,0 +1,164 @@
+"""Generate golden vectors by running the REFERENCE NeuRay modules on CPU.
+
+Run in the build container only (needs /root/reference, read-only):
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/weights_seed0.npz and tests/golden/case_*.npz.  The reference's
+own tests hold no golden vectors for the render path, so these are
+produced from the reference itself: seeded random weights built by the reference
+constructors (so they carry its kaiming init), the seeded synthetic scene of
+oracle/neuray_oracle.make_scene, and NeuralRayBaseRenderer.render_impl plus the
+step-by-step functions render_by_depth calls (network/renderer.py:168-203).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness  # noqa: E402
+from oracle import neuray_oracle as orc  # noqa: E402
+
+
+def to_t(d):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}
+
+
+def build_renderer(ns, cfg, seed=0):
+    torch.manual_seed(seed)
+    r = ns.renderer.NeuralRayBaseRenderer(cfg)
+    r.eval()
+    return r
+
+
+def hot_weights(renderer):
+    sd = renderer.state_dict()
+    keep = ('dist_decoder.', 'agg_net.', 'fine_dist_decoder.', 'fine_agg_net.')
+    return {k: v.detach().numpy().copy() for k, v in sd.items() if k.startswith(keep)}
+
+
+def coords_for_case(rng, h, w, rn, integer):
+    if integer:
+        xs = rng.randint(0, w, size=rn)
+        ys = rng.randint(0, h, size=rn)
+        return np.stack([xs, ys], -1)[None].astype(np.float32)
+    return (rng.rand(1, rn, 2) * np.array([w - 1, h - 1])).astype(np.float32)
+
+
+def run_case(ns, name, cfg, h, w, rfn, rn, seed, is_train, integer_coords, depth_range=(2.0, 6.0),
+             save_intermediates=False, tweak=None, que_imgs=False):
+    que, ref = orc.make_scene(h, w, rfn, seed=seed, depth_range=depth_range, que_imgs=que_imgs)
+    if tweak is not None:
+        tweak(que, ref)
+    rng = np.random.RandomState(seed + 1000)
+    que['coords'] = coords_for_case(rng, h, w, rn, integer_coords)
+    renderer = build_renderer(ns, cfg, seed=0)
+    # Ks_inv exactly as the reference computes it (torch.inverse, render_ops.py:20)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+
+    tq, tr = to_t(que), to_t(ref)
+    tq.pop('Ks_inv')
+    captured = {}
+    real_rand = torch.rand
+
+    def rand_capture(*a, **k):
+        out = real_rand(*a, **k)
+        captured.setdefault('u', out.clone())
+        return out
+
+    torch.rand = rand_capture
+    try:
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            out = renderer.render_impl(tq, tr, is_train)
+    finally:
+        torch.rand = real_rand
+
+    save = {'cfg_json': np.array(repr(cfg)), 'h': h, 'w': w, 'rfn': rfn, 'rn': rn, 'seed': seed,
+            'is_train': int(is_train)}
+    for k, v in que.items():
+        save['que.' + k] = v
+    for k, v in ref.items():
+        save['ref.' + k] = v
+    for k, v in out.items():
+        save['out.' + k] = v.numpy()
+    if 'u' in captured:
+        save['u'] = captured['u'].numpy()
+
+    if save_intermediates:
+        ro = ns.render_ops
+        with torch.no_grad():
+            que_depth, _ = ro.sample_depth(tq['depth_range'], tq['coords'], renderer.cfg['depth_sample_num'], False)
+            que_dists = ro.depth2inv_dists(que_depth, tq['depth_range'])
+            que_pts, que_dir = ro.depth2points(tq, que_depth)
+            prj = ro.project_points_dict(tr, que_pts)
+            prj = renderer.predict_proj_ray_prob(prj, tr, que_dists, False)
+            prj = renderer.get_img_feats(tr, prj)
+            mean, var, vis, aw = renderer.dist_decoder(prj['ray_feats'])
+            density, colors = renderer.agg_net(prj, que_dir)
+        save.update({'mid.que_depth': que_depth.numpy(), 'mid.que_dists': que_dists.numpy(),
+                     'mid.que_pts': que_pts.numpy(), 'mid.que_dir': que_dir.numpy(),
+                     'mid.density': density.numpy(), 'mid.colors': colors.numpy(),
+                     'mid.mean': mean.numpy(), 'mid.var': var.numpy(), 'mid.aw': aw.numpy()})
+        if vis is not None:
+            save['mid.vis_dec'] = vis.numpy()
+        for k, v in prj.items():
+            save['mid.prj.' + k] = v.numpy()
+    path = os.path.join(HERE, 'case_%s.npz' % name)
+    np.savez_compressed(path, **save)
+    print('wrote', path, {k: tuple(v.shape) for k, v in out.items()})
+    return renderer
+
+
+def main():
+    ns = ref_harness.import_reference()
+    torch.set_num_threads(4)
+
+    base = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}}
+
+    # A: small, with every intermediate; fractional coords; 3 views, 16+16 samples
+    cfg_a = {**base, 'depth_sample_num': 16, 'fine_depth_sample_num': 16,
+             'agg_net_cfg': {'sample_num': 16}, 'fine_agg_net_cfg': {'sample_num': 16}, 'render_depth': True}
+    r = run_case(ns, 'a_small', cfg_a, 48, 48, 3, 40, seed=0, is_train=False, integer_coords=False,
+                 save_intermediates=True)
+    # weights are identical for every case (same constructors, same seed, sample_num does not
+    # change parameters); the vis-decoder variant below needs its own file.
+    np.savez_compressed(os.path.join(HERE, 'weights_seed0.npz'), **hot_weights(r))
+
+    # B: reference defaults 64+64, 8 views, non-square image, integer pixel coords (gen config 2 shape)
+    cfg_b = {**base}
+    run_case(ns, 'b_default', cfg_b, 48, 64, 8, 24, seed=1, is_train=False, integer_coords=True)
+
+    # C: adversarial geometry - wide depth range so many samples leave every frustum, one reference
+    # camera placed so that samples fall behind it (quirk A.9.1: no z>0 test), one far away.
+    def tweak_c(que, ref):
+        ref['poses'][1] = orc.look_at_pose(orc.sphere_pos(2.5, 30.0, 25.0), target=orc.sphere_pos(8.0, 30.0, 25.0))
+        ref['poses'][2] = orc.look_at_pose(orc.sphere_pos(9.0, 200.0, -40.0))
+        ref['depth_range'][2] = np.array([5.0, 13.0], np.float32)
+    cfg_c = {**base, 'depth_sample_num': 32, 'fine_depth_sample_num': 32,
+             'agg_net_cfg': {'sample_num': 32}, 'fine_agg_net_cfg': {'sample_num': 32}}
+    run_case(ns, 'c_adversarial', cfg_c, 48, 48, 4, 32, seed=2, is_train=False, integer_coords=False,
+             depth_range=(0.8, 9.0), save_intermediates=True, tweak=tweak_c)
+
+    # D: training mode (random u drawn by the reference on CPU), self hit prob, coarse decoder WITH vis
+    cfg_d = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': True}, 'use_self_hit_prob': True,
+             'depth_sample_num': 8, 'fine_depth_sample_num': 32, 'render_depth': True,
+             'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 32}}
+    r = run_case(ns, 'd_train_vis', cfg_d, 48, 48, 5, 16, seed=3, is_train=True, integer_coords=True,
+                 que_imgs=True)
+    np.savez_compressed(os.path.join(HERE, 'weights_seed0_vis.npz'), **hot_weights(r))
+
+    # E: fine_depth_use_all (64 coarse + 64 fine = 128 samples in the fine pass)
+    cfg_e = {**base, 'depth_sample_num': 64, 'fine_depth_sample_num': 64, 'fine_depth_use_all': True,
+             'fine_agg_net_cfg': {'sample_num': 128}}
+    run_case(ns, 'e_use_all', cfg_e, 48, 48, 2, 8, seed=4, is_train=False, integer_coords=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,95 @@
+"""Import harness for the *reference* NeuRay modules (read-only, /root/reference).
+
+TEST INFRASTRUCTURE ONLY.  Used by tests/golden/make_golden.py in the build
+container to generate golden vectors; it never runs on the GPU box (the
+reference tree does not exist there) and nothing in neuray_amd/ imports it.
+
+Recipe follows SURVEY.md section 8(c): insert dummy third-party modules in
+sys.modules (easydict, skimage, cv2, ...) and patch the hard-coded "cuda:0" in
+IBRNetWithNeuRay.posenc (network/ibrnet.py:312) so the modules run on CPU.
+Nothing under /root/reference is modified or copied.
+"""
+import sys
+import types
+import os
+
+REFERENCE_ROOT = os.environ.get("NEURAY_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "network"))
+
+
+class _Permissive(types.ModuleType):
+    """Stub module: any missing attribute resolves to a dummy callable/class."""
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        dummy = type(item, (), {"__init__": lambda self, *a, **k: None,
+                                "__call__": lambda self, *a, **k: None})
+        setattr(self, item, dummy)
+        return dummy
+
+
+def _stub(name, **attrs):
+    m = _Permissive(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    import torch.nn as nn
+    if "easydict" not in sys.modules:
+        _stub("easydict", EasyDict=dict)
+    for n in ["skimage", "skimage.io", "skimage.metrics", "h5py", "plyfile", "transforms3d",
+              "transforms3d.axangles", "transforms3d.euler", "kornia", "kornia.utils", "tensorboardX",
+              "imageio", "sklearn", "sklearn.decomposition", "sklearn.manifold"]:
+        if n not in sys.modules:
+            _stub(n)
+    sys.modules["skimage.io"].imsave = lambda *a, **k: None
+    sys.modules["skimage.io"].imread = lambda *a, **k: None
+    if "cv2" not in sys.modules:
+        _stub("cv2", INTER_LINEAR=1, INTER_NEAREST=0, INTER_AREA=3, INTER_CUBIC=2,
+              SOLVEPNP_ITERATIVE=0, SOLVEPNP_EPNP=1, BORDER_CONSTANT=0)
+    if "inplace_abn" not in sys.modules:
+        _stub("inplace_abn", ABN=nn.BatchNorm2d, InPlaceABN=nn.BatchNorm2d)
+    sys.modules["kornia.utils"].create_meshgrid = lambda *a, **k: None
+
+
+def import_reference():
+    """Returns a namespace with the reference hot-path modules (CPU-patched)."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import numpy as np
+    import torch
+    import network.ibrnet as ibrnet
+
+    def posenc_cpu(self, d_hid, n_samples):
+        # same table as network/ibrnet.py:305-313 without the .to("cuda:0")
+        def get_position_angle_vec(position):
+            return [position / np.power(10000, 2 * (hid_j // 2) / d_hid) for hid_j in range(d_hid)]
+        t = np.array([get_position_angle_vec(pos_i) for pos_i in range(n_samples)])
+        t[:, 0::2] = np.sin(t[:, 0::2])
+        t[:, 1::2] = np.cos(t[:, 1::2])
+        return torch.from_numpy(t).float().unsqueeze(0)
+
+    ibrnet.IBRNetWithNeuRay.posenc = posenc_cpu
+    import network.render_ops as render_ops
+    import network.ops as ops
+    import network.dist_decoder as dist_decoder
+    import network.aggregate_net as aggregate_net
+    ns = types.SimpleNamespace(render_ops=render_ops, ops=ops, dist_decoder=dist_decoder,
+                               aggregate_net=aggregate_net, ibrnet=ibrnet)
+    try:
+        import network.renderer as renderer
+        ns.renderer = renderer
+    except Exception as e:  # pragma: no cover
+        ns.renderer = None
+        ns.renderer_error = e
+    return ns

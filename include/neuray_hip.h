@@ -1,0 +1,131 @@
+/* neuray_hip.h - C ABI of libneuray_hip.so: the MI355X-native (gfx950) NeuRay per-ray render path.
+ *
+ * The reference (liuyuan-pal/NeuRay) has no FFI layer: its "operator API" for this path is the Python
+ * module surface network/render_ops.py + network/renderer.py.  Each entry point below
+ * names the reference function(s) it replaces; neuray_amd/network/*.py binds them with ctypes and keeps
+ * the reference's call surface on top (INTEGRATION.md shows the binding a maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; neuray_last_error() gives the message
+ *   - "dev" pointers are device (HIP) pointers to contiguous fp32 unless stated; "host" pointers are CPU
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and never synchronise the host
+ *   - all arrays are borrowed for the duration of the enqueued work; outputs are caller-allocated
+ *   - a single query view per call (qn = 1), as in NeuralRayBaseRenderer.render (network/renderer.py:228-254)
+ */
+#ifndef NEURAY_HIP_H
+#define NEURAY_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEURAY_ABI_VERSION 1
+#define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
+#define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
+#define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
+#define NEURAY_PASS_TENSORS 68   /* length of the tensor array of neuray_pack_pass_weights */
+#define NEURAY_DBG_FIELDS 16
+#define NEURAY_MAX_VIEWS 16
+#define NEURAY_MAX_SAMPLES 128
+
+int neuray_abi_version(void);
+const char* neuray_last_error(void);
+/* 1 if the library was built for the GPU (hipcc, gfx950); 0 for the CPU test emulator build */
+int neuray_is_device_build(void);
+
+/* ---- weights --------------------------------------------------------------------------------------
+ * Packs the state_dict tensors of ONE pass (dist_decoder + agg_net, or fine_dist_decoder + fine_agg_net;
+ * names and shapes: SURVEY.md Appendix B) into the per-lane MFMA fragment layout the kernels read.
+ * `tensors` holds NEURAY_PASS_TENSORS host pointers in the order of enum nr::PassTensor (nr_layout.h):
+ *   mean_decoder.{0,2,4}.{weight,bias}, var_decoder.*, aw_decoder.*, vis_decoder.* (6 NULLs when the decoder
+ *   has no vis head), prob_embed.{0,2}.*, ray_dir_fc.{0,2}.*, base_fc.{0,2}.*, vis_fc.{0,2}.*, vis_fc2.{0,2}.*,
+ *   geometry_fc.{0,2}.*, ray_attention.{w_qs,w_ks,w_vs,fc}.weight, ray_attention.layer_norm.{weight,bias},
+ *   out_geometry_fc.{0,2}.*, rgb_fc.{0,2,4}.*, neuray_fc.{0,2}.*
+ * Replaces: nn.Module parameter access of network/dist_decoder.py:64-97, network/aggregate_net.py:27-31,
+ * network/ibrnet.py:249-293. */
+size_t neuray_packed_pass_floats(void);
+int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_host);
+
+/* ---- camera constants -------------------------------------------------------------------------------
+ * view_const[v] = { H = K[R|t] (12), centre -R^T t (3), -1/near, -1/far, pad }   render_ops.py:94,110
+ * query_const   = { K^-1 (9), pose (12), centre (3), -1/near, -1/far, near, far } render_ops.py:15-21
+ * (K^-1 is supplied by the caller: the reference uses torch.inverse, render_ops.py:20). */
+int neuray_setup_views(const float* poses_dev /*[n][3][4]*/, const float* Ks_dev /*[n][3][3]*/,
+                       const float* depth_range_dev /*[n][2]*/, int n, float* view_const_dev, void* stream);
+int neuray_setup_query(const float* pose_dev /*[3][4]*/, const float* Kinv_dev /*[3][3]*/,
+                       const float* depth_range_dev /*[2]*/, float* query_const_dev, void* stream);
+
+/* ---- map relayout: NCHW -> channels-last with c_pad >= c channels (zero filled) -------------------------
+ * Feature maps are gathered with one contiguous 128-byte line per bilinear tap (32 ch) and images as
+ * RGBA texels (c = 3, c_pad = 4).  Replaces the implicit NCHW layout of F.grid_sample, network/ops.py:32. */
+int neuray_relayout_nhwc(const float* src_dev, float* dst_dev, int n, int c, int h, int w, int c_pad, void* stream);
+
+/* ---- a1: sample_depth (network/render_ops.py:146-170, random_sample=False) -> depth [rn][dn] ------------ */
+int neuray_sample_coarse_depth(const float* que_depth_range_dev /*[2]*/, int rn, int dn, float* depth_dev, void* stream);
+
+/* ---- a2-a14: one render pass over the sample points of a ray batch ------------------------------------------
+ * Replaces, fused: depth2inv_dists, depth2points, project_points_dict (render_ops.py:27-52,82-144),
+ * predict_proj_ray_prob, get_img_feats (renderer.py:67-83,127-135), DefaultAggregationNet.forward
+ * (aggregate_net.py:34-68) and IBRNetWithNeuRay.forward up to geometry_fc and the colour blend
+ * (ibrnet.py:315-355,362-367).
+ * point_out[rn*dn][NEURAY_POINT_REC] = { geometry feature (16), blended rgb (3), number of valid views (1) }.
+ * dbg (optional, may be NULL): [rn*dn][rfn][NEURAY_DBG_FIELDS] =
+ *   { mask, u, v, z, hit_prob, vis, mu0, mu1, s0, s1, aw, vis_dec, sigmoid(neuray_fc), vis', vis'', rgb logit }. */
+typedef struct NeurayPointsArgs {
+    const float* query_const_dev;
+    const float* view_const_dev;   /* [rfn][NEURAY_VIEW_CONST] */
+    const float* coords_dev;       /* [rn][2] pixel (x,y) */
+    const float* depth_dev;        /* [rn][dn] ascending sample depths */
+    const float* ray_feats_nhwc_dev;   /* [rfn][fh][fw][32] */
+    const float* img_feats_nhwc_dev;   /* [rfn][fh][fw][32] */
+    const float* rgba_dev;             /* [rfn][h][w][4] */
+    const float* packed_weights_dev;   /* neuray_pack_pass_weights output, uploaded */
+    float* point_out_dev;
+    float* dbg_dev;
+    int rfn, rn, dn, h, w, fh, fw;
+    int has_vis_head;    /* this pass's decoder has a vis_decoder */
+    int use_vis;         /* the COARSE decoder's cfg['use_vis'] (renderer.py:75 uses it for both passes) */
+    float var_bias;      /* dist_decoder cfg['bias_val'] (0.05) */
+    int tiles_per_wave;  /* 0 = default */
+} NeurayPointsArgs;
+int neuray_render_points(const NeurayPointsArgs* args, void* stream);
+
+/* ---- a14-a16: per-ray attention + sigma head + compositing ---------------------------------------------------
+ * Replaces: `+ pos_encoding`, MultiHeadAttention, out_geometry_fc (ibrnet.py:356-360), network_rendering
+ * (renderer.py:157-166), alpha_values2hit_prob (render_ops.py:72-80), ray_mask / render_depth
+ * (renderer.py:195-202).  pos_enc [dn][16] is the sinusoid table of ibrnet.py:305-313. */
+typedef struct NeurayRaysArgs {
+    const float* point_rec_dev;     /* [rn][dn][NEURAY_POINT_REC] */
+    const float* depth_dev;         /* [rn][dn] */
+    const float* pos_enc_dev;       /* [dn][16] */
+    const float* packed_weights_dev;
+    float* hit_prob_dev;            /* [rn][dn] */
+    float* pixel_dev;               /* [rn][3] */
+    float* render_depth_dev;        /* [rn] or NULL */
+    unsigned char* ray_mask_dev;    /* [rn] or NULL */
+    float* density_dev;             /* [rn][dn] or NULL */
+    int rn, dn, ray_mask_view_num, ray_mask_point_num;
+} NeurayRaysArgs;
+int neuray_render_rays(const NeurayRaysArgs* args, void* stream);
+
+/* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
+ * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,
+ * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)]. */
+int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_dev, const float* hit_prob_dev,
+                             const float* u_dev, int rn, int dn, int fdn, int use_all, float* out_dev, void* stream);
+
+/* ---- a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
+ * render_ops.py:54-70): bilinear, padding_mode='border'.  feats [b][c][fh][fw], points [b][n][2] pixel (x,y) in
+ * units of the (w_full, h_full) image, mask [b][n] or NULL, out [b][n][c]. */
+int neuray_interpolate_feats(const float* feats_dev, const float* points_dev, const float* mask_dev, int b, int n, int c,
+                             int fh, int fw, int h_full, int w_full, int align_corners, float* out_dev, void* stream);
+
+/* ---- hardware self test of the MFMA operand layout the kernels assume (16x4 @ 4x16) ----------------------------- */
+int neuray_mfma_selftest(const float* A_dev, const float* B_dev, float* D_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""ctypes binding of include/neuray_hip.h.
+
+The product path loads neuray_amd/libneuray_hip.so (hipcc, gfx950) and raises if it is missing:
+there is NO CPU or eager-PyTorch fallback for the hot path.  `bind()` is also used by the CPU
+test-suite to bind tests/emu/_build/libneuray_emu.so (the kernel sources compiled for a CPU fiber
+emulator) - test infrastructure that the package itself never loads.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libneuray_hip.so')
+
+PASS_TENSORS = 68
+POINT_REC = 20
+VIEW_CONST = 20
+QUERY_CONST = 28
+DBG_FIELDS = 16
+MAX_VIEWS = 16
+MAX_SAMPLES = 128
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class NeurayPointsArgs(C.Structure):
+    _fields_ = [
+        ('query_const_dev', C.c_void_p), ('view_const_dev', C.c_void_p), ('coords_dev', C.c_void_p),
+        ('depth_dev', C.c_void_p), ('ray_feats_nhwc_dev', C.c_void_p), ('img_feats_nhwc_dev', C.c_void_p),
+        ('rgba_dev', C.c_void_p), ('packed_weights_dev', C.c_void_p), ('point_out_dev', C.c_void_p),
+        ('dbg_dev', C.c_void_p),
+        ('rfn', C.c_int), ('rn', C.c_int), ('dn', C.c_int), ('h', C.c_int), ('w', C.c_int), ('fh', C.c_int),
+        ('fw', C.c_int), ('has_vis_head', C.c_int), ('use_vis', C.c_int), ('var_bias', C.c_float),
+        ('tiles_per_wave', C.c_int),
+    ]
+
+
+class NeurayRaysArgs(C.Structure):
+    _fields_ = [
+        ('point_rec_dev', C.c_void_p), ('depth_dev', C.c_void_p), ('pos_enc_dev', C.c_void_p),
+        ('packed_weights_dev', C.c_void_p), ('hit_prob_dev', C.c_void_p), ('pixel_dev', C.c_void_p),
+        ('render_depth_dev', C.c_void_p), ('ray_mask_dev', C.c_void_p), ('density_dev', C.c_void_p),
+        ('rn', C.c_int), ('dn', C.c_int), ('ray_mask_view_num', C.c_int), ('ray_mask_point_num', C.c_int),
+    ]
+
+
+# every symbol include/neuray_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    'neuray_abi_version': (C.c_int, []),
+    'neuray_last_error': (C.c_char_p, []),
+    'neuray_is_device_build': (C.c_int, []),
+    'neuray_packed_pass_floats': (C.c_size_t, []),
+    'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    'neuray_setup_views': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_setup_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_relayout_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'neuray_sample_coarse_depth': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_render_points': (C.c_int, [C.POINTER(NeurayPointsArgs), C.c_void_p]),
+    'neuray_render_rays': (C.c_int, [C.POINTER(NeurayRaysArgs), C.c_void_p]),
+    'neuray_sample_fine_depth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_interpolate_feats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_mfma_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+class NeurayLibError(RuntimeError):
+    pass
+
+
+def bind(path):
+    """dlopen `path` and attach prototypes for every symbol of the C ABI (raises if one is missing)."""
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+_LIB = None
+
+
+def load():
+    """The product library (HIP, gfx950).  Raises loudly if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise NeurayLibError(
+                "neuray_amd: %s not found - build it with `python -m neuray_amd.build` (hipcc, gfx950). "
+                "There is no CPU/eager fallback for the render path." % LIB_PATH)
+        lib = bind(LIB_PATH)
+        if lib.neuray_is_device_build() != 1:
+            raise NeurayLibError("neuray_amd: %s is not a device build" % LIB_PATH)
+        _LIB = lib
+    return _LIB
+
+
+def check(lib, rc):
+    if rc != 0:
+        raise RuntimeError("neuray_hip: " + lib.neuray_last_error().decode('utf-8', 'replace'))

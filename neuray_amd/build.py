@@ -1,0 +1,34 @@
+"""Builds neuray_amd/libneuray_hip.so for gfx950 with hipcc (in-tree, so the .so travels with the repo).
+
+    python -m neuray_amd.build [-f]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libneuray_hip.so')
+SOURCES = [os.path.join(CSRC, 'neuray_hip.hip'), os.path.join(CSRC, 'nr_pack.cpp')]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
+    [os.path.join(os.path.dirname(HERE), 'include', 'neuray_hip.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value', '-Wno-comment']
+
+
+def needs_build():
+    return not os.path.exists(OUT) or any(os.path.getmtime(OUT) < os.path.getmtime(d) for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [HIPCC] + FLAGS + SOURCES + ['-o', OUT]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='-f' in sys.argv, verbose=True))

@@ -1,0 +1,181 @@
+// C ABI of libneuray_hip.so (declared in include/neuray_hip.h).  Host-side launch logic only; the device
+// code lives in nr_kernels.h / nr_device.h.  Built with hipcc --offload-arch=gfx950 (product) or, for the
+// CPU test emulator, g++ -DNEURAY_EMU (tests/emu/build_emu.py).
+#include "nr_kernels.h"
+#include "nr_pack.h"
+#include "../../include/neuray_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+int grid_for(long long work_items, int per_block, int max_blocks) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+static_assert(NEURAY_POINT_REC == nr::kPointRec, "abi");
+static_assert(NEURAY_VIEW_CONST == nr::kViewConst, "abi");
+static_assert(NEURAY_QUERY_CONST == nr::kQueryConst, "abi");
+static_assert(NEURAY_PASS_TENSORS == nr::T_COUNT, "abi");
+static_assert(NEURAY_DBG_FIELDS == nr::kDbgFields, "abi");
+static_assert(NEURAY_MAX_SAMPLES == nr::kMaxSamples, "abi");
+
+template <int NT, bool HAS_VIS>
+int launch_points(const nr::PointParams& p, void* stream) {
+    const int npts = p.rn * p.dn;
+    const size_t smem = nr::point_smem_bytes<NT>(p.rfn);
+    if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
+    // persistent-style grid: enough workgroups to fill 256 CUs several times over, grid-stride beyond
+    const int grid = grid_for(npts, 16 * NT, 256 * 8);
+    const int threads = 64 * p.rfn;
+#ifndef NEURAY_EMU
+    if (threads <= 512) {
+        auto k = nr::points_kernel<NT, HAS_VIS, 512>;
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(threads), smem, (hipStream_t)stream, p);
+    } else {
+        auto k = nr::points_kernel<NT, HAS_VIS, 1024>;
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(threads), smem, (hipStream_t)stream, p);
+    }
+#else
+    NR_LAUNCH((nr::points_kernel<NT, HAS_VIS, 1024>), dim3(grid), dim3(threads), smem, stream, p);
+#endif
+    return check_launch("neuray_render_points");
+}
+
+}  // namespace
+
+extern "C" {
+
+int neuray_abi_version(void) { return NEURAY_ABI_VERSION; }
+const char* neuray_last_error(void) { return g_err; }
+int neuray_is_device_build(void) {
+#ifdef NEURAY_EMU
+    return 0;
+#else
+    return 1;
+#endif
+}
+
+size_t neuray_packed_pass_floats(void) { return (size_t)nr::kPackedPassFloats; }
+
+int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_host) {
+    if (!tensors_host || !packed_host) return fail("neuray_pack_pass_weights: null argument");
+    const int rc = nr::pack_pass_weights(tensors_host, packed_host);
+    if (rc) return fail("neuray_pack_pass_weights: tensor %d of the pass is missing", rc - 1);
+    return 0;
+}
+
+int neuray_setup_views(const float* poses, const float* Ks, const float* depth_range, int n, float* out, void* stream) {
+    if (n < 1 || n > NEURAY_MAX_VIEWS) return fail("neuray_setup_views: n=%d outside [1,%d]", n, NEURAY_MAX_VIEWS);
+    NR_LAUNCH(nr::view_setup_kernel, dim3(1), dim3(64), 0, stream, poses, Ks, depth_range, n, out);
+    return check_launch("neuray_setup_views");
+}
+
+int neuray_setup_query(const float* pose, const float* Kinv, const float* depth_range, float* out, void* stream) {
+    NR_LAUNCH(nr::query_setup_kernel, dim3(1), dim3(64), 0, stream, pose, Kinv, depth_range, out);
+    return check_launch("neuray_setup_query");
+}
+
+int neuray_relayout_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad, void* stream) {
+    if (c_pad < c || n < 1) return fail("neuray_relayout_nhwc: bad shape n=%d c=%d c_pad=%d", n, c, c_pad);
+    const int grid = grid_for((long long)n * h * w, 256, 256 * 16);
+    NR_LAUNCH(nr::relayout_kernel, dim3(grid), dim3(256), 0, stream, src, dst, n, c, h, w, c_pad);
+    return check_launch("neuray_relayout_nhwc");
+}
+
+int neuray_sample_coarse_depth(const float* depth_range, int rn, int dn, float* depth, void* stream) {
+    if (dn <= 2) return fail("neuray_sample_coarse_depth: dn=%d must be > 2 (render_ops.py:157)", dn);
+    const int grid = grid_for((long long)rn * dn, 256, 256 * 8);
+    NR_LAUNCH(nr::coarse_depth_kernel, dim3(grid), dim3(256), 0, stream, depth_range, rn, dn, depth);
+    return check_launch("neuray_sample_coarse_depth");
+}
+
+int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
+    if (!a) return fail("neuray_render_points: null args");
+    if (a->rfn < 1 || a->rfn > NEURAY_MAX_VIEWS) return fail("neuray_render_points: rfn=%d outside [1,%d]", a->rfn, NEURAY_MAX_VIEWS);
+    if (a->dn <= 2 || a->rn < 1) return fail("neuray_render_points: bad rn=%d dn=%d", a->rn, a->dn);
+    if (a->use_vis && !a->has_vis_head) return fail("neuray_render_points: use_vis set but the decoder has no vis head");
+    if ((long long)a->rn * a->dn > 0x7fffffffLL / 2) return fail("neuray_render_points: rn*dn too large for one call");
+    nr::PointParams p;
+    p.que_const = a->query_const_dev; p.view_const = a->view_const_dev; p.coords = a->coords_dev; p.depth = a->depth_dev;
+    p.ray_feats = a->ray_feats_nhwc_dev; p.img_feats = a->img_feats_nhwc_dev; p.rgba = a->rgba_dev;
+    p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev;
+    p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
+    p.use_vis = a->use_vis; p.var_bias = a->var_bias;
+    const int nt = a->tiles_per_wave ? a->tiles_per_wave : 2;
+    // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
+    // reference-view path when the coarse decoder has use_vis = False: quirk A.9.2)
+    const bool vis = a->has_vis_head && a->use_vis;
+    if (nt == 1) return vis ? launch_points<1, true>(p, stream) : launch_points<1, false>(p, stream);
+    if (nt == 2) return vis ? launch_points<2, true>(p, stream) : launch_points<2, false>(p, stream);
+    return fail("neuray_render_points: tiles_per_wave=%d not built (1 or 2)", nt);
+}
+
+int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {
+    if (!a) return fail("neuray_render_rays: null args");
+    if (a->dn < 1 || a->dn > 4 * NEURAY_MAX_SAMPLES) return fail("neuray_render_rays: dn=%d unsupported", a->dn);
+    nr::RayParams p;
+    p.point_rec = a->point_rec_dev; p.depth = a->depth_dev; p.pos_enc = a->pos_enc_dev; p.weights = a->packed_weights_dev;
+    p.hit_prob = a->hit_prob_dev; p.pixel = a->pixel_dev; p.render_depth = a->render_depth_dev; p.ray_mask = a->ray_mask_dev;
+    p.density = a->density_dev; p.rn = a->rn; p.dn = a->dn;
+    p.mask_view_num = a->ray_mask_view_num; p.mask_point_num = a->ray_mask_point_num;
+    const size_t smem = nr::ray_smem_bytes(a->dn);
+    if (smem > 160 * 1024) return fail("neuray_render_rays: dn=%d needs %zu bytes of LDS", a->dn, smem);
+    const int grid = grid_for(a->rn, nr::kRayWaves, 256 * 16);
+#ifndef NEURAY_EMU
+    if (smem > 64 * 1024) hipFuncSetAttribute((const void*)nr::rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+    NR_LAUNCH(nr::rays_kernel, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+    return check_launch("neuray_render_rays");
+}
+
+int neuray_sample_fine_depth(const float* query_const, const float* depth, const float* hit_prob, const float* u,
+                             int rn, int dn, int fdn, int use_all, float* out, void* stream) {
+    if (dn < 2 || dn > NEURAY_MAX_SAMPLES || fdn < 1 || fdn > NEURAY_MAX_SAMPLES)
+        return fail("neuray_sample_fine_depth: dn=%d fdn=%d outside [2,%d]", dn, fdn, NEURAY_MAX_SAMPLES);
+    nr::FineParams p;
+    p.que_const = query_const; p.depth = depth; p.hit_prob = hit_prob; p.u = u; p.out = out;
+    p.rn = rn; p.dn = dn; p.fdn = fdn; p.use_all = use_all;
+    const int grid = grid_for(rn, nr::kRayWaves, 256 * 16);
+    NR_LAUNCH(nr::fine_kernel, dim3(grid), dim3(64 * nr::kRayWaves), 0, stream, p);
+    return check_launch("neuray_sample_fine_depth");
+}
+
+int neuray_interpolate_feats(const float* feats, const float* points, const float* mask, int b, int n, int c, int fh, int fw,
+                             int h_full, int w_full, int align_corners, float* out, void* stream) {
+    if (b < 1 || n < 1 || c < 1) return fail("neuray_interpolate_feats: bad shape b=%d n=%d c=%d", b, n, c);
+    const int grid = grid_for((long long)b * n, 256, 256 * 8);
+    NR_LAUNCH(nr::interpolate_kernel, dim3(grid), dim3(256), 0, stream, feats, points, mask, b, n, c, fh, fw, h_full, w_full,
+              align_corners, out);
+    return check_launch("neuray_interpolate_feats");
+}
+
+int neuray_mfma_selftest(const float* A, const float* B, float* D, void* stream) {
+    NR_LAUNCH(nr::mfma_selftest_kernel, dim3(1), dim3(64), 0, stream, A, B, D);
+    return check_launch("neuray_mfma_selftest");
+}
+
+}  // extern "C"

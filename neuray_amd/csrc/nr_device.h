@@ -1,0 +1,269 @@
+// Device functions of the NeuRay per-ray path for gfx950.  Each block cites the reference lines it
+// replaces (paths relative to the reference tree) and follows the rounding contract of DESIGN.md:
+// camera algebra uses explicit __fmul_rn/__fadd_rn sequences (no FMA contraction) in the same order as
+// the oracle, so validity masks and texel indices are bit-identical between the two.
+#pragma once
+#include "nr_platform.h"
+#include "nr_layout.h"
+
+namespace nr {
+
+// ---------------------------------------------------------------------------------------------
+// ordered small algebra
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations (PyTorch semantics: ELU alpha=1 via exp(x)-1, Softplus beta=1 threshold=20)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// a1  coarse depth sample i of dn, uniform in inverse depth       network/render_ops.py:146-170
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coarse_depth(float near, float far, int i, int dn) {
+    const float inv_near = __fdiv_rn(1.0f, near);
+    const float diff = __fsub_rn(__fdiv_rn(1.0f, far), inv_near);
+    float tick;
+    if (i == 0) tick = 0.0f;
+    else if (i == dn - 1) tick = diff;
+    else tick = __fmul_rn(__fdiv_rn(diff, (float)(dn - 1)), (float)i);
+    return __fdiv_rn(1.0f, __fadd_rn(inv_near, tick));
+}
+
+// normalised inverse depth s = (-1/d - near') / (far' - near'),  near' = -1/near, far' = -1/far
+//   network/render_ops.py:46-52, dist_decoder.py:16-22
+__device__ __forceinline__ float norm_inv_depth(float d, float nearp, float farp) {
+    return __fdiv_rn(__fsub_rn(__fdiv_rn(-1.0f, d), nearp), __fsub_rn(farp, nearp));
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2  query ray                                                   network/render_ops.py:4-39
+//   qc = query constants: [0..8] K^-1, [9..20] pose, [21..23] centre
+// ---------------------------------------------------------------------------------------------
+struct Ray { float cx, cy, cz, dx, dy, dz, qx, qy, qz; };   // centre, un-normalised dir, que_dir = -dir/|dir|
+
+__device__ __forceinline__ Ray make_ray(const float* __restrict__ qc, float x, float y) {
+    Ray r;
+    const float cam0 = dot3(qc[0], qc[1], qc[2], x, y, 1.0f);
+    const float cam1 = dot3(qc[3], qc[4], qc[5], x, y, 1.0f);
+    const float cam2 = dot3(qc[6], qc[7], qc[8], x, y, 1.0f);
+    const float* P = qc + 9;   // pose row-major 3x4; rot = R^T -> row i of rot is column i of R
+    r.cx = qc[21]; r.cy = qc[22]; r.cz = qc[23];
+    const float w0 = dot3(P[0], P[4], P[8], cam0, cam1, cam2);
+    const float w1 = dot3(P[1], P[5], P[9], cam0, cam1, cam2);
+    const float w2 = dot3(P[2], P[6], P[10], cam0, cam1, cam2);
+    r.dx = __fsub_rn(__fadd_rn(w0, r.cx), r.cx);
+    r.dy = __fsub_rn(__fadd_rn(w1, r.cy), r.cy);
+    r.dz = __fsub_rn(__fadd_rn(w2, r.cz), r.cz);
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r.dx, r.dx), __fmul_rn(r.dy, r.dy)), __fmul_rn(r.dz, r.dz)));
+    r.qx = __fdiv_rn(-r.dx, nrm); r.qy = __fdiv_rn(-r.dy, nrm); r.qz = __fdiv_rn(-r.dz, nrm);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4-a6  projection into one reference view                        network/render_ops.py:82-130
+//   vc = view constants: [0..11] H = K[R|t], [12..14] centre
+// ---------------------------------------------------------------------------------------------
+struct Proj { float u, v, z, mask, dirx, diry, dirz; };
+
+__device__ __forceinline__ Proj project_point(const float* __restrict__ vc, float px, float py, float pz, float w_img, float h_img) {
+    Proj o;
+    const float c0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vc[0], px), __fmul_rn(vc[1], py)), __fmul_rn(vc[2], pz)), vc[3]);
+    const float c1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vc[4], px), __fmul_rn(vc[5], py)), __fmul_rn(vc[6], pz)), vc[7]);
+    float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vc[8], px), __fmul_rn(vc[9], py)), __fmul_rn(vc[10], pz)), vc[11]);
+    const bool bad = fabsf(z) < 1e-4f;          // no z>0 test: quirk A.9.1
+    if (bad) z = 1e-3f;
+    o.u = __fdiv_rn(c0, z); o.v = __fdiv_rn(c1, z); o.z = z;
+    const bool outside = (o.u < -0.5f) | (o.u >= w_img - 0.5f) | (o.v < -0.5f) | (o.v >= h_img - 0.5f);
+    o.mask = (!bad && !outside) ? 1.0f : 0.0f;
+    const float dx = __fsub_rn(px, vc[12]), dy = __fsub_rn(py, vc[13]), dz = __fsub_rn(pz, vc[14]);
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float den = fmaxf(nrm, 1e-5f);
+    o.dirx = __fdiv_rn(-dx, den); o.diry = __fdiv_rn(-dy, den); o.dirz = __fdiv_rn(-dz, den);
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7  bilinear taps (grid_sample, padding_mode='border')        network/ops.py:14-34
+//   pixel coordinate p (full-res units) -> clamped texel coordinate; align_corners=True for maps at
+//   full resolution (rgb), False otherwise (render_ops.py:64-68).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float texel_coord(float p, float size_full, float size_map, bool align) {
+    const float n = __fsub_rn(__fmul_rn(__fdiv_rn(p, __fsub_rn(size_full, 1.0f)), 2.0f), 1.0f);
+    float ix;
+    if (align) ix = __fmul_rn(__fdiv_rn(__fadd_rn(n, 1.0f), 2.0f), __fsub_rn(size_map, 1.0f));
+    else ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(n, 1.0f), size_map), 1.0f), 2.0f);
+    return fminf(__fsub_rn(size_map, 1.0f), fmaxf(ix, 0.0f));
+}
+
+struct Taps { int o00, o10, o01, o11; float w00, w10, w01, w11; };   // texel offsets (y*W + x) and weights
+
+__device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_full, int mw, int mh) {
+    const bool align = (mw == w_full) && (mh == h_full);
+    const float ix = texel_coord(u, (float)w_full, (float)mw, align);
+    const float iy = texel_coord(v, (float)h_full, (float)mh, align);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + 1 < mw ? x0 + 1 : mw - 1;   // weight is exactly 0 when clamped
+    const int yb = y0 + 1 < mh ? y0 + 1 : mh - 1;
+    const float wx1 = __fsub_rn(ix, x0f), wy1 = __fsub_rn(iy, y0f);
+    const float wx0 = __fsub_rn(__fadd_rn(x0f, 1.0f), ix), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), iy);
+    Taps t;
+    t.o00 = y0 * mw + x0; t.o10 = y0 * mw + x1; t.o01 = yb * mw + x0; t.o11 = yb * mw + x1;
+    t.w00 = __fmul_rn(wx0, wy0); t.w10 = __fmul_rn(wx1, wy0); t.w01 = __fmul_rn(wx0, wy1); t.w11 = __fmul_rn(wx1, wy1);
+    if (x0 + 1 > mw - 1) { t.w10 = 0.0f; t.w11 = 0.0f; }
+    if (y0 + 1 > mh - 1) { t.w01 = 0.0f; t.w11 = 0.0f; }
+    return t;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float blend4(float a, float b, float c, float d, const Taps& t) {
+    return ((a * t.w00 + b * t.w10) + c * t.w01) + d * t.w11;
+}
+
+// channels-last gather of 8 consecutive channels (this lane group's slice) of a 32-channel map
+__device__ __forceinline__ void gather8(const float* __restrict__ base, const Taps& t, float mask, float (&out)[8]) {
+    const float4 a0 = ld4(base + (size_t)t.o00 * 32), a1 = ld4(base + (size_t)t.o00 * 32 + 4);
+    const float4 b0 = ld4(base + (size_t)t.o10 * 32), b1 = ld4(base + (size_t)t.o10 * 32 + 4);
+    const float4 c0 = ld4(base + (size_t)t.o01 * 32), c1 = ld4(base + (size_t)t.o01 * 32 + 4);
+    const float4 d0 = ld4(base + (size_t)t.o11 * 32), d1 = ld4(base + (size_t)t.o11 * 32 + 4);
+    out[0] = blend4(a0.x, b0.x, c0.x, d0.x, t) * mask; out[1] = blend4(a0.y, b0.y, c0.y, d0.y, t) * mask;
+    out[2] = blend4(a0.z, b0.z, c0.z, d0.z, t) * mask; out[3] = blend4(a0.w, b0.w, c0.w, d0.w, t) * mask;
+    out[4] = blend4(a1.x, b1.x, c1.x, d1.x, t) * mask; out[5] = blend4(a1.y, b1.y, c1.y, d1.y, t) * mask;
+    out[6] = blend4(a1.z, b1.z, c1.z, d1.z, t) * mask; out[7] = blend4(a1.w, b1.w, c1.w, d1.w, t) * mask;
+}
+
+__device__ __forceinline__ void gather_rgb(const float* __restrict__ base, const Taps& t, float mask, float (&out)[3]) {
+    const float4 a = ld4(base + (size_t)t.o00 * 4), b = ld4(base + (size_t)t.o10 * 4);
+    const float4 c = ld4(base + (size_t)t.o01 * 4), d = ld4(base + (size_t)t.o11 * 4);
+    out[0] = blend4(a.x, b.x, c.x, d.x, t) * mask;
+    out[1] = blend4(a.y, b.y, c.y, d.y, t) * mask;
+    out[2] = blend4(a.z, b.z, c.z, d.z, t) * mask;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10  mixture-of-logistics probabilities of one projected sample      network/dist_decoder.py:109-140
+//   t: normalised inverse depth on the reference ray, lo/hi: half intervals (dist_decoder.py:34-38)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void logistic_prob(float t, float lo, float hi, float mu0, float mu1, float s0, float s1,
+                                              float aw, float nu, bool use_vis, float& visibility, float& hit) {
+    const float near = t - lo, far = t + hi;
+    float c00 = 0.5f + 0.5f * tanhf((near - mu0) * s0), c01 = 0.5f + 0.5f * tanhf((near - mu1) * s1);
+    float c10 = 0.5f + 0.5f * tanhf((far - mu0) * s0), c11 = 0.5f + 0.5f * tanhf((far - mu1) * s1);
+    if (use_vis) { c00 *= nu; c01 *= nu; c10 *= nu; c11 *= nu; }
+    const float m0 = aw, m1 = 1.0f - aw;
+    visibility = (1.0f - c00) * m0 + (1.0f - c01) * m1;
+    hit = (c10 - c00) * m0 + (c11 - c01) * m1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA MLP layers (layout: nr_layout.h).  NT = point tiles (16 points each) processed per wave.
+//   xq[t][4*kq + j] : B operands of the quad K-steps,  x1[t][k1] : B operands of the single K-steps
+//   acc[t][mo]      : accumulators (D layout), caller decides the initial value
+// ---------------------------------------------------------------------------------------------
+template <int L, int NT>
+__device__ __forceinline__ void layer_bias(const float* __restrict__ W, int lane, v4f (&acc)[NT][kShape[L].mt_out]) {
+    constexpr int MT = kShape[L].mt_out;
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo) {
+        const float4 b = ld4(W + bias_offset(L) + (mo * 4 + (lane >> 4)) * 4);
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) { acc[t][mo][0] = b.x; acc[t][mo][1] = b.y; acc[t][mo][2] = b.z; acc[t][mo][3] = b.w; }
+    }
+}
+
+// accumulate one output tile `mo` (may be a runtime value) of layer L
+template <int L, int NT, int KQX, int K1X>
+__device__ __forceinline__ void layer_tile(const float* __restrict__ W, int lane, int mo,
+                                           const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
+    constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
+    static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
+    NR_PRAGMA_UNROLL
+    for (int kq = 0; kq < KQ; ++kq) {
+        const float4 a = ld4(W + quads_offset(L) + ((mo * KQ + kq) * 64 + lane) * 4);
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
+            acc[t] = nr_mfma16(a.y, xq[t][4 * kq + 1], acc[t]);
+            acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
+            acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
+        }
+    }
+    NR_PRAGMA_UNROLL
+    for (int k1 = 0; k1 < K1; ++k1) {
+        const float a = W[single_offset(L) + (mo * K1 + k1) * 64 + lane];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a, x1[t][k1], acc[t]);
+    }
+}
+
+template <int L, int NT, int KQX, int K1X>
+__device__ __forceinline__ void layer_acc(const float* __restrict__ W, int lane, const float (&xq)[NT][KQX],
+                                          const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out]) {
+    constexpr int MT = kShape[L].mt_out;
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo) {
+        v4f a[NT];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) a[t] = acc[t][mo];
+        layer_tile<L, NT>(W, lane, mo, xq, x1, a);
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
+    }
+}
+
+// y = act(W x + b) with D-layout output registers y[t][4*mo + r]
+enum Act { ACT_NONE, ACT_ELU, ACT_RELU };
+template <int A> __device__ __forceinline__ float apply_act(float x) {
+    if (A == ACT_ELU) return elu(x);
+    if (A == ACT_RELU) return fmaxf(x, 0.0f);
+    return x;
+}
+
+template <int L, int NT, int A, int KQX, int K1X>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, int lane, const float (&xq)[NT][KQX],
+                                          const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {
+    constexpr int MT = kShape[L].mt_out;
+    v4f acc[NT][MT];
+    layer_bias<L, NT>(W, lane, acc);
+    layer_acc<L, NT>(W, lane, xq, x1, acc);
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int mo = 0; mo < MT; ++mo)
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; ++r) y[t][4 * mo + r] = apply_act<A>(acc[t][mo][r]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide all-reduce over the view-waves (one wave per reference view).
+//   red: LDS scratch of (nw + 1) * RMAX * 64 floats.  Deterministic (views summed in order 0..nw-1),
+//   identical result in every wave.  Two barriers per round (reduce-scatter, then all-gather).
+// ---------------------------------------------------------------------------------------------
+enum RedOp { RED_SUM, RED_MAX };
+template <int R, int RMAX, int OP>
+__device__ __forceinline__ void block_allreduce(float (&v)[R], float* red, int wave, int nw, int lane) {
+    static_assert(R <= RMAX, "allreduce scratch too small");
+    NR_PRAGMA_UNROLL
+    for (int r = 0; r < R; ++r) red[(wave * RMAX + r) * 64 + lane] = v[r];
+    __syncthreads();
+    for (int r = wave; r < R; r += nw) {
+        float s = red[r * 64 + lane];
+        for (int w = 1; w < nw; ++w) {
+            const float o = red[(w * RMAX + r) * 64 + lane];
+            s = (OP == RED_SUM) ? s + o : fmaxf(s, o);
+        }
+        red[(nw * RMAX + r) * 64 + lane] = s;
+    }
+    __syncthreads();
+    NR_PRAGMA_UNROLL
+    for (int r = 0; r < R; ++r) v[r] = red[(nw * RMAX + r) * 64 + lane];
+}
+
+}  // namespace nr

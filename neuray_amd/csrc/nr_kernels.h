@@ -1,0 +1,747 @@
+// Kernels of the NeuRay per-ray render path (gfx950).  See DESIGN.md for the decomposition:
+//   view_setup   : per-view / query camera constants                     (render_ops.py:15-16,94)
+//   relayout     : NCHW -> channels-last maps (one 128 B line per bilinear tap)
+//   coarse_depth : a1
+//   points (P)   : a2-a14 minus attention, one wave per reference view, MFMA fp32 MLP stack
+//   rays (R)     : attention over the samples of a ray, sigma head, compositing (a14-a16)
+//   fine (F)     : inverse-CDF resampling + sort (a17)
+#pragma once
+#include "nr_device.h"
+
+namespace nr {
+
+// -------------------------------------------------------------------------------------------------
+// view / query constants
+// -------------------------------------------------------------------------------------------------
+__global__ void view_setup_kernel(const float* __restrict__ poses, const float* __restrict__ Ks,
+                                  const float* __restrict__ depth_range, int n, float* __restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float* P = poses + v * 12;
+    const float* K = Ks + v * 9;
+    float* o = out + v * kViewConst;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            o[i * 4 + j] = dot3(K[i * 3 + 0], K[i * 3 + 1], K[i * 3 + 2], P[j], P[4 + j], P[8 + j]);
+    for (int i = 0; i < 3; ++i) o[12 + i] = dot3(-P[i], -P[4 + i], -P[8 + i], P[3], P[7], P[11]);
+    o[15] = __fdiv_rn(-1.0f, depth_range[2 * v]);
+    o[16] = __fdiv_rn(-1.0f, depth_range[2 * v + 1]);
+    o[17] = 0.0f; o[18] = 0.0f; o[19] = 0.0f;
+}
+
+__global__ void query_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
+                                   const float* __restrict__ depth_range, float* __restrict__ o) {
+    if (blockIdx.x * blockDim.x + threadIdx.x != 0) return;
+    for (int i = 0; i < 9; ++i) o[i] = Kinv[i];
+    for (int i = 0; i < 12; ++i) o[9 + i] = pose[i];
+    for (int i = 0; i < 3; ++i) o[21 + i] = dot3(-pose[i], -pose[4 + i], -pose[8 + i], pose[3], pose[7], pose[11]);
+    o[24] = __fdiv_rn(-1.0f, depth_range[0]);
+    o[25] = __fdiv_rn(-1.0f, depth_range[1]);
+    o[26] = depth_range[0]; o[27] = depth_range[1];
+}
+
+// -------------------------------------------------------------------------------------------------
+// NCHW -> NHWC (c_pad >= c channels, padding zero-filled).  One thread per (n, y, x).
+// -------------------------------------------------------------------------------------------------
+__global__ void relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w, int c_pad) {
+    const long long total = (long long)n * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / ((long long)h * w);
+        const long long pix = i - img * h * w;
+        const float* s = src + img * c * h * w + pix;
+        float* d = dst + i * c_pad;
+        for (int ch = 0; ch < c_pad; ++ch) d[ch] = ch < c ? s[(long long)ch * h * w] : 0.0f;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// a1: coarse depths [rn][dn]
+// -------------------------------------------------------------------------------------------------
+__global__ void coarse_depth_kernel(const float* __restrict__ depth_range, int rn, int dn, float* __restrict__ out) {
+    const float near = depth_range[0], far = depth_range[1];
+    const long long total = (long long)rn * dn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        out[i] = coarse_depth(near, far, (int)(i % dn), dn);
+}
+
+// -------------------------------------------------------------------------------------------------
+// point kernel
+// -------------------------------------------------------------------------------------------------
+struct PointParams {
+    const float* que_const;    // [kQueryConst]
+    const float* view_const;   // [rfn][kViewConst]
+    const float* coords;       // [rn][2] pixel (x, y)
+    const float* depth;        // [rn][dn]
+    const float* ray_feats;    // [rfn][fh][fw][32]
+    const float* img_feats;    // [rfn][fh][fw][32]
+    const float* rgba;         // [rfn][h][w][4]
+    const float* weights;      // packed pass weights
+    float* point_out;          // [rn*dn][kPointRec]
+    float* dbg;                // optional [rn*dn][rfn][16]
+    int rfn, rn, dn, h, w, fh, fw;
+    int use_vis;               // the COARSE decoder's use_vis governs compute_prob in both passes (renderer.py:75)
+    float var_bias;            // AddBias value of var_decoder (dist_decoder.py:81)
+};
+
+constexpr int kDbgFields = 16;
+
+__device__ __forceinline__ float sel4(int g, float a, float b, float c, float d) {
+    return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+}
+
+template <int NT>
+constexpr int point_rmax() { return 12 * NT; }
+
+template <int NT>
+inline size_t point_smem_bytes(int rfn) { return sizeof(float) * 64 * ((size_t)(rfn + 1) * point_rmax<NT>() + 16 * NT); }
+
+template <int NT, bool HAS_VIS, int MAXT>
+__global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
+    NR_DYNAMIC_SMEM(float, smem);
+    constexpr int RMAX = point_rmax<NT>();
+    const int lane = threadIdx.x & 63;
+    const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
+    const int nw = p.rfn;
+    const int g = lane >> 4, c = lane & 15;
+    float* red = smem;
+    float* xch = smem + (size_t)(nw + 1) * RMAX * 64;
+    const float* __restrict__ W = p.weights;
+    const float* __restrict__ vc = p.view_const + wave * kViewConst;
+    const float* __restrict__ qc = p.que_const;
+    const float vnearp = vc[15], vfarp = vc[16];
+    const float qnearp = qc[24], qfarp = qc[25];
+    const float* rf_base = p.ray_feats + (size_t)wave * p.fh * p.fw * 32 + 8 * g;
+    const float* if_base = p.img_feats + (size_t)wave * p.fh * p.fw * 32 + 8 * g;
+    const float* rgb_base = p.rgba + (size_t)wave * p.h * p.w * 4;
+    const int npts = p.rn * p.dn;
+    const int dn = p.dn;
+    const int nwork = nw < 4 ? nw : 4;
+    const bool use_vis = p.use_vis != 0;
+
+    for (int base = blockIdx.x * (16 * NT); base < npts; base += gridDim.x * (16 * NT)) {
+        // ---------------- geometry + gather (a2-a8) -------------------------------------------
+        int pidx[NT]; bool pvalid[NT];
+        float mask[NT], dlt[NT][4], fray[NT][8], fimg[NT][8], rgb[NT][3], tref[NT], lo[NT], hi[NT];
+        float dbg_u[NT], dbg_v[NT], dbg_z[NT];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            int pi = base + 16 * t + c;
+            pvalid[t] = pi < npts;
+            pi = pi < npts ? pi : npts - 1;
+            pidx[t] = pi;
+            const int ray = pi / dn, smp = pi - ray * dn;
+            const Ray r = make_ray(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
+            const float* drow = p.depth + (size_t)ray * dn;
+            const float d = drow[smp];
+            const float s_c = norm_inv_depth(d, qnearp, qfarp);
+            // half intervals in normalised inverse depth (render_ops.py:46-52, dist_decoder.py:34-38)
+            const float s_n = norm_inv_depth(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qfarp);
+            const float s_p = norm_inv_depth(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp);
+            const float half_c = (smp == dn - 1) ? 500000.0f : __fdiv_rn(__fsub_rn(s_n, s_c), 2.0f);
+            const float half_p = __fdiv_rn(__fsub_rn(s_c, s_p), 2.0f);
+            hi[t] = half_c;
+            lo[t] = (smp == 0) ? half_c : half_p;
+            const float px = __fadd_rn(r.cx, __fmul_rn(r.dx, d));
+            const float py = __fadd_rn(r.cy, __fmul_rn(r.dy, d));
+            const float pz = __fadd_rn(r.cz, __fmul_rn(r.dz, d));
+            const Proj pr = project_point(vc, px, py, pz, (float)p.w, (float)p.h);
+            mask[t] = pr.mask;
+            dlt[t][0] = pr.dirx - r.qx; dlt[t][1] = pr.diry - r.qy; dlt[t][2] = pr.dirz - r.qz;
+            dlt[t][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
+            tref[t] = norm_inv_depth(fmaxf(pr.z, 1e-5f), vnearp, vfarp);
+            dbg_u[t] = pr.u; dbg_v[t] = pr.v; dbg_z[t] = pr.z;
+            const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
+            gather8(rf_base, tf, pr.mask, fray[t]);
+            gather8(if_base, tf, pr.mask, fimg[t]);
+            const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
+            gather_rgb(rgb_base, tc, pr.mask, rgb[t]);
+        }
+        float none[NT][1];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) none[t][0] = 0.0f;
+
+        // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
+        float hit[NT], vis[NT];
+        float dbg_mu0[NT], dbg_mu1[NT], dbg_s0[NT], dbg_s1[NT], dbg_aw[NT], dbg_nu[NT];
+        {
+            float cat[NT][16], h1[NT][8], h2[NT][8], fin[NT][4];
+            layer_fwd<L_DM1, NT, ACT_ELU>(W, lane, fray, none, h1);
+            layer_fwd<L_DM2, NT, ACT_ELU>(W, lane, h1, none, h2);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) cat[t][s] = h2[t][s];
+            layer_fwd<L_DV1, NT, ACT_ELU>(W, lane, fray, none, h1);
+            layer_fwd<L_DV2, NT, ACT_ELU>(W, lane, h1, none, h2);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) cat[t][8 + s] = h2[t][s];
+            layer_fwd<L_DFIN_MS, NT, ACT_NONE>(W, lane, cat, none, fin);
+            float mu0[NT], mu1[NT], s0[NT], s1[NT], aw[NT], nu[NT];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                mu0[t] = softplus(fin[t][0]); mu1[t] = softplus(fin[t][1]);
+                s0[t] = softplus(fin[t][2]) + p.var_bias; s1[t] = softplus(fin[t][3]) + p.var_bias;
+            }
+            layer_fwd<L_DA1, NT, ACT_ELU>(W, lane, fray, none, h1);
+            layer_fwd<L_DA2, NT, ACT_ELU>(W, lane, h1, none, h2);
+            if (HAS_VIS) {
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t)
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < 8; ++s) cat[t][s] = h2[t][s];
+                layer_fwd<L_DS1, NT, ACT_ELU>(W, lane, fray, none, h1);
+                layer_fwd<L_DS2, NT, ACT_ELU>(W, lane, h1, none, h2);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t)
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < 8; ++s) cat[t][8 + s] = h2[t][s];
+                layer_fwd<L_DFIN_AV, NT, ACT_NONE>(W, lane, cat, none, fin);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) { aw[t] = sigmoidf(fin[t][0]); nu[t] = sigmoidf(fin[t][1]); }
+            } else {
+                layer_fwd<L_DFIN_A, NT, ACT_NONE>(W, lane, h2, none, fin);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) { aw[t] = sigmoidf(fin[t][0]); nu[t] = 1.0f; }
+            }
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                float v_, h_;
+                logistic_prob(tref[t], lo[t], hi[t], mu0[t], mu1[t], s0[t], s1[t], aw[t], nu[t], use_vis && HAS_VIS, v_, h_);
+                vis[t] = v_ * mask[t]; hit[t] = h_ * mask[t];
+                dbg_mu0[t] = mu0[t]; dbg_mu1[t] = mu1[t]; dbg_s0[t] = s0[t]; dbg_s1[t] = s1[t]; dbg_aw[t] = aw[t]; dbg_nu[t] = nu[t];
+            }
+        }
+
+        // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
+        float e[NT][8];
+        {
+            float x1[NT][1], h[NT][8];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                x1[t][0] = sel4(g, (hit[t] - 0.5f) * 2.0f, (vis[t] - 0.5f) * 2.0f, 0.0f, 0.0f);
+            layer_fwd<L_PE1, NT, ACT_RELU>(W, lane, fray, x1, h);
+            layer_fwd<L_PE2, NT, ACT_NONE>(W, lane, h, none, e);
+        }
+        // ---------------- ray_dir_fc, rgb_feat + direction_feat     ibrnet.py:324-327 -----------------
+        float gi[NT][8], gr[NT][3];
+        {
+            float x1[NT][1], h[NT][4], df[NT][12];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) x1[t][0] = sel4(g, dlt[t][0], dlt[t][1], dlt[t][2], dlt[t][3]);
+            layer_fwd<L_RD1, NT, ACT_ELU>(W, lane, none, x1, h);
+            layer_fwd<L_RD2, NT, ACT_ELU>(W, lane, h, none, df);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) gi[t][s] = fimg[t][s] + df[t][s];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 3; ++j) gr[t][j] = rgb[t][j] + df[t][8 + j];
+            }
+        }
+        // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
+        float sn[NT];
+        {
+            float h[NT][4], o[NT][4];
+            layer_fwd<L_NF1, NT, ACT_ELU>(W, lane, e, none, h);
+            layer_fwd<L_NF2, NT, ACT_NONE>(W, lane, h, none, o);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) sn[t] = sigmoidf(o[t][0]);
+        }
+        // ---------------- cross-view weighted mean / variance       ibrnet.py:334-340 ---------------------
+        float msum[NT], wv[NT];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) msum[t] = mask[t];
+        block_allreduce<NT, RMAX, RED_SUM>(msum, red, wave, nw, lane);
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) wv[t] = mask[t] / (msum[t] + 1e-8f);
+
+        v4f accv[NT][4];
+        {
+            float stat[4][NT * 11];   // mean0, var0, mean1, var1  ([t*11 + 0..7] img part, [t*11 + 8..10] rgb part)
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 2; ++k) {            // k = 0: weight0 = sigmoid(neuray_fc) * weight, k = 1: weight
+                float wk[NT];
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) wk[t] = k == 0 ? sn[t] * wv[t] : wv[t];
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) {
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < 8; ++s) stat[2 * k][t * 11 + s] = gi[t][s] * wk[t];
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) stat[2 * k][t * 11 + 8 + j] = gr[t][j] * wk[t];
+                }
+                block_allreduce<NT * 11, RMAX, RED_SUM>(stat[2 * k], red, wave, nw, lane);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) {
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < 8; ++s) { const float d_ = gi[t][s] - stat[2 * k][t * 11 + s]; stat[2 * k + 1][t * 11 + s] = wk[t] * (d_ * d_); }
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) { const float d_ = gr[t][j] - stat[2 * k][t * 11 + 8 + j]; stat[2 * k + 1][t * 11 + 8 + j] = wk[t] * (d_ * d_); }
+                }
+                block_allreduce<NT * 11, RMAX, RED_SUM>(stat[2 * k + 1], red, wave, nw, lane);
+            }
+            // base_fc.0, per-point part: W[:, 0:140] [mean0 var0 mean1 var1] + bias, tiles split over the waves
+            if (wave < nwork) {
+                float xq[NT][36];
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) {
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 4; ++j) {
+                        NR_PRAGMA_UNROLL
+                        for (int s = 0; s < 8; ++s) xq[t][8 * j + s] = stat[j][t * 11 + s];
+                        xq[t][32 + j] = sel4(g, stat[j][t * 11 + 8], stat[j][t * 11 + 9], stat[j][t * 11 + 10], 0.0f);
+                    }
+                }
+                for (int mo = wave; mo < 4; mo += nw) {
+                    v4f acc[NT];
+                    const float4 b = ld4(W + bias_offset(L_BG) + (mo * 4 + g) * 4);
+                    NR_PRAGMA_UNROLL
+                    for (int t = 0; t < NT; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
+                    layer_tile<L_BG, NT>(W, lane, mo, xq, none, acc);
+                    NR_PRAGMA_UNROLL
+                    for (int t = 0; t < NT; ++t)
+                        NR_PRAGMA_UNROLL
+                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+                }
+            }
+            __syncthreads();
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                NR_PRAGMA_UNROLL
+                for (int mo = 0; mo < 4; ++mo)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) accv[t][mo][r] = xch[((mo * NT + t) * 4 + r) * 64 + lane];
+        }
+        // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
+        float x[NT][8], vis2[NT], z[NT];
+        float dbg_visp[NT];
+        {
+            float xq[NT][16], x1[NT][1], h64[NT][16];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) { xq[t][s] = gi[t][s]; xq[t][8 + s] = e[t][s]; }
+                x1[t][0] = sel4(g, gr[t][0], gr[t][1], gr[t][2], 0.0f);
+            }
+            layer_acc<L_BV, NT>(W, lane, xq, x1, accv);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                NR_PRAGMA_UNROLL
+                for (int mo = 0; mo < 4; ++mo)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) h64[t][4 * mo + r] = elu(accv[t][mo][r]);
+            layer_fwd<L_B2, NT, ACT_ELU>(W, lane, h64, none, x);
+        }
+        {
+            float xin[NT][8], h[NT][8], y[NT][12], o[NT][4];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) xin[t][s] = x[t][s] * wv[t];
+            layer_fwd<L_VF1, NT, ACT_ELU>(W, lane, xin, none, h);
+            layer_fwd<L_VF2, NT, ACT_ELU>(W, lane, h, none, y);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                const float visp = sigmoidf(y[t][8]) * mask[t];      // sigmoid on an ELU output: quirk A.9.4
+                dbg_visp[t] = visp;
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) { x[t][s] = x[t][s] + y[t][s]; xin[t][s] = x[t][s] * visp; }
+            }
+            layer_fwd<L_V21, NT, ACT_ELU>(W, lane, xin, none, h);
+            layer_fwd<L_V22, NT, ACT_NONE>(W, lane, h, none, o);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) vis2[t] = sigmoidf(o[t][0]) * mask[t];
+            float x1[NT][2], h16[NT][4], h8[NT][4];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                x1[t][0] = sel4(g, vis2[t], dlt[t][0], dlt[t][1], dlt[t][2]);
+                x1[t][1] = sel4(g, dlt[t][3], 0.0f, 0.0f, 0.0f);
+            }
+            layer_fwd<L_RF1, NT, ACT_ELU>(W, lane, x, x1, h16);
+            layer_fwd<L_RF2, NT, ACT_ELU>(W, lane, h16, none, h8);
+            layer_fwd<L_RF3, NT, ACT_NONE>(W, lane, h8, none, o);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) z[t] = mask[t] > 0.0f ? o[t][0] : -1e9f;
+        }
+        // ---------------- cross-view: blending softmax, visibility-weighted mean/var  ibrnet.py:350-367 ---
+        float zmax[NT];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) zmax[t] = z[t];
+        block_allreduce<NT, RMAX, RED_MAX>(zmax, red, wave, nw, lane);
+        float ev[NT], sums[NT * 2];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) { ev[t] = expf(z[t] - zmax[t]); sums[2 * t] = vis2[t]; sums[2 * t + 1] = ev[t]; }
+        block_allreduce<NT * 2, RMAX, RED_SUM>(sums, red, wave, nw, lane);
+        float big[NT * 12], wh[NT];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            wh[t] = vis2[t] / (sums[2 * t] + 1e-8f);
+            const float beta = ev[t] / sums[2 * t + 1];
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < 8; ++s) big[t * 12 + s] = x[t][s] * wh[t];
+            big[t * 12 + 8] = wh[t];
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 3; ++j) big[t * 12 + 9 + j] = rgb[t][j] * beta;
+        }
+        block_allreduce<NT * 12, RMAX, RED_SUM>(big, red, wave, nw, lane);
+        float var[NT * 8];
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t)
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < 8; ++s) { const float d_ = x[t][s] - big[t * 12 + s]; var[t * 8 + s] = wh[t] * (d_ * d_); }
+        block_allreduce<NT * 8, RMAX, RED_SUM>(var, red, wave, nw, lane);
+
+        // ---------------- geometry_fc (a14), tiles of layer 1 split over the waves   ibrnet.py:353-354 -----
+        if (wave < nwork) {
+            float xq[NT][16], x1[NT][1];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) { xq[t][s] = big[t * 12 + s]; xq[t][8 + s] = var[t * 8 + s]; }
+                x1[t][0] = sel4(g, big[t * 12 + 8] / (float)nw, 0.0f, 0.0f, 0.0f);
+            }
+            for (int mo = wave; mo < 4; mo += nw) {
+                v4f acc[NT];
+                const float4 b = ld4(W + bias_offset(L_GF1) + (mo * 4 + g) * 4);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
+                layer_tile<L_GF1, NT>(W, lane, mo, xq, x1, acc);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu(acc[t][r]);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float h[NT][16], G[NT][4];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) h[t][k] = xch[((k >> 2) * NT + t) * 4 * 64 + (k & 3) * 64 + lane];
+            layer_fwd<L_GF2, NT, ACT_ELU>(W, lane, h, none, G);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                if (pvalid[t])
+                    *reinterpret_cast<float4*>(p.point_out + (size_t)pidx[t] * kPointRec + 4 * g) = make_float4(G[t][0], G[t][1], G[t][2], G[t][3]);
+        }
+        if (wave == (nw > 1 ? 1 : 0) && g == 0) {
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                if (pvalid[t])
+                    *reinterpret_cast<float4*>(p.point_out + (size_t)pidx[t] * kPointRec + 16) =
+                        make_float4(big[t * 12 + 9], big[t * 12 + 10], big[t * 12 + 11], msum[t]);
+        }
+        if (p.dbg && g == 0) {
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
+                if (pvalid[t]) {
+                    float* d = p.dbg + ((size_t)pidx[t] * nw + wave) * kDbgFields;
+                    d[0] = mask[t]; d[1] = dbg_u[t]; d[2] = dbg_v[t]; d[3] = dbg_z[t]; d[4] = hit[t]; d[5] = vis[t];
+                    d[6] = dbg_mu0[t]; d[7] = dbg_mu1[t]; d[8] = dbg_s0[t]; d[9] = dbg_s1[t]; d[10] = dbg_aw[t];
+                    d[11] = dbg_nu[t]; d[12] = sn[t]; d[13] = dbg_visp[t]; d[14] = vis2[t]; d[15] = z[t];
+                }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// ray kernel: one wave per ray.  + positional encoding, 4-head self attention over the dn samples,
+// LayerNorm, sigma head, alpha compositing, ray mask, depth.       ibrnet.py:52-102,356-360;
+// renderer.py:163-165,195-202; render_ops.py:72-80
+// -------------------------------------------------------------------------------------------------
+struct RayParams {
+    const float* point_rec;   // [rn][dn][kPointRec]
+    const float* depth;       // [rn][dn]
+    const float* pos_enc;     // [dn][16]
+    const float* weights;     // packed pass weights (ray part at kPackedPointFloats)
+    float* hit_prob;          // [rn][dn]
+    float* pixel;             // [rn][3]
+    float* render_depth;      // [rn] or null
+    unsigned char* ray_mask;  // [rn] or null
+    float* density;           // [rn][dn] or null (debug / tests)
+    int rn, dn, mask_view_num, mask_point_num;
+};
+
+constexpr int kRayWaves = 4;
+inline size_t ray_smem_bytes(int dn) { return sizeof(float) * kRayWaves * ((size_t)dn * 32 + (size_t)dn * 2); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+    NR_PRAGMA_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
+    NR_DYNAMIC_SMEM(float, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
+    const int dn = p.dn;
+    float* ks = smem + (size_t)wave * (dn * 34);
+    float* vs = ks + dn * 16;
+    float* tr = vs + dn * 16;        // [dn] transmittance factors
+    float* al = tr + dn;             // [dn] alpha
+    const float* __restrict__ RW = p.weights + kPackedPointFloats;
+    const int nch = (dn + 63) >> 6;
+    const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
+
+    for (int it = blockIdx.x; it < nray_iter; it += gridDim.x) {
+        int ray = it * kRayWaves + wave;
+        const bool rvalid = ray < p.rn;
+        ray = rvalid ? ray : p.rn - 1;
+        const float* rec = p.point_rec + (size_t)ray * dn * kPointRec;
+        // ---- phase 1: K, V of every sample -> LDS
+        for (int ch = 0; ch < nch; ++ch) {
+            const int i = ch * 64 + lane;
+            if (i < dn) {
+                float G[16];
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) G[k] = rec[(size_t)i * kPointRec + k] + p.pos_enc[i * 16 + k];
+                NR_PRAGMA_UNROLL
+                for (int o = 0; o < 16; ++o) {
+                    float kk = 0.0f, vv = 0.0f;
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 16; ++k) { kk += RW[RW_WK + o * 16 + k] * G[k]; vv += RW[RW_WV + o * 16 + k] * G[k]; }
+                    ks[i * 16 + o] = kk; vs[i * 16 + o] = vv;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: attention row, LayerNorm, sigma, alpha
+        for (int ch = 0; ch < nch; ++ch) {
+            const int i = ch * 64 + lane;
+            if (i < dn) {
+                float G[16], q[16], o[16];
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) G[k] = rec[(size_t)i * kPointRec + k] + p.pos_enc[i * 16 + k];
+                const float nvalid = rec[(size_t)i * kPointRec + 19];
+                NR_PRAGMA_UNROLL
+                for (int oo = 0; oo < 16; ++oo) {
+                    float s = 0.0f;
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 16; ++k) s += RW[RW_WQ + oo * 16 + k] * G[k];
+                    q[oo] = s / 2.0f;       // temperature = sqrt(d_k) = 2
+                }
+                const bool masked = !(nvalid > 1.0f);   // query-row mask: quirk A.9.3
+                NR_PRAGMA_UNROLL
+                for (int hh = 0; hh < 4; ++hh) {
+                    float mx = -INFINITY;
+                    for (int j = 0; j < dn; ++j) {
+                        const float4 kj = ld4(ks + j * 16 + hh * 4);
+                        float s = ((q[hh * 4] * kj.x + q[hh * 4 + 1] * kj.y) + q[hh * 4 + 2] * kj.z) + q[hh * 4 + 3] * kj.w;
+                        s = masked ? -1e9f : s;
+                        mx = fmaxf(mx, s);
+                    }
+                    float den = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                    for (int j = 0; j < dn; ++j) {
+                        const float4 kj = ld4(ks + j * 16 + hh * 4);
+                        float s = ((q[hh * 4] * kj.x + q[hh * 4 + 1] * kj.y) + q[hh * 4 + 2] * kj.z) + q[hh * 4 + 3] * kj.w;
+                        s = masked ? -1e9f : s;
+                        const float e_ = expf(s - mx);
+                        const float4 vj = ld4(vs + j * 16 + hh * 4);
+                        den += e_; a0 += e_ * vj.x; a1 += e_ * vj.y; a2 += e_ * vj.z; a3 += e_ * vj.w;
+                    }
+                    o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
+                }
+                float y[16], mean = 0.0f;
+                NR_PRAGMA_UNROLL
+                for (int oo = 0; oo < 16; ++oo) {
+                    float s = 0.0f;
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 16; ++k) s += RW[RW_FC + oo * 16 + k] * o[k];
+                    y[oo] = s + G[oo];
+                    mean += y[oo];
+                }
+                mean /= 16.0f;
+                float var = 0.0f;
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) { const float d_ = y[k] - mean; var += d_ * d_; }
+                var /= 16.0f;
+                const float rstd = 1.0f / sqrtf(var + 1e-6f);
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) y[k] = (y[k] - mean) * rstd * RW[RW_LNW + k] + RW[RW_LNB + k];
+                float sg = RW[RW_OG2B];
+                NR_PRAGMA_UNROLL
+                for (int oo = 0; oo < 16; ++oo) {
+                    float s = RW[RW_OG0B + oo];
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 16; ++k) s += RW[RW_OG0W + oo * 16 + k] * y[k];
+                    sg += RW[RW_OG2W + oo] * elu(s);
+                }
+                sg = fmaxf(sg, 0.0f);
+                if (nvalid < 1.0f) sg = 0.0f;
+                if (p.density && rvalid) p.density[(size_t)ray * dn + i] = sg;
+                const float alpha = 1.0f - expf(-fmaxf(sg, 0.0f));
+                al[i] = alpha;
+                tr[i] = (1.0f - alpha) + 1e-10f;
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: compositing (sequential transmittance product per lane: bit-exact cumprod order)
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f;
+        int cnt = 0;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int i = ch * 64 + lane;
+            const bool ok = i < dn;
+            float T = 1.0f;
+            for (int j = 0; j < dn; ++j) { const float tj = tr[j]; T = (j < i) ? T * tj : T; }
+            const float hp = ok ? al[ok ? i : 0] * T : 0.0f;
+            const float* rc = rec + (size_t)(ok ? i : 0) * kPointRec;
+            if (ok && rvalid) p.hit_prob[(size_t)ray * dn + i] = hp;
+            cr += hp * rc[16]; cg += hp * rc[17]; cb += hp * rc[18];
+            cd += hp * p.depth[(size_t)ray * dn + (ok ? i : 0)];
+            const unsigned long long b = __ballot(ok && rc[19] > (float)p.mask_view_num);
+            cnt += __builtin_popcountll(b);
+        }
+        cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); cd = wave_sum(cd);
+        if (lane == 0 && rvalid) {
+            p.pixel[(size_t)ray * 3] = cr; p.pixel[(size_t)ray * 3 + 1] = cg; p.pixel[(size_t)ray * 3 + 2] = cb;
+            if (p.render_depth) p.render_depth[ray] = cd;
+            if (p.ray_mask) p.ray_mask[ray] = cnt > p.mask_point_num ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// fine kernel: inverse-CDF resampling in normalised inverse depth, then ascending sort.
+//   render_ops.py:172-229, renderer.py:210-213.  One wave per ray.
+// -------------------------------------------------------------------------------------------------
+struct FineParams {
+    const float* que_const;
+    const float* depth;      // [rn][dn]
+    const float* hit_prob;   // [rn][dn]
+    const float* u;          // [rn][fdn] or null -> stratified (k + 0.5)/fdn
+    float* out;              // [rn][nout], nout = fdn (+ dn when use_all)
+    int rn, dn, fdn, use_all;
+};
+
+constexpr int kMaxSamples = 128;   // dn, fdn <= 128
+constexpr int kMaxSort = 256;
+
+__global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
+    __shared__ float s_s[kRayWaves][kMaxSamples];
+    __shared__ float s_pdf[kRayWaves][kMaxSamples];
+    __shared__ float s_cdf[kRayWaves][kMaxSamples + 1];
+    __shared__ float s_edge[kRayWaves][kMaxSamples + 1];
+    __shared__ float s_sort[kRayWaves][kMaxSort];
+    const int lane = threadIdx.x & 63;
+    const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
+    const int dn = p.dn, fdn = p.fdn;
+    const int nout = fdn + (p.use_all ? dn : 0);
+    int npad = 1;
+    while (npad < nout) npad <<= 1;
+    const float nearp = p.que_const[24], farp = p.que_const[25];
+    float* ss = s_s[wave]; float* pdf = s_pdf[wave]; float* cdf = s_cdf[wave]; float* edge = s_edge[wave]; float* srt = s_sort[wave];
+    const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
+    for (int it = blockIdx.x; it < nray_iter; it += gridDim.x) {
+        int ray = it * kRayWaves + wave;
+        const bool rvalid = ray < p.rn;
+        ray = rvalid ? ray : p.rn - 1;
+        const float* drow = p.depth + (size_t)ray * dn;
+        const float* hrow = p.hit_prob + (size_t)ray * dn;
+        float tot = 0.0f;
+        for (int i = lane; i < ((dn + 63) & ~63); i += 64) {
+            float hp = 0.0f;
+            if (i < dn) { ss[i] = norm_inv_depth(drow[i], nearp, farp); hp = hrow[i] + 1e-5f; pdf[i] = hp; }
+            tot += hp;
+        }
+        tot = wave_sum(tot);
+        __syncthreads();
+        for (int i = lane; i < dn; i += 64) pdf[i] = pdf[i] / tot;
+        __syncthreads();
+        for (int i = lane; i <= dn; i += 64) {
+            // sequential prefix sum (bit-exact cumsum order)
+            float cdfv = 0.0f;
+            for (int j = 0; j < dn; ++j) { const float pj = pdf[j]; cdfv = (j < i) ? cdfv + pj : cdfv; }
+            cdf[i] = cdfv;
+            edge[i] = (i == 0) ? ss[0] : (i == dn ? ss[dn - 1] : __fdiv_rn(__fadd_rn(ss[i], ss[i - 1]), 2.0f));
+        }
+        __syncthreads();
+        const float interval = (float)(1.0 / (double)fdn);
+        for (int k = lane; k < npad; k += 64) {
+            float val = INFINITY;
+            if (k < fdn) {
+                const float uu = p.u ? p.u[(size_t)ray * fdn + k] : __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)k, interval));
+                int idx = 0;
+                for (int m = 0; m <= dn; ++m) idx += (cdf[m] <= uu) ? 1 : 0;     // searchsorted(right=True)
+                const int below = idx - 1 > 0 ? idx - 1 : 0;
+                const int above = idx < dn ? idx : dn;
+                float denom = __fsub_rn(cdf[above], cdf[below]);
+                if (denom < 1e-5f) denom = 1.0f;
+                const float tt = __fdiv_rn(__fsub_rn(uu, cdf[below]), denom);
+                float sf = __fadd_rn(edge[below], __fmul_rn(tt, __fsub_rn(edge[above], edge[below])));
+                sf = __fadd_rn(__fmul_rn(sf, __fsub_rn(farp, nearp)), nearp);
+                val = __fdiv_rn(-1.0f, sf);
+            } else if (k < nout) {
+                val = drow[k - fdn];
+            }
+            srt[k] = val;
+        }
+        __syncthreads();
+        // bitonic sort (ascending) of npad values in LDS
+        for (int kk = 2; kk <= npad; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < npad; i += 64) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const float a = srt[i], b = srt[ixj];
+                        const bool up = (i & kk) == 0;
+                        if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        if (rvalid)
+            for (int k = lane; k < nout; k += 64) p.out[(size_t)ray * nout + k] = srt[k];
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
+// render_ops.py:54-70).  One thread per (batch, point); used for pixel_colors_gt and the auxiliary
+// (non per-sample) gathers.  points [b][n][2] pixel (x,y) in units of the (w_full, h_full) image.
+// -------------------------------------------------------------------------------------------------
+__global__ void interpolate_kernel(const float* __restrict__ feats, const float* __restrict__ points,
+                                   const float* __restrict__ mask, int b, int n, int c, int fh, int fw,
+                                   int h_full, int w_full, int align, float* __restrict__ out) {
+    const long long total = (long long)b * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int bi = (int)(i / n);
+        const float u = points[2 * i], v = points[2 * i + 1];
+        const float ix = texel_coord(u, (float)w_full, (float)fw, align != 0);
+        const float iy = texel_coord(v, (float)h_full, (float)fh, align != 0);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const int x1 = x0 + 1 < fw ? x0 + 1 : fw - 1, yb = y0 + 1 < fh ? y0 + 1 : fh - 1;
+        const float wx1 = __fsub_rn(ix, x0f), wy1 = __fsub_rn(iy, y0f);
+        const float wx0 = __fsub_rn(__fadd_rn(x0f, 1.0f), ix), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), iy);
+        Taps t;
+        t.o00 = y0 * fw + x0; t.o10 = y0 * fw + x1; t.o01 = yb * fw + x0; t.o11 = yb * fw + x1;
+        t.w00 = __fmul_rn(wx0, wy0); t.w10 = __fmul_rn(wx1, wy0); t.w01 = __fmul_rn(wx0, wy1); t.w11 = __fmul_rn(wx1, wy1);
+        if (x0 + 1 > fw - 1) { t.w10 = 0.0f; t.w11 = 0.0f; }
+        if (y0 + 1 > fh - 1) { t.w01 = 0.0f; t.w11 = 0.0f; }
+        const float m = mask ? mask[i] : 1.0f;
+        const float* f = feats + (size_t)bi * c * fh * fw;
+        for (int ch = 0; ch < c; ++ch) {
+            const float* pl = f + (size_t)ch * fh * fw;
+            out[i * c + ch] = blend4(pl[t.o00], pl[t.o10], pl[t.o01], pl[t.o11], t) * m;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// MFMA layout self-test: D = A * B with A, B both asymmetric; host checks against a plain triple loop.
+// -------------------------------------------------------------------------------------------------
+__global__ void mfma_selftest_kernel(const float* __restrict__ A /*16x4*/, const float* __restrict__ B /*4x16*/,
+                                     float* __restrict__ D /*16x16*/) {
+    const int lane = threadIdx.x & 63;
+    v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
+    acc = nr_mfma16(A[(lane & 15) * 4 + (lane >> 4)], B[(lane >> 4) * 16 + (lane & 15)], acc);
+    for (int r = 0; r < 4; ++r) D[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+}
+
+}  // namespace nr

@@ -1,0 +1,113 @@
+// Packed-weight layout of one render pass, shared by the host packer (nr_pack.cpp) and the kernels.
+//
+// Every MLP layer of the per-ray path (reference: network/dist_decoder.py:64-97,
+// network/aggregate_net.py:27-31, network/ibrnet.py:249-293) is stored as MFMA "A" fragments for
+// v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand (M = output features) and the sample points
+// as the N dimension, so that a layer's D registers are directly the next layer's B operands:
+//
+//   lane l = 16*g + c   (c = point column 0..15, g = lane group 0..3)
+//   an activation vector with T tiles of 16 features lives in registers x[4*t + r]:
+//        "D layout":      x[4t+r] (lane c,g)  = feature 16t + 4g + r of point c
+//   a layer consumes a list of K-steps; K-step s takes one register per tile as the B operand and the
+//   lane group g contributes input feature in_map(s, g).  K-steps are stored in quads ("KQ", one
+//   float4 per lane = 4 K-steps) plus optional single K-steps ("K1", one float per lane) used for the
+//   few scalar inputs (hit/vis, direction difference, rgb part).
+//
+//   w_quads [(mo*KQ + kq)*64 + lane]  float4 : component j = W[out_map(mo, c)][in_map(4kq+j, g)]
+//   w_single[(mo*K1 + k1)*64 + lane]  float  :               W[out_map(mo, c)][in1_map(k1, g)]
+//   bias    [mo*4 + g]                float4 : component r = bias[out_map(mo, 4g + r)]
+//
+// Rows/columns mapped to -1 are stored as 0, so padded features stay exactly 0 through ELU/ReLU.
+#pragma once
+
+namespace nr {
+
+enum LayerId {
+    // dist decoder heads (mean, var, aw, vis): 32 -> 32 -> 32                    dist_decoder.py:64-97
+    L_DM1, L_DM2, L_DV1, L_DV2, L_DA1, L_DA2, L_DS1, L_DS2,
+    L_DFIN_MS,   // [mu0 mu1 s0 s1] pre-activations from h2(mean) ++ h2(var), replicated in all lane groups
+    L_DFIN_A,    // [aw] from h2(aw)                      (decoder without vis head)
+    L_DFIN_AV,   // [aw vis] from h2(aw) ++ h2(vis)       (decoder with vis head)
+    L_PE1, L_PE2,            // prob_embed 34 -> 32 -> 32                           aggregate_net.py:27-31
+    L_RD1, L_RD2,            // ray_dir_fc 4 -> 16 -> 35                            ibrnet.py:249-252
+    L_NF1, L_NF2,            // neuray_fc 32 -> 8 -> 1                              ibrnet.py:287-291
+    L_BG,                    // base_fc.0 columns [mean0 var0 mean1 var1] (per point) ibrnet.py:254
+    L_BV,                    // base_fc.0 columns [rgb_feat neuray_feat]  (per view)
+    L_B2,                    // base_fc.2 64 -> 32
+    L_VF1, L_VF2,            // vis_fc 32 -> 32 -> 33                               ibrnet.py:259-263
+    L_V21, L_V22,            // vis_fc2 32 -> 32 -> 1                               ibrnet.py:265-269
+    L_RF1, L_RF2, L_RF3,     // rgb_fc 37 -> 16 -> 8 -> 1                           ibrnet.py:281-285
+    L_GF1, L_GF2,            // geometry_fc 65 -> 64 -> 16                          ibrnet.py:271-274
+    L_COUNT
+};
+
+struct LayerShape { int mt_out, kq, k1; };
+
+constexpr LayerShape kShape[L_COUNT] = {
+    {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0},
+    {1, 4, 0}, {1, 2, 0}, {1, 4, 0},
+    {2, 2, 1}, {2, 2, 0},
+    {1, 0, 1}, {3, 1, 0},
+    {1, 2, 0}, {1, 1, 0},
+    {4, 9, 0}, {4, 4, 1}, {2, 4, 0},
+    {2, 2, 0}, {3, 2, 0},
+    {2, 2, 0}, {1, 2, 0},
+    {1, 2, 2}, {1, 1, 0}, {1, 1, 0},
+    {4, 4, 1}, {1, 4, 0},
+};
+
+// sizes in floats
+constexpr int quads_floats(int l) { return kShape[l].mt_out * kShape[l].kq * 64 * 4; }
+constexpr int single_floats(int l) { return kShape[l].mt_out * kShape[l].k1 * 64; }
+constexpr int bias_floats(int l) { return kShape[l].mt_out * 16; }
+constexpr int layer_floats(int l) { return quads_floats(l) + single_floats(l) + bias_floats(l); }
+
+constexpr int layer_offset(int l) {   // float offset of layer l inside the packed pass buffer
+    int off = 0;
+    for (int i = 0; i < l; ++i) off += layer_floats(i);
+    return off;
+}
+constexpr int quads_offset(int l) { return layer_offset(l); }
+constexpr int single_offset(int l) { return layer_offset(l) + quads_floats(l); }
+constexpr int bias_offset(int l) { return layer_offset(l) + quads_floats(l) + single_floats(l); }
+
+constexpr int kPackedPointFloats = layer_offset(L_COUNT);
+
+// ---- weights of the ray kernel (attention + sigma head), plain row-major ------------------------
+//   reference: network/ibrnet.py:52-102 (MultiHeadAttention 4 heads x d_k=4, no bias), :276-279
+constexpr int RW_WQ = 0, RW_WK = 256, RW_WV = 512, RW_FC = 768, RW_LNW = 1024, RW_LNB = 1040,
+              RW_OG0W = 1056, RW_OG0B = 1312, RW_OG2W = 1328, RW_OG2B = 1344, kPackedRayFloats = 1348;
+
+constexpr int kPackedPassFloats = kPackedPointFloats + kPackedRayFloats;
+
+// ---- per-point record written by the point kernel and read by the ray kernel -------------------
+//   [0..15] geometry feature (geometry_fc output, before the positional encoding), [16..18] blended rgb,
+//   [19] number of valid views
+constexpr int kPointRec = 20;
+
+// ---- per-view constants produced by the view-setup kernel ---------------------------------------
+//   [0..11] H = K [R|t] (row major 3x4), [12..14] camera centre -R^T t, [15] -1/near, [16] -1/far
+constexpr int kViewConst = 20;
+// query constants: [0..8] K^-1, [9..20] pose 3x4, [21..23] centre, [24] -1/near, [25] -1/far
+constexpr int kQueryConst = 28;
+
+// tensor order of the `tensors` array of neuray_pack_pass_weights (host pointers, fp32, contiguous)
+enum PassTensor {
+    T_MEAN0_W, T_MEAN0_B, T_MEAN2_W, T_MEAN2_B, T_MEAN4_W, T_MEAN4_B,
+    T_VAR0_W, T_VAR0_B, T_VAR2_W, T_VAR2_B, T_VAR4_W, T_VAR4_B,
+    T_AW0_W, T_AW0_B, T_AW2_W, T_AW2_B, T_AW4_W, T_AW4_B,
+    T_VIS0_W, T_VIS0_B, T_VIS2_W, T_VIS2_B, T_VIS4_W, T_VIS4_B,     // may be NULL (no vis head)
+    T_PE0_W, T_PE0_B, T_PE2_W, T_PE2_B,
+    T_RD0_W, T_RD0_B, T_RD2_W, T_RD2_B,
+    T_BASE0_W, T_BASE0_B, T_BASE2_W, T_BASE2_B,
+    T_VF0_W, T_VF0_B, T_VF2_W, T_VF2_B,
+    T_V20_W, T_V20_B, T_V22_W, T_V22_B,
+    T_GF0_W, T_GF0_B, T_GF2_W, T_GF2_B,
+    T_WQ, T_WK, T_WV, T_FC, T_LN_W, T_LN_B,
+    T_OG0_W, T_OG0_B, T_OG2_W, T_OG2_B,
+    T_RF0_W, T_RF0_B, T_RF2_W, T_RF2_B, T_RF4_W, T_RF4_B,
+    T_NF0_W, T_NF0_B, T_NF2_W, T_NF2_B,
+    T_COUNT
+};
+
+}  // namespace nr

@@ -1,0 +1,202 @@
+// Host packer: reference state_dict tensors -> per-lane MFMA A fragments.  Layout: nr_layout.h.
+#include "nr_pack.h"
+
+#include <cstring>
+
+namespace nr {
+
+void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bias, const LayerMaps& maps) {
+    const LayerShape s = kShape[layer];
+    float* q = dst + quads_offset(layer);
+    float* s1 = dst + single_offset(layer);
+    float* b = dst + bias_offset(layer);
+    for (int mo = 0; mo < s.mt_out; ++mo) {
+        for (int kq = 0; kq < s.kq; ++kq)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int o = maps.out_map[mo * 16 + (lane & 15)];
+                    const int i = maps.in_map[(4 * kq + j) * 4 + (lane >> 4)];
+                    q[((mo * s.kq + kq) * 64 + lane) * 4 + j] = (o >= 0 && i >= 0) ? W[o * ldw + i] : 0.0f;
+                }
+        for (int k1 = 0; k1 < s.k1; ++k1)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = maps.out_map[mo * 16 + (lane & 15)];
+                const int i = maps.in1_map[k1 * 4 + (lane >> 4)];
+                s1[(mo * s.k1 + k1) * 64 + lane] = (o >= 0 && i >= 0) ? W[o * ldw + i] : 0.0f;
+            }
+        for (int m = 0; m < 16; ++m) {
+            const int o = maps.out_map[mo * 16 + m];
+            b[mo * 16 + m] = (o >= 0 && bias) ? bias[o] : 0.0f;
+        }
+    }
+}
+
+namespace {
+
+std::vector<int> out_natural(int mt_out, int n_real) {
+    std::vector<int> m(mt_out * 16);
+    for (int i = 0; i < mt_out * 16; ++i) m[i] = i < n_real ? i : -1;
+    return m;
+}
+// one tile whose rows 4g+r carry weight row r (r < n_real) in every lane group g
+std::vector<int> out_replicated(int n_real) {
+    std::vector<int> m(16);
+    for (int g = 0; g < 4; ++g)
+        for (int r = 0; r < 4; ++r) m[4 * g + r] = r < n_real ? r : -1;
+    return m;
+}
+// 32 gathered channels: k-step s (0..7), lane group g <-> channel 8g + s
+void in_gathered32(std::vector<int>& in, int col0) {
+    for (int s = 0; s < 8; ++s)
+        for (int g = 0; g < 4; ++g) in.push_back(col0 + 8 * g + s);
+}
+// D layout: k-step 4t + r, lane group g <-> feature 16t + 4g + r
+void in_dlayout(std::vector<int>& in, int col0, int nfeat, int ntiles) {
+    for (int t = 0; t < ntiles; ++t)
+        for (int r = 0; r < 4; ++r)
+            for (int g = 0; g < 4; ++g) {
+                const int f = 16 * t + 4 * g + r;
+                in.push_back(f < nfeat ? col0 + f : -1);
+            }
+}
+
+void pack_mlp32(float* dst, int l1, int l2, const float* w0, const float* b0, const float* w2, const float* b2) {
+    LayerMaps m1; m1.out_map = out_natural(2, 32); in_gathered32(m1.in_map, 0);
+    pack_layer(dst, l1, w0, 32, b0, m1);
+    LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
+    pack_layer(dst, l2, w2, 32, b2, m2);
+}
+
+}  // namespace
+
+int pack_pass_weights(const float* const* t, float* dst) {
+    for (int i = 0; i < T_COUNT; ++i) {
+        const bool optional = (i >= T_VIS0_W && i <= T_VIS4_B);
+        if (!t[i] && !optional) return 1 + i;
+    }
+    const bool has_vis = t[T_VIS0_W] != nullptr;
+    if (has_vis)
+        for (int i = T_VIS0_W; i <= T_VIS4_B; ++i) if (!t[i]) return 1 + i;
+    std::memset(dst, 0, sizeof(float) * kPackedPassFloats);
+
+    // ---- dist decoder -----------------------------------------------------------------------
+    pack_mlp32(dst, L_DM1, L_DM2, t[T_MEAN0_W], t[T_MEAN0_B], t[T_MEAN2_W], t[T_MEAN2_B]);
+    pack_mlp32(dst, L_DV1, L_DV2, t[T_VAR0_W], t[T_VAR0_B], t[T_VAR2_W], t[T_VAR2_B]);
+    pack_mlp32(dst, L_DA1, L_DA2, t[T_AW0_W], t[T_AW0_B], t[T_AW2_W], t[T_AW2_B]);
+    if (has_vis) pack_mlp32(dst, L_DS1, L_DS2, t[T_VIS0_W], t[T_VIS0_B], t[T_VIS2_W], t[T_VIS2_B]);
+    {   // [mu0 mu1 s0 s1] = blockdiag(mean.4, var.4) applied to h2(mean) ++ h2(var)
+        float W[4 * 64] = {0}, B[4];
+        for (int r = 0; r < 2; ++r)
+            for (int k = 0; k < 32; ++k) {
+                W[r * 64 + k] = t[T_MEAN4_W][r * 32 + k];
+                W[(2 + r) * 64 + 32 + k] = t[T_VAR4_W][r * 32 + k];
+            }
+        B[0] = t[T_MEAN4_B][0]; B[1] = t[T_MEAN4_B][1]; B[2] = t[T_VAR4_B][0]; B[3] = t[T_VAR4_B][1];
+        LayerMaps m; m.out_map = out_replicated(4);
+        in_dlayout(m.in_map, 0, 32, 2); in_dlayout(m.in_map, 32, 32, 2);
+        pack_layer(dst, L_DFIN_MS, W, 64, B, m);
+    }
+    {
+        LayerMaps m; m.out_map = out_replicated(1); in_dlayout(m.in_map, 0, 32, 2);
+        pack_layer(dst, L_DFIN_A, t[T_AW4_W], 32, t[T_AW4_B], m);
+    }
+    if (has_vis) {
+        float W[2 * 64] = {0}, B[2];
+        for (int k = 0; k < 32; ++k) { W[k] = t[T_AW4_W][k]; W[64 + 32 + k] = t[T_VIS4_W][k]; }
+        B[0] = t[T_AW4_B][0]; B[1] = t[T_VIS4_B][0];
+        LayerMaps m; m.out_map = out_replicated(2);
+        in_dlayout(m.in_map, 0, 32, 2); in_dlayout(m.in_map, 32, 32, 2);
+        pack_layer(dst, L_DFIN_AV, W, 64, B, m);
+    }
+    // ---- prob_embed: input [ray_feats(32), hit, vis] ---------------------------------------------
+    {
+        LayerMaps m; m.out_map = out_natural(2, 32); in_gathered32(m.in_map, 0);
+        for (int g = 0; g < 4; ++g) m.in1_map.push_back(g < 2 ? 32 + g : -1);
+        pack_layer(dst, L_PE1, t[T_PE0_W], 34, t[T_PE0_B], m);
+        LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
+        pack_layer(dst, L_PE2, t[T_PE2_W], 32, t[T_PE2_B], m2);
+    }
+    // ---- ray_dir_fc: 4 -> 16 -> 35; output rows re-ordered to [img channels in gathered order | rgb]
+    {
+        LayerMaps m; m.out_map = out_natural(1, 16);
+        for (int g = 0; g < 4; ++g) m.in1_map.push_back(g);
+        pack_layer(dst, L_RD1, t[T_RD0_W], 4, t[T_RD0_B], m);
+        LayerMaps m2; m2.out_map.assign(48, -1);
+        for (int tt = 0; tt < 2; ++tt)
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 4; ++r) m2.out_map[tt * 16 + 4 * g + r] = 3 + (8 * g + 4 * tt + r);
+        for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 3; ++r) m2.out_map[32 + 4 * g + r] = r;
+        in_dlayout(m2.in_map, 0, 16, 1);
+        pack_layer(dst, L_RD2, t[T_RD2_W], 16, t[T_RD2_B], m2);
+    }
+    // ---- neuray_fc 32 -> 8 -> 1 ---------------------------------------------------------------------
+    {
+        LayerMaps m; m.out_map = out_natural(1, 8); in_dlayout(m.in_map, 0, 32, 2);
+        pack_layer(dst, L_NF1, t[T_NF0_W], 32, t[T_NF0_B], m);
+        LayerMaps m2; m2.out_map = out_replicated(1); in_dlayout(m2.in_map, 0, 8, 1);
+        pack_layer(dst, L_NF2, t[T_NF2_W], 8, t[T_NF2_B], m2);
+    }
+    // ---- base_fc.0 (64 x 207), columns [mean0 var0 mean1 var1 | rgb_feat neuray_feat]   ibrnet.py:340-342
+    {
+        LayerMaps m; m.out_map = out_natural(4, 64);
+        for (int j = 0; j < 4; ++j) in_gathered32(m.in_map, 35 * j + 3);
+        for (int j = 0; j < 4; ++j)                       // quad 8: k-step j = rgb part of statistic j
+            for (int g = 0; g < 4; ++g) m.in_map.push_back(g < 3 ? 35 * j + g : -1);
+        pack_layer(dst, L_BG, t[T_BASE0_W], 207, t[T_BASE0_B], m);
+        LayerMaps v; v.out_map = out_natural(4, 64);
+        in_gathered32(v.in_map, 140 + 3);
+        in_dlayout(v.in_map, 175, 32, 2);
+        for (int g = 0; g < 4; ++g) v.in1_map.push_back(g < 3 ? 140 + g : -1);
+        pack_layer(dst, L_BV, t[T_BASE0_W], 207, nullptr, v);
+        LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 64, 4);
+        pack_layer(dst, L_B2, t[T_BASE2_W], 64, t[T_BASE2_B], m2);
+    }
+    // ---- vis_fc 32 -> 32 -> 33 (row 32 = visibility logit, replicated) -----------------------------
+    {
+        LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 32, 2);
+        pack_layer(dst, L_VF1, t[T_VF0_W], 32, t[T_VF0_B], m);
+        LayerMaps m2; m2.out_map.assign(48, -1);
+        for (int i = 0; i < 32; ++i) m2.out_map[i] = i;
+        for (int g = 0; g < 4; ++g) m2.out_map[32 + 4 * g] = 32;
+        in_dlayout(m2.in_map, 0, 32, 2);
+        pack_layer(dst, L_VF2, t[T_VF2_W], 32, t[T_VF2_B], m2);
+    }
+    // ---- vis_fc2 32 -> 32 -> 1 -----------------------------------------------------------------------
+    {
+        LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 32, 2);
+        pack_layer(dst, L_V21, t[T_V20_W], 32, t[T_V20_B], m);
+        LayerMaps m2; m2.out_map = out_replicated(1); in_dlayout(m2.in_map, 0, 32, 2);
+        pack_layer(dst, L_V22, t[T_V22_W], 32, t[T_V22_B], m2);
+    }
+    // ---- rgb_fc [x(32), vis(1), ray_diff(4)] -> 16 -> 8 -> 1 -----------------------------------------
+    {
+        LayerMaps m; m.out_map = out_natural(1, 16); in_dlayout(m.in_map, 0, 32, 2);
+        for (int g = 0; g < 4; ++g) m.in1_map.push_back(32 + g);          // vis, d0, d1, d2
+        for (int g = 0; g < 4; ++g) m.in1_map.push_back(g == 0 ? 36 : -1);  // d3 (dot product)
+        pack_layer(dst, L_RF1, t[T_RF0_W], 37, t[T_RF0_B], m);
+        LayerMaps m2; m2.out_map = out_natural(1, 8); in_dlayout(m2.in_map, 0, 16, 1);
+        pack_layer(dst, L_RF2, t[T_RF2_W], 16, t[T_RF2_B], m2);
+        LayerMaps m3; m3.out_map = out_replicated(1); in_dlayout(m3.in_map, 0, 8, 1);
+        pack_layer(dst, L_RF3, t[T_RF4_W], 8, t[T_RF4_B], m3);
+    }
+    // ---- geometry_fc [mean(32), var(32), mean weight(1)] -> 64 -> 16 --------------------------------
+    {
+        LayerMaps m; m.out_map = out_natural(4, 64);
+        in_dlayout(m.in_map, 0, 32, 2); in_dlayout(m.in_map, 32, 32, 2);
+        for (int g = 0; g < 4; ++g) m.in1_map.push_back(g == 0 ? 64 : -1);
+        pack_layer(dst, L_GF1, t[T_GF0_W], 65, t[T_GF0_B], m);
+        LayerMaps m2; m2.out_map = out_natural(1, 16); in_dlayout(m2.in_map, 0, 64, 4);
+        pack_layer(dst, L_GF2, t[T_GF2_W], 64, t[T_GF2_B], m2);
+    }
+    // ---- ray kernel weights (row major copies) ---------------------------------------------------------
+    float* r = dst + kPackedPointFloats;
+    std::memcpy(r + RW_WQ, t[T_WQ], 256 * 4); std::memcpy(r + RW_WK, t[T_WK], 256 * 4);
+    std::memcpy(r + RW_WV, t[T_WV], 256 * 4); std::memcpy(r + RW_FC, t[T_FC], 256 * 4);
+    std::memcpy(r + RW_LNW, t[T_LN_W], 16 * 4); std::memcpy(r + RW_LNB, t[T_LN_B], 16 * 4);
+    std::memcpy(r + RW_OG0W, t[T_OG0_W], 256 * 4); std::memcpy(r + RW_OG0B, t[T_OG0_B], 16 * 4);
+    std::memcpy(r + RW_OG2W, t[T_OG2_W], 16 * 4); std::memcpy(r + RW_OG2B, t[T_OG2_B], 4);
+    return 0;
+}
+
+}  // namespace nr

@@ -1,0 +1,22 @@
+// Host-side packing of the reference state_dict tensors into MFMA A-fragments (see nr_layout.h).
+#pragma once
+#include <cstddef>
+#include <vector>
+#include "nr_layout.h"
+
+namespace nr {
+
+struct LayerMaps {
+    std::vector<int> out_map;   // [mt_out*16]  MFMA row m of tile mo -> weight row (or -1)
+    std::vector<int> in_map;    // [kq*4][4]    (k-step, lane group) -> weight column (or -1)
+    std::vector<int> in1_map;   // [k1][4]
+};
+
+// Writes layer `layer` (quads, singles, bias) at its offset inside `dst` (kPackedPassFloats floats).
+void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bias, const LayerMaps& maps);
+
+// tensors: array of T_COUNT host pointers in PassTensor order (vis-head entries may be null).
+// Returns 0 on success, non-zero if a required tensor is missing.
+int pack_pass_weights(const float* const* tensors, float* dst);
+
+}  // namespace nr

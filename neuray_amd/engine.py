@@ -1,0 +1,240 @@
+"""RenderEngine: drives the HIP kernels of the per-ray render path from torch tensors.
+
+This is host plumbing (device buffers, streams, argument marshalling) around the C ABI of
+include/neuray_hip.h; all arithmetic of the hot path happens in libneuray_hip.so.  One engine per
+process / device.  The reference functions each step replaces are cited in include/neuray_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DIST_HEADS = ('mean_decoder', 'var_decoder', 'aw_decoder', 'vis_decoder')
+
+
+def pass_tensor_keys(dist_prefix, agg_prefix):
+    """state_dict keys of one pass in the order of enum nr::PassTensor (csrc/nr_layout.h)."""
+    keys = []
+    for head in _DIST_HEADS:
+        for i in (0, 2, 4):
+            keys += ['%s%s.%d.weight' % (dist_prefix, head, i), '%s%s.%d.bias' % (dist_prefix, head, i)]
+    for i in (0, 2):
+        keys += ['%sprob_embed.%d.weight' % (agg_prefix, i), '%sprob_embed.%d.bias' % (agg_prefix, i)]
+    impl = agg_prefix + 'agg_impl.'
+    for name in ('ray_dir_fc', 'base_fc', 'vis_fc', 'vis_fc2', 'geometry_fc'):
+        for i in (0, 2):
+            keys += ['%s%s.%d.weight' % (impl, name, i), '%s%s.%d.bias' % (impl, name, i)]
+    keys += [impl + 'ray_attention.w_qs.weight', impl + 'ray_attention.w_ks.weight', impl + 'ray_attention.w_vs.weight',
+             impl + 'ray_attention.fc.weight', impl + 'ray_attention.layer_norm.weight', impl + 'ray_attention.layer_norm.bias']
+    for i in (0, 2):
+        keys += ['%sout_geometry_fc.%d.weight' % (impl, i), '%sout_geometry_fc.%d.bias' % (impl, i)]
+    for i in (0, 2, 4):
+        keys += ['%srgb_fc.%d.weight' % (impl, i), '%srgb_fc.%d.bias' % (impl, i)]
+    for i in (0, 2):
+        keys += ['%sneuray_fc.%d.weight' % (impl, i), '%sneuray_fc.%d.bias' % (impl, i)]
+    assert len(keys) == _lib.PASS_TENSORS
+    return keys
+
+
+def posenc_table(d_hid, n_samples):
+    """Sinusoid table of IBRNetWithNeuRay.posenc (network/ibrnet.py:305-313), numpy float64 -> float32."""
+    pos = np.arange(n_samples, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    t = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    t[:, 0::2] = np.sin(t[:, 0::2])
+    t[:, 1::2] = np.cos(t[:, 1::2])
+    return torch.from_numpy(t.astype(np.float32))
+
+
+class PackedPass:
+    """Device-resident packed weights of one pass (dist decoder + aggregation net)."""
+
+    def __init__(self, dev_tensor, has_vis_head):
+        self.dev = dev_tensor
+        self.has_vis_head = has_vis_head
+
+
+class ViewSet:
+    """Per-render() constants of the reference views: camera constants + channels-last maps."""
+
+    def __init__(self, view_const, ray_feats, img_feats, rgba, rfn, h, w, fh, fw):
+        self.view_const, self.ray_feats, self.img_feats, self.rgba = view_const, ray_feats, img_feats, rgba
+        self.rfn, self.h, self.w, self.fh, self.fw = rfn, h, w, fh, fw
+
+
+class RenderEngine:
+    def __init__(self, device, _test_lib=None, tiles_per_wave=0):
+        """device: torch device of the HIP GPU.  `_test_lib` is for the CPU test-suite only (binds the
+        emulator build of the same kernels); the product path always uses libneuray_hip.so."""
+        self.device = torch.device(device)
+        if _test_lib is None:
+            if self.device.type != 'cuda':
+                raise RuntimeError("neuray_amd.RenderEngine needs a HIP device (got %s): the render path has no CPU "
+                                   "fallback" % self.device)
+            self.lib = _lib.load()
+        else:
+            self.lib = _test_lib
+        self.tiles_per_wave = tiles_per_wave
+        self._posenc = {}
+        # optional kernel timing: set to a list and every point/ray launch appends
+        # (name, start_event, end_event, n_points) recorded on the launch stream (HIP events)
+        self.timing = None
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        if self.device.type == 'cuda':
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def _f32(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _check(self, rc):
+        _lib.check(self.lib, rc)
+
+    def _event_pair(self):
+        if self.timing is None or self.device.type != 'cuda':
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        return e0, e1
+
+    def _event_done(self, ev, name, n):
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+            self.timing.append((name, ev[0], ev[1], n))
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def pack_pass(self, state_dict, dist_prefix, agg_prefix):
+        """state_dict (tensors or ndarrays, reference key names) -> PackedPass on the device."""
+        keys = pass_tensor_keys(dist_prefix, agg_prefix)
+        host, ptrs = [], (C.c_void_p * _lib.PASS_TENSORS)()
+        has_vis = (dist_prefix + 'vis_decoder.0.weight') in state_dict
+        for i, k in enumerate(keys):
+            if k not in state_dict:
+                if '.vis_decoder.' in k and not has_vis:
+                    ptrs[i] = None
+                    continue
+                raise KeyError("neuray_amd: missing weight %s" % k)
+            v = state_dict[k]
+            t = torch.as_tensor(v).detach().to('cpu', torch.float32).contiguous()
+            host.append(t)
+            ptrs[i] = t.data_ptr()
+        n = self.lib.neuray_packed_pass_floats()
+        packed = torch.empty(n, dtype=torch.float32)
+        self._check(self.lib.neuray_pack_pass_weights(ptrs, C.c_void_p(packed.data_ptr())))
+        return PackedPass(packed.to(self.device), has_vis)
+
+    def posenc(self, dn):
+        if dn not in self._posenc:
+            self._posenc[dn] = posenc_table(16, dn).to(self.device)
+        return self._posenc[dn]
+
+    # ------------------------------------------------------------------------------------------
+    def prepare_views(self, ref_imgs_info):
+        """ref_imgs_info: dict with imgs [rfn,3,h,w], poses, Ks, depth_range, ray_feats, img_feats (NCHW)."""
+        imgs = self._f32(ref_imgs_info['imgs'])
+        rfn, _, h, w = imgs.shape
+        rf, imf = self._f32(ref_imgs_info['ray_feats']), self._f32(ref_imgs_info['img_feats'])
+        assert rf.shape == imf.shape and rf.shape[0] == rfn and rf.shape[1] == 32, (rf.shape, imf.shape)
+        fh, fw = rf.shape[-2:]
+        if rfn > _lib.MAX_VIEWS:
+            raise RuntimeError("neuray_amd: %d reference views > %d" % (rfn, _lib.MAX_VIEWS))
+        s = self._stream()
+        vc = self.empty(rfn, _lib.VIEW_CONST)
+        poses, Ks, dr = self._f32(ref_imgs_info['poses']), self._f32(ref_imgs_info['Ks']), self._f32(ref_imgs_info['depth_range'])
+        self._check(self.lib.neuray_setup_views(poses.data_ptr(), Ks.data_ptr(), dr.data_ptr(), rfn, vc.data_ptr(), s))
+        rf_l, if_l, rgba = self.empty(rfn, fh, fw, 32), self.empty(rfn, fh, fw, 32), self.empty(rfn, h, w, 4)
+        self._check(self.lib.neuray_relayout_nhwc(rf.data_ptr(), rf_l.data_ptr(), rfn, 32, fh, fw, 32, s))
+        self._check(self.lib.neuray_relayout_nhwc(imf.data_ptr(), if_l.data_ptr(), rfn, 32, fh, fw, 32, s))
+        self._check(self.lib.neuray_relayout_nhwc(imgs.data_ptr(), rgba.data_ptr(), rfn, 3, h, w, 4, s))
+        return ViewSet(vc, rf_l, if_l, rgba, rfn, h, w, fh, fw)
+
+    def prepare_query(self, que_imgs_info):
+        """-> query constant block.  K^-1 by torch.inverse exactly as the reference (render_ops.py:20)."""
+        pose = self._f32(que_imgs_info['poses'])
+        assert pose.shape[0] == 1, "one query view per render() call (qn = 1)"
+        Ks = self._f32(que_imgs_info['Ks'])
+        kinv = self._f32(que_imgs_info['Ks_inv']) if 'Ks_inv' in que_imgs_info else torch.inverse(Ks)
+        dr = self._f32(que_imgs_info['depth_range'])
+        qc = self.empty(_lib.QUERY_CONST)
+        self._check(self.lib.neuray_setup_query(pose.data_ptr(), kinv.contiguous().data_ptr(), dr.data_ptr(), qc.data_ptr(),
+                                                self._stream()))
+        return qc
+
+    # ------------------------------------------------------------------------------------------
+    def sample_coarse_depth(self, que_depth_range, rn, dn):
+        dr = self._f32(que_depth_range).reshape(-1)[:2].contiguous()
+        depth = self.empty(rn, dn)
+        self._check(self.lib.neuray_sample_coarse_depth(dr.data_ptr(), rn, dn, depth.data_ptr(), self._stream()))
+        return depth
+
+    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None):
+        rn, dn = depth.shape
+        out = self.empty(rn, fdn + (dn if use_all else 0))
+        u_ptr = None
+        if u is not None:
+            u = self._f32(u).reshape(rn, fdn)
+            u_ptr = u.data_ptr()
+        self._check(self.lib.neuray_sample_fine_depth(qconst.data_ptr(), depth.data_ptr(), hit_prob.data_ptr(), u_ptr,
+                                                      rn, dn, fdn, int(use_all), out.data_ptr(), self._stream()))
+        return out
+
+    def interpolate_feats(self, feats, points, h=None, w=None, align_corners=False, mask=None):
+        """network/ops.py:14-34 (padding_mode='border' as used on the render path) -> [b,n,c]"""
+        feats, points = self._f32(feats), self._f32(points)
+        b, c, fh, fw = feats.shape
+        n = points.shape[1]
+        if h is None and w is None:
+            h, w = fh, fw
+        out = self.empty(b, n, c)
+        m = self._f32(mask) if mask is not None else None
+        self._check(self.lib.neuray_interpolate_feats(feats.data_ptr(), points.data_ptr(), m.data_ptr() if m is not None else None,
+                                                      b, n, c, fh, fw, int(h), int(w), int(bool(align_corners)), out.data_ptr(),
+                                                      self._stream()))
+        return out
+
+    def render_pass(self, qconst, views, coords, depth, packed, use_vis, var_bias=0.05, ray_mask_view_num=2,
+                    ray_mask_point_num=8, want_depth=False, want_density=False, want_dbg=False):
+        """One pass (coarse or fine) over rays `coords` [rn,2] at sample depths `depth` [rn,dn].
+        -> dict(hit_prob [rn,dn], pixel [rn,3], ray_mask [rn] bool, render_depth?, density?, dbg?)"""
+        coords, depth = self._f32(coords), self._f32(depth)
+        rn, dn = depth.shape
+        assert coords.shape == (rn, 2)
+        s = self._stream()
+        rec = self.empty(rn * dn, _lib.POINT_REC)
+        dbg = self.empty(rn * dn, views.rfn, _lib.DBG_FIELDS) if want_dbg else None
+        a = _lib.NeurayPointsArgs(
+            qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(),
+            views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
+            rec.data_ptr(), dbg.data_ptr() if want_dbg else None,
+            views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
+            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.tiles_per_wave))
+        ev = self._event_pair()
+        self._check(self.lib.neuray_render_points(C.byref(a), s))
+        self._event_done(ev, 'points', rn * dn)
+        out = {'hit_prob': self.empty(rn, dn), 'pixel': self.empty(rn, 3),
+               'ray_mask': self.empty(rn, dtype=torch.uint8)}
+        if want_depth:
+            out['render_depth'] = self.empty(rn)
+        if want_density:
+            out['density'] = self.empty(rn, dn)
+        r = _lib.NeurayRaysArgs(
+            rec.data_ptr(), depth.data_ptr(), self.posenc(dn).data_ptr(), packed.dev.data_ptr(),
+            out['hit_prob'].data_ptr(), out['pixel'].data_ptr(),
+            out['render_depth'].data_ptr() if want_depth else None, out['ray_mask'].data_ptr(),
+            out['density'].data_ptr() if want_density else None,
+            rn, dn, int(ray_mask_view_num), int(ray_mask_point_num))
+        ev = self._event_pair()
+        self._check(self.lib.neuray_render_rays(C.byref(r), s))
+        self._event_done(ev, 'rays', rn * dn)
+        out['ray_mask'] = out['ray_mask'].bool()
+        out['point_rec'] = rec.view(rn, dn, _lib.POINT_REC)
+        if want_dbg:
+            out['dbg'] = dbg.view(rn, dn, views.rfn, _lib.DBG_FIELDS)
+        return out

@@ -1,0 +1,30 @@
+"""Builds tests/emu/_build/libneuray_emu.so: the product kernel sources compiled for the CPU fiber
+emulator (hip_emu.h).  TEST INFRASTRUCTURE ONLY - never loaded by neuray_amd, never timed."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'neuray_amd', 'csrc')
+OUT_DIR = os.path.join(HERE, '_build')
+OUT = os.path.join(OUT_DIR, 'libneuray_emu.so')
+SOURCES = [os.path.join(CSRC, 'neuray_hip.hip'), os.path.join(CSRC, 'nr_pack.cpp'), os.path.join(HERE, 'hip_emu.cpp')]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
+    [os.path.join(HERE, 'hip_emu.h'), os.path.join(ROOT, 'include', 'neuray_hip.h')]
+
+
+def build(force=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = ['g++', '-std=c++17', '-O2', '-g0', '-fPIC', '-shared', '-DNEURAY_EMU', '-ffp-contract=off',
+           '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', OUT]
+    for s in SOURCES:
+        cmd += ['-x', 'c++', s]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='-f' in sys.argv))

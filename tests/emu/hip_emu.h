@@ -1,0 +1,178 @@
+// CPU emulation of the small HIP/CDNA subset used by neuray_amd/csrc/*.  TEST INFRASTRUCTURE ONLY.
+//
+// The product kernels are written against a handful of wrappers (nr_mfma16, nr_shfl*, NR_LAUNCH,
+// __syncthreads, __shared__).  Building the same sources with -DNEURAY_EMU and this header gives a
+// host library (tests/emu/_build/libneuray_emu.so) in which every HIP thread is a ucontext fiber:
+// a wave is 64 fibers, cross-lane operations and barriers are rendezvous points, and the fp32 MFMA
+// is the k-ordered fmaf chain the hardware implements (cdna_hip_programming.md section 3).  It exists so
+// that kernel logic can be checked against the oracle in the CPU-only container; nothing under
+// neuray_amd/ ever loads it and it is never timed.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+#include <atomic>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int2 { int x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __shared__ static thread_local
+
+namespace emu {
+
+constexpr int WAVE = 64;
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+struct WaveState {
+    int active = 0;     // lanes not yet finished
+    int arrived = 0;
+    unsigned gen = 0;
+    // double-buffered operand slots (parity = gen & 1)
+    float fa[2][WAVE], fb[2][WAVE];
+    uint64_t bits[2];
+};
+
+struct Lane {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    unsigned tid = 0;
+    bool done = false;
+    int wait_kind = 0;       // 0 runnable, 1 wave, 2 block
+    unsigned wait_gen = 0;
+};
+
+struct Block {
+    dim3 bidx, bdim, gdim;
+    std::vector<Lane> lanes;
+    std::vector<WaveState> waves;
+    int blk_active = 0, blk_arrived = 0;
+    unsigned blk_gen = 0;
+    char* dyn_smem = nullptr;
+    ucontext_t main_ctx;
+    const std::function<void()>* body = nullptr;
+};
+
+extern thread_local Block* g_blk;
+extern thread_local Lane* g_lane;
+
+struct TidProxy { unsigned y = 0, z = 0; struct X { operator unsigned() const { return g_lane->tid; } } x; };
+struct BidProxy { struct X { operator unsigned() const { return g_blk->bidx.x; } } x;
+                  struct Y { operator unsigned() const { return g_blk->bidx.y; } } y; unsigned z = 0; };
+struct BdimProxy { struct X { operator unsigned() const { return g_blk->bdim.x; } } x; unsigned y = 1, z = 1; };
+struct GdimProxy { struct X { operator unsigned() const { return g_blk->gdim.x; } } x;
+                   struct Y { operator unsigned() const { return g_blk->gdim.y; } } y; unsigned z = 1; };
+
+void yield_lane();
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+
+static inline WaveState& my_wave() { return g_blk->waves[g_lane->tid / WAVE]; }
+static inline int my_lane() { return g_lane->tid % WAVE; }
+
+// rendezvous of the (still active) lanes of this wave; returns the parity used for this round
+static inline int wave_sync() {
+    WaveState& w = my_wave();
+    unsigned gen = w.gen;
+    if (++w.arrived >= w.active) { w.arrived = 0; w.gen = gen + 1; return gen & 1; }
+    g_lane->wait_kind = 1; g_lane->wait_gen = gen;
+    yield_lane();
+    return gen & 1;
+}
+static inline void block_sync() {
+    Block* b = g_blk;
+    unsigned gen = b->blk_gen;
+    if (++b->blk_arrived >= b->blk_active) { b->blk_arrived = 0; b->blk_gen = gen + 1; return; }
+    g_lane->wait_kind = 2; g_lane->wait_gen = gen;
+    yield_lane();
+}
+
+}  // namespace emu
+
+static emu::TidProxy threadIdx;
+static emu::BidProxy blockIdx;
+static emu::BdimProxy blockDim;
+static emu::GdimProxy gridDim;
+
+static inline void __syncthreads() { emu::block_sync(); }
+
+// ---- cross-lane primitives -------------------------------------------------------------------
+static inline float emu_shfl_f(float v, int src) {
+    emu::WaveState& w = emu::my_wave();
+    int par = w.gen & 1;
+    w.fa[par][emu::my_lane()] = v;
+    emu::wave_sync();
+    return w.fa[par][src & 63];
+}
+static inline float __shfl(float v, int src) { return emu_shfl_f(v, src); }
+static inline float __shfl_xor(float v, int m) { return emu_shfl_f(v, emu::my_lane() ^ m); }
+static inline float __shfl_up(float v, int d) { int l = emu::my_lane(); return emu_shfl_f(v, l - d < 0 ? l : l - d); }
+static inline float __shfl_down(float v, int d) { int l = emu::my_lane(); return emu_shfl_f(v, l + d > 63 ? l : l + d); }
+static inline int __shfl(int v, int src) { float f; memcpy(&f, &v, 4); f = emu_shfl_f(f, src); memcpy(&v, &f, 4); return v; }
+static inline int __shfl_xor(int v, int m) { return __shfl(v, emu::my_lane() ^ m); }
+static inline int __shfl_up(int v, int d) { int l = emu::my_lane(); return __shfl(v, l - d < 0 ? l : l - d); }
+static inline int __shfl_down(int v, int d) { int l = emu::my_lane(); return __shfl(v, l + d > 63 ? l : l + d); }
+static inline unsigned long long __ballot(int pred) {
+    emu::WaveState& w = emu::my_wave();
+    int par = w.gen & 1;
+    w.fa[par][emu::my_lane()] = pred ? 1.0f : 0.0f;
+    emu::wave_sync();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) if (w.fa[par][i] != 0.0f) m |= (1ull << i);
+    return m;
+}
+
+// ---- fp32 MFMA 16x16x4: D = A(16x4) * B(4x16) + C, k-ordered fmaf chain -----------------------
+typedef float v4f __attribute__((vector_size(16)));
+static inline v4f nr_mfma16(float a, float b, v4f c) {
+    emu::WaveState& w = emu::my_wave();
+    int par = w.gen & 1;
+    int l = emu::my_lane();
+    w.fa[par][l] = a;   // A[m = l&15][k = l>>4]
+    w.fb[par][l] = b;   // B[k = l>>4][n = l&15]
+    emu::wave_sync();
+    int n = l & 15, g = l >> 4;
+    v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        int m = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.fa[par][k * 16 + m], w.fb[par][k * 16 + n], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+// ---- exact-rounding helpers (same names as the HIP device intrinsics) --------------------------
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __fsqrt_rn(float a) { return sqrtf(a); }
+
+#define NR_DYNAMIC_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::g_blk->dyn_smem)
+#define NR_LAUNCH(kernel, grid, block, smem, stream, ...)                                   \
+    do { std::function<void()> _body = [=]() { kernel(__VA_ARGS__); };                       \
+         emu::launch((grid), (block), (smem), _body); } while (0)

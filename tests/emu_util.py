@@ -1,0 +1,30 @@
+"""Helpers for the CPU test-suite: bind the emulator build of the kernels (tests/emu)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+
+_EMU = None
+
+
+def emu_lib():
+    global _EMU
+    if _EMU is None:
+        import build_emu
+        from neuray_amd import _lib
+        _EMU = _lib.bind(build_emu.build())
+        assert _EMU.neuray_is_device_build() == 0
+    return _EMU
+
+
+def emu_engine(**kw):
+    from neuray_amd.engine import RenderEngine
+    return RenderEngine('cpu', _test_lib=emu_lib(), **kw)
+
+
+def to_torch(d, device='cpu'):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in d.items()}

@@ -1,0 +1,188 @@
+"""bench.py - rays/sec of the NeuRay per-ray render path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (coarse + fine render_impl over every ray batch) over one synthetic
+"lego-800" image: 800x800 = 640,000 rays, 8 reference views, 64 coarse + 32 fine samples (the configuration
+BASELINE.json's metric is quoted on), seeded random weights and feature maps; inputs are
+resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL),
+images sharded across ranks (no data-path collective; rays and images are independent), weak scaling; the timed
+region is bracketed by barrier + synchronize and the max over ranks is taken.
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the MFMA point kernel):
+achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream).
+`cpu_baseline` times the numpy oracle (a port of the reference algorithm) on a bounded sample of the same
+workload on the host cores; it is the only place this file touches oracle/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from neuray_amd import synthetic  # noqa: E402
+from neuray_amd.network.renderer import NeuralRayBaseRenderer  # noqa: E402
+
+H = W = 800
+RFN = 8
+DN_COARSE = 64
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA dense peak
+
+
+def algorithmic_macs_per_point(rfn, vis_head_used):
+    """MACs of the point kernel per sample point (factored base_fc; SURVEY.md 8(d) 'minimal' count
+    minus the attention / sigma head that live in the ray kernel)."""
+    dist = 3 * (32 * 32 * 2) + 32 * 2 + 32 * 2 + 32 * 1 + (32 * 32 * 2 + 32 if vis_head_used else 0)
+    per_view = (dist + (34 * 32 + 32 * 32) + (4 * 16 + 16 * 35) + (32 * 8 + 8) + ((35 + 32) * 64 + 64 * 32)
+                + (32 * 32 + 32 * 33) + (32 * 32 + 32) + (37 * 16 + 16 * 8 + 8))
+    per_point = 140 * 64 + (65 * 64 + 64 * 16)
+    return rfn * per_view + per_point
+
+
+def build_case(device, fdn, seed):
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False},
+           'depth_sample_num': DN_COARSE, 'fine_depth_sample_num': fdn,
+           'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
+           'ray_batch_num': 32768}
+    torch.manual_seed(0)
+    renderer = NeuralRayBaseRenderer(cfg).eval()
+    weights = {k: v.detach().numpy().copy() for k, v in renderer.state_dict().items()}
+    renderer = renderer.to(device)
+    que, ref = synthetic.make_scene(H, W, RFN, seed=seed)
+    que['coords'] = synthetic.meshgrid_coords(H, W)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    tq = {k: torch.from_numpy(v).to(device) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v).to(device) for k, v in ref.items()}
+    return cfg, renderer, weights, que, ref, tq, tr
+
+
+def render_image(renderer, tq, tr):
+    q = dict(tq)
+    r = {k: v for k, v in tr.items() if not k.startswith('_')}   # fresh dict: relayout is part of the step
+    with torch.no_grad():
+        return renderer.render(q, r, False)
+
+
+def cpu_baseline(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
+    """Oracle (numpy port of the reference algorithm) on `sample_rays` rays of the same workload."""
+    from oracle import neuray_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+    n = que['coords'].shape[1]
+    idx = np.linspace(0, n - 1, sample_rays).astype(np.int64)
+    outs = []
+    t0 = time.perf_counter()
+    for i in range(0, sample_rays, chunk):
+        q = dict(que)
+        q['coords'] = que['coords'][:, idx[i:i + chunk]]
+        outs.append(orc.render_impl(weights, ocfg, q, ref)['pixel_colors_nr_fine'])
+    dt = time.perf_counter() - t0
+    want = np.concatenate(outs, 1)
+    got = got_pixels[:, idx]
+    err = np.abs(got - want).max(-1)
+    return {
+        'value': sample_rays / dt, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
+        'sample': '%d rays of the same 800x800 image (every %d-th ray), coarse+fine, numpy oracle, %.1f s'
+                  % (sample_rays, max(1, n // sample_rays), dt),
+    }, {
+        'psnr_vs_oracle_db': synthetic.psnr_uint8(got, want),
+        'max_abs_err_vs_oracle': float(err.max()),
+        'frac_rays_within_2e-4': float(np.mean(err <= 2e-4)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--fine-samples', type=int, default=32, help='32 = BASELINE.json wording, 64 = reference default')
+    ap.add_argument('--cpu-sample-rays', type=int, default=8192)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=rank)
+    eng = renderer.engine(device)
+    nrays = H * W
+
+    for _ in range(args.warmup):
+        out = render_image(renderer, tq, tr)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    eng.timing = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = render_image(renderer, tq, tr)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    timing, eng.timing = eng.timing, None
+
+    if rank == 0:
+        value = world * args.steps * nrays / dt
+        # dominant kernel: the point kernel.  Duration from HIP events on the launch stream.
+        pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in timing if name == 'points']
+        rays_k = [e0.elapsed_time(e1) * 1e-3 for name, e0, e1, n in timing if name == 'rays']
+        t_pts = sum(t for t, _ in pts)
+        n_pts = sum(n for _, n in pts)
+        flops_pt = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False)
+        achieved = flops_pt * n_pts / t_pts / 1e12
+        line = {
+            'metric': 'rays/sec (64 coarse+%d fine samples), lego 800x800 synthetic' % args.fine_samples,
+            'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'fp32', 'data': 'synthetic',
+            'config': {'workload': 'lego-800 synthetic (nerf_synthetic/lego/black_800 shape): 800x800 = 640000 rays/image, '
+                                   '8 ref views, 64 coarse + %d fine samples, maps 200x200x32, 1 image per step per GPU'
+                                   % args.fine_samples,
+                       'ray_batch': cfg['ray_batch_num'], 'parallelism': 'images sharded over %d GPU(s), no collective' % world},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'nr::points_kernel', 'launches': len(pts),
+                         'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
+                         'algorithmic_flops_per_point': flops_pt,
+                         'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt},
+        }
+        if not args.no_cpu_baseline and args.cpu_sample_rays > 0:
+            base, parity = cpu_baseline(cfg, weights, que, ref, out['pixel_colors_nr_fine'].cpu().numpy(),
+                                        args.cpu_sample_rays, 1024)
+            line['cpu_baseline'] = base
+            line['parity'] = parity
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

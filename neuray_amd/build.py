@@ -13,7 +13,11 @@ SOURCES = [os.path.join(CSRC, 'neuray_hip.hip'), os.path.join(CSRC, 'nr_pack.cpp
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
     [os.path.join(os.path.dirname(HERE), 'include', 'neuray_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value', '-Wno-comment']
+# -ffp-contract=off: arithmetic is exactly as written (explicit fmaf where fusion is wanted), so a ray's result does
+# not depend on which tile slot / lane it lands in (hipcc otherwise SLP-packs the unrolled tile copies and contracts
+# packed and scalar leftovers differently) - required for bitwise batching / sharding invariance.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-unused-value',
+         '-Wno-comment']
 
 
 def needs_build():

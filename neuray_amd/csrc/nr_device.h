@@ -1,6 +1,6 @@
 // Device functions of the NeuRay per-ray path for gfx950.  Each block cites the reference lines it
 // replaces (paths relative to the reference tree) and follows the rounding contract of DESIGN.md:
-// camera algebra uses explicit __fmul_rn/__fadd_rn sequences (no FMA contraction) in the same order as
+// camera algebra uses explicit rn_mul/rn_add sequences (no FMA contraction) in the same order as
 // the oracle, so validity masks and texel indices are bit-identical between the two.
 #pragma once
 #include "nr_platform.h"
@@ -12,7 +12,7 @@ namespace nr {
 // ordered small algebra
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+    return rn_add(rn_add(rn_mul(a0, b0), rn_mul(a1, b1)), rn_mul(a2, b2));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -26,19 +26,19 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 // a1  coarse depth sample i of dn, uniform in inverse depth       network/render_ops.py:146-170
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float coarse_depth(float near, float far, int i, int dn) {
-    const float inv_near = __fdiv_rn(1.0f, near);
-    const float diff = __fsub_rn(__fdiv_rn(1.0f, far), inv_near);
+    const float inv_near = rn_div(1.0f, near);
+    const float diff = rn_sub(rn_div(1.0f, far), inv_near);
     float tick;
     if (i == 0) tick = 0.0f;
     else if (i == dn - 1) tick = diff;
-    else tick = __fmul_rn(__fdiv_rn(diff, (float)(dn - 1)), (float)i);
-    return __fdiv_rn(1.0f, __fadd_rn(inv_near, tick));
+    else tick = rn_mul(rn_div(diff, (float)(dn - 1)), (float)i);
+    return rn_div(1.0f, rn_add(inv_near, tick));
 }
 
 // normalised inverse depth s = (-1/d - near') / (far' - near'),  near' = -1/near, far' = -1/far
 //   network/render_ops.py:46-52, dist_decoder.py:16-22
 __device__ __forceinline__ float norm_inv_depth(float d, float nearp, float farp) {
-    return __fdiv_rn(__fsub_rn(__fdiv_rn(-1.0f, d), nearp), __fsub_rn(farp, nearp));
+    return rn_div(rn_sub(rn_div(-1.0f, d), nearp), rn_sub(farp, nearp));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -57,11 +57,11 @@ __device__ __forceinline__ Ray make_ray(const float* __restrict__ qc, float x, f
     const float w0 = dot3(P[0], P[4], P[8], cam0, cam1, cam2);
     const float w1 = dot3(P[1], P[5], P[9], cam0, cam1, cam2);
     const float w2 = dot3(P[2], P[6], P[10], cam0, cam1, cam2);
-    r.dx = __fsub_rn(__fadd_rn(w0, r.cx), r.cx);
-    r.dy = __fsub_rn(__fadd_rn(w1, r.cy), r.cy);
-    r.dz = __fsub_rn(__fadd_rn(w2, r.cz), r.cz);
-    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(r.dx, r.dx), __fmul_rn(r.dy, r.dy)), __fmul_rn(r.dz, r.dz)));
-    r.qx = __fdiv_rn(-r.dx, nrm); r.qy = __fdiv_rn(-r.dy, nrm); r.qz = __fdiv_rn(-r.dz, nrm);
+    r.dx = rn_sub(rn_add(w0, r.cx), r.cx);
+    r.dy = rn_sub(rn_add(w1, r.cy), r.cy);
+    r.dz = rn_sub(rn_add(w2, r.cz), r.cz);
+    const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(r.dx, r.dx), rn_mul(r.dy, r.dy)), rn_mul(r.dz, r.dz)));
+    r.qx = rn_div(-r.dx, nrm); r.qy = rn_div(-r.dy, nrm); r.qz = rn_div(-r.dz, nrm);
     return r;
 }
 
@@ -73,18 +73,18 @@ struct Proj { float u, v, z, mask, dirx, diry, dirz; };
 
 __device__ __forceinline__ Proj project_point(const float* __restrict__ vc, float px, float py, float pz, float w_img, float h_img) {
     Proj o;
-    const float c0 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vc[0], px), __fmul_rn(vc[1], py)), __fmul_rn(vc[2], pz)), vc[3]);
-    const float c1 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vc[4], px), __fmul_rn(vc[5], py)), __fmul_rn(vc[6], pz)), vc[7]);
-    float z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vc[8], px), __fmul_rn(vc[9], py)), __fmul_rn(vc[10], pz)), vc[11]);
+    const float c0 = rn_add(rn_add(rn_add(rn_mul(vc[0], px), rn_mul(vc[1], py)), rn_mul(vc[2], pz)), vc[3]);
+    const float c1 = rn_add(rn_add(rn_add(rn_mul(vc[4], px), rn_mul(vc[5], py)), rn_mul(vc[6], pz)), vc[7]);
+    float z = rn_add(rn_add(rn_add(rn_mul(vc[8], px), rn_mul(vc[9], py)), rn_mul(vc[10], pz)), vc[11]);
     const bool bad = fabsf(z) < 1e-4f;          // no z>0 test: quirk A.9.1
     if (bad) z = 1e-3f;
-    o.u = __fdiv_rn(c0, z); o.v = __fdiv_rn(c1, z); o.z = z;
+    o.u = rn_div(c0, z); o.v = rn_div(c1, z); o.z = z;
     const bool outside = (o.u < -0.5f) | (o.u >= w_img - 0.5f) | (o.v < -0.5f) | (o.v >= h_img - 0.5f);
     o.mask = (!bad && !outside) ? 1.0f : 0.0f;
-    const float dx = __fsub_rn(px, vc[12]), dy = __fsub_rn(py, vc[13]), dz = __fsub_rn(pz, vc[14]);
-    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float dx = rn_sub(px, vc[12]), dy = rn_sub(py, vc[13]), dz = rn_sub(pz, vc[14]);
+    const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(dx, dx), rn_mul(dy, dy)), rn_mul(dz, dz)));
     const float den = fmaxf(nrm, 1e-5f);
-    o.dirx = __fdiv_rn(-dx, den); o.diry = __fdiv_rn(-dy, den); o.dirz = __fdiv_rn(-dz, den);
+    o.dirx = rn_div(-dx, den); o.diry = rn_div(-dy, den); o.dirz = rn_div(-dz, den);
     return o;
 }
 
@@ -94,11 +94,11 @@ __device__ __forceinline__ Proj project_point(const float* __restrict__ vc, floa
 //   full resolution (rgb), False otherwise (render_ops.py:64-68).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float texel_coord(float p, float size_full, float size_map, bool align) {
-    const float n = __fsub_rn(__fmul_rn(__fdiv_rn(p, __fsub_rn(size_full, 1.0f)), 2.0f), 1.0f);
+    const float n = rn_sub(rn_mul(rn_div(p, rn_sub(size_full, 1.0f)), 2.0f), 1.0f);
     float ix;
-    if (align) ix = __fmul_rn(__fdiv_rn(__fadd_rn(n, 1.0f), 2.0f), __fsub_rn(size_map, 1.0f));
-    else ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(n, 1.0f), size_map), 1.0f), 2.0f);
-    return fminf(__fsub_rn(size_map, 1.0f), fmaxf(ix, 0.0f));
+    if (align) ix = rn_mul(rn_div(rn_add(n, 1.0f), 2.0f), rn_sub(size_map, 1.0f));
+    else ix = rn_div(rn_sub(rn_mul(rn_add(n, 1.0f), size_map), 1.0f), 2.0f);
+    return fminf(rn_sub(size_map, 1.0f), fmaxf(ix, 0.0f));
 }
 
 struct Taps { int o00, o10, o01, o11; float w00, w10, w01, w11; };   // texel offsets (y*W + x) and weights
@@ -111,11 +111,11 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_fu
     const int x0 = (int)x0f, y0 = (int)y0f;
     const int x1 = x0 + 1 < mw ? x0 + 1 : mw - 1;   // weight is exactly 0 when clamped
     const int yb = y0 + 1 < mh ? y0 + 1 : mh - 1;
-    const float wx1 = __fsub_rn(ix, x0f), wy1 = __fsub_rn(iy, y0f);
-    const float wx0 = __fsub_rn(__fadd_rn(x0f, 1.0f), ix), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), iy);
+    const float wx1 = rn_sub(ix, x0f), wy1 = rn_sub(iy, y0f);
+    const float wx0 = rn_sub(rn_add(x0f, 1.0f), ix), wy0 = rn_sub(rn_add(y0f, 1.0f), iy);
     Taps t;
     t.o00 = y0 * mw + x0; t.o10 = y0 * mw + x1; t.o01 = yb * mw + x0; t.o11 = yb * mw + x1;
-    t.w00 = __fmul_rn(wx0, wy0); t.w10 = __fmul_rn(wx1, wy0); t.w01 = __fmul_rn(wx0, wy1); t.w11 = __fmul_rn(wx1, wy1);
+    t.w00 = rn_mul(wx0, wy0); t.w10 = rn_mul(wx1, wy0); t.w01 = rn_mul(wx0, wy1); t.w11 = rn_mul(wx1, wy1);
     if (x0 + 1 > mw - 1) { t.w10 = 0.0f; t.w11 = 0.0f; }
     if (y0 + 1 > mh - 1) { t.w01 = 0.0f; t.w11 = 0.0f; }
     return t;
@@ -124,7 +124,7 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_fu
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 __device__ __forceinline__ float blend4(float a, float b, float c, float d, const Taps& t) {
-    return ((a * t.w00 + b * t.w10) + c * t.w01) + d * t.w11;
+    return fmaf(d, t.w11, fmaf(c, t.w01, fmaf(b, t.w10, a * t.w00)));
 }
 
 // channels-last gather of 8 consecutive channels (this lane group's slice) of a 32-channel map
@@ -154,12 +154,12 @@ __device__ __forceinline__ void gather_rgb(const float* __restrict__ base, const
 __device__ __forceinline__ void logistic_prob(float t, float lo, float hi, float mu0, float mu1, float s0, float s1,
                                               float aw, float nu, bool use_vis, float& visibility, float& hit) {
     const float near = t - lo, far = t + hi;
-    float c00 = 0.5f + 0.5f * tanhf((near - mu0) * s0), c01 = 0.5f + 0.5f * tanhf((near - mu1) * s1);
-    float c10 = 0.5f + 0.5f * tanhf((far - mu0) * s0), c11 = 0.5f + 0.5f * tanhf((far - mu1) * s1);
+    float c00 = fmaf(0.5f, tanhf((near - mu0) * s0), 0.5f), c01 = fmaf(0.5f, tanhf((near - mu1) * s1), 0.5f);
+    float c10 = fmaf(0.5f, tanhf((far - mu0) * s0), 0.5f), c11 = fmaf(0.5f, tanhf((far - mu1) * s1), 0.5f);
     if (use_vis) { c00 *= nu; c01 *= nu; c10 *= nu; c11 *= nu; }
     const float m0 = aw, m1 = 1.0f - aw;
-    visibility = (1.0f - c00) * m0 + (1.0f - c01) * m1;
-    hit = (c10 - c00) * m0 + (c11 - c01) * m1;
+    visibility = fmaf(1.0f - c01, m1, (1.0f - c00) * m0);
+    hit = fmaf(c11 - c01, m1, (c10 - c00) * m0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -24,8 +24,8 @@ __global__ void view_setup_kernel(const float* __restrict__ poses, const float* 
         for (int j = 0; j < 4; ++j)
             o[i * 4 + j] = dot3(K[i * 3 + 0], K[i * 3 + 1], K[i * 3 + 2], P[j], P[4 + j], P[8 + j]);
     for (int i = 0; i < 3; ++i) o[12 + i] = dot3(-P[i], -P[4 + i], -P[8 + i], P[3], P[7], P[11]);
-    o[15] = __fdiv_rn(-1.0f, depth_range[2 * v]);
-    o[16] = __fdiv_rn(-1.0f, depth_range[2 * v + 1]);
+    o[15] = rn_div(-1.0f, depth_range[2 * v]);
+    o[16] = rn_div(-1.0f, depth_range[2 * v + 1]);
     o[17] = 0.0f; o[18] = 0.0f; o[19] = 0.0f;
 }
 
@@ -35,8 +35,8 @@ __global__ void query_setup_kernel(const float* __restrict__ pose, const float* 
     for (int i = 0; i < 9; ++i) o[i] = Kinv[i];
     for (int i = 0; i < 12; ++i) o[9 + i] = pose[i];
     for (int i = 0; i < 3; ++i) o[21 + i] = dot3(-pose[i], -pose[4 + i], -pose[8 + i], pose[3], pose[7], pose[11]);
-    o[24] = __fdiv_rn(-1.0f, depth_range[0]);
-    o[25] = __fdiv_rn(-1.0f, depth_range[1]);
+    o[24] = rn_div(-1.0f, depth_range[0]);
+    o[25] = rn_div(-1.0f, depth_range[1]);
     o[26] = depth_range[0]; o[27] = depth_range[1];
 }
 
@@ -137,13 +137,13 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             // half intervals in normalised inverse depth (render_ops.py:46-52, dist_decoder.py:34-38)
             const float s_n = norm_inv_depth(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qfarp);
             const float s_p = norm_inv_depth(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp);
-            const float half_c = (smp == dn - 1) ? 500000.0f : __fdiv_rn(__fsub_rn(s_n, s_c), 2.0f);
-            const float half_p = __fdiv_rn(__fsub_rn(s_c, s_p), 2.0f);
+            const float half_c = (smp == dn - 1) ? 500000.0f : rn_div(rn_sub(s_n, s_c), 2.0f);
+            const float half_p = rn_div(rn_sub(s_c, s_p), 2.0f);
             hi[t] = half_c;
             lo[t] = (smp == 0) ? half_c : half_p;
-            const float px = __fadd_rn(r.cx, __fmul_rn(r.dx, d));
-            const float py = __fadd_rn(r.cy, __fmul_rn(r.dy, d));
-            const float pz = __fadd_rn(r.cz, __fmul_rn(r.dz, d));
+            const float px = rn_add(r.cx, rn_mul(r.dx, d));
+            const float py = rn_add(r.cy, rn_mul(r.dy, d));
+            const float pz = rn_add(r.cz, rn_mul(r.dz, d));
             const Proj pr = project_point(vc, px, py, pz, (float)p.w, (float)p.h);
             mask[t] = pr.mask;
             dlt[t][0] = pr.dirx - r.qx; dlt[t][1] = pr.diry - r.qy; dlt[t][2] = pr.dirz - r.qz;
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
                 for (int o = 0; o < 16; ++o) {
                     float kk = 0.0f, vv = 0.0f;
                     NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) { kk += RW[RW_WK + o * 16 + k] * G[k]; vv += RW[RW_WV + o * 16 + k] * G[k]; }
+                    for (int k = 0; k < 16; ++k) { kk = fmaf(RW[RW_WK + o * 16 + k], G[k], kk); vv = fmaf(RW[RW_WV + o * 16 + k], G[k], vv); }
                     ks[i * 16 + o] = kk; vs[i * 16 + o] = vv;
                 }
             }
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
                 for (int oo = 0; oo < 16; ++oo) {
                     float s = 0.0f;
                     NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) s += RW[RW_WQ + oo * 16 + k] * G[k];
+                    for (int k = 0; k < 16; ++k) s = fmaf(RW[RW_WQ + oo * 16 + k], G[k], s);
                     q[oo] = s / 2.0f;       // temperature = sqrt(d_k) = 2
                 }
                 const bool masked = !(nvalid > 1.0f);   // query-row mask: quirk A.9.3
@@ -530,18 +530,18 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
                     float mx = -INFINITY;
                     for (int j = 0; j < dn; ++j) {
                         const float4 kj = ld4(ks + j * 16 + hh * 4);
-                        float s = ((q[hh * 4] * kj.x + q[hh * 4 + 1] * kj.y) + q[hh * 4 + 2] * kj.z) + q[hh * 4 + 3] * kj.w;
+                        float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
                         s = masked ? -1e9f : s;
                         mx = fmaxf(mx, s);
                     }
                     float den = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
                     for (int j = 0; j < dn; ++j) {
                         const float4 kj = ld4(ks + j * 16 + hh * 4);
-                        float s = ((q[hh * 4] * kj.x + q[hh * 4 + 1] * kj.y) + q[hh * 4 + 2] * kj.z) + q[hh * 4 + 3] * kj.w;
+                        float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
                         s = masked ? -1e9f : s;
                         const float e_ = expf(s - mx);
                         const float4 vj = ld4(vs + j * 16 + hh * 4);
-                        den += e_; a0 += e_ * vj.x; a1 += e_ * vj.y; a2 += e_ * vj.z; a3 += e_ * vj.w;
+                        den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
                     }
                     o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
                 }
@@ -550,25 +550,25 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
                 for (int oo = 0; oo < 16; ++oo) {
                     float s = 0.0f;
                     NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) s += RW[RW_FC + oo * 16 + k] * o[k];
+                    for (int k = 0; k < 16; ++k) s = fmaf(RW[RW_FC + oo * 16 + k], o[k], s);
                     y[oo] = s + G[oo];
                     mean += y[oo];
                 }
                 mean /= 16.0f;
                 float var = 0.0f;
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) { const float d_ = y[k] - mean; var += d_ * d_; }
+                for (int k = 0; k < 16; ++k) { const float d_ = y[k] - mean; var = fmaf(d_, d_, var); }
                 var /= 16.0f;
                 const float rstd = 1.0f / sqrtf(var + 1e-6f);
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) y[k] = (y[k] - mean) * rstd * RW[RW_LNW + k] + RW[RW_LNB + k];
+                for (int k = 0; k < 16; ++k) y[k] = fmaf((y[k] - mean) * rstd, RW[RW_LNW + k], RW[RW_LNB + k]);
                 float sg = RW[RW_OG2B];
                 NR_PRAGMA_UNROLL
                 for (int oo = 0; oo < 16; ++oo) {
                     float s = RW[RW_OG0B + oo];
                     NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) s += RW[RW_OG0W + oo * 16 + k] * y[k];
-                    sg += RW[RW_OG2W + oo] * elu(s);
+                    for (int k = 0; k < 16; ++k) s = fmaf(RW[RW_OG0W + oo * 16 + k], y[k], s);
+                    sg = fmaf(RW[RW_OG2W + oo], elu(s), sg);
                 }
                 sg = fmaxf(sg, 0.0f);
                 if (nvalid < 1.0f) sg = 0.0f;
@@ -590,8 +590,8 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
             const float hp = ok ? al[ok ? i : 0] * T : 0.0f;
             const float* rc = rec + (size_t)(ok ? i : 0) * kPointRec;
             if (ok && rvalid) p.hit_prob[(size_t)ray * dn + i] = hp;
-            cr += hp * rc[16]; cg += hp * rc[17]; cb += hp * rc[18];
-            cd += hp * p.depth[(size_t)ray * dn + (ok ? i : 0)];
+            cr = fmaf(hp, rc[16], cr); cg = fmaf(hp, rc[17], cg); cb = fmaf(hp, rc[18], cb);
+            cd = fmaf(hp, p.depth[(size_t)ray * dn + (ok ? i : 0)], cd);
             const unsigned long long b = __ballot(ok && rc[19] > (float)p.mask_view_num);
             cnt += __builtin_popcountll(b);
         }
@@ -657,24 +657,24 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
             float cdfv = 0.0f;
             for (int j = 0; j < dn; ++j) { const float pj = pdf[j]; cdfv = (j < i) ? cdfv + pj : cdfv; }
             cdf[i] = cdfv;
-            edge[i] = (i == 0) ? ss[0] : (i == dn ? ss[dn - 1] : __fdiv_rn(__fadd_rn(ss[i], ss[i - 1]), 2.0f));
+            edge[i] = (i == 0) ? ss[0] : (i == dn ? ss[dn - 1] : rn_div(rn_add(ss[i], ss[i - 1]), 2.0f));
         }
         __syncthreads();
         const float interval = (float)(1.0 / (double)fdn);
         for (int k = lane; k < npad; k += 64) {
             float val = INFINITY;
             if (k < fdn) {
-                const float uu = p.u ? p.u[(size_t)ray * fdn + k] : __fadd_rn(__fmul_rn(0.5f, interval), __fmul_rn((float)k, interval));
+                const float uu = p.u ? p.u[(size_t)ray * fdn + k] : rn_add(rn_mul(0.5f, interval), rn_mul((float)k, interval));
                 int idx = 0;
                 for (int m = 0; m <= dn; ++m) idx += (cdf[m] <= uu) ? 1 : 0;     // searchsorted(right=True)
                 const int below = idx - 1 > 0 ? idx - 1 : 0;
                 const int above = idx < dn ? idx : dn;
-                float denom = __fsub_rn(cdf[above], cdf[below]);
+                float denom = rn_sub(cdf[above], cdf[below]);
                 if (denom < 1e-5f) denom = 1.0f;
-                const float tt = __fdiv_rn(__fsub_rn(uu, cdf[below]), denom);
-                float sf = __fadd_rn(edge[below], __fmul_rn(tt, __fsub_rn(edge[above], edge[below])));
-                sf = __fadd_rn(__fmul_rn(sf, __fsub_rn(farp, nearp)), nearp);
-                val = __fdiv_rn(-1.0f, sf);
+                const float tt = rn_div(rn_sub(uu, cdf[below]), denom);
+                float sf = rn_add(edge[below], rn_mul(tt, rn_sub(edge[above], edge[below])));
+                sf = rn_add(rn_mul(sf, rn_sub(farp, nearp)), nearp);
+                val = rn_div(-1.0f, sf);
             } else if (k < nout) {
                 val = drow[k - fdn];
             }
@@ -717,11 +717,11 @@ __global__ void interpolate_kernel(const float* __restrict__ feats, const float*
         const float x0f = floorf(ix), y0f = floorf(iy);
         const int x0 = (int)x0f, y0 = (int)y0f;
         const int x1 = x0 + 1 < fw ? x0 + 1 : fw - 1, yb = y0 + 1 < fh ? y0 + 1 : fh - 1;
-        const float wx1 = __fsub_rn(ix, x0f), wy1 = __fsub_rn(iy, y0f);
-        const float wx0 = __fsub_rn(__fadd_rn(x0f, 1.0f), ix), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), iy);
+        const float wx1 = rn_sub(ix, x0f), wy1 = rn_sub(iy, y0f);
+        const float wx0 = rn_sub(rn_add(x0f, 1.0f), ix), wy0 = rn_sub(rn_add(y0f, 1.0f), iy);
         Taps t;
         t.o00 = y0 * fw + x0; t.o10 = y0 * fw + x1; t.o01 = yb * fw + x0; t.o11 = yb * fw + x1;
-        t.w00 = __fmul_rn(wx0, wy0); t.w10 = __fmul_rn(wx1, wy0); t.w01 = __fmul_rn(wx0, wy1); t.w11 = __fmul_rn(wx1, wy1);
+        t.w00 = rn_mul(wx0, wy0); t.w10 = rn_mul(wx1, wy0); t.w01 = rn_mul(wx0, wy1); t.w11 = rn_mul(wx1, wy1);
         if (x0 + 1 > fw - 1) { t.w10 = 0.0f; t.w11 = 0.0f; }
         if (y0 + 1 > fh - 1) { t.w01 = 0.0f; t.w11 = 0.0f; }
         const float m = mask ? mask[i] : 1.0f;

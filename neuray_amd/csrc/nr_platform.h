@@ -32,3 +32,27 @@ __device__ __forceinline__ v4f nr_mfma16(float a, float b, v4f c) {
 #endif
 
 #define NR_WAVE 64
+
+// ---- exactly rounded single operations (the "rounding contract") --------------------------------------
+// HIP's __fadd_rn/__fmul_rn are plain `a + b` / `a * b` compiled with fp-contract=fast, so a product feeding a
+// sum is still fused into an FMA after inlining.  These helpers are compiled with contraction off (the fmul and
+// fadd carry no `contract` flag, so they are never fused), which makes the camera algebra bit-identical to the
+// numpy oracle.  Division and sqrt are IEEE-correct under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.
+namespace nr {
+#ifdef NEURAY_EMU
+__device__ __forceinline__ float rn_mul(float a, float b) { volatile float r = a * b; return r; }
+__device__ __forceinline__ float rn_add(float a, float b) { volatile float r = a + b; return r; }
+__device__ __forceinline__ float rn_sub(float a, float b) { volatile float r = a - b; return r; }
+__device__ __forceinline__ float rn_div(float a, float b) { volatile float r = a / b; return r; }
+__device__ __forceinline__ float rn_sqrt(float a) { return sqrtf(a); }
+#else
+#pragma clang fp contract(off)
+__device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float rn_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float rn_sqrt(float a) { return __builtin_sqrtf(a); }
+#pragma clang fp contract(fast)
+#endif
+}  // namespace nr

@@ -605,66 +605,6 @@ def render_impl(weights, cfg, que, ref, is_train=False, u=None, coarse_hit_prob=
 
 
 # --------------------------------------------------------------------------------------
-# synthetic scene; shared by tests, smoke() and bench.py
+# synthetic scene generator + PSNR: shared input generator, lives in the package (numpy only)
 # --------------------------------------------------------------------------------------
-def look_at_pose(cam_pos, target=(0, 0, 0), up=(0, 0, 1)):
-    """OpenCV world->camera [R|t]: camera at cam_pos looking at target (z forward, y down)."""
-    cam_pos = np.asarray(cam_pos, np.float64)
-    z = np.asarray(target, np.float64) - cam_pos
-    z /= np.linalg.norm(z)
-    x = np.cross(z, np.asarray(up, np.float64))
-    x /= np.linalg.norm(x)
-    y = np.cross(z, x)
-    R = np.stack([x, y, z], 0)
-    t = -R @ cam_pos
-    return np.concatenate([R, t[:, None]], 1).astype(np.float32)
-
-
-def sphere_pos(radius, azim_deg, elev_deg):
-    a, e = np.deg2rad(azim_deg), np.deg2rad(elev_deg)
-    return np.array([radius * np.cos(e) * np.cos(a), radius * np.cos(e) * np.sin(a), radius * np.sin(e)])
-
-
-def make_scene(h=800, w=800, rfn=8, seed=0, depth_range=(2.0, 6.0), radius=4.03, feat_dim=32,
-               que_imgs=False, fov_x=0.6911112070083618):
-    """Seeded synthetic 'lego-like' scene: cameras on a sphere looking at the origin,
-    random images and feature maps (the per-image encoders are bypassed)."""
-    rng = np.random.RandomState(seed)
-    f = 0.5 * w / np.tan(0.5 * fov_x)
-    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
-    offs = [(-5, 5), (5, -5), (-10, -8), (10, 8), (-15, 12), (15, -12), (-20, -3), (20, 3),
-            (-25, 15), (25, -15), (-30, 6), (30, -6), (0, 20), (0, -20), (12, 18), (-12, -18)]
-    assert rfn <= len(offs)
-    que_pose = look_at_pose(sphere_pos(radius, 30.0, 25.0))
-    ref_poses = np.stack([look_at_pose(sphere_pos(radius, 30.0 + a, 25.0 + e)) for a, e in offs[:rfn]])
-    fh, fw = h // 4, w // 4
-    ref = {
-        'imgs': rng.rand(rfn, 3, h, w).astype(np.float32),
-        'poses': ref_poses.astype(np.float32),
-        'Ks': np.repeat(K[None], rfn, 0),
-        'depth_range': np.repeat(np.asarray(depth_range, np.float32)[None], rfn, 0),
-        'ray_feats': rng.randn(rfn, feat_dim, fh, fw).astype(np.float32),
-        'img_feats': rng.randn(rfn, feat_dim, fh, fw).astype(np.float32),
-    }
-    que = {
-        'poses': que_pose[None], 'Ks': K[None].copy(),
-        'depth_range': np.asarray(depth_range, np.float32)[None],
-    }
-    if que_imgs:
-        que['imgs'] = rng.rand(1, 3, h, w).astype(np.float32)
-        que['ray_feats'] = rng.randn(1, feat_dim, fh, fw).astype(np.float32)
-    return que, ref
-
-
-def meshgrid_coords(h, w):
-    """x-fastest pixel grid [1,h*w,2] as utils/imgs_info.py:122-131"""
-    xs, ys = np.meshgrid(np.arange(w), np.arange(h))
-    return np.stack([xs, ys], -1).reshape(1, -1, 2).astype(np.float32)
-
-
-def psnr_uint8(a, b):
-    """PSNR on uint8-quantised images, as network/metrics.py:14-27"""
-    qa = np.clip(np.round(a * 255), 0, 255)
-    qb = np.clip(np.round(b * 255), 0, 255)
-    mse = np.mean((qa - qb) ** 2)
-    return float('inf') if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse))
+from neuray_amd.synthetic import look_at_pose, sphere_pos, make_scene, meshgrid_coords, psnr_uint8  # noqa: E402,F401

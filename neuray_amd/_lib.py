@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libneuray_hip.so')
+LIB_PATH = os.environ.get('NEURAY_HIP_LIB', os.path.join(HERE, 'libneuray_hip.so'))   # env override: A/B debugging only
 
 PASS_TENSORS = 68
 POINT_REC = 20

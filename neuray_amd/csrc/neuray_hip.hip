@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -41,28 +42,30 @@ static_assert(NEURAY_PASS_TENSORS == nr::T_COUNT, "abi");
 static_assert(NEURAY_DBG_FIELDS == nr::kDbgFields, "abi");
 static_assert(NEURAY_MAX_SAMPLES == nr::kMaxSamples, "abi");
 
-template <int NT, bool HAS_VIS>
-int launch_points(const nr::PointParams& p, void* stream) {
+template <int NT, bool HAS_VIS, int OWN>
+int launch_points_own(const nr::PointParams& p, void* stream) {
     const int npts = p.rn * p.dn;
     const size_t smem = nr::point_smem_bytes<NT>(p.rfn);
     if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
     // persistent-style grid: enough workgroups to fill 256 CUs several times over, grid-stride beyond
-    const int grid = grid_for(npts, 16 * NT, 256 * 8);
+    int grid = grid_for(npts, 16 * NT, 256 * 8);
+    if (const char* e = getenv("NEURAY_MAX_GRID")) grid = grid < atoi(e) ? grid : atoi(e);   // test knob: force grid-stride
     const int threads = 64 * p.rfn;
+    // one build per (NT, vis, OWN): __launch_bounds__(1024) caps the kernel at 128 VGPRs, so two 8-wave workgroups
+    // (rfn = 8) share a CU (4 waves per SIMD) - measured faster than the 162-VGPR / 1-workgroup build
+    auto k = nr::points_kernel<NT, HAS_VIS, OWN, 1024>;
 #ifndef NEURAY_EMU
-    if (threads <= 512) {
-        auto k = nr::points_kernel<NT, HAS_VIS, 512>;
-        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(threads), smem, (hipStream_t)stream, p);
-    } else {
-        auto k = nr::points_kernel<NT, HAS_VIS, 1024>;
-        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(threads), smem, (hipStream_t)stream, p);
-    }
-#else
-    NR_LAUNCH((nr::points_kernel<NT, HAS_VIS, 1024>), dim3(grid), dim3(threads), smem, stream, p);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
+    NR_LAUNCH(k, dim3(grid), dim3(threads), smem, stream, p);
     return check_launch("neuray_render_points");
+}
+
+template <int NT, bool HAS_VIS>
+int launch_points(const nr::PointParams& p, void* stream) {
+    if (p.rfn >= 4) return launch_points_own<NT, HAS_VIS, 1>(p, stream);
+    if (p.rfn >= 2) return launch_points_own<NT, HAS_VIS, 2>(p, stream);
+    return launch_points_own<NT, HAS_VIS, 4>(p, stream);
 }
 
 }  // namespace
@@ -125,7 +128,8 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev;
     p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
     p.use_vis = a->use_vis; p.var_bias = a->var_bias;
-    const int nt = a->tiles_per_wave ? a->tiles_per_wave : 2;
+    int nt = a->tiles_per_wave ? a->tiles_per_wave : 2;
+    if (const char* e = getenv("NEURAY_NT")) nt = atoi(e);   // tuning knob
     // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
     // reference-view path when the coarse decoder has use_vis = False: quirk A.9.2)
     const bool vis = a->has_vis_head && a->use_vis;
@@ -146,7 +150,7 @@ int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {
     if (smem > 160 * 1024) return fail("neuray_render_rays: dn=%d needs %zu bytes of LDS", a->dn, smem);
     const int grid = grid_for(a->rn, nr::kRayWaves, 256 * 16);
 #ifndef NEURAY_EMU
-    if (smem > 64 * 1024) hipFuncSetAttribute((const void*)nr::rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)nr::rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
     NR_LAUNCH(nr::rays_kernel, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
     return check_launch("neuray_render_rays");

@@ -18,9 +18,22 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
 // ---------------------------------------------------------------------------------------------
 // activations (PyTorch semantics: ELU alpha=1 via exp(x)-1, Softplus beta=1 threshold=20)
 // ---------------------------------------------------------------------------------------------
+// Built on the hardware exp2/log2/rcp (about 1 ulp each): absolute error ~1e-7 per activation, two orders of
+// magnitude inside the fp32 parity tolerance (tests/test_render_parity.py), at 5 VALU instructions per ELU instead
+// of ~18 for the libm-exact expf (the precise forms made the point kernel VALU-bound: 10.8 VALU per MFMA).
+#ifdef NR_PRECISE_MATH
 __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : nr_fast_exp(x) - 1.0f; }
+__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : nr_fast_log(1.0f + nr_fast_exp(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return nr_fast_rcp(1.0f + nr_fast_exp(-x)); }
+__device__ __forceinline__ float tanh_(float x) {   // 1 - 2/(exp(2x)+1); saturates cleanly to +-1
+    return 1.0f - 2.0f * nr_fast_rcp(nr_fast_exp(2.0f * x) + 1.0f);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // a1  coarse depth sample i of dn, uniform in inverse depth       network/render_ops.py:146-170
@@ -127,21 +140,22 @@ __device__ __forceinline__ float blend4(float a, float b, float c, float d, cons
     return fmaf(d, t.w11, fmaf(c, t.w01, fmaf(b, t.w10, a * t.w00)));
 }
 
-// channels-last gather of 8 consecutive channels (this lane group's slice) of a 32-channel map
-__device__ __forceinline__ void gather8(const float* __restrict__ base, const Taps& t, float mask, float (&out)[8]) {
-    const float4 a0 = ld4(base + (size_t)t.o00 * 32), a1 = ld4(base + (size_t)t.o00 * 32 + 4);
-    const float4 b0 = ld4(base + (size_t)t.o10 * 32), b1 = ld4(base + (size_t)t.o10 * 32 + 4);
-    const float4 c0 = ld4(base + (size_t)t.o01 * 32), c1 = ld4(base + (size_t)t.o01 * 32 + 4);
-    const float4 d0 = ld4(base + (size_t)t.o11 * 32), d1 = ld4(base + (size_t)t.o11 * 32 + 4);
+// channels-last gather of 8 consecutive channels (this lane group's slice, byte offset goff = 32*g) of a
+// 32-channel map: two 16-byte loads per tap, a texel's 128-byte line is covered by the 4 lane groups
+__device__ __forceinline__ void gather8(nr_mbuf map, int goff, const Taps& t, float mask, float (&out)[8]) {
+    const float4 a0 = nr_buf_ld4(map, t.o00 * 128 + goff, 0), a1 = nr_buf_ld4(map, t.o00 * 128 + goff, 16);
+    const float4 b0 = nr_buf_ld4(map, t.o10 * 128 + goff, 0), b1 = nr_buf_ld4(map, t.o10 * 128 + goff, 16);
+    const float4 c0 = nr_buf_ld4(map, t.o01 * 128 + goff, 0), c1 = nr_buf_ld4(map, t.o01 * 128 + goff, 16);
+    const float4 d0 = nr_buf_ld4(map, t.o11 * 128 + goff, 0), d1 = nr_buf_ld4(map, t.o11 * 128 + goff, 16);
     out[0] = blend4(a0.x, b0.x, c0.x, d0.x, t) * mask; out[1] = blend4(a0.y, b0.y, c0.y, d0.y, t) * mask;
     out[2] = blend4(a0.z, b0.z, c0.z, d0.z, t) * mask; out[3] = blend4(a0.w, b0.w, c0.w, d0.w, t) * mask;
     out[4] = blend4(a1.x, b1.x, c1.x, d1.x, t) * mask; out[5] = blend4(a1.y, b1.y, c1.y, d1.y, t) * mask;
     out[6] = blend4(a1.z, b1.z, c1.z, d1.z, t) * mask; out[7] = blend4(a1.w, b1.w, c1.w, d1.w, t) * mask;
 }
 
-__device__ __forceinline__ void gather_rgb(const float* __restrict__ base, const Taps& t, float mask, float (&out)[3]) {
-    const float4 a = ld4(base + (size_t)t.o00 * 4), b = ld4(base + (size_t)t.o10 * 4);
-    const float4 c = ld4(base + (size_t)t.o01 * 4), d = ld4(base + (size_t)t.o11 * 4);
+__device__ __forceinline__ void gather_rgb(nr_mbuf map, const Taps& t, float mask, float (&out)[3]) {
+    const float4 a = nr_buf_ld4(map, t.o00 * 16, 0), b = nr_buf_ld4(map, t.o10 * 16, 0);
+    const float4 c = nr_buf_ld4(map, t.o01 * 16, 0), d = nr_buf_ld4(map, t.o11 * 16, 0);
     out[0] = blend4(a.x, b.x, c.x, d.x, t) * mask;
     out[1] = blend4(a.y, b.y, c.y, d.y, t) * mask;
     out[2] = blend4(a.z, b.z, c.z, d.z, t) * mask;
@@ -154,8 +168,8 @@ __device__ __forceinline__ void gather_rgb(const float* __restrict__ base, const
 __device__ __forceinline__ void logistic_prob(float t, float lo, float hi, float mu0, float mu1, float s0, float s1,
                                               float aw, float nu, bool use_vis, float& visibility, float& hit) {
     const float near = t - lo, far = t + hi;
-    float c00 = fmaf(0.5f, tanhf((near - mu0) * s0), 0.5f), c01 = fmaf(0.5f, tanhf((near - mu1) * s1), 0.5f);
-    float c10 = fmaf(0.5f, tanhf((far - mu0) * s0), 0.5f), c11 = fmaf(0.5f, tanhf((far - mu1) * s1), 0.5f);
+    float c00 = fmaf(0.5f, tanh_((near - mu0) * s0), 0.5f), c01 = fmaf(0.5f, tanh_((near - mu1) * s1), 0.5f);
+    float c10 = fmaf(0.5f, tanh_((far - mu0) * s0), 0.5f), c11 = fmaf(0.5f, tanh_((far - mu1) * s1), 0.5f);
     if (use_vis) { c00 *= nu; c01 *= nu; c10 *= nu; c11 *= nu; }
     const float m0 = aw, m1 = 1.0f - aw;
     visibility = fmaf(1.0f - c01, m1, (1.0f - c00) * m0);
@@ -168,11 +182,11 @@ __device__ __forceinline__ void logistic_prob(float t, float lo, float hi, float
 //   acc[t][mo]      : accumulators (D layout), caller decides the initial value
 // ---------------------------------------------------------------------------------------------
 template <int L, int NT>
-__device__ __forceinline__ void layer_bias(const float* __restrict__ W, int lane, v4f (&acc)[NT][kShape[L].mt_out]) {
+__device__ __forceinline__ void layer_bias(nr_wbuf W, int lane, v4f (&acc)[NT][kShape[L].mt_out]) {
     constexpr int MT = kShape[L].mt_out;
     NR_PRAGMA_UNROLL
     for (int mo = 0; mo < MT; ++mo) {
-        const float4 b = ld4(W + bias_offset(L) + (mo * 4 + (lane >> 4)) * 4);
+        const float4 b = nr_buf_ld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) { acc[t][mo][0] = b.x; acc[t][mo][1] = b.y; acc[t][mo][2] = b.z; acc[t][mo][3] = b.w; }
     }
@@ -180,13 +194,13 @@ __device__ __forceinline__ void layer_bias(const float* __restrict__ W, int lane
 
 // accumulate one output tile `mo` (may be a runtime value) of layer L
 template <int L, int NT, int KQX, int K1X>
-__device__ __forceinline__ void layer_tile(const float* __restrict__ W, int lane, int mo,
+__device__ __forceinline__ void layer_tile(nr_wbuf W, int lane, int mo,
                                            const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
     constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
     static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
     NR_PRAGMA_UNROLL
     for (int kq = 0; kq < KQ; ++kq) {
-        const float4 a = ld4(W + quads_offset(L) + ((mo * KQ + kq) * 64 + lane) * 4);
+        const float4 a = nr_buf_ld4(W, lane * 16, (quads_offset(L) + (mo * KQ + kq) * 256) * 4);
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) {
             acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
@@ -197,14 +211,41 @@ __device__ __forceinline__ void layer_tile(const float* __restrict__ W, int lane
     }
     NR_PRAGMA_UNROLL
     for (int k1 = 0; k1 < K1; ++k1) {
-        const float a = W[single_offset(L) + (mo * K1 + k1) * 64 + lane];
+        const float a = nr_buf_ld1(W, lane * 4, (single_offset(L) + (mo * K1 + k1) * 64) * 4);
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a, x1[t][k1], acc[t]);
+    }
+}
+
+// accumulate a K-slice (quads [KQ0, KQ0+KQN), singles [K10, K10+K1N)) of output tile `mo` of layer L; the
+// operand arrays hold only the slice.  Used to stream cross-view statistics into an owner wave's accumulator.
+template <int L, int NT, int KQ0, int KQN, int K10, int K1N, int KQX, int K1X>
+__device__ __forceinline__ void layer_tile_slice(nr_wbuf W, int lane, int mo,
+                                                 const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
+    constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
+    static_assert(KQ0 + KQN <= KQ && K10 + K1N <= K1, "slice outside the layer");
+    static_assert(KQX >= (KQN > 0 ? 4 * KQN : 1) && K1X >= (K1N > 0 ? K1N : 1), "operand arrays too small");
+    NR_PRAGMA_UNROLL
+    for (int kq = 0; kq < KQN; ++kq) {
+        const float4 a = nr_buf_ld4(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0 + kq) * 256) * 4);
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
+            acc[t] = nr_mfma16(a.y, xq[t][4 * kq + 1], acc[t]);
+            acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
+            acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
+        }
+    }
+    NR_PRAGMA_UNROLL
+    for (int k1 = 0; k1 < K1N; ++k1) {
+        const float a = nr_buf_ld1(W, lane * 4, (single_offset(L) + (mo * K1 + K10 + k1) * 64) * 4);
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a, x1[t][k1], acc[t]);
     }
 }
 
 template <int L, int NT, int KQX, int K1X>
-__device__ __forceinline__ void layer_acc(const float* __restrict__ W, int lane, const float (&xq)[NT][KQX],
+__device__ __forceinline__ void layer_acc(nr_wbuf W, int lane, const float (&xq)[NT][KQX],
                                           const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out]) {
     constexpr int MT = kShape[L].mt_out;
     NR_PRAGMA_UNROLL
@@ -227,12 +268,14 @@ template <int A> __device__ __forceinline__ float apply_act(float x) {
 }
 
 template <int L, int NT, int A, int KQX, int K1X>
-__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, int lane, const float (&xq)[NT][KQX],
+__device__ __forceinline__ void layer_fwd(nr_wbuf W, int lane, const float (&xq)[NT][KQX],
                                           const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {
     constexpr int MT = kShape[L].mt_out;
     v4f acc[NT][MT];
+    NR_SCHED_FENCE();
     layer_bias<L, NT>(W, lane, acc);
     layer_acc<L, NT>(W, lane, xq, x1, acc);
+    NR_SCHED_FENCE();
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t)
         NR_PRAGMA_UNROLL

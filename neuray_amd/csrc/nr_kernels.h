@@ -95,7 +95,29 @@ constexpr int point_rmax() { return 12 * NT; }
 template <int NT>
 inline size_t point_smem_bytes(int rfn) { return sizeof(float) * 64 * ((size_t)(rfn + 1) * point_rmax<NT>() + 16 * NT); }
 
-template <int NT, bool HAS_VIS, int MAXT>
+// owner waves accumulate one cross-view statistic (8 image channels in gathered order + 3 rgb channels per tile)
+// into their tile(s) of base_fc.0's per-point part: statistic STAT uses quads [2*STAT, 2*STAT+2) and single STAT
+template <int NT, int OWN, int STAT>
+__device__ __forceinline__ void bg_accumulate(nr_wbuf W, int lane, int g, int wave, int nw,
+                                              const float (&st)[NT * 11], v4f (&accg)[OWN][NT]) {
+    float xq[NT][8], x1[NT][1];
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t) {
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < 8; ++s) xq[t][s] = st[t * 11 + s];
+        x1[t][0] = sel4(g, st[t * 11 + 8], st[t * 11 + 9], st[t * 11 + 10], 0.0f);
+    }
+    NR_PRAGMA_UNROLL
+    for (int j = 0; j < OWN; ++j) {
+        const int mo = wave + j * nw;
+        if (mo < 4) layer_tile_slice<L_BG, NT, 2 * STAT, 2, STAT, 1>(W, lane, mo, xq, x1, accg[j]);
+    }
+}
+
+// Point kernel.  One workgroup = rfn waves (wave v <-> reference view v) x NT tiles of 16 sample points.
+//   OWN = number of 16-feature output tiles of the per-point layers (base_fc.0 global part, geometry_fc.0) a wave
+//         owns: 1 for rfn >= 4, 2 for rfn in {2,3}, 4 for rfn = 1.
+template <int NT, bool HAS_VIS, int OWN, int MAXT>
 __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     constexpr int RMAX = point_rmax<NT>();
@@ -105,24 +127,25 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
     const int g = lane >> 4, c = lane & 15;
     float* red = smem;
     float* xch = smem + (size_t)(nw + 1) * RMAX * 64;
-    const float* __restrict__ W = p.weights;
+    const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
     const float* __restrict__ vc = p.view_const + wave * kViewConst;
     const float* __restrict__ qc = p.que_const;
     const float vnearp = vc[15], vfarp = vc[16];
     const float qnearp = qc[24], qfarp = qc[25];
-    const float* rf_base = p.ray_feats + (size_t)wave * p.fh * p.fw * 32 + 8 * g;
-    const float* if_base = p.img_feats + (size_t)wave * p.fh * p.fw * 32 + 8 * g;
-    const float* rgb_base = p.rgba + (size_t)wave * p.h * p.w * 4;
+    const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
+    const nr_mbuf rf_map = nr_make_mbuf(p.ray_feats + (size_t)wave * fmap, sizeof(float) * fmap);
+    const nr_mbuf if_map = nr_make_mbuf(p.img_feats + (size_t)wave * fmap, sizeof(float) * fmap);
+    const nr_mbuf rgb_map = nr_make_mbuf(p.rgba + (size_t)wave * imap, sizeof(float) * imap);
+    const int goff = 32 * g;
     const int npts = p.rn * p.dn;
     const int dn = p.dn;
-    const int nwork = nw < 4 ? nw : 4;
     const bool use_vis = p.use_vis != 0;
+    const bool dbg_lane = (p.dbg != nullptr) && (g == 0);
 
     for (int base = blockIdx.x * (16 * NT); base < npts; base += gridDim.x * (16 * NT)) {
         // ---------------- geometry + gather (a2-a8) -------------------------------------------
         int pidx[NT]; bool pvalid[NT];
         float mask[NT], dlt[NT][4], fray[NT][8], fimg[NT][8], rgb[NT][3], tref[NT], lo[NT], hi[NT];
-        float dbg_u[NT], dbg_v[NT], dbg_z[NT];
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) {
             int pi = base + 16 * t + c;
@@ -149,12 +172,15 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             dlt[t][0] = pr.dirx - r.qx; dlt[t][1] = pr.diry - r.qy; dlt[t][2] = pr.dirz - r.qz;
             dlt[t][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
             tref[t] = norm_inv_depth(fmaxf(pr.z, 1e-5f), vnearp, vfarp);
-            dbg_u[t] = pr.u; dbg_v[t] = pr.v; dbg_z[t] = pr.z;
+            if (dbg_lane && pvalid[t]) {
+                float* d_ = p.dbg + ((size_t)pi * nw + wave) * kDbgFields;
+                d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
+            }
             const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
-            gather8(rf_base, tf, pr.mask, fray[t]);
-            gather8(if_base, tf, pr.mask, fimg[t]);
+            gather8(rf_map, goff, tf, pr.mask, fray[t]);
+            gather8(if_map, goff, tf, pr.mask, fimg[t]);
             const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
-            gather_rgb(rgb_base, tc, pr.mask, rgb[t]);
+            gather_rgb(rgb_map, tc, pr.mask, rgb[t]);
         }
         float none[NT][1];
         NR_PRAGMA_UNROLL
@@ -162,7 +188,6 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
 
         // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
         float hit[NT], vis[NT];
-        float dbg_mu0[NT], dbg_mu1[NT], dbg_s0[NT], dbg_s1[NT], dbg_aw[NT], dbg_nu[NT];
         {
             float cat[NT][16], h1[NT][8], h2[NT][8], fin[NT][4];
             layer_fwd<L_DM1, NT, ACT_ELU>(W, lane, fray, none, h1);
@@ -210,7 +235,11 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
                 float v_, h_;
                 logistic_prob(tref[t], lo[t], hi[t], mu0[t], mu1[t], s0[t], s1[t], aw[t], nu[t], use_vis && HAS_VIS, v_, h_);
                 vis[t] = v_ * mask[t]; hit[t] = h_ * mask[t];
-                dbg_mu0[t] = mu0[t]; dbg_mu1[t] = mu1[t]; dbg_s0[t] = s0[t]; dbg_s1[t] = s1[t]; dbg_aw[t] = aw[t]; dbg_nu[t] = nu[t];
+                if (dbg_lane && pvalid[t]) {
+                    float* d_ = p.dbg + ((size_t)pidx[t] * nw + wave) * kDbgFields;
+                    d_[4] = hit[t]; d_[5] = vis[t]; d_[6] = mu0[t]; d_[7] = mu1[t]; d_[8] = s0[t]; d_[9] = s1[t];
+                    d_[10] = aw[t]; d_[11] = nu[t];
+                }
             }
         }
 
@@ -250,6 +279,8 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             for (int t = 0; t < NT; ++t) sn[t] = sigmoidf(o[t][0]);
         }
         // ---------------- cross-view weighted mean / variance       ibrnet.py:334-340 ---------------------
+        // Each statistic is all-reduced over the view-waves and immediately consumed by the owner waves as a
+        // K-slice of base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
         float msum[NT], wv[NT];
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) msum[t] = mask[t];
@@ -259,51 +290,62 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
 
         v4f accv[NT][4];
         {
-            float stat[4][NT * 11];   // mean0, var0, mean1, var1  ([t*11 + 0..7] img part, [t*11 + 8..10] rgb part)
+            v4f accg[OWN][NT];
             NR_PRAGMA_UNROLL
-            for (int k = 0; k < 2; ++k) {            // k = 0: weight0 = sigmoid(neuray_fc) * weight, k = 1: weight
-                float wk[NT];
+            for (int j = 0; j < OWN; ++j) {
+                const int mo = wave + j * nw;
+                const float4 b = nr_buf_ld4(W, g * 16, (bias_offset(L_BG) + (mo < 4 ? mo : 0) * 16) * 4);
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) wk[t] = k == 0 ? sn[t] * wv[t] : wv[t];
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) {
-                    NR_PRAGMA_UNROLL
-                    for (int s = 0; s < 8; ++s) stat[2 * k][t * 11 + s] = gi[t][s] * wk[t];
-                    NR_PRAGMA_UNROLL
-                    for (int j = 0; j < 3; ++j) stat[2 * k][t * 11 + 8 + j] = gr[t][j] * wk[t];
-                }
-                block_allreduce<NT * 11, RMAX, RED_SUM>(stat[2 * k], red, wave, nw, lane);
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) {
-                    NR_PRAGMA_UNROLL
-                    for (int s = 0; s < 8; ++s) { const float d_ = gi[t][s] - stat[2 * k][t * 11 + s]; stat[2 * k + 1][t * 11 + s] = wk[t] * (d_ * d_); }
-                    NR_PRAGMA_UNROLL
-                    for (int j = 0; j < 3; ++j) { const float d_ = gr[t][j] - stat[2 * k][t * 11 + 8 + j]; stat[2 * k + 1][t * 11 + 8 + j] = wk[t] * (d_ * d_); }
-                }
-                block_allreduce<NT * 11, RMAX, RED_SUM>(stat[2 * k + 1], red, wave, nw, lane);
+                for (int t = 0; t < NT; ++t) { accg[j][t][0] = b.x; accg[j][t][1] = b.y; accg[j][t][2] = b.z; accg[j][t][3] = b.w; }
             }
-            // base_fc.0, per-point part: W[:, 0:140] [mean0 var0 mean1 var1] + bias, tiles split over the waves
-            if (wave < nwork) {
-                float xq[NT][36];
+            float st[NT * 11], sv[NT * 11], wk[NT];
+            // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                wk[t] = sn[t] * wv[t];
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) {
-                    NR_PRAGMA_UNROLL
-                    for (int j = 0; j < 4; ++j) {
-                        NR_PRAGMA_UNROLL
-                        for (int s = 0; s < 8; ++s) xq[t][8 * j + s] = stat[j][t * 11 + s];
-                        xq[t][32 + j] = sel4(g, stat[j][t * 11 + 8], stat[j][t * 11 + 9], stat[j][t * 11 + 10], 0.0f);
-                    }
-                }
-                for (int mo = wave; mo < 4; mo += nw) {
-                    v4f acc[NT];
-                    const float4 b = ld4(W + bias_offset(L_BG) + (mo * 4 + g) * 4);
-                    NR_PRAGMA_UNROLL
-                    for (int t = 0; t < NT; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
-                    layer_tile<L_BG, NT>(W, lane, mo, xq, none, acc);
+                for (int s = 0; s < 8; ++s) st[t * 11 + s] = gi[t][s] * wk[t];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 3; ++j) st[t * 11 + 8 + j] = gr[t][j] * wk[t];
+            }
+            block_allreduce<NT * 11, RMAX, RED_SUM>(st, red, wave, nw, lane);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) { const float d_ = gi[t][s] - st[t * 11 + s]; sv[t * 11 + s] = wk[t] * (d_ * d_); }
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 3; ++j) { const float d_ = gr[t][j] - st[t * 11 + 8 + j]; sv[t * 11 + 8 + j] = wk[t] * (d_ * d_); }
+            }
+            bg_accumulate<NT, OWN, 0>(W, lane, g, wave, nw, st, accg);
+            block_allreduce<NT * 11, RMAX, RED_SUM>(sv, red, wave, nw, lane);
+            bg_accumulate<NT, OWN, 1>(W, lane, g, wave, nw, sv, accg);
+            // k = 1: weight -> mean1, var1
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) st[t * 11 + s] = gi[t][s] * wv[t];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 3; ++j) st[t * 11 + 8 + j] = gr[t][j] * wv[t];
+            }
+            block_allreduce<NT * 11, RMAX, RED_SUM>(st, red, wave, nw, lane);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 8; ++s) { const float d_ = gi[t][s] - st[t * 11 + s]; sv[t * 11 + s] = wv[t] * (d_ * d_); }
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 3; ++j) { const float d_ = gr[t][j] - st[t * 11 + 8 + j]; sv[t * 11 + 8 + j] = wv[t] * (d_ * d_); }
+            }
+            bg_accumulate<NT, OWN, 2>(W, lane, g, wave, nw, st, accg);
+            block_allreduce<NT * 11, RMAX, RED_SUM>(sv, red, wave, nw, lane);
+            bg_accumulate<NT, OWN, 3>(W, lane, g, wave, nw, sv, accg);
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < OWN; ++j) {
+                const int mo = wave + j * nw;
+                if (mo < 4) {
                     NR_PRAGMA_UNROLL
                     for (int t = 0; t < NT; ++t)
                         NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = accg[j][t][r];
                 }
             }
             __syncthreads();
@@ -316,7 +358,6 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
         }
         // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
         float x[NT][8], vis2[NT], z[NT];
-        float dbg_visp[NT];
         {
             float xq[NT][16], x1[NT][1], h64[NT][16];
             NR_PRAGMA_UNROLL
@@ -342,12 +383,12 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
                 for (int s = 0; s < 8; ++s) xin[t][s] = x[t][s] * wv[t];
             layer_fwd<L_VF1, NT, ACT_ELU>(W, lane, xin, none, h);
             layer_fwd<L_VF2, NT, ACT_ELU>(W, lane, h, none, y);
+            float visp[NT];
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) {
-                const float visp = sigmoidf(y[t][8]) * mask[t];      // sigmoid on an ELU output: quirk A.9.4
-                dbg_visp[t] = visp;
+                visp[t] = sigmoidf(y[t][8]) * mask[t];      // sigmoid on an ELU output: quirk A.9.4
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) { x[t][s] = x[t][s] + y[t][s]; xin[t][s] = x[t][s] * visp; }
+                for (int s = 0; s < 8; ++s) { x[t][s] = x[t][s] + y[t][s]; xin[t][s] = x[t][s] * visp[t]; }
             }
             layer_fwd<L_V21, NT, ACT_ELU>(W, lane, xin, none, h);
             layer_fwd<L_V22, NT, ACT_NONE>(W, lane, h, none, o);
@@ -363,7 +404,13 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             layer_fwd<L_RF2, NT, ACT_ELU>(W, lane, h16, none, h8);
             layer_fwd<L_RF3, NT, ACT_NONE>(W, lane, h8, none, o);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) z[t] = mask[t] > 0.0f ? o[t][0] : -1e9f;
+            for (int t = 0; t < NT; ++t) {
+                z[t] = mask[t] > 0.0f ? o[t][0] : -1e9f;
+                if (dbg_lane && pvalid[t]) {
+                    float* d_ = p.dbg + ((size_t)pidx[t] * nw + wave) * kDbgFields;
+                    d_[12] = sn[t]; d_[13] = visp[t]; d_[14] = vis2[t]; d_[15] = z[t];
+                }
+            }
         }
         // ---------------- cross-view: blending softmax, visibility-weighted mean/var  ibrnet.py:350-367 ---
         float zmax[NT];
@@ -372,7 +419,7 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
         block_allreduce<NT, RMAX, RED_MAX>(zmax, red, wave, nw, lane);
         float ev[NT], sums[NT * 2];
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) { ev[t] = expf(z[t] - zmax[t]); sums[2 * t] = vis2[t]; sums[2 * t + 1] = ev[t]; }
+        for (int t = 0; t < NT; ++t) { ev[t] = nr_fast_exp(z[t] - zmax[t]); sums[2 * t] = vis2[t]; sums[2 * t + 1] = ev[t]; }
         block_allreduce<NT * 2, RMAX, RED_SUM>(sums, red, wave, nw, lane);
         float big[NT * 12], wh[NT];
         NR_PRAGMA_UNROLL
@@ -386,32 +433,51 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             for (int j = 0; j < 3; ++j) big[t * 12 + 9 + j] = rgb[t][j] * beta;
         }
         block_allreduce<NT * 12, RMAX, RED_SUM>(big, red, wave, nw, lane);
-        float var[NT * 8];
+        // geometry_fc.0 (a14): owner waves stream the mean part, then the variance part   ibrnet.py:353-354
+        v4f accf[OWN][NT];
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t)
+        for (int j = 0; j < OWN; ++j) {
+            const int mo = wave + j * nw;
+            const float4 b = nr_buf_ld4(W, g * 16, (bias_offset(L_GF1) + (mo < 4 ? mo : 0) * 16) * 4);
             NR_PRAGMA_UNROLL
-            for (int s = 0; s < 8; ++s) { const float d_ = x[t][s] - big[t * 12 + s]; var[t * 8 + s] = wh[t] * (d_ * d_); }
-        block_allreduce<NT * 8, RMAX, RED_SUM>(var, red, wave, nw, lane);
-
-        // ---------------- geometry_fc (a14), tiles of layer 1 split over the waves   ibrnet.py:353-354 -----
-        if (wave < nwork) {
-            float xq[NT][16], x1[NT][1];
+            for (int t = 0; t < NT; ++t) { accf[j][t][0] = b.x; accf[j][t][1] = b.y; accf[j][t][2] = b.z; accf[j][t][3] = b.w; }
+        }
+        float var[NT * 8];
+        {
+            float xq[NT][8], x1[NT][1];
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) {
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) { xq[t][s] = big[t * 12 + s]; xq[t][8 + s] = var[t * 8 + s]; }
+                for (int s = 0; s < 8; ++s) {
+                    const float d_ = x[t][s] - big[t * 12 + s];
+                    var[t * 8 + s] = wh[t] * (d_ * d_);
+                    xq[t][s] = big[t * 12 + s];
+                }
                 x1[t][0] = sel4(g, big[t * 12 + 8] / (float)nw, 0.0f, 0.0f, 0.0f);
             }
-            for (int mo = wave; mo < 4; mo += nw) {
-                v4f acc[NT];
-                const float4 b = ld4(W + bias_offset(L_GF1) + (mo * 4 + g) * 4);
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < OWN; ++j) {
+                const int mo = wave + j * nw;
+                if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, lane, mo, xq, x1, accf[j]);
+            }
+        }
+        block_allreduce<NT * 8, RMAX, RED_SUM>(var, red, wave, nw, lane);
+        {
+            float xq[NT][8];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t)
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
-                layer_tile<L_GF1, NT>(W, lane, mo, xq, x1, acc);
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t)
+                for (int s = 0; s < 8; ++s) xq[t][s] = var[t * 8 + s];
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < OWN; ++j) {
+                const int mo = wave + j * nw;
+                if (mo < 4) {
+                    layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, lane, mo, xq, none, accf[j]);
                     NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu(acc[t][r]);
+                    for (int t = 0; t < NT; ++t)
+                        NR_PRAGMA_UNROLL
+                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu(accf[j][t][r]);
+                }
             }
         }
         __syncthreads();
@@ -420,7 +486,7 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t)
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) h[t][k] = xch[((k >> 2) * NT + t) * 4 * 64 + (k & 3) * 64 + lane];
+                for (int k = 0; k < 16; ++k) h[t][k] = xch[(((k >> 2) * NT + t) * 4 + (k & 3)) * 64 + lane];
             layer_fwd<L_GF2, NT, ACT_ELU>(W, lane, h, none, G);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t)
@@ -433,16 +499,6 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
                 if (pvalid[t])
                     *reinterpret_cast<float4*>(p.point_out + (size_t)pidx[t] * kPointRec + 16) =
                         make_float4(big[t * 12 + 9], big[t * 12 + 10], big[t * 12 + 11], msum[t]);
-        }
-        if (p.dbg && g == 0) {
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
-                if (pvalid[t]) {
-                    float* d = p.dbg + ((size_t)pidx[t] * nw + wave) * kDbgFields;
-                    d[0] = mask[t]; d[1] = dbg_u[t]; d[2] = dbg_v[t]; d[3] = dbg_z[t]; d[4] = hit[t]; d[5] = vis[t];
-                    d[6] = dbg_mu0[t]; d[7] = dbg_mu1[t]; d[8] = dbg_s0[t]; d[9] = dbg_s1[t]; d[10] = dbg_aw[t];
-                    d[11] = dbg_nu[t]; d[12] = sn[t]; d[13] = dbg_visp[t]; d[14] = vis2[t]; d[15] = z[t];
-                }
         }
     }
 }

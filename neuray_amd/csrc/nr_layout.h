@@ -49,7 +49,7 @@ constexpr LayerShape kShape[L_COUNT] = {
     {2, 2, 1}, {2, 2, 0},
     {1, 0, 1}, {3, 1, 0},
     {1, 2, 0}, {1, 1, 0},
-    {4, 9, 0}, {4, 4, 1}, {2, 4, 0},
+    {4, 8, 4}, {4, 4, 1}, {2, 4, 0},
     {2, 2, 0}, {3, 2, 0},
     {2, 2, 0}, {1, 2, 0},
     {1, 2, 2}, {1, 1, 0}, {1, 1, 0},

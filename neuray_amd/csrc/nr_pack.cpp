@@ -141,8 +141,8 @@ int pack_pass_weights(const float* const* t, float* dst) {
     {
         LayerMaps m; m.out_map = out_natural(4, 64);
         for (int j = 0; j < 4; ++j) in_gathered32(m.in_map, 35 * j + 3);
-        for (int j = 0; j < 4; ++j)                       // quad 8: k-step j = rgb part of statistic j
-            for (int g = 0; g < 4; ++g) m.in_map.push_back(g < 3 ? 35 * j + g : -1);
+        for (int j = 0; j < 4; ++j)                       // single k-step j = rgb part of statistic j
+            for (int g = 0; g < 4; ++g) m.in1_map.push_back(g < 3 ? 35 * j + g : -1);
         pack_layer(dst, L_BG, t[T_BASE0_W], 207, t[T_BASE0_B], m);
         LayerMaps v; v.out_map = out_natural(4, 64);
         in_gathered32(v.in_map, 140 + 3);

@@ -33,6 +33,80 @@ __device__ __forceinline__ v4f nr_mfma16(float a, float b, v4f c) {
 
 #define NR_WAVE 64
 
+// ---- read-only buffers addressed as {SGPR descriptor, one per-lane byte offset VGPR, scalar byte offset} --------
+// buffer_load needs no per-load 64-bit address register pair; with plain pointers hipcc hoisted ~150 loop-invariant
+// fragment addresses out of the point loop and spilled them.
+#ifdef NEURAY_EMU
+struct nr_buf { const char* p; };
+static inline nr_buf nr_make_buf(const float* p, size_t bytes) { (void)bytes; return nr_buf{(const char*)p}; }
+static inline float4 nr_buf_ld4(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
+static inline float nr_buf_ld1(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
+#else
+// pointer-based variant (debug A/B): same interface, plain global loads
+struct nr_pbuf { const char* p; };
+__device__ __forceinline__ nr_pbuf nr_make_pbuf(const float* p, size_t) { return nr_pbuf{(const char*)p}; }
+__device__ __forceinline__ float4 nr_buf_ld4(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
+__device__ __forceinline__ float nr_buf_ld1(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
+struct nr_buf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ nr_buf nr_make_buf(const float* p, size_t bytes) {
+    nr_buf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+    return b;
+}
+__device__ __forceinline__ float4 nr_buf_ld4(nr_buf b, int voff, int soff) {
+    // NOTE: cast the WHOLE vector.  Element-wise `__builtin_bit_cast(float, u.x)` on the builtin's result makes
+    // hipcc (ROCm 7.2) narrow the load to buffer_load_dword and replicate .x into y/z/w (tests/hw/bufprobe.hip).
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4u u = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0);
+    const v4f_ f = __builtin_bit_cast(v4f_, u);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ float nr_buf_ld1(nr_buf b, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+#endif
+
+#if defined(NEURAY_EMU)
+typedef nr_buf nr_wbuf; typedef nr_buf nr_mbuf;
+#define nr_make_wbuf nr_make_buf
+#define nr_make_mbuf nr_make_buf
+#else
+#ifdef NR_PTR_WEIGHTS
+typedef nr_pbuf nr_wbuf;
+#define nr_make_wbuf nr_make_pbuf
+#else
+typedef nr_buf nr_wbuf;
+#define nr_make_wbuf nr_make_buf
+#endif
+#ifdef NR_PTR_MAPS
+typedef nr_pbuf nr_mbuf;
+#define nr_make_mbuf nr_make_pbuf
+#else
+typedef nr_buf nr_mbuf;
+#define nr_make_mbuf nr_make_buf
+#endif
+#endif
+
+// scheduling fence: keeps hipcc from hoisting the next layers' weight-fragment loads across layer boundaries (it
+// otherwise clusters loads until it overshoots the VGPR budget and spills)
+#ifdef NEURAY_EMU
+#define NR_SCHED_FENCE() do {} while (0)
+#else
+#define NR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32: ~1 ulp each)
+#ifdef NEURAY_EMU
+static inline float nr_fast_exp(float x) { return expf(x); }
+static inline float nr_fast_log(float x) { return logf(x); }
+static inline float nr_fast_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float nr_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float nr_fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float nr_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
 // ---- exactly rounded single operations (the "rounding contract") --------------------------------------
 // HIP's __fadd_rn/__fmul_rn are plain `a + b` / `a * b` compiled with fp-contract=fast, so a product feeding a
 // sum is still fused into an FMA after inlining.  These helpers are compiled with contraction off (the fmul and

@@ -88,7 +88,7 @@ typedef struct NeurayPointsArgs {
     int has_vis_head;    /* this pass's decoder has a vis_decoder */
     int use_vis;         /* the COARSE decoder's cfg['use_vis'] (renderer.py:75 uses it for both passes) */
     float var_bias;      /* dist_decoder cfg['bias_val'] (0.05) */
-    int tiles_per_wave;  /* 0 = default */
+    int views_per_wave;  /* reference views processed by one wavefront: 0 = default (2), 1 or 2 */
 } NeurayPointsArgs;
 int neuray_render_points(const NeurayPointsArgs* args, void* stream);
 

@@ -30,7 +30,7 @@ class NeurayPointsArgs(C.Structure):
         ('dbg_dev', C.c_void_p),
         ('rfn', C.c_int), ('rn', C.c_int), ('dn', C.c_int), ('h', C.c_int), ('w', C.c_int), ('fh', C.c_int),
         ('fw', C.c_int), ('has_vis_head', C.c_int), ('use_vis', C.c_int), ('var_bias', C.c_float),
-        ('tiles_per_wave', C.c_int),
+        ('views_per_wave', C.c_int),
     ]
 
 

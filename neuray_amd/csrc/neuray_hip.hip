@@ -42,18 +42,18 @@ static_assert(NEURAY_PASS_TENSORS == nr::T_COUNT, "abi");
 static_assert(NEURAY_DBG_FIELDS == nr::kDbgFields, "abi");
 static_assert(NEURAY_MAX_SAMPLES == nr::kMaxSamples, "abi");
 
-template <int NT, bool HAS_VIS, int OWN>
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MINW>
 int launch_points_own(const nr::PointParams& p, void* stream) {
     const int npts = p.rn * p.dn;
-    const size_t smem = nr::point_smem_bytes<NT>(p.rfn);
+    const int nwaves = (p.rfn + VPW - 1) / VPW;
+    const size_t smem = nr::point_smem_bytes<NT>(nwaves);
     if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
     // persistent-style grid: enough workgroups to fill 256 CUs several times over, grid-stride beyond
-    int grid = grid_for(npts, 16 * NT, 256 * 8);
+    int grid = grid_for(npts, 16 * NT, 256 * 16);
     if (const char* e = getenv("NEURAY_MAX_GRID")) grid = grid < atoi(e) ? grid : atoi(e);   // test knob: force grid-stride
-    const int threads = 64 * p.rfn;
-    // one build per (NT, vis, OWN): __launch_bounds__(1024) caps the kernel at 128 VGPRs, so two 8-wave workgroups
-    // (rfn = 8) share a CU (4 waves per SIMD) - measured faster than the 162-VGPR / 1-workgroup build
-    auto k = nr::points_kernel<NT, HAS_VIS, OWN, 1024>;
+    const int threads = 64 * nwaves;
+    // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")
+    auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW>;
 #ifndef NEURAY_EMU
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
@@ -61,11 +61,22 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     return check_launch("neuray_render_points");
 }
 
-template <int NT, bool HAS_VIS>
+template <int NT, int VPW, bool HAS_VIS, int MINW>
 int launch_points(const nr::PointParams& p, void* stream) {
-    if (p.rfn >= 4) return launch_points_own<NT, HAS_VIS, 1>(p, stream);
-    if (p.rfn >= 2) return launch_points_own<NT, HAS_VIS, 2>(p, stream);
-    return launch_points_own<NT, HAS_VIS, 4>(p, stream);
+    const int nwaves = (p.rfn + VPW - 1) / VPW;
+    if (nwaves >= 4) return launch_points_own<NT, VPW, HAS_VIS, 1, MINW>(p, stream);
+    if (nwaves >= 2) return launch_points_own<NT, VPW, HAS_VIS, 2, MINW>(p, stream);
+    return launch_points_own<NT, VPW, HAS_VIS, 4, MINW>(p, stream);
+}
+
+// Built decompositions (measured on MI355X, DESIGN.md "point kernel tuning"):
+//   views_per_wave = 2, 168 VGPRs, 3 waves per SIMD  - default (1.75 M rays/s on the lego-800 workload)
+//   views_per_wave = 1, 128 VGPRs, 4 waves per SIMD  - single reference view, and the A/B reference
+template <bool HAS_VIS>
+int launch_points_cfg(const nr::PointParams& p, int vpw, void* stream) {
+    if (vpw == 2) return launch_points<1, 2, HAS_VIS, 3>(p, stream);
+    if (vpw == 1) return launch_points<1, 1, HAS_VIS, 4>(p, stream);
+    return fail("neuray_render_points: views_per_wave=%d is not built (1 or 2)", vpw);
 }
 
 }  // namespace
@@ -128,14 +139,15 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev;
     p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
     p.use_vis = a->use_vis; p.var_bias = a->var_bias;
-    int nt = a->tiles_per_wave ? a->tiles_per_wave : 2;
-    if (const char* e = getenv("NEURAY_NT")) nt = atoi(e);   // tuning knob
+    p.stagger_groups = getenv("NEURAY_STAGGER") ? atoi(getenv("NEURAY_STAGGER")) : 0;      // tuning knobs
+    p.stagger_units = getenv("NEURAY_STAGGER_UNITS") ? atoi(getenv("NEURAY_STAGGER_UNITS")) : 6;
+    // work decomposition: reference views processed per wave (0 = default)
+    int vpw = a->views_per_wave ? a->views_per_wave : (a->rfn >= 2 ? 2 : 1);
+    if (const char* e = getenv("NEURAY_VPW")) vpw = atoi(e);     // tuning / test knob
     // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
     // reference-view path when the coarse decoder has use_vis = False: quirk A.9.2)
     const bool vis = a->has_vis_head && a->use_vis;
-    if (nt == 1) return vis ? launch_points<1, true>(p, stream) : launch_points<1, false>(p, stream);
-    if (nt == 2) return vis ? launch_points<2, true>(p, stream) : launch_points<2, false>(p, stream);
-    return fail("neuray_render_points: tiles_per_wave=%d not built (1 or 2)", nt);
+    return vis ? launch_points_cfg<true>(p, vpw, stream) : launch_points_cfg<false>(p, vpw, stream);
 }
 
 int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {

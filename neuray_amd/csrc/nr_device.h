@@ -26,6 +26,11 @@ __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
+#elif defined(NR_ABLATE) && (NR_ABLATE & 2)
+__device__ __forceinline__ float elu(float x) { return x; }
+__device__ __forceinline__ float softplus(float x) { return x; }
+__device__ __forceinline__ float sigmoidf(float x) { return x; }
+__device__ __forceinline__ float tanh_(float x) { return x; }
 #else
 __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : nr_fast_exp(x) - 1.0f; }
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : nr_fast_log(1.0f + nr_fast_exp(x)); }
@@ -136,26 +141,57 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_fu
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// weight-fragment / map loads (separate entry points so that timing ablations can stub one class)
+__device__ __forceinline__ float4 wld4(nr_wbuf W, int voff, int soff) {
+#if defined(NR_ABLATE) && (NR_ABLATE & 4)
+    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
+#else
+    return nr_buf_ld4(W, voff, soff);
+#endif
+}
+__device__ __forceinline__ float wld1(nr_wbuf W, int voff, int soff) {
+#if defined(NR_ABLATE) && (NR_ABLATE & 4)
+    return 1e-3f * voff;
+#else
+    return nr_buf_ld1(W, voff, soff);
+#endif
+}
+// a staged phase of the packed weights in LDS: same byte offsets as the global buffer, rebased to the phase start
+struct LdsW { const float* base; int begin_bytes; };
+__device__ __forceinline__ float4 wld4(LdsW w, int voff, int soff) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
+__device__ __forceinline__ float wld1(LdsW w, int voff, int soff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
+__device__ __forceinline__ float4 mld4(nr_mbuf M, int voff, int soff) {
+#if defined(NR_ABLATE) && (NR_ABLATE & 16)
+    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
+#else
+    return nr_buf_ld4(M, voff, soff);
+#endif
+}
+
 __device__ __forceinline__ float blend4(float a, float b, float c, float d, const Taps& t) {
     return fmaf(d, t.w11, fmaf(c, t.w01, fmaf(b, t.w10, a * t.w00)));
 }
 
 // channels-last gather of 8 consecutive channels (this lane group's slice, byte offset goff = 32*g) of a
 // 32-channel map: two 16-byte loads per tap, a texel's 128-byte line is covered by the 4 lane groups
-__device__ __forceinline__ void gather8(nr_mbuf map, int goff, const Taps& t, float mask, float (&out)[8]) {
-    const float4 a0 = nr_buf_ld4(map, t.o00 * 128 + goff, 0), a1 = nr_buf_ld4(map, t.o00 * 128 + goff, 16);
-    const float4 b0 = nr_buf_ld4(map, t.o10 * 128 + goff, 0), b1 = nr_buf_ld4(map, t.o10 * 128 + goff, 16);
-    const float4 c0 = nr_buf_ld4(map, t.o01 * 128 + goff, 0), c1 = nr_buf_ld4(map, t.o01 * 128 + goff, 16);
-    const float4 d0 = nr_buf_ld4(map, t.o11 * 128 + goff, 0), d1 = nr_buf_ld4(map, t.o11 * 128 + goff, 16);
+__device__ __forceinline__ void gather8(nr_mbuf map, int goff, int soff, const Taps& t, float mask, float (&out)[8]) {
+    const float4 a0 = mld4(map, t.o00 * 128 + goff, soff), a1 = mld4(map, t.o00 * 128 + goff, soff + 16);
+    const float4 b0 = mld4(map, t.o10 * 128 + goff, soff), b1 = mld4(map, t.o10 * 128 + goff, soff + 16);
+    const float4 c0 = mld4(map, t.o01 * 128 + goff, soff), c1 = mld4(map, t.o01 * 128 + goff, soff + 16);
+    const float4 d0 = mld4(map, t.o11 * 128 + goff, soff), d1 = mld4(map, t.o11 * 128 + goff, soff + 16);
     out[0] = blend4(a0.x, b0.x, c0.x, d0.x, t) * mask; out[1] = blend4(a0.y, b0.y, c0.y, d0.y, t) * mask;
     out[2] = blend4(a0.z, b0.z, c0.z, d0.z, t) * mask; out[3] = blend4(a0.w, b0.w, c0.w, d0.w, t) * mask;
     out[4] = blend4(a1.x, b1.x, c1.x, d1.x, t) * mask; out[5] = blend4(a1.y, b1.y, c1.y, d1.y, t) * mask;
     out[6] = blend4(a1.z, b1.z, c1.z, d1.z, t) * mask; out[7] = blend4(a1.w, b1.w, c1.w, d1.w, t) * mask;
 }
 
-__device__ __forceinline__ void gather_rgb(nr_mbuf map, const Taps& t, float mask, float (&out)[3]) {
-    const float4 a = nr_buf_ld4(map, t.o00 * 16, 0), b = nr_buf_ld4(map, t.o10 * 16, 0);
-    const float4 c = nr_buf_ld4(map, t.o01 * 16, 0), d = nr_buf_ld4(map, t.o11 * 16, 0);
+__device__ __forceinline__ void gather_rgb(nr_mbuf map, int soff, const Taps& t, float mask, float (&out)[3]) {
+    const float4 a = mld4(map, t.o00 * 16, soff), b = mld4(map, t.o10 * 16, soff);
+    const float4 c = mld4(map, t.o01 * 16, soff), d = mld4(map, t.o11 * 16, soff);
     out[0] = blend4(a.x, b.x, c.x, d.x, t) * mask;
     out[1] = blend4(a.y, b.y, c.y, d.y, t) * mask;
     out[2] = blend4(a.z, b.z, c.z, d.z, t) * mask;
@@ -181,82 +217,99 @@ __device__ __forceinline__ void logistic_prob(float t, float lo, float hi, float
 //   xq[t][4*kq + j] : B operands of the quad K-steps,  x1[t][k1] : B operands of the single K-steps
 //   acc[t][mo]      : accumulators (D layout), caller decides the initial value
 // ---------------------------------------------------------------------------------------------
-template <int L, int NT>
-__device__ __forceinline__ void layer_bias(nr_wbuf W, int lane, v4f (&acc)[NT][kShape[L].mt_out]) {
+template <int L, int NT, class WS>
+__device__ __forceinline__ void layer_bias(WS W, int lane, v4f (&acc)[NT][kShape[L].mt_out]) {
     constexpr int MT = kShape[L].mt_out;
     NR_PRAGMA_UNROLL
     for (int mo = 0; mo < MT; ++mo) {
-        const float4 b = nr_buf_ld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
+        const float4 b = wld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) { acc[t][mo][0] = b.x; acc[t][mo][1] = b.y; acc[t][mo][2] = b.z; acc[t][mo][3] = b.w; }
     }
 }
 
-// accumulate one output tile `mo` (may be a runtime value) of layer L
-template <int L, int NT, int KQX, int K1X>
-__device__ __forceinline__ void layer_tile(nr_wbuf W, int lane, int mo,
-                                           const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
-    constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
-    static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
+// One quad of A fragments feeds 4 K-steps x NT slots of MFMAs.
+template <int NT, int KQX>
+__device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (&xq)[NT][KQX], v4f (&acc)[NT]) {
     NR_PRAGMA_UNROLL
-    for (int kq = 0; kq < KQ; ++kq) {
-        const float4 a = nr_buf_ld4(W, lane * 16, (quads_offset(L) + (mo * KQ + kq) * 256) * 4);
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
-            acc[t] = nr_mfma16(a.y, xq[t][4 * kq + 1], acc[t]);
-            acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
-            acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
-        }
-    }
+    for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
     NR_PRAGMA_UNROLL
-    for (int k1 = 0; k1 < K1; ++k1) {
-        const float a = nr_buf_ld1(W, lane * 4, (single_offset(L) + (mo * K1 + k1) * 64) * 4);
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a, x1[t][k1], acc[t]);
-    }
+    for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.y, xq[t][4 * kq + 1], acc[t]);
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
 }
 
-// accumulate a K-slice (quads [KQ0, KQ0+KQN), singles [K10, K10+K1N)) of output tile `mo` of layer L; the
-// operand arrays hold only the slice.  Used to stream cross-view statistics into an owner wave's accumulator.
-template <int L, int NT, int KQ0, int KQN, int K10, int K1N, int KQX, int K1X>
-__device__ __forceinline__ void layer_tile_slice(nr_wbuf W, int lane, int mo,
+// accumulate a K-slice (quads [KQ0, KQ0+KQN), singles [K10, K10+K1N)) of output tile `mo` (may be a runtime value)
+// of layer L; the operand arrays hold only the slice.  The fragment stream is software-pipelined: the load of
+// fragment i+1 is issued before the MFMAs of fragment i (hipcc otherwise emits load -> wait -> MFMAs per fragment and
+// exposes the full LDS / L2 latency in front of every 4*NT MFMAs).
+template <int L, int NT, int KQ0, int KQN, int K10, int K1N, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
                                                  const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
     constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
     static_assert(KQ0 + KQN <= KQ && K10 + K1N <= K1, "slice outside the layer");
     static_assert(KQX >= (KQN > 0 ? 4 * KQN : 1) && K1X >= (K1N > 0 ? K1N : 1), "operand arrays too small");
+    float s1[K1N > 0 ? K1N : 1];
     NR_PRAGMA_UNROLL
-    for (int kq = 0; kq < KQN; ++kq) {
-        const float4 a = nr_buf_ld4(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0 + kq) * 256) * 4);
+    for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, lane * 4, (single_offset(L) + (mo * K1 + K10 + k1) * 64) * 4);
+    if (KQN > 0) {
+        float4 cur = wld4(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0) * 256) * 4);
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
-            acc[t] = nr_mfma16(a.y, xq[t][4 * kq + 1], acc[t]);
-            acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
-            acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
+        for (int kq = 0; kq < KQN; ++kq) {
+            float4 nxt = cur;
+            if (kq + 1 < KQN) nxt = wld4(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0 + kq + 1) * 256) * 4);
+            NR_PIN();
+            mfma_quad<NT>(cur, kq, xq, acc);
+            cur = nxt;
         }
     }
     NR_PRAGMA_UNROLL
-    for (int k1 = 0; k1 < K1N; ++k1) {
-        const float a = nr_buf_ld1(W, lane * 4, (single_offset(L) + (mo * K1 + K10 + k1) * 64) * 4);
+    for (int k1 = 0; k1 < K1N; ++k1)
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a, x1[t][k1], acc[t]);
-    }
+        for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(s1[k1], x1[t][k1], acc[t]);
 }
 
-template <int L, int NT, int KQX, int K1X>
-__device__ __forceinline__ void layer_acc(nr_wbuf W, int lane, const float (&xq)[NT][KQX],
+// accumulate one whole output tile `mo` of layer L
+template <int L, int NT, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_tile(WS W, int lane, int mo,
+                                           const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
+    layer_tile_slice<L, NT, 0, kShape[L].kq, 0, kShape[L].k1>(W, lane, mo, xq, x1, acc);
+}
+
+// all output tiles of layer L; the fragment stream (tile-major) is pipelined across tile boundaries too
+template <int L, int NT, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_acc(WS W, int lane, const float (&xq)[NT][KQX],
                                           const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out]) {
-    constexpr int MT = kShape[L].mt_out;
+    constexpr int MT = kShape[L].mt_out, KQ = kShape[L].kq, K1 = kShape[L].k1;
+    static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
+    float s1[MT * K1 > 0 ? MT * K1 : 1];
     NR_PRAGMA_UNROLL
-    for (int mo = 0; mo < MT; ++mo) {
-        v4f a[NT];
+    for (int i = 0; i < MT * K1; ++i) s1[i] = wld1(W, lane * 4, (single_offset(L) + i * 64) * 4);
+    if (KQ > 0) {
+        float4 cur = wld4(W, lane * 16, quads_offset(L) * 4);
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) a[t] = acc[t][mo];
-        layer_tile<L, NT>(W, lane, mo, xq, x1, a);
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
+        for (int i = 0; i < MT * KQ; ++i) {
+            float4 nxt = cur;
+            if (i + 1 < MT * KQ) nxt = wld4(W, lane * 16, (quads_offset(L) + (i + 1) * 256) * 4);
+            NR_PIN();
+            const int mo = i / KQ, kq = i % KQ;
+            v4f a[NT];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) a[t] = acc[t][mo];
+            mfma_quad<NT>(cur, kq, xq, a);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
+            cur = nxt;
+        }
     }
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo)
+        NR_PRAGMA_UNROLL
+        for (int k1 = 0; k1 < K1; ++k1)
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) acc[t][mo] = nr_mfma16(s1[mo * K1 + k1], x1[t][k1], acc[t][mo]);
 }
 
 // y = act(W x + b) with D-layout output registers y[t][4*mo + r]
@@ -267,8 +320,8 @@ template <int A> __device__ __forceinline__ float apply_act(float x) {
     return x;
 }
 
-template <int L, int NT, int A, int KQX, int K1X>
-__device__ __forceinline__ void layer_fwd(nr_wbuf W, int lane, const float (&xq)[NT][KQX],
+template <int L, int NT, int A, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_fwd(WS W, int lane, const float (&xq)[NT][KQX],
                                           const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {
     constexpr int MT = kShape[L].mt_out;
     v4f acc[NT][MT];
@@ -285,6 +338,34 @@ __device__ __forceinline__ void layer_fwd(nr_wbuf W, int lane, const float (&xq)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage one phase of the packed weights into LDS, cooperatively (every thread copies 16-byte pieces), so that the
+// waves read their MFMA A fragments with ds_read_b128 instead of stalling on an L2 round trip per layer.
+// Barriers: one before the copy (the previous phase's readers are done), one after (the copy is visible).
+// ---------------------------------------------------------------------------------------------
+template <int PH>
+__device__ __forceinline__ LdsW stage_phase(float* wl, nr_wbuf W, int tid, int nthreads) {
+    constexpr int begin = phase_begin(PH), n4 = phase_floats(PH) / 4;
+    static_assert(phase_floats(PH) % 4 == 0 && phase_floats(PH) <= kWeightLdsFloats, "phase does not fit the LDS stage");
+    float4* dst = reinterpret_cast<float4*>(wl);
+    __syncthreads();
+    for (int i = tid; i < n4; i += 4 * nthreads) {
+        float4 v[4];
+        NR_PRAGMA_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            const int j = i + u * nthreads;
+            v[u] = nr_buf_ld4(W, (j < n4 ? j : 0) * 16, begin * 4);
+        }
+        NR_PRAGMA_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            const int j = i + u * nthreads;
+            if (j < n4) dst[j] = v[u];
+        }
+    }
+    __syncthreads();
+    return LdsW{wl, begin * 4};
+}
+
+// ---------------------------------------------------------------------------------------------
 // block-wide all-reduce over the view-waves (one wave per reference view).
 //   red: LDS scratch of (nw + 1) * RMAX * 64 floats.  Deterministic (views summed in order 0..nw-1),
 //   identical result in every wave.  Two barriers per round (reduce-scatter, then all-gather).
@@ -293,6 +374,9 @@ enum RedOp { RED_SUM, RED_MAX };
 template <int R, int RMAX, int OP>
 __device__ __forceinline__ void block_allreduce(float (&v)[R], float* red, int wave, int nw, int lane) {
     static_assert(R <= RMAX, "allreduce scratch too small");
+#if defined(NR_ABLATE) && (NR_ABLATE & 1)
+    return;
+#endif
     NR_PRAGMA_UNROLL
     for (int r = 0; r < R; ++r) red[(wave * RMAX + r) * 64 + lane] = v[r];
     __syncthreads();

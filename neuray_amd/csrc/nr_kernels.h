@@ -81,6 +81,8 @@ struct PointParams {
     int rfn, rn, dn, h, w, fh, fw;
     int use_vis;               // the COARSE decoder's use_vis governs compute_prob in both passes (renderer.py:75)
     float var_bias;            // AddBias value of var_decoder (dist_decoder.py:81)
+    int stagger_groups;        // >1: delay workgroup start by (blockIdx/256 % groups) * stagger_units sleeps
+    int stagger_units;
 };
 
 constexpr int kDbgFields = 16;
@@ -93,7 +95,9 @@ template <int NT>
 constexpr int point_rmax() { return 12 * NT; }
 
 template <int NT>
-inline size_t point_smem_bytes(int rfn) { return sizeof(float) * 64 * ((size_t)(rfn + 1) * point_rmax<NT>() + 16 * NT); }
+inline size_t point_smem_bytes(int nwaves) {
+    return sizeof(float) * (64 * ((size_t)(nwaves + 1) * point_rmax<NT>() + 16 * NT) + kWeightLdsFloats);
+}
 
 // owner waves accumulate one cross-view statistic (8 image channels in gathered order + 3 rgb channels per tile)
 // into their tile(s) of base_fc.0's per-point part: statistic STAT uses quads [2*STAT, 2*STAT+2) and single STAT
@@ -114,38 +118,65 @@ __device__ __forceinline__ void bg_accumulate(nr_wbuf W, int lane, int g, int wa
     }
 }
 
-// Point kernel.  One workgroup = rfn waves (wave v <-> reference view v) x NT tiles of 16 sample points.
+// sum (or max) over the VPW view slots of each tile, then over the waves of the workgroup
+template <int NT, int VPW, int R, int RMAX, int OP>
+__device__ __forceinline__ void view_allreduce(const float (&v)[NT * VPW][R], float (&out)[NT * R], float* red, int wave,
+                                               int nw, int lane) {
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int r = 0; r < R; ++r) {
+            float a = v[t][r];
+            NR_PRAGMA_UNROLL
+            for (int vv = 1; vv < VPW; ++vv) a = (OP == RED_SUM) ? a + v[vv * NT + t][r] : fmaxf(a, v[vv * NT + t][r]);
+            out[t * R + r] = a;
+        }
+    block_allreduce<NT * R, RMAX, OP>(out, red, wave, nw, lane);
+}
+
+// Point kernel.  One workgroup = ceil(rfn / VPW) waves x NT tiles of 16 sample points; wave w processes the reference
+// views [w*VPW, w*VPW + VPW) of every tile ("slots": slot s = vv*NT + t).  The slots of a wave share every weight
+// fragment and give the MFMA pipe NS independent accumulator chains.
 //   OWN = number of 16-feature output tiles of the per-point layers (base_fc.0 global part, geometry_fc.0) a wave
-//         owns: 1 for rfn >= 4, 2 for rfn in {2,3}, 4 for rfn = 1.
-template <int NT, bool HAS_VIS, int OWN, int MAXT>
-__global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
+//         owns: ceil(4 / nwaves).
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW>
+__global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     constexpr int RMAX = point_rmax<NT>();
+    constexpr int NS = NT * VPW;
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
-    const int nw = p.rfn;
+    const int nw = (p.rfn + VPW - 1) / VPW;          // waves per workgroup
     const int g = lane >> 4, c = lane & 15;
     float* red = smem;
     float* xch = smem + (size_t)(nw + 1) * RMAX * 64;
+    float* wl = xch + 16 * NT * 64;                  // staged weights of the current phase
+    const int tid = threadIdx.x, nthreads = 64 * nw;
     const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
-    const float* __restrict__ vc = p.view_const + wave * kViewConst;
     const float* __restrict__ qc = p.que_const;
-    const float vnearp = vc[15], vfarp = vc[16];
     const float qnearp = qc[24], qfarp = qc[25];
     const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
-    const nr_mbuf rf_map = nr_make_mbuf(p.ray_feats + (size_t)wave * fmap, sizeof(float) * fmap);
-    const nr_mbuf if_map = nr_make_mbuf(p.img_feats + (size_t)wave * fmap, sizeof(float) * fmap);
-    const nr_mbuf rgb_map = nr_make_mbuf(p.rgba + (size_t)wave * imap, sizeof(float) * imap);
+    const nr_mbuf rf_map = nr_make_mbuf(p.ray_feats, sizeof(float) * fmap * p.rfn);
+    const nr_mbuf if_map = nr_make_mbuf(p.img_feats, sizeof(float) * fmap * p.rfn);
+    const nr_mbuf rgb_map = nr_make_mbuf(p.rgba, sizeof(float) * imap * p.rfn);
     const int goff = 32 * g;
     const int npts = p.rn * p.dn;
     const int dn = p.dn;
     const bool use_vis = p.use_vis != 0;
     const bool dbg_lane = (p.dbg != nullptr) && (g == 0);
+#ifndef NEURAY_EMU
+    // de-phase the workgroups that share a CU: identical work + simultaneous start would keep their memory phases
+    // and MFMA phases aligned for the whole launch, so the matrix pipe idles while everybody loads
+    if (p.stagger_groups > 1) {
+        const int d = (int)((blockIdx.x / 256) % p.stagger_groups) * p.stagger_units;
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     for (int base = blockIdx.x * (16 * NT); base < npts; base += gridDim.x * (16 * NT)) {
         // ---------------- geometry + gather (a2-a8) -------------------------------------------
         int pidx[NT]; bool pvalid[NT];
-        float mask[NT], dlt[NT][4], fray[NT][8], fimg[NT][8], rgb[NT][3], tref[NT], lo[NT], hi[NT];
+        float mask[NS], dlt[NS][4], fray[NS][8], fimg[NS][8], rgb[NS][3], tref[NS], lo[NT], hi[NT];
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) {
             int pi = base + 16 * t + c;
@@ -167,177 +198,183 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             const float px = rn_add(r.cx, rn_mul(r.dx, d));
             const float py = rn_add(r.cy, rn_mul(r.dy, d));
             const float pz = rn_add(r.cz, rn_mul(r.dz, d));
-            const Proj pr = project_point(vc, px, py, pz, (float)p.w, (float)p.h);
-            mask[t] = pr.mask;
-            dlt[t][0] = pr.dirx - r.qx; dlt[t][1] = pr.diry - r.qy; dlt[t][2] = pr.dirz - r.qz;
-            dlt[t][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
-            tref[t] = norm_inv_depth(fmaxf(pr.z, 1e-5f), vnearp, vfarp);
-            if (dbg_lane && pvalid[t]) {
-                float* d_ = p.dbg + ((size_t)pi * nw + wave) * kDbgFields;
-                d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
+            NR_PRAGMA_UNROLL
+            for (int vv = 0; vv < VPW; ++vv) {
+                const int s = vv * NT + t;
+                const int vraw = wave * VPW + vv;
+                const bool vok = vraw < p.rfn;                // padding view when rfn % VPW != 0: masked out
+                const int view = vok ? vraw : p.rfn - 1;
+                const float* __restrict__ vc = p.view_const + view * kViewConst;
+                Proj pr = project_point(vc, px, py, pz, (float)p.w, (float)p.h);
+                if (!vok) pr.mask = 0.0f;
+                mask[s] = pr.mask;
+                dlt[s][0] = pr.dirx - r.qx; dlt[s][1] = pr.diry - r.qy; dlt[s][2] = pr.dirz - r.qz;
+                dlt[s][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
+                tref[s] = norm_inv_depth(fmaxf(pr.z, 1e-5f), vc[15], vc[16]);
+                if (dbg_lane && pvalid[t] && vok) {
+                    float* d_ = p.dbg + ((size_t)pi * p.rfn + view) * kDbgFields;
+                    d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
+                }
+                const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
+                const int fsoff = view * (int)(fmap * sizeof(float)), isoff = view * (int)(imap * sizeof(float));
+                gather8(rf_map, goff, fsoff, tf, pr.mask, fray[s]);
+                gather8(if_map, goff, fsoff, tf, pr.mask, fimg[s]);
+                const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
+                gather_rgb(rgb_map, isoff, tc, pr.mask, rgb[s]);
             }
-            const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
-            gather8(rf_map, goff, tf, pr.mask, fray[t]);
-            gather8(if_map, goff, tf, pr.mask, fimg[t]);
-            const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
-            gather_rgb(rgb_map, tc, pr.mask, rgb[t]);
         }
-        float none[NT][1];
+        float none[NS][1];
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) none[t][0] = 0.0f;
+        for (int s = 0; s < NS; ++s) none[s][0] = 0.0f;
 
         // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
-        float hit[NT], vis[NT];
+        float hit[NS], vis[NS];
         {
-            float cat[NT][16], h1[NT][8], h2[NT][8], fin[NT][4];
-            layer_fwd<L_DM1, NT, ACT_ELU>(W, lane, fray, none, h1);
-            layer_fwd<L_DM2, NT, ACT_ELU>(W, lane, h1, none, h2);
+            float cat[NS][16], h1[NS][8], h2[NS][8], fin[NS][4];
+            const LdsW W1 = stage_phase<PH_DIST_MS>(wl, W, tid, nthreads);
+            layer_fwd<L_DM1, NS, ACT_ELU>(W1, lane, fray, none, h1);
+            layer_fwd<L_DM2, NS, ACT_ELU>(W1, lane, h1, none, h2);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) cat[t][s] = h2[t][s];
-            layer_fwd<L_DV1, NT, ACT_ELU>(W, lane, fray, none, h1);
-            layer_fwd<L_DV2, NT, ACT_ELU>(W, lane, h1, none, h2);
+                for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
+            layer_fwd<L_DV1, NS, ACT_ELU>(W1, lane, fray, none, h1);
+            layer_fwd<L_DV2, NS, ACT_ELU>(W1, lane, h1, none, h2);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) cat[t][8 + s] = h2[t][s];
-            layer_fwd<L_DFIN_MS, NT, ACT_NONE>(W, lane, cat, none, fin);
-            float mu0[NT], mu1[NT], s0[NT], s1[NT], aw[NT], nu[NT];
+                for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
+            layer_fwd<L_DFIN_MS, NS, ACT_NONE>(W1, lane, cat, none, fin);
+            float mu0[NS], mu1[NS], s0[NS], s1[NS], aw[NS], nu[NS];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                mu0[t] = softplus(fin[t][0]); mu1[t] = softplus(fin[t][1]);
-                s0[t] = softplus(fin[t][2]) + p.var_bias; s1[t] = softplus(fin[t][3]) + p.var_bias;
+            for (int s = 0; s < NS; ++s) {
+                mu0[s] = softplus(fin[s][0]); mu1[s] = softplus(fin[s][1]);
+                s0[s] = softplus(fin[s][2]) + p.var_bias; s1[s] = softplus(fin[s][3]) + p.var_bias;
             }
-            layer_fwd<L_DA1, NT, ACT_ELU>(W, lane, fray, none, h1);
-            layer_fwd<L_DA2, NT, ACT_ELU>(W, lane, h1, none, h2);
+            const LdsW W2 = stage_phase<HAS_VIS ? PH_DIST_AV : PH_DIST_A>(wl, W, tid, nthreads);
+            layer_fwd<L_DA1, NS, ACT_ELU>(W2, lane, fray, none, h1);
+            layer_fwd<L_DA2, NS, ACT_ELU>(W2, lane, h1, none, h2);
             if (HAS_VIS) {
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t)
+                for (int s = 0; s < NS; ++s)
                     NR_PRAGMA_UNROLL
-                    for (int s = 0; s < 8; ++s) cat[t][s] = h2[t][s];
-                layer_fwd<L_DS1, NT, ACT_ELU>(W, lane, fray, none, h1);
-                layer_fwd<L_DS2, NT, ACT_ELU>(W, lane, h1, none, h2);
+                    for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
+                layer_fwd<L_DS1, NS, ACT_ELU>(W2, lane, fray, none, h1);
+                layer_fwd<L_DS2, NS, ACT_ELU>(W2, lane, h1, none, h2);
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t)
+                for (int s = 0; s < NS; ++s)
                     NR_PRAGMA_UNROLL
-                    for (int s = 0; s < 8; ++s) cat[t][8 + s] = h2[t][s];
-                layer_fwd<L_DFIN_AV, NT, ACT_NONE>(W, lane, cat, none, fin);
+                    for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
+                layer_fwd<L_DFIN_AV, NS, ACT_NONE>(W2, lane, cat, none, fin);
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) { aw[t] = sigmoidf(fin[t][0]); nu[t] = sigmoidf(fin[t][1]); }
+                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fin[s][0]); nu[s] = sigmoidf(fin[s][1]); }
             } else {
-                layer_fwd<L_DFIN_A, NT, ACT_NONE>(W, lane, h2, none, fin);
+                layer_fwd<L_DFIN_A, NS, ACT_NONE>(W2, lane, h2, none, fin);
                 NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) { aw[t] = sigmoidf(fin[t][0]); nu[t] = 1.0f; }
+                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fin[s][0]); nu[s] = 1.0f; }
             }
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
+            for (int s = 0; s < NS; ++s) {
+                const int t = s % NT;
                 float v_, h_;
-                logistic_prob(tref[t], lo[t], hi[t], mu0[t], mu1[t], s0[t], s1[t], aw[t], nu[t], use_vis && HAS_VIS, v_, h_);
-                vis[t] = v_ * mask[t]; hit[t] = h_ * mask[t];
-                if (dbg_lane && pvalid[t]) {
-                    float* d_ = p.dbg + ((size_t)pidx[t] * nw + wave) * kDbgFields;
-                    d_[4] = hit[t]; d_[5] = vis[t]; d_[6] = mu0[t]; d_[7] = mu1[t]; d_[8] = s0[t]; d_[9] = s1[t];
-                    d_[10] = aw[t]; d_[11] = nu[t];
+                logistic_prob(tref[s], lo[t], hi[t], mu0[s], mu1[s], s0[s], s1[s], aw[s], nu[s], use_vis && HAS_VIS, v_, h_);
+                vis[s] = v_ * mask[s]; hit[s] = h_ * mask[s];
+                const int vraw = wave * VPW + s / NT;
+                if (dbg_lane && pvalid[t] && vraw < p.rfn) {
+                    float* d_ = p.dbg + ((size_t)pidx[t] * p.rfn + vraw) * kDbgFields;
+                    d_[4] = hit[s]; d_[5] = vis[s]; d_[6] = mu0[s]; d_[7] = mu1[s]; d_[8] = s0[s]; d_[9] = s1[s];
+                    d_[10] = aw[s]; d_[11] = nu[s];
                 }
             }
         }
 
         // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
-        float e[NT][8];
+        const LdsW W3 = stage_phase<PH_EMBED>(wl, W, tid, nthreads);
+        float e[NS][8];
         {
-            float x1[NT][1], h[NT][8];
+            float x1[NS][1], h[NS][8];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
-                x1[t][0] = sel4(g, (hit[t] - 0.5f) * 2.0f, (vis[t] - 0.5f) * 2.0f, 0.0f, 0.0f);
-            layer_fwd<L_PE1, NT, ACT_RELU>(W, lane, fray, x1, h);
-            layer_fwd<L_PE2, NT, ACT_NONE>(W, lane, h, none, e);
+            for (int s = 0; s < NS; ++s)
+                x1[s][0] = sel4(g, (hit[s] - 0.5f) * 2.0f, (vis[s] - 0.5f) * 2.0f, 0.0f, 0.0f);
+            layer_fwd<L_PE1, NS, ACT_RELU>(W3, lane, fray, x1, h);
+            layer_fwd<L_PE2, NS, ACT_NONE>(W3, lane, h, none, e);
         }
         // ---------------- ray_dir_fc, rgb_feat + direction_feat     ibrnet.py:324-327 -----------------
-        float gi[NT][8], gr[NT][3];
+        float gi[NS][8], gr[NS][3];
         {
-            float x1[NT][1], h[NT][4], df[NT][12];
+            float x1[NS][1], h[NS][4], df[NS][12];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) x1[t][0] = sel4(g, dlt[t][0], dlt[t][1], dlt[t][2], dlt[t][3]);
-            layer_fwd<L_RD1, NT, ACT_ELU>(W, lane, none, x1, h);
-            layer_fwd<L_RD2, NT, ACT_ELU>(W, lane, h, none, df);
+            for (int s = 0; s < NS; ++s) x1[s][0] = sel4(g, dlt[s][0], dlt[s][1], dlt[s][2], dlt[s][3]);
+            layer_fwd<L_RD1, NS, ACT_ELU>(W3, lane, none, x1, h);
+            layer_fwd<L_RD2, NS, ACT_ELU>(W3, lane, h, none, df);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
+            for (int s = 0; s < NS; ++s) {
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) gi[t][s] = fimg[t][s] + df[t][s];
+                for (int k = 0; k < 8; ++k) gi[s][k] = fimg[s][k] + df[s][k];
                 NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) gr[t][j] = rgb[t][j] + df[t][8 + j];
+                for (int j = 0; j < 3; ++j) gr[s][j] = rgb[s][j] + df[s][8 + j];
             }
         }
         // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
-        float sn[NT];
+        float sn[NS];
         {
-            float h[NT][4], o[NT][4];
-            layer_fwd<L_NF1, NT, ACT_ELU>(W, lane, e, none, h);
-            layer_fwd<L_NF2, NT, ACT_NONE>(W, lane, h, none, o);
+            float h[NS][4], o[NS][4];
+            layer_fwd<L_NF1, NS, ACT_ELU>(W3, lane, e, none, h);
+            layer_fwd<L_NF2, NS, ACT_NONE>(W3, lane, h, none, o);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) sn[t] = sigmoidf(o[t][0]);
+            for (int s = 0; s < NS; ++s) sn[s] = sigmoidf(o[s][0]);
         }
         // ---------------- cross-view weighted mean / variance       ibrnet.py:334-340 ---------------------
-        // Each statistic is all-reduced over the view-waves and immediately consumed by the owner waves as a
-        // K-slice of base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
-        float msum[NT], wv[NT];
+        // Each statistic is all-reduced over the views and immediately consumed by the owner waves as a K-slice of
+        // base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
+        const LdsW W4 = stage_phase<PH_BASE>(wl, W, tid, nthreads);   // used after the statistics below
+        float msum[NT], wv[NS];
+        {
+            float m1[NS][1];
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s) m1[s][0] = mask[s];
+            view_allreduce<NT, VPW, 1, RMAX, RED_SUM>(m1, msum, red, wave, nw, lane);
+        }
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) msum[t] = mask[t];
-        block_allreduce<NT, RMAX, RED_SUM>(msum, red, wave, nw, lane);
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) wv[t] = mask[t] / (msum[t] + 1e-8f);
+        for (int s = 0; s < NS; ++s) wv[s] = mask[s] / (msum[s % NT] + 1e-8f);
 
-        v4f accv[NT][4];
+        v4f accv[NS][4];
         {
             v4f accg[OWN][NT];
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
-                const float4 b = nr_buf_ld4(W, g * 16, (bias_offset(L_BG) + (mo < 4 ? mo : 0) * 16) * 4);
+                const float4 b = wld4(W, g * 16, (bias_offset(L_BG) + (mo < 4 ? mo : 0) * 16) * 4);
                 NR_PRAGMA_UNROLL
                 for (int t = 0; t < NT; ++t) { accg[j][t][0] = b.x; accg[j][t][1] = b.y; accg[j][t][2] = b.z; accg[j][t][3] = b.w; }
             }
-            float st[NT * 11], sv[NT * 11], wk[NT];
-            // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0
+            float part[NS][11], st[NT * 11], sv[NT * 11], wk[NS];
+            // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0 ;  k = 1: weight -> mean1, var1
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                wk[t] = sn[t] * wv[t];
+            for (int k = 0; k < 2; ++k) {
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) st[t * 11 + s] = gi[t][s] * wk[t];
+                for (int s = 0; s < NS; ++s) {
+                    wk[s] = k == 0 ? sn[s] * wv[s] : wv[s];
+                    NR_PRAGMA_UNROLL
+                    for (int q = 0; q < 8; ++q) part[s][q] = gi[s][q] * wk[s];
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) part[s][8 + j] = gr[s][j] * wk[s];
+                }
+                view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, st, red, wave, nw, lane);
                 NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) st[t * 11 + 8 + j] = gr[t][j] * wk[t];
+                for (int s = 0; s < NS; ++s) {
+                    const int t = s % NT;
+                    NR_PRAGMA_UNROLL
+                    for (int q = 0; q < 8; ++q) { const float d_ = gi[s][q] - st[t * 11 + q]; part[s][q] = wk[s] * (d_ * d_); }
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) { const float d_ = gr[s][j] - st[t * 11 + 8 + j]; part[s][8 + j] = wk[s] * (d_ * d_); }
+                }
+                if (k == 0) bg_accumulate<NT, OWN, 0>(W, lane, g, wave, nw, st, accg);
+                else bg_accumulate<NT, OWN, 2>(W, lane, g, wave, nw, st, accg);
+                view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, sv, red, wave, nw, lane);
+                if (k == 0) bg_accumulate<NT, OWN, 1>(W, lane, g, wave, nw, sv, accg);
+                else bg_accumulate<NT, OWN, 3>(W, lane, g, wave, nw, sv, accg);
             }
-            block_allreduce<NT * 11, RMAX, RED_SUM>(st, red, wave, nw, lane);
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) { const float d_ = gi[t][s] - st[t * 11 + s]; sv[t * 11 + s] = wk[t] * (d_ * d_); }
-                NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) { const float d_ = gr[t][j] - st[t * 11 + 8 + j]; sv[t * 11 + 8 + j] = wk[t] * (d_ * d_); }
-            }
-            bg_accumulate<NT, OWN, 0>(W, lane, g, wave, nw, st, accg);
-            block_allreduce<NT * 11, RMAX, RED_SUM>(sv, red, wave, nw, lane);
-            bg_accumulate<NT, OWN, 1>(W, lane, g, wave, nw, sv, accg);
-            // k = 1: weight -> mean1, var1
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) st[t * 11 + s] = gi[t][s] * wv[t];
-                NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) st[t * 11 + 8 + j] = gr[t][j] * wv[t];
-            }
-            block_allreduce<NT * 11, RMAX, RED_SUM>(st, red, wave, nw, lane);
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) { const float d_ = gi[t][s] - st[t * 11 + s]; sv[t * 11 + s] = wv[t] * (d_ * d_); }
-                NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) { const float d_ = gr[t][j] - st[t * 11 + 8 + j]; sv[t * 11 + 8 + j] = wv[t] * (d_ * d_); }
-            }
-            bg_accumulate<NT, OWN, 2>(W, lane, g, wave, nw, st, accg);
-            block_allreduce<NT * 11, RMAX, RED_SUM>(sv, red, wave, nw, lane);
-            bg_accumulate<NT, OWN, 3>(W, lane, g, wave, nw, sv, accg);
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
@@ -350,129 +387,138 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
             }
             __syncthreads();
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
                 for (int mo = 0; mo < 4; ++mo)
                     NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) accv[t][mo][r] = xch[((mo * NT + t) * 4 + r) * 64 + lane];
+                    for (int r = 0; r < 4; ++r) accv[s][mo][r] = xch[((mo * NT + s % NT) * 4 + r) * 64 + lane];
         }
         // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
-        float x[NT][8], vis2[NT], z[NT];
+        float x[NS][8], vis2[NS], z[NS];
         {
-            float xq[NT][16], x1[NT][1], h64[NT][16];
+            float xq[NS][16], x1[NS][1], h64[NS][16];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
+            for (int s = 0; s < NS; ++s) {
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) { xq[t][s] = gi[t][s]; xq[t][8 + s] = e[t][s]; }
-                x1[t][0] = sel4(g, gr[t][0], gr[t][1], gr[t][2], 0.0f);
+                for (int k = 0; k < 8; ++k) { xq[s][k] = gi[s][k]; xq[s][8 + k] = e[s][k]; }
+                x1[s][0] = sel4(g, gr[s][0], gr[s][1], gr[s][2], 0.0f);
             }
-            layer_acc<L_BV, NT>(W, lane, xq, x1, accv);
+            layer_acc<L_BV, NS>(W4, lane, xq, x1, accv);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
                 for (int mo = 0; mo < 4; ++mo)
                     NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) h64[t][4 * mo + r] = elu(accv[t][mo][r]);
-            layer_fwd<L_B2, NT, ACT_ELU>(W, lane, h64, none, x);
+                    for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu(accv[s][mo][r]);
+            layer_fwd<L_B2, NS, ACT_ELU>(W4, lane, h64, none, x);
         }
         {
-            float xin[NT][8], h[NT][8], y[NT][12], o[NT][4];
+            const LdsW W5 = stage_phase<PH_TAIL>(wl, W, tid, nthreads);
+            float xin[NS][8], h[NS][8], y[NS][12], o[NS][4];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) xin[t][s] = x[t][s] * wv[t];
-            layer_fwd<L_VF1, NT, ACT_ELU>(W, lane, xin, none, h);
-            layer_fwd<L_VF2, NT, ACT_ELU>(W, lane, h, none, y);
-            float visp[NT];
+                for (int k = 0; k < 8; ++k) xin[s][k] = x[s][k] * wv[s];
+            layer_fwd<L_VF1, NS, ACT_ELU>(W5, lane, xin, none, h);
+            layer_fwd<L_VF2, NS, ACT_ELU>(W5, lane, h, none, y);
+            float visp[NS];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                visp[t] = sigmoidf(y[t][8]) * mask[t];      // sigmoid on an ELU output: quirk A.9.4
+            for (int s = 0; s < NS; ++s) {
+                visp[s] = sigmoidf(y[s][8]) * mask[s];      // sigmoid on an ELU output: quirk A.9.4
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) { x[t][s] = x[t][s] + y[t][s]; xin[t][s] = x[t][s] * visp[t]; }
+                for (int k = 0; k < 8; ++k) { x[s][k] = x[s][k] + y[s][k]; xin[s][k] = x[s][k] * visp[s]; }
             }
-            layer_fwd<L_V21, NT, ACT_ELU>(W, lane, xin, none, h);
-            layer_fwd<L_V22, NT, ACT_NONE>(W, lane, h, none, o);
+            layer_fwd<L_V21, NS, ACT_ELU>(W5, lane, xin, none, h);
+            layer_fwd<L_V22, NS, ACT_NONE>(W5, lane, h, none, o);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) vis2[t] = sigmoidf(o[t][0]) * mask[t];
-            float x1[NT][2], h16[NT][4], h8[NT][4];
+            for (int s = 0; s < NS; ++s) vis2[s] = sigmoidf(o[s][0]) * mask[s];
+            float x1[NS][2], h16[NS][4], h8[NS][4];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                x1[t][0] = sel4(g, vis2[t], dlt[t][0], dlt[t][1], dlt[t][2]);
-                x1[t][1] = sel4(g, dlt[t][3], 0.0f, 0.0f, 0.0f);
+            for (int s = 0; s < NS; ++s) {
+                x1[s][0] = sel4(g, vis2[s], dlt[s][0], dlt[s][1], dlt[s][2]);
+                x1[s][1] = sel4(g, dlt[s][3], 0.0f, 0.0f, 0.0f);
             }
-            layer_fwd<L_RF1, NT, ACT_ELU>(W, lane, x, x1, h16);
-            layer_fwd<L_RF2, NT, ACT_ELU>(W, lane, h16, none, h8);
-            layer_fwd<L_RF3, NT, ACT_NONE>(W, lane, h8, none, o);
+            layer_fwd<L_RF1, NS, ACT_ELU>(W5, lane, x, x1, h16);
+            layer_fwd<L_RF2, NS, ACT_ELU>(W5, lane, h16, none, h8);
+            layer_fwd<L_RF3, NS, ACT_NONE>(W5, lane, h8, none, o);
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                z[t] = mask[t] > 0.0f ? o[t][0] : -1e9f;
-                if (dbg_lane && pvalid[t]) {
-                    float* d_ = p.dbg + ((size_t)pidx[t] * nw + wave) * kDbgFields;
-                    d_[12] = sn[t]; d_[13] = visp[t]; d_[14] = vis2[t]; d_[15] = z[t];
+            for (int s = 0; s < NS; ++s) {
+                const int t = s % NT;
+                z[s] = mask[s] > 0.0f ? o[s][0] : -1e9f;
+                const int vraw = wave * VPW + s / NT;
+                if (dbg_lane && pvalid[t] && vraw < p.rfn) {
+                    float* d_ = p.dbg + ((size_t)pidx[t] * p.rfn + vraw) * kDbgFields;
+                    d_[12] = sn[s]; d_[13] = visp[s]; d_[14] = vis2[s]; d_[15] = z[s];
                 }
             }
         }
         // ---------------- cross-view: blending softmax, visibility-weighted mean/var  ibrnet.py:350-367 ---
-        float zmax[NT];
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) zmax[t] = z[t];
-        block_allreduce<NT, RMAX, RED_MAX>(zmax, red, wave, nw, lane);
-        float ev[NT], sums[NT * 2];
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) { ev[t] = nr_fast_exp(z[t] - zmax[t]); sums[2 * t] = vis2[t]; sums[2 * t + 1] = ev[t]; }
-        block_allreduce<NT * 2, RMAX, RED_SUM>(sums, red, wave, nw, lane);
-        float big[NT * 12], wh[NT];
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) {
-            wh[t] = vis2[t] / (sums[2 * t] + 1e-8f);
-            const float beta = ev[t] / sums[2 * t + 1];
+        float zmax[NT], sums[NT * 2], big[NT * 12], wh[NS];
+        {
+            float z1[NS][1];
             NR_PRAGMA_UNROLL
-            for (int s = 0; s < 8; ++s) big[t * 12 + s] = x[t][s] * wh[t];
-            big[t * 12 + 8] = wh[t];
+            for (int s = 0; s < NS; ++s) z1[s][0] = z[s];
+            view_allreduce<NT, VPW, 1, RMAX, RED_MAX>(z1, zmax, red, wave, nw, lane);
+            float ev[NS], s2[NS][2];
             NR_PRAGMA_UNROLL
-            for (int j = 0; j < 3; ++j) big[t * 12 + 9 + j] = rgb[t][j] * beta;
+            for (int s = 0; s < NS; ++s) { ev[s] = nr_fast_exp(z[s] - zmax[s % NT]); s2[s][0] = vis2[s]; s2[s][1] = ev[s]; }
+            view_allreduce<NT, VPW, 2, RMAX, RED_SUM>(s2, sums, red, wave, nw, lane);
+            float b12[NS][12];
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s) {
+                const int t = s % NT;
+                wh[s] = vis2[s] / (sums[2 * t] + 1e-8f);
+                const float beta = ev[s] / sums[2 * t + 1];
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 8; ++k) b12[s][k] = x[s][k] * wh[s];
+                b12[s][8] = wh[s];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 3; ++j) b12[s][9 + j] = rgb[s][j] * beta;
+            }
+            view_allreduce<NT, VPW, 12, RMAX, RED_SUM>(b12, big, red, wave, nw, lane);
         }
-        block_allreduce<NT * 12, RMAX, RED_SUM>(big, red, wave, nw, lane);
         // geometry_fc.0 (a14): owner waves stream the mean part, then the variance part   ibrnet.py:353-354
         v4f accf[OWN][NT];
         NR_PRAGMA_UNROLL
         for (int j = 0; j < OWN; ++j) {
             const int mo = wave + j * nw;
-            const float4 b = nr_buf_ld4(W, g * 16, (bias_offset(L_GF1) + (mo < 4 ? mo : 0) * 16) * 4);
+            const float4 b = wld4(W, g * 16, (bias_offset(L_GF1) + (mo < 4 ? mo : 0) * 16) * 4);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) { accf[j][t][0] = b.x; accf[j][t][1] = b.y; accf[j][t][2] = b.z; accf[j][t][3] = b.w; }
         }
         float var[NT * 8];
         {
-            float xq[NT][8], x1[NT][1];
+            float xq[NT][8], x1[NT][1], v8[NS][8];
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s)
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 8; ++k) { const float d_ = x[s][k] - big[(s % NT) * 12 + k]; v8[s][k] = wh[s] * (d_ * d_); }
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) {
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) {
-                    const float d_ = x[t][s] - big[t * 12 + s];
-                    var[t * 8 + s] = wh[t] * (d_ * d_);
-                    xq[t][s] = big[t * 12 + s];
-                }
-                x1[t][0] = sel4(g, big[t * 12 + 8] / (float)nw, 0.0f, 0.0f, 0.0f);
+                for (int k = 0; k < 8; ++k) xq[t][k] = big[t * 12 + k];
+                x1[t][0] = sel4(g, big[t * 12 + 8] / (float)p.rfn, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
                 if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, lane, mo, xq, x1, accf[j]);
             }
+            view_allreduce<NT, VPW, 8, RMAX, RED_SUM>(v8, var, red, wave, nw, lane);
         }
-        block_allreduce<NT * 8, RMAX, RED_SUM>(var, red, wave, nw, lane);
         {
-            float xq[NT][8];
+            float xq[NT][8], nonet[NT][1];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                nonet[t][0] = 0.0f;
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 8; ++s) xq[t][s] = var[t * 8 + s];
+                for (int k = 0; k < 8; ++k) xq[t][k] = var[t * 8 + k];
+            }
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
                 if (mo < 4) {
-                    layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, lane, mo, xq, none, accf[j]);
+                    layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, lane, mo, xq, nonet, accf[j]);
                     NR_PRAGMA_UNROLL
                     for (int t = 0; t < NT; ++t)
                         NR_PRAGMA_UNROLL
@@ -482,12 +528,14 @@ __global__ void __launch_bounds__(MAXT) points_kernel(PointParams p) {
         }
         __syncthreads();
         if (wave == 0) {
-            float h[NT][16], G[NT][4];
+            float h[NT][16], G[NT][4], nonet[NT][1];
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                nonet[t][0] = 0.0f;
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) h[t][k] = xch[(((k >> 2) * NT + t) * 4 + (k & 3)) * 64 + lane];
-            layer_fwd<L_GF2, NT, ACT_ELU>(W, lane, h, none, G);
+            }
+            layer_fwd<L_GF2, NT, ACT_ELU>(W, lane, h, nonet, G);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t)
                 if (pvalid[t])

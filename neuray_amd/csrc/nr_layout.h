@@ -24,9 +24,12 @@ namespace nr {
 
 enum LayerId {
     // dist decoder heads (mean, var, aw, vis): 32 -> 32 -> 32                    dist_decoder.py:64-97
-    L_DM1, L_DM2, L_DV1, L_DV2, L_DA1, L_DA2, L_DS1, L_DS2,
+    // (order = LDS staging phases, see kPhase below)
+    L_DM1, L_DM2, L_DV1, L_DV2,
     L_DFIN_MS,   // [mu0 mu1 s0 s1] pre-activations from h2(mean) ++ h2(var), replicated in all lane groups
+    L_DA1, L_DA2,
     L_DFIN_A,    // [aw] from h2(aw)                      (decoder without vis head)
+    L_DS1, L_DS2,
     L_DFIN_AV,   // [aw vis] from h2(aw) ++ h2(vis)       (decoder with vis head)
     L_PE1, L_PE2,            // prob_embed 34 -> 32 -> 32                           aggregate_net.py:27-31
     L_RD1, L_RD2,            // ray_dir_fc 4 -> 16 -> 35                            ibrnet.py:249-252
@@ -44,8 +47,12 @@ enum LayerId {
 struct LayerShape { int mt_out, kq, k1; };
 
 constexpr LayerShape kShape[L_COUNT] = {
-    {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0},
-    {1, 4, 0}, {1, 2, 0}, {1, 4, 0},
+    {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0},
+    {1, 4, 0},
+    {2, 2, 0}, {2, 2, 0},
+    {1, 2, 0},
+    {2, 2, 0}, {2, 2, 0},
+    {1, 4, 0},
     {2, 2, 1}, {2, 2, 0},
     {1, 0, 1}, {3, 1, 0},
     {1, 2, 0}, {1, 1, 0},
@@ -72,6 +79,27 @@ constexpr int single_offset(int l) { return layer_offset(l) + quads_floats(l); }
 constexpr int bias_offset(int l) { return layer_offset(l) + quads_floats(l) + single_floats(l); }
 
 constexpr int kPackedPointFloats = layer_offset(L_COUNT);
+
+// ---- LDS staging phases of the point kernel: contiguous layer ranges [first, last] copied into LDS by the whole
+// workgroup before they are used (the per-point layers L_BG, L_GF1, L_GF2 are read from global by their owner waves)
+enum PhaseId { PH_DIST_MS, PH_DIST_A, PH_DIST_AV, PH_EMBED, PH_BASE, PH_TAIL, PH_COUNT };
+struct PhaseRange { int first, last; };
+constexpr PhaseRange kPhase[PH_COUNT] = {
+    {L_DM1, L_DFIN_MS},      // mean + var heads and their final layer
+    {L_DA1, L_DFIN_A},       // aw head (decoder without vis head)
+    {L_DA1, L_DFIN_AV},      // aw + vis heads
+    {L_PE1, L_NF2},          // prob_embed, ray_dir_fc, neuray_fc
+    {L_BV, L_B2},            // base_fc per-view part + second layer
+    {L_VF1, L_RF3},          // vis_fc, vis_fc2, rgb_fc
+};
+constexpr int phase_begin(int ph) { return layer_offset(kPhase[ph].first); }
+constexpr int phase_floats(int ph) { return layer_offset(kPhase[ph].last + 1) - layer_offset(kPhase[ph].first); }
+constexpr int max_phase_floats() {
+    int m = 0;
+    for (int i = 0; i < PH_COUNT; ++i) m = phase_floats(i) > m ? phase_floats(i) : m;
+    return m;
+}
+constexpr int kWeightLdsFloats = max_phase_floats();
 
 // ---- weights of the ray kernel (attention + sigma head), plain row-major ------------------------
 //   reference: network/ibrnet.py:52-102 (MultiHeadAttention 4 heads x d_k=4, no bias), :276-279

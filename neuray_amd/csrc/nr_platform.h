@@ -54,6 +54,9 @@ __device__ __forceinline__ nr_buf nr_make_buf(const float* p, size_t bytes) {
     return b;
 }
 __device__ __forceinline__ float4 nr_buf_ld4(nr_buf b, int voff, int soff) {
+#if defined(NR_ABLATE) && (NR_ABLATE & 8)
+    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
+#endif
     // NOTE: cast the WHOLE vector.  Element-wise `__builtin_bit_cast(float, u.x)` on the builtin's result makes
     // hipcc (ROCm 7.2) narrow the load to buffer_load_dword and replicate .x into y/z/w (tests/hw/bufprobe.hip).
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -88,12 +91,23 @@ typedef nr_buf nr_mbuf;
 #endif
 #endif
 
+// pins program order at this point (the machine scheduler otherwise sinks a prefetch load back to its first use)
+#ifdef NEURAY_EMU
+#define NR_PIN() do {} while (0)
+#else
+#define NR_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // scheduling fence: keeps hipcc from hoisting the next layers' weight-fragment loads across layer boundaries (it
 // otherwise clusters loads until it overshoots the VGPR budget and spills)
 #ifdef NEURAY_EMU
 #define NR_SCHED_FENCE() do {} while (0)
 #else
+#ifdef NR_LAYER_FENCE
 #define NR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NR_SCHED_FENCE() do {} while (0)
+#endif
 #endif
 
 // fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32: ~1 ulp each)

@@ -65,7 +65,7 @@ class ViewSet:
 
 
 class RenderEngine:
-    def __init__(self, device, _test_lib=None, tiles_per_wave=0):
+    def __init__(self, device, _test_lib=None, views_per_wave=0):
         """device: torch device of the HIP GPU.  `_test_lib` is for the CPU test-suite only (binds the
         emulator build of the same kernels); the product path always uses libneuray_hip.so."""
         self.device = torch.device(device)
@@ -76,7 +76,7 @@ class RenderEngine:
             self.lib = _lib.load()
         else:
             self.lib = _test_lib
-        self.tiles_per_wave = tiles_per_wave
+        self.views_per_wave = views_per_wave
         self._posenc = {}
         # optional kernel timing: set to a list and every point/ray launch appends
         # (name, start_event, end_event, n_points) recorded on the launch stream (HIP events)
@@ -214,7 +214,7 @@ class RenderEngine:
             views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
             rec.data_ptr(), dbg.data_ptr() if want_dbg else None,
             views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
-            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.tiles_per_wave))
+            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.views_per_wave))
         ev = self._event_pair()
         self._check(self.lib.neuray_render_points(C.byref(a), s))
         self._event_done(ev, 'points', rn * dn)

@@ -18,7 +18,7 @@ def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = ['g++', '-std=c++17', '-O2', '-g0', '-fPIC', '-shared', '-DNEURAY_EMU', '-ffp-contract=off',
+    cmd = ['g++', '-std=c++17', '-O2', '-g', '-rdynamic', '-fPIC', '-shared', '-DNEURAY_EMU', '-ffp-contract=off',
            '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', OUT]
     for s in SOURCES:
         cmd += ['-x', 'c++', s]

@@ -2,6 +2,9 @@
 #include "hip_emu.h"
 
 #include <mutex>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 namespace emu {
 
@@ -65,7 +68,16 @@ static void run_block(Block& b, std::vector<char*>& stacks) {
     g_blk = nullptr; g_lane = nullptr;
 }
 
+static void watchdog(int) {
+    void* bt[64];
+    int n = backtrace(bt, 64);
+    fprintf(stderr, "hip_emu watchdog: kernel still running; backtrace of the active fiber:\n");
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(3);
+}
+
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+    if (const char* w = getenv("NEURAY_EMU_WATCHDOG")) { signal(SIGALRM, watchdog); alarm(atoi(w)); }
     const unsigned nblocks = grid.x * grid.y;
     unsigned nthr = std::thread::hardware_concurrency();
     const char* env = getenv("NEURAY_EMU_THREADS");
@@ -87,10 +99,11 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
         }
         for (char* s : stacks) free(s);
     };
-    if (nthr == 1) { worker(); return; }
+    if (nthr == 1) { worker(); alarm(0); return; }
     std::vector<std::thread> pool;
     for (unsigned i = 0; i < nthr; ++i) pool.emplace_back(worker);
     for (auto& t : pool) t.join();
+    alarm(0);
 }
 
 }  // namespace emu

@@ -208,3 +208,36 @@ def test_render_loop_drops_hit_prob_and_concats(backend):
     assert got['pixel_colors_nr_fine'].shape == (1, que['coords'].shape[1], 3)
     err = np.max(np.abs(got['pixel_colors_nr'].cpu().numpy() - out['pixel_colors_nr']))
     assert err <= TOL_PIXEL
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('vpw', [1, 2])
+@pytest.mark.parametrize('name', ['a_small', 'd_train_vis', 'e_use_all'])
+def test_both_wave_decompositions(name, vpw, backend):
+    """views_per_wave = 1 and 2 (odd view counts pad a masked view; rfn 2, 3, 5 exercise OWN = 2 / 4 tiles per
+    wave) give the same result up to the summation order of the cross-view reductions."""
+    cfg, que, ref, out, mid, extra = load_case(name)
+    if name == 'd_train_vis':
+        cfg = {**cfg, 'use_self_hit_prob': False}
+    r, dev = make_renderer(cfg, load_weights(case_uses_vis_weights(name)), backend)
+    r.engine(dev).views_per_wave = vpw
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        got = r.render_impl(to_torch(que, dev), to_torch(ref, dev), extra['is_train'])
+    assert np.max(np.abs(got['pixel_colors_nr'].cpu().numpy() - out['pixel_colors_nr'])) <= TOL_PIXEL
+    assert np.max(np.abs(got['hit_prob_nr'].cpu().numpy() - out['hit_prob_nr'])) <= TOL_HIT
+    assert np.array_equal(got['ray_mask'].cpu().numpy(), out['ray_mask'])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_single_reference_view(backend):
+    """rfn = 1: one wave owns all four tiles of the per-point layers."""
+    cfg, que, ref, out, mid, extra = load_case('a_small')
+    weights = load_weights(False)
+    ref1 = {k: v[:1] for k, v in ref.items()}
+    r, dev = make_renderer(cfg, weights, backend)
+    with torch.no_grad():
+        got = r.render_impl(to_torch(que, dev), to_torch(ref1, dev), False)
+    want = orc.render_impl(weights, oracle_cfg(cfg), que, ref1)
+    assert np.max(np.abs(got['pixel_colors_nr'].cpu().numpy() - want['pixel_colors_nr'])) <= 1e-5
+    assert np.max(np.abs(got['hit_prob_nr'].cpu().numpy() - want['hit_prob_nr'])) <= 1e-5

@@ -1,0 +1,54 @@
+"""Multi-GPU partitioning of the render path.
+
+Rays are independent and the renderer is bitwise batching-invariant, so the path shards with NO data-path
+collective: every rank holds the weights and the reference maps and renders a disjoint set of images, or a disjoint
+contiguous ray range of one image.  The only communication is an optional all-gather of the rendered tiles when one
+image is split (RCCL over xGMI on the GPU box: torch.distributed backend "nccl"; "gloo" in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced [start, end) of n items for `rank` of `world` (first n % world ranks get one extra)."""
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def images_for_rank(num_images, rank, world):
+    """Image-level sharding (zero communication): rank r renders images r, r + world, ..."""
+    return list(range(rank, num_images, world))
+
+
+def render_ray_shard(renderer, que_imgs_info, ref_imgs_info, rank, world, is_train=False):
+    """Render this rank's contiguous ray range of one query image.  Returns (outputs, (start, end))."""
+    coords = que_imgs_info['coords']
+    start, end = shard_range(coords.shape[1], rank, world)
+    q = dict(que_imgs_info)
+    q['coords'] = coords[:, start:end]
+    return renderer.render(q, ref_imgs_info, is_train), (start, end)
+
+
+def gather_tiles(local, n_total, rank, world, group=None):
+    """All-gather per-ray tensors [1, n_local, ...] of the ranks' contiguous shards into [1, n_total, ...]."""
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    pad = max(sizes)
+    out = {}
+    for k, v in local.items():
+        t = v.to(torch.float32) if v.dtype == torch.bool else v
+        buf = torch.zeros((v.shape[0], pad) + tuple(v.shape[2:]), dtype=t.dtype, device=t.device)
+        buf[:, :v.shape[1]] = t
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        full = torch.cat([p[:, :s] for p, s in zip(parts, sizes)], 1)
+        out[k] = full.bool() if v.dtype == torch.bool else full
+    return out
+
+
+def render_image_sharded(renderer, que_imgs_info, ref_imgs_info, group=None):
+    """One image split over all ranks of the default (or given) process group; every rank gets the full image."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = que_imgs_info['coords'].shape[1]
+    local, _ = render_ray_shard(renderer, que_imgs_info, ref_imgs_info, rank, world)
+    return gather_tiles(local, n, rank, world, group)

@@ -570,7 +570,8 @@ struct RayParams {
 };
 
 constexpr int kRayWaves = 4;
-inline size_t ray_smem_bytes(int dn) { return sizeof(float) * kRayWaves * ((size_t)dn * 32 + (size_t)dn * 2); }
+// LDS: attention / sigma-head weights (shared by the workgroup) + per wave K, V, transmittance factors, alpha
+inline size_t ray_smem_bytes(int dn) { return sizeof(float) * (kPackedRayFloats + 12 + kRayWaves * ((size_t)dn * 34)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
     NR_PRAGMA_UNROLL
@@ -578,16 +579,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
+// y[16] = M[16x16] x[16] with M row-major in LDS (every lane reads the same address: broadcast, conflict-free)
+__device__ __forceinline__ void matvec16(const float* __restrict__ M, const float (&x)[16], float (&y)[16]) {
+    NR_PRAGMA_UNROLL
+    for (int o = 0; o < 16; ++o) {
+        float s = 0.0f;
+        NR_PRAGMA_UNROLL
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 w = ld4(M + o * 16 + 4 * k4);
+            s = fmaf(w.x, x[4 * k4], s); s = fmaf(w.y, x[4 * k4 + 1], s);
+            s = fmaf(w.z, x[4 * k4 + 2], s); s = fmaf(w.w, x[4 * k4 + 3], s);
+        }
+        y[o] = s;
+        if ((o & 1) == 1) NR_PIN();     // bound the scheduler's load clustering (it would hold all 64 rows in VGPRs)
+    }
+}
+
+__global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
     const int dn = p.dn;
-    float* ks = smem + (size_t)wave * (dn * 34);
+    float* RW = smem + nr_opaque_zero();               // [kPackedRayFloats] (+ pad to a 16-byte multiple)
+    float* ks = smem + kPackedRayFloats + 12 + (size_t)wave * (dn * 34);
     float* vs = ks + dn * 16;
     float* tr = vs + dn * 16;        // [dn] transmittance factors
     float* al = tr + dn;             // [dn] alpha
-    const float* __restrict__ RW = p.weights + kPackedPointFloats;
+    for (int i = threadIdx.x; i < kPackedRayFloats; i += blockDim.x) RW[i] = p.weights[kPackedPointFloats + i];
+    __syncthreads();
     const int nch = (dn + 63) >> 6;
     const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
 
@@ -597,37 +616,43 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
         ray = rvalid ? ray : p.rn - 1;
         const float* rec = p.point_rec + (size_t)ray * dn * kPointRec;
         // ---- phase 1: K, V of every sample -> LDS
+        // (compiler barrier: keeps hipcc from hoisting the uniform LDS weight reads out of the ray loop into SGPRs)
+        asm volatile("" ::: "memory");
         for (int ch = 0; ch < nch; ++ch) {
             const int i = ch * 64 + lane;
             if (i < dn) {
-                float G[16];
+                float G[16], y[16];
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) G[k] = rec[(size_t)i * kPointRec + k] + p.pos_enc[i * 16 + k];
-                NR_PRAGMA_UNROLL
-                for (int o = 0; o < 16; ++o) {
-                    float kk = 0.0f, vv = 0.0f;
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) { kk = fmaf(RW[RW_WK + o * 16 + k], G[k], kk); vv = fmaf(RW[RW_WV + o * 16 + k], G[k], vv); }
-                    ks[i * 16 + o] = kk; vs[i * 16 + o] = vv;
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 a = ld4(rec + (size_t)i * kPointRec + 4 * k4), b = ld4(p.pos_enc + i * 16 + 4 * k4);
+                    G[4 * k4] = a.x + b.x; G[4 * k4 + 1] = a.y + b.y; G[4 * k4 + 2] = a.z + b.z; G[4 * k4 + 3] = a.w + b.w;
                 }
+                matvec16(RW + RW_WK, G, y);
+                NR_PRAGMA_UNROLL
+                for (int k4 = 0; k4 < 4; ++k4)
+                    *reinterpret_cast<float4*>(ks + i * 16 + 4 * k4) = make_float4(y[4 * k4], y[4 * k4 + 1], y[4 * k4 + 2], y[4 * k4 + 3]);
+                matvec16(RW + RW_WV, G, y);
+                NR_PRAGMA_UNROLL
+                for (int k4 = 0; k4 < 4; ++k4)
+                    *reinterpret_cast<float4*>(vs + i * 16 + 4 * k4) = make_float4(y[4 * k4], y[4 * k4 + 1], y[4 * k4 + 2], y[4 * k4 + 3]);
             }
         }
         __syncthreads();
         // ---- phase 2: attention row, LayerNorm, sigma, alpha
         for (int ch = 0; ch < nch; ++ch) {
             const int i = ch * 64 + lane;
+            asm volatile("" ::: "memory");
             if (i < dn) {
                 float G[16], q[16], o[16];
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) G[k] = rec[(size_t)i * kPointRec + k] + p.pos_enc[i * 16 + k];
-                const float nvalid = rec[(size_t)i * kPointRec + 19];
-                NR_PRAGMA_UNROLL
-                for (int oo = 0; oo < 16; ++oo) {
-                    float s = 0.0f;
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) s = fmaf(RW[RW_WQ + oo * 16 + k], G[k], s);
-                    q[oo] = s / 2.0f;       // temperature = sqrt(d_k) = 2
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 a = ld4(rec + (size_t)i * kPointRec + 4 * k4), b = ld4(p.pos_enc + i * 16 + 4 * k4);
+                    G[4 * k4] = a.x + b.x; G[4 * k4 + 1] = a.y + b.y; G[4 * k4 + 2] = a.z + b.z; G[4 * k4 + 3] = a.w + b.w;
                 }
+                const float nvalid = rec[(size_t)i * kPointRec + 19];
+                matvec16(RW + RW_WQ, G, q);
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) q[k] = q[k] / 2.0f;      // temperature = sqrt(d_k) = 2 (exact)
                 const bool masked = !(nvalid > 1.0f);   // query-row mask: quirk A.9.3
                 NR_PRAGMA_UNROLL
                 for (int hh = 0; hh < 4; ++hh) {
@@ -643,21 +668,16 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
                         const float4 kj = ld4(ks + j * 16 + hh * 4);
                         float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
                         s = masked ? -1e9f : s;
-                        const float e_ = expf(s - mx);
+                        const float e_ = nr_fast_exp(s - mx);
                         const float4 vj = ld4(vs + j * 16 + hh * 4);
                         den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
                     }
                     o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
                 }
                 float y[16], mean = 0.0f;
+                matvec16(RW + RW_FC, o, y);
                 NR_PRAGMA_UNROLL
-                for (int oo = 0; oo < 16; ++oo) {
-                    float s = 0.0f;
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) s = fmaf(RW[RW_FC + oo * 16 + k], o[k], s);
-                    y[oo] = s + G[oo];
-                    mean += y[oo];
-                }
+                for (int k = 0; k < 16; ++k) { y[k] += G[k]; mean += y[k]; }
                 mean /= 16.0f;
                 float var = 0.0f;
                 NR_PRAGMA_UNROLL
@@ -666,14 +686,10 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
                 const float rstd = 1.0f / sqrtf(var + 1e-6f);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) y[k] = fmaf((y[k] - mean) * rstd, RW[RW_LNW + k], RW[RW_LNB + k]);
+                matvec16(RW + RW_OG0W, y, o);
                 float sg = RW[RW_OG2B];
                 NR_PRAGMA_UNROLL
-                for (int oo = 0; oo < 16; ++oo) {
-                    float s = RW[RW_OG0B + oo];
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 16; ++k) s = fmaf(RW[RW_OG0W + oo * 16 + k], y[k], s);
-                    sg = fmaf(RW[RW_OG2W + oo], elu(s), sg);
-                }
+                for (int k = 0; k < 16; ++k) sg = fmaf(RW[RW_OG2W + k], elu(o[k] + RW[RW_OG0B + k]), sg);
                 sg = fmaxf(sg, 0.0f);
                 if (nvalid < 1.0f) sg = 0.0f;
                 if (p.density && rvalid) p.density[(size_t)ray * dn + i] = sg;
@@ -694,9 +710,10 @@ __global__ void __launch_bounds__(256) rays_kernel(RayParams p) {
             const float hp = ok ? al[ok ? i : 0] * T : 0.0f;
             const float* rc = rec + (size_t)(ok ? i : 0) * kPointRec;
             if (ok && rvalid) p.hit_prob[(size_t)ray * dn + i] = hp;
-            cr = fmaf(hp, rc[16], cr); cg = fmaf(hp, rc[17], cg); cb = fmaf(hp, rc[18], cb);
+            const float4 c4 = ld4(rc + 16);
+            cr = fmaf(hp, c4.x, cr); cg = fmaf(hp, c4.y, cg); cb = fmaf(hp, c4.z, cb);
             cd = fmaf(hp, p.depth[(size_t)ray * dn + (ok ? i : 0)], cd);
-            const unsigned long long b = __ballot(ok && rc[19] > (float)p.mask_view_num);
+            const unsigned long long b = __ballot(ok && c4.w > (float)p.mask_view_num);
             cnt += __builtin_popcountll(b);
         }
         cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); cd = wave_sum(cd);

@@ -91,6 +91,15 @@ typedef nr_buf nr_mbuf;
 #endif
 #endif
 
+// a zero the compiler cannot see through, in a VGPR: `base + nr_opaque_zero()` keeps LDS reads of workgroup-uniform data
+// on one address register + immediate offsets (otherwise hipcc materialises every uniform address in an SGPR, copies
+// it to a VGPR and spills: 1085 v_mov + 450 lane moves in the ray kernel)
+#ifdef NEURAY_EMU
+static inline int nr_opaque_zero() { return 0; }
+#else
+__device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+#endif
+
 // pins program order at this point (the machine scheduler otherwise sinks a prefetch load back to its first use)
 #ifdef NEURAY_EMU
 #define NR_PIN() do {} while (0)

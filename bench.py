@@ -102,6 +102,34 @@ def cpu_baseline(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
     }
 
 
+def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch=4096):
+    """'Stock PyTorch-ROCm' baseline (the denominator of the north star's >= 10x): the eager-PyTorch
+    port of the reference's op sequence (oracle/torch_eager_port.py; the reference tree itself does not exist on
+    the GPU box) on the same device, same workload, the reference's default 4096-ray batches (render.py:205)."""
+    from oracle import torch_eager_port as tep
+    w = {k: torch.from_numpy(v).to(device) for k, v in weights.items()}
+    ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+    n = tq['coords'].shape[1]
+    starts = np.linspace(0, n - rays_per_batch, batches + 1).astype(np.int64)
+
+    def run(st):
+        q = dict(tq)
+        q['coords'] = tq['coords'][:, st:st + rays_per_batch]
+        with torch.no_grad():
+            return tep.render_impl(w, ocfg, q, tr)
+
+    run(int(starts[0]))
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for st in starts[1:]:
+        run(int(st))
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {'value': batches * rays_per_batch / dt, 'unit': 'rays/s',
+            'what': 'eager-PyTorch port of the reference op sequence on the same MI355X, %d batches of %d rays'
+                    % (batches, rays_per_batch)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -110,6 +138,7 @@ def main():
     ap.add_argument('--fine-samples', type=int, default=32, help='32 = BASELINE.json wording, 64 = reference default')
     ap.add_argument('--cpu-sample-rays', type=int, default=8192)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eager-baseline', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -178,6 +207,10 @@ def main():
                                         args.cpu_sample_rays, 1024)
             line['cpu_baseline'] = base
             line['parity'] = parity
+        if not args.no_eager_baseline and not args.no_cpu_baseline:
+            eb = eager_torch_baseline(cfg, weights, tq, tr, device)
+            eb['speedup_vs_eager'] = value / world / eb['value']
+            line['eager_torch_baseline'] = eb
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -87,3 +87,21 @@ def test_render_impl_chained_end_to_end(name):
         assert err.max() <= 5e-3, (k, float(err.max()))
         assert orc.psnr_uint8(got[k], out[k]) >= 60.0
     assert np.array_equal(got['ray_mask_fine'], out['ray_mask_fine'])
+
+
+@pytest.mark.parametrize('name', ['a_small', 'b_default', 'c_adversarial', 'e_use_all'])
+def test_torch_eager_port_matches_reference(name):
+    """The eager-PyTorch port used as the 'stock PyTorch-ROCm' baseline in bench.py is the reference's computation."""
+    import torch
+    from oracle import torch_eager_port as tep
+    cfg, que, ref, out, mid, extra = load_case(name)
+    w = {k: torch.from_numpy(v) for k, v in load_weights(False).items()}
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v) for k, v in ref.items()}
+    with torch.no_grad():
+        got = tep.render_impl(w, {**orc.DEFAULT_CFG, **oracle_cfg(cfg)}, tq, tr)
+    assert np.max(np.abs(got['pixel_colors_nr'].numpy() - out['pixel_colors_nr'])) <= TOL_PIXEL
+    assert np.max(np.abs(got['hit_prob_nr'].numpy() - out['hit_prob_nr'])) <= TOL_HIT
+    assert np.array_equal(got['ray_mask'].numpy(), out['ray_mask'])
+    err = np.max(np.abs(got['pixel_colors_nr_fine'].numpy() - out['pixel_colors_nr_fine']), -1)
+    assert np.mean(err <= TOL_PIXEL) >= 0.95 and err.max() <= 5e-3

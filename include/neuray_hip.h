@@ -112,7 +112,8 @@ int neuray_render_rays(const NeurayRaysArgs* args, void* stream);
 
 /* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
  * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,
- * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)]. */
+ * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)].
+ * use_all: bit 0 = merge the coarse depths (fine_depth_use_all), bit 1 = skip the sort (the bare render_ops function). */
 int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_dev, const float* hit_prob_dev,
                              const float* u_dev, int rn, int dn, int fdn, int use_all, float* out_dev, void* stream);
 
@@ -121,6 +122,30 @@ int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_de
  * units of the (w_full, h_full) image, mask [b][n] or NULL, out [b][n][c]. */
 int neuray_interpolate_feats(const float* feats_dev, const float* points_dev, const float* mask_dev, int b, int n, int c,
                              int fh, int fw, int h_full, int w_full, int align_corners, float* out_dev, void* stream);
+
+/* ---- stand-alone ops of the network.render_ops surface (same device code as the fused kernels) -----------------------
+ * a2  coords2rays / depth2points (render_ops.py:4-39): centers, dirs [rn][3] (may be NULL); with pts != NULL also
+ *     pts, que_dir [rn][dn][3] from depth [rn][dn]. */
+int neuray_rays_points(const float* query_const_dev, const float* coords_dev, const float* depth_dev, int rn, int dn,
+                       float* centers_dev, float* dirs_dev, float* pts_dev, float* que_dir_dev, void* stream);
+/* a3  depth2dists (inverse = 0) / depth2inv_dists (inverse = 1, que_depth_range = [near, far]) (render_ops.py:41-52) */
+int neuray_depth_dists(const float* depth_dev, const float* que_depth_range_dev, int inverse, int rows, int dn,
+                       float* out_dev, void* stream);
+/* a4-a6  project_points_ref_views (render_ops.py:82-130): pts [pn][3] -> dir [rfn][pn][3], pts2d [rfn][pn][2],
+ *     depth [rfn][pn], mask [rfn][pn] (bytes 0/1; no z > 0 test, quirk A.9.1) */
+int neuray_project_points(const float* view_const_dev, const float* pts_dev, int rfn, int pn, int h, int w, float* dir_dev,
+                          float* pts2d_dev, float* depth_dev, unsigned char* mask_dev, void* stream);
+/* a15 alpha_values2hit_prob (render_ops.py:72-80), rows x dn */
+int neuray_alpha2hit_prob(const float* alpha_dev, int rows, int dn, float* out_dev, void* stream);
+
+/* ---- a9 stand-alone: MixtureLogisticsDistDecoder.forward / predict_mean on arbitrary rows (dist_decoder.py:99-107,147-149).
+ * feats [n][32] -> mean [n][2], var [n][2] (bias_val included), aw [n], vis [n] (vis only with a vis head, else NULL). */
+int neuray_dist_decoder_rows(const float* feats_dev, const float* packed_weights_dev, int n, int has_vis_head, float var_bias,
+                             float* mean_dev, float* var_dev, float* aw_dev, float* vis_dev, void* stream);
+/* ---- a19: compute_prob(is_ref=False) of the query rays' own distributions (renderer.py:137-155, dist_decoder.py:39-46).
+ * vis_dev NULL = the decoder's use_vis is False.  out [rn][dn]. */
+int neuray_self_hit_prob(const float* query_const_dev, const float* depth_dev, const float* mean_dev, const float* var_dev,
+                         const float* aw_dev, const float* vis_dev, int rn, int dn, float* out_dev, void* stream);
 
 /* ---- hardware self test of the MFMA operand layout the kernels assume (16x4 @ 4x16) ----------------------------- */
 int neuray_mfma_selftest(const float* A_dev, const float* B_dev, float* D_dev, void* stream);

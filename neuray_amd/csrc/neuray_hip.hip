@@ -174,7 +174,7 @@ int neuray_sample_fine_depth(const float* query_const, const float* depth, const
         return fail("neuray_sample_fine_depth: dn=%d fdn=%d outside [2,%d]", dn, fdn, NEURAY_MAX_SAMPLES);
     nr::FineParams p;
     p.que_const = query_const; p.depth = depth; p.hit_prob = hit_prob; p.u = u; p.out = out;
-    p.rn = rn; p.dn = dn; p.fdn = fdn; p.use_all = use_all;
+    p.rn = rn; p.dn = dn; p.fdn = fdn; p.use_all = use_all & 1; p.no_sort = (use_all >> 1) & 1;
     const int grid = grid_for(rn, nr::kRayWaves, 256 * 16);
     NR_LAUNCH(nr::fine_kernel, dim3(grid), dim3(64 * nr::kRayWaves), 0, stream, p);
     return check_launch("neuray_sample_fine_depth");
@@ -187,6 +187,54 @@ int neuray_interpolate_feats(const float* feats, const float* points, const floa
     NR_LAUNCH(nr::interpolate_kernel, dim3(grid), dim3(256), 0, stream, feats, points, mask, b, n, c, fh, fw, h_full, w_full,
               align_corners, out);
     return check_launch("neuray_interpolate_feats");
+}
+
+int neuray_rays_points(const float* query_const, const float* coords, const float* depth, int rn, int dn, float* centers,
+                       float* dirs, float* pts, float* que_dir, void* stream) {
+    if (rn < 1 || (pts && (dn < 1 || !depth || !que_dir))) return fail("neuray_rays_points: bad arguments rn=%d dn=%d", rn, dn);
+    const int grid = grid_for((long long)rn * (pts ? dn : 1), 256, 256 * 8);
+    NR_LAUNCH(nr::rays_points_kernel, dim3(grid), dim3(256), 0, stream, query_const, coords, depth, rn, dn, centers, dirs, pts, que_dir);
+    return check_launch("neuray_rays_points");
+}
+
+int neuray_depth_dists(const float* depth, const float* que_depth_range, int inverse, int rows, int dn, float* out, void* stream) {
+    if (rows < 1 || dn < 1 || (inverse && !que_depth_range)) return fail("neuray_depth_dists: bad arguments");
+    const int grid = grid_for((long long)rows * dn, 256, 256 * 8);
+    NR_LAUNCH(nr::dists_kernel, dim3(grid), dim3(256), 0, stream, depth, que_depth_range, inverse, rows, dn, out);
+    return check_launch("neuray_depth_dists");
+}
+
+int neuray_project_points(const float* view_const, const float* pts, int rfn, int pn, int h, int w, float* dir, float* pts2d,
+                          float* depth, unsigned char* mask, void* stream) {
+    if (rfn < 1 || pn < 1) return fail("neuray_project_points: bad shape rfn=%d pn=%d", rfn, pn);
+    const int grid = grid_for((long long)rfn * pn, 256, 256 * 8);
+    NR_LAUNCH(nr::project_kernel, dim3(grid), dim3(256), 0, stream, view_const, pts, rfn, pn, h, w, dir, pts2d, depth, mask);
+    return check_launch("neuray_project_points");
+}
+
+int neuray_alpha2hit_prob(const float* alpha, int rows, int dn, float* out, void* stream) {
+    if (rows < 1 || dn < 1) return fail("neuray_alpha2hit_prob: bad shape");
+    const int grid = grid_for(rows, 64, 256 * 8);
+    NR_LAUNCH(nr::hit_prob_kernel, dim3(grid), dim3(64), 0, stream, alpha, rows, dn, out);
+    return check_launch("neuray_alpha2hit_prob");
+}
+
+int neuray_dist_decoder_rows(const float* feats, const float* packed_weights, int n, int has_vis_head, float var_bias,
+                             float* mean, float* var, float* aw, float* vis, void* stream) {
+    if (n < 1) return fail("neuray_dist_decoder_rows: n=%d", n);
+    if (has_vis_head && !vis) return fail("neuray_dist_decoder_rows: vis output missing");
+    const int grid = grid_for(n, 32 * 4, 256 * 8);
+    if (has_vis_head) NR_LAUNCH(nr::decoder_rows_kernel<true>, dim3(grid), dim3(256), 0, stream, feats, packed_weights, n, var_bias, mean, var, aw, vis);
+    else NR_LAUNCH(nr::decoder_rows_kernel<false>, dim3(grid), dim3(256), 0, stream, feats, packed_weights, n, var_bias, mean, var, aw, vis);
+    return check_launch("neuray_dist_decoder_rows");
+}
+
+int neuray_self_hit_prob(const float* query_const, const float* depth, const float* mean, const float* var, const float* aw,
+                         const float* vis, int rn, int dn, float* out, void* stream) {
+    if (rn < 1 || dn < 2) return fail("neuray_self_hit_prob: bad shape rn=%d dn=%d", rn, dn);
+    const int grid = grid_for((long long)rn * dn, 256, 256 * 8);
+    NR_LAUNCH(nr::self_hit_prob_kernel, dim3(grid), dim3(256), 0, stream, query_const, depth, mean, var, aw, vis, rn, dn, out);
+    return check_launch("neuray_self_hit_prob");
 }
 
 int neuray_mfma_selftest(const float* A, const float* B, float* D, void* stream) {

@@ -97,7 +97,8 @@ __device__ __forceinline__ Proj project_point(const float* __restrict__ vc, floa
     const bool bad = fabsf(z) < 1e-4f;          // no z>0 test: quirk A.9.1
     if (bad) z = 1e-3f;
     o.u = rn_div(c0, z); o.v = rn_div(c1, z); o.z = z;
-    const bool outside = (o.u < -0.5f) | (o.u >= w_img - 0.5f) | (o.v < -0.5f) | (o.v >= h_img - 0.5f);
+    // w_img <= 0: no image-bounds test (stand-alone project_points_coords, render_ops.py:82-104)
+    const bool outside = (w_img > 0.0f) && ((o.u < -0.5f) | (o.u >= w_img - 0.5f) | (o.v < -0.5f) | (o.v >= h_img - 0.5f));
     o.mask = (!bad && !outside) ? 1.0f : 0.0f;
     const float dx = rn_sub(px, vc[12]), dy = rn_sub(py, vc[13]), dz = rn_sub(pz, vc[14]);
     const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(dx, dx), rn_mul(dy, dy)), rn_mul(dz, dz)));

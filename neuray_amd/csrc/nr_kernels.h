@@ -736,7 +736,7 @@ struct FineParams {
     const float* hit_prob;   // [rn][dn]
     const float* u;          // [rn][fdn] or null -> stratified (k + 0.5)/fdn
     float* out;              // [rn][nout], nout = fdn (+ dn when use_all)
-    int rn, dn, fdn, use_all;
+    int rn, dn, fdn, use_all, no_sort;
 };
 
 constexpr int kMaxSamples = 128;   // dn, fdn <= 128
@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
         }
         __syncthreads();
         // bitonic sort (ascending) of npad values in LDS
-        for (int kk = 2; kk <= npad; kk <<= 1)
+        for (int kk = 2; kk <= npad && !p.no_sort; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
                 for (int i = lane; i < npad; i += 64) {
                     const int ixj = i ^ j;
@@ -851,6 +851,173 @@ __global__ void interpolate_kernel(const float* __restrict__ feats, const float*
             const float* pl = f + (size_t)ch * fh * fw;
             out[i * c + ch] = blend4(pl[t.o00], pl[t.o10], pl[t.o01], pl[t.o11], t) * m;
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Stand-alone ops of the network.render_ops surface (same device functions as the fused point kernel), used by the
+// host mirror neuray_amd/network/render_ops.py and by the function-level parity tests.
+// -------------------------------------------------------------------------------------------------
+// a2: coords2rays / depth2points (render_ops.py:4-39).  centers/dirs [rn][3]; pts, que_dir [rn][dn][3] (may be null)
+__global__ void rays_points_kernel(const float* __restrict__ qc, const float* __restrict__ coords, const float* __restrict__ depth,
+                                   int rn, int dn, float* __restrict__ centers, float* __restrict__ dirs,
+                                   float* __restrict__ pts, float* __restrict__ que_dir) {
+    const long long total = (long long)rn * (pts ? dn : 1);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ray = pts ? (int)(i / dn) : (int)i;
+        const Ray r = make_ray(qc, coords[2 * ray], coords[2 * ray + 1]);
+        if (!pts || i % dn == 0) {
+            if (centers) { centers[3 * ray] = r.cx; centers[3 * ray + 1] = r.cy; centers[3 * ray + 2] = r.cz; }
+            if (dirs) { dirs[3 * ray] = r.dx; dirs[3 * ray + 1] = r.dy; dirs[3 * ray + 2] = r.dz; }
+        }
+        if (pts) {
+            const float d = depth[i];
+            pts[3 * i] = rn_add(r.cx, rn_mul(r.dx, d)); pts[3 * i + 1] = rn_add(r.cy, rn_mul(r.dy, d));
+            pts[3 * i + 2] = rn_add(r.cz, rn_mul(r.dz, d));
+            que_dir[3 * i] = r.qx; que_dir[3 * i + 1] = r.qy; que_dir[3 * i + 2] = r.qz;
+        }
+    }
+}
+
+// a3: depth2dists (inv = 0) / depth2inv_dists (inv = 1, range = [near, far] of the query) (render_ops.py:41-52)
+__global__ void dists_kernel(const float* __restrict__ depth, const float* __restrict__ range, int inv, int rows, int dn,
+                             float* __restrict__ out) {
+    const long long total = (long long)rows * dn;
+    float nearp = 0.0f, farp = 1.0f;
+    if (inv) { nearp = rn_div(-1.0f, range[0]); farp = rn_div(-1.0f, range[1]); }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % dn);
+        if (s == dn - 1) { out[i] = 1e6f; continue; }
+        const float a = inv ? norm_inv_depth(depth[i], nearp, farp) : depth[i];
+        const float b = inv ? norm_inv_depth(depth[i + 1], nearp, farp) : depth[i + 1];
+        out[i] = rn_sub(b, a);
+    }
+}
+
+// a4-a6: project_points_ref_views (render_ops.py:82-130).  pts [pn][3] -> dir [rfn][pn][3], pts2d [rfn][pn][2],
+// depth [rfn][pn], mask [rfn][pn] (0/1 bytes)
+__global__ void project_kernel(const float* __restrict__ view_const, const float* __restrict__ pts, int rfn, int pn, int h, int w,
+                               float* __restrict__ dir, float* __restrict__ pts2d, float* __restrict__ depth,
+                               unsigned char* __restrict__ mask) {
+    const long long total = (long long)rfn * pn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / pn);
+        const long long pi = i - (long long)v * pn;
+        const Proj pr = project_point(view_const + v * kViewConst, pts[3 * pi], pts[3 * pi + 1], pts[3 * pi + 2], (float)w, (float)h);
+        dir[3 * i] = pr.dirx; dir[3 * i + 1] = pr.diry; dir[3 * i + 2] = pr.dirz;
+        pts2d[2 * i] = pr.u; pts2d[2 * i + 1] = pr.v; depth[i] = pr.z; mask[i] = pr.mask > 0.0f ? 1 : 0;
+    }
+}
+
+// a15: alpha_values2hit_prob (render_ops.py:72-80): hit = alpha * exclusive cumprod(1 - alpha + 1e-10), sequential order
+__global__ void hit_prob_kernel(const float* __restrict__ alpha, int rows, int dn, float* __restrict__ out) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+        float T = 1.0f;
+        for (int i = 0; i < dn; ++i) {
+            const float a = alpha[r * dn + i];
+            out[r * dn + i] = a * T;
+            T = T * ((1.0f - a) + 1e-10f);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// a9 stand-alone: MixtureLogisticsDistDecoder.forward on arbitrary rows (dist_decoder.py:99-107).  feats [n][32]
+// row major -> mean [n][2], var [n][2] (bias included), aw [n], vis [n] (only with a vis head).  One wave handles
+// 2 tiles of 16 rows; same MFMA layers and packed weights as the point kernel (weights straight from global).
+// -------------------------------------------------------------------------------------------------
+template <bool HAS_VIS>
+__global__ void __launch_bounds__(256) decoder_rows_kernel(const float* __restrict__ feats, const float* __restrict__ weights, int n,
+                                                           float var_bias, float* __restrict__ mean, float* __restrict__ var,
+                                                           float* __restrict__ aw, float* __restrict__ vis) {
+    constexpr int NS = 2;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wave_global = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const nr_wbuf W = nr_make_wbuf(weights, sizeof(float) * kPackedPassFloats);
+    for (int base = wave_global * 16 * NS; base < n; base += nwaves * 16 * NS) {
+        float f[NS][8], none[NS][1];
+        int row[NS]; bool ok[NS];
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < NS; ++s) {
+            int r = base + 16 * s + c;
+            ok[s] = r < n; r = ok[s] ? r : n - 1; row[s] = r; none[s][0] = 0.0f;
+            const float4 a = ld4(feats + (size_t)r * 32 + 8 * g), b = ld4(feats + (size_t)r * 32 + 8 * g + 4);
+            f[s][0] = a.x; f[s][1] = a.y; f[s][2] = a.z; f[s][3] = a.w; f[s][4] = b.x; f[s][5] = b.y; f[s][6] = b.z; f[s][7] = b.w;
+        }
+        float cat[NS][16], h1[NS][8], h2[NS][8], fin[NS][4];
+        layer_fwd<L_DM1, NS, ACT_ELU>(W, lane, f, none, h1);
+        layer_fwd<L_DM2, NS, ACT_ELU>(W, lane, h1, none, h2);
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < NS; ++s)
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
+        layer_fwd<L_DV1, NS, ACT_ELU>(W, lane, f, none, h1);
+        layer_fwd<L_DV2, NS, ACT_ELU>(W, lane, h1, none, h2);
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < NS; ++s)
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
+        layer_fwd<L_DFIN_MS, NS, ACT_NONE>(W, lane, cat, none, fin);
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < NS; ++s)
+            if (ok[s] && g == 0) {
+                mean[2 * row[s]] = softplus(fin[s][0]); mean[2 * row[s] + 1] = softplus(fin[s][1]);
+                var[2 * row[s]] = softplus(fin[s][2]) + var_bias; var[2 * row[s] + 1] = softplus(fin[s][3]) + var_bias;
+            }
+        layer_fwd<L_DA1, NS, ACT_ELU>(W, lane, f, none, h1);
+        layer_fwd<L_DA2, NS, ACT_ELU>(W, lane, h1, none, h2);
+        if (HAS_VIS) {
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s)
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
+            layer_fwd<L_DS1, NS, ACT_ELU>(W, lane, f, none, h1);
+            layer_fwd<L_DS2, NS, ACT_ELU>(W, lane, h1, none, h2);
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s)
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
+            layer_fwd<L_DFIN_AV, NS, ACT_NONE>(W, lane, cat, none, fin);
+        } else {
+            layer_fwd<L_DFIN_A, NS, ACT_NONE>(W, lane, h2, none, fin);
+        }
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < NS; ++s)
+            if (ok[s] && g == 0) {
+                aw[row[s]] = sigmoidf(fin[s][0]);
+                if (HAS_VIS) vis[row[s]] = sigmoidf(fin[s][1]);
+            }
+    }
+}
+
+// a19: compute_prob(is_ref=False) of a ray's own decoded distribution (dist_decoder.py:39-46,109-140; renderer.py:137-155)
+//   mean, var [rn][2], aw, vis [rn] (vis may be null), depth [rn][dn] -> hit_prob [rn][dn]
+__global__ void self_hit_prob_kernel(const float* __restrict__ qc, const float* __restrict__ depth, const float* __restrict__ mean,
+                                     const float* __restrict__ var, const float* __restrict__ aw, const float* __restrict__ vis,
+                                     int rn, int dn, float* __restrict__ out) {
+    const float nearp = qc[24], farp = qc[25];
+    const long long total = (long long)rn * dn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ray = (int)(i / dn), smp = (int)(i - (long long)ray * dn);
+        const float* drow = depth + (size_t)ray * dn;
+        // normalised inverse depth of the query samples: the interval fed in is que_dists = depth2inv_dists(depth)
+        // (un-clamped), the positions are clamped at 1e-5 (dist_decoder.py:24-28)
+        const float t_c = norm_inv_depth(fmaxf(drow[smp], 1e-5f), nearp, farp);
+        float lo, hi;
+        if (smp == 0) {
+            const float half0 = rn_div(rn_sub(norm_inv_depth(drow[1], nearp, farp), norm_inv_depth(drow[0], nearp, farp)), 2.0f);
+            lo = rn_sub(t_c, half0);
+        } else {
+            lo = rn_div(rn_add(norm_inv_depth(fmaxf(drow[smp - 1], 1e-5f), nearp, farp), t_c), 2.0f);
+        }
+        if (smp == dn - 1) hi = rn_add(t_c, 500000.0f);
+        else hi = rn_div(rn_add(t_c, norm_inv_depth(fmaxf(drow[smp + 1], 1e-5f), nearp, farp)), 2.0f);
+        float v_, h_;
+        const float nu = vis ? vis[ray] : 1.0f;
+        // logistic_prob takes (t, lo_half, hi_half) with near = t - lo_half, far = t + hi_half
+        logistic_prob(0.0f, -lo, hi, mean[2 * ray], mean[2 * ray + 1], var[2 * ray], var[2 * ray + 1], aw[ray], nu, vis != nullptr, v_, h_);
+        out[i] = h_;
     }
 }
 

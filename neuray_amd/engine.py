@@ -160,11 +160,11 @@ class RenderEngine:
         pose = self._f32(que_imgs_info['poses'])
         assert pose.shape[0] == 1, "one query view per render() call (qn = 1)"
         Ks = self._f32(que_imgs_info['Ks'])
-        kinv = self._f32(que_imgs_info['Ks_inv']) if 'Ks_inv' in que_imgs_info else torch.inverse(Ks)
+        # torch.inverse returns a column-major tensor: make it contiguous and keep it bound until the launch
+        kinv = self._f32(que_imgs_info['Ks_inv'] if 'Ks_inv' in que_imgs_info else torch.inverse(Ks))
         dr = self._f32(que_imgs_info['depth_range'])
         qc = self.empty(_lib.QUERY_CONST)
-        self._check(self.lib.neuray_setup_query(pose.data_ptr(), kinv.contiguous().data_ptr(), dr.data_ptr(), qc.data_ptr(),
-                                                self._stream()))
+        self._check(self.lib.neuray_setup_query(pose.data_ptr(), kinv.data_ptr(), dr.data_ptr(), qc.data_ptr(), self._stream()))
         return qc
 
     # ------------------------------------------------------------------------------------------
@@ -174,7 +174,7 @@ class RenderEngine:
         self._check(self.lib.neuray_sample_coarse_depth(dr.data_ptr(), rn, dn, depth.data_ptr(), self._stream()))
         return depth
 
-    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None):
+    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None, sort=True):
         rn, dn = depth.shape
         out = self.empty(rn, fdn + (dn if use_all else 0))
         u_ptr = None
@@ -182,7 +182,76 @@ class RenderEngine:
             u = self._f32(u).reshape(rn, fdn)
             u_ptr = u.data_ptr()
         self._check(self.lib.neuray_sample_fine_depth(qconst.data_ptr(), depth.data_ptr(), hit_prob.data_ptr(), u_ptr,
-                                                      rn, dn, fdn, int(use_all), out.data_ptr(), self._stream()))
+                                                      rn, dn, fdn, int(use_all) | (0 if sort else 2), out.data_ptr(),
+                                                      self._stream()))
+        return out
+
+    def setup_views(self, poses, Ks, depth_range):
+        poses, Ks, dr = self._f32(poses), self._f32(Ks), self._f32(depth_range)
+        vc = self.empty(poses.shape[0], _lib.VIEW_CONST)
+        self._check(self.lib.neuray_setup_views(poses.data_ptr(), Ks.data_ptr(), dr.data_ptr(), poses.shape[0], vc.data_ptr(),
+                                                self._stream()))
+        return vc
+
+    def rays_points(self, qconst, coords, depth=None):
+        """coords2rays / depth2points for one query view: -> centers, dirs [rn,3] (, pts, que_dir [rn,dn,3])"""
+        coords = self._f32(coords)
+        rn = coords.shape[0]
+        centers, dirs = self.empty(rn, 3), self.empty(rn, 3)
+        if depth is None:
+            self._check(self.lib.neuray_rays_points(qconst.data_ptr(), coords.data_ptr(), None, rn, 1, centers.data_ptr(),
+                                                    dirs.data_ptr(), None, None, self._stream()))
+            return centers, dirs
+        depth = self._f32(depth)
+        dn = depth.shape[1]
+        pts, qdir = self.empty(rn, dn, 3), self.empty(rn, dn, 3)
+        self._check(self.lib.neuray_rays_points(qconst.data_ptr(), coords.data_ptr(), depth.data_ptr(), rn, dn, centers.data_ptr(),
+                                                dirs.data_ptr(), pts.data_ptr(), qdir.data_ptr(), self._stream()))
+        return centers, dirs, pts, qdir
+
+    def depth_dists(self, depth, que_depth_range):
+        depth = self._f32(depth)
+        out = torch.empty_like(depth)
+        dr = self._f32(que_depth_range).reshape(-1)[:2].contiguous() if que_depth_range is not None else None
+        rows = depth.numel() // depth.shape[-1]
+        self._check(self.lib.neuray_depth_dists(depth.data_ptr(), dr.data_ptr() if dr is not None else None,
+                                                int(dr is not None), rows, depth.shape[-1], out.data_ptr(), self._stream()))
+        return out
+
+    def project_points(self, view_const, pts, rfn, h, w):
+        pts = self._f32(pts)
+        pn = pts.shape[0]
+        d, p2, z = self.empty(rfn, pn, 3), self.empty(rfn, pn, 2), self.empty(rfn, pn)
+        m = self.empty(rfn, pn, dtype=torch.uint8)
+        self._check(self.lib.neuray_project_points(view_const.data_ptr(), pts.data_ptr(), rfn, pn, int(h), int(w), d.data_ptr(),
+                                                   p2.data_ptr(), z.data_ptr(), m.data_ptr(), self._stream()))
+        return d, p2, z, m.bool()
+
+    def alpha2hit_prob(self, alpha):
+        alpha = self._f32(alpha)
+        out = torch.empty_like(alpha)
+        self._check(self.lib.neuray_alpha2hit_prob(alpha.data_ptr(), alpha.numel() // alpha.shape[-1], alpha.shape[-1],
+                                                   out.data_ptr(), self._stream()))
+        return out
+
+    def dist_decoder_rows(self, feats, packed, var_bias=0.05):
+        """MixtureLogisticsDistDecoder.forward on [..., 32] rows -> mean [...,2], var [...,2], vis [...,1] or None, aw [...,1]"""
+        feats = self._f32(feats)
+        lead = feats.shape[:-1]
+        n = feats.numel() // 32
+        mean, var, aw = self.empty(n, 2), self.empty(n, 2), self.empty(n)
+        vis = self.empty(n) if packed.has_vis_head else None
+        self._check(self.lib.neuray_dist_decoder_rows(feats.data_ptr(), packed.dev.data_ptr(), n, int(packed.has_vis_head),
+                                                      float(var_bias), mean.data_ptr(), var.data_ptr(), aw.data_ptr(),
+                                                      vis.data_ptr() if vis is not None else None, self._stream()))
+        return (mean.view(*lead, 2), var.view(*lead, 2), vis.view(*lead, 1) if vis is not None else None, aw.view(*lead, 1))
+
+    def self_hit_prob(self, qconst, depth, mean, var, aw, vis):
+        depth = self._f32(depth)
+        rn, dn = depth.shape
+        out = self.empty(rn, dn)
+        self._check(self.lib.neuray_self_hit_prob(qconst.data_ptr(), depth.data_ptr(), mean.data_ptr(), var.data_ptr(), aw.data_ptr(),
+                                                  vis.data_ptr() if vis is not None else None, rn, dn, out.data_ptr(), self._stream()))
         return out
 
     def interpolate_feats(self, feats, points, h=None, w=None, align_corners=False, mask=None):

@@ -75,8 +75,6 @@ class NeuralRayBaseRenderer(nn.Module):
         if is_train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("neuray_amd: the HIP render path is forward-only in this round (no backward "
                                       "kernels yet); call under torch.no_grad()")
-        if is_train and self.cfg['use_self_hit_prob']:
-            raise NotImplementedError("neuray_amd: use_self_hit_prob (renderer.py:137-155) is not built yet")
         coords = que_imgs_info['coords']
         assert coords.shape[0] == 1 and que_depth.shape[0] == 1, "one query view per call (qn = 1)"
         eng = self.engine(coords.device)
@@ -92,6 +90,8 @@ class NeuralRayBaseRenderer(nn.Module):
                               ray_mask_view_num=self.cfg['ray_mask_view_num'], ray_mask_point_num=self.cfg['ray_mask_point_num'],
                               want_depth=self.cfg['render_depth'])
         outputs = {'pixel_colors_nr': res['pixel'][None], 'hit_prob_nr': res['hit_prob'][None]}
+        if is_train and self.cfg['use_self_hit_prob']:
+            outputs['hit_prob_self'] = self.predict_self_hit_prob(que_imgs_info, que_depth, is_fine)
         if 'imgs' in que_imgs_info:
             outputs['pixel_colors_gt'] = eng.interpolate_feats(que_imgs_info['imgs'], coords, align_corners=True)
         if self.cfg['use_ray_mask']:
@@ -99,6 +99,17 @@ class NeuralRayBaseRenderer(nn.Module):
         if self.cfg['render_depth']:
             outputs['render_depth'] = res['render_depth'][None]
         return outputs
+
+    def predict_self_hit_prob(self, que_imgs_info, que_depth, is_fine):
+        """network/renderer.py:137-155: decode the query view's own visibility feature along its rays."""
+        coords = que_imgs_info['coords']
+        eng = self.engine(coords.device)
+        _, _, h, w = que_imgs_info['imgs'].shape
+        feats = eng.interpolate_feats(que_imgs_info['ray_feats'], coords, h, w, align_corners=False)      # [1,rn,32]
+        dec = self.fine_dist_decoder if is_fine else self.dist_decoder
+        mean, var, vis, aw = eng.dist_decoder_rows(feats[0], self._packed_pass(eng, is_fine), dec.cfg['bias_val'])
+        vis = vis if dec.cfg['use_vis'] else None
+        return eng.self_hit_prob(que_imgs_info['_neuray_qconst'], que_depth[0], mean, var, aw, vis)[None]
 
     def fine_render_impl(self, coarse_render_info, que_imgs_info, ref_imgs_info, is_train):
         """network/renderer.py:205-215"""

@@ -139,11 +139,8 @@ def test_fine_sampling_matches_reference(name, backend):
 @pytest.mark.parametrize('name', CASES)
 def test_render_impl_matches_reference(name, backend):
     """Full coarse+fine render_impl against the golden outputs of the reference renderer."""
-    override = {'use_self_hit_prob': False} if name == 'd_train_vis' else None
-    cfg, que, ref, out, mid, extra, weights, got, _ = run_case(name, backend, override)
+    cfg, que, ref, out, mid, extra, weights, got, _ = run_case(name, backend)
     for k, v in out.items():
-        if k.startswith('hit_prob_self'):
-            continue
         assert k in got, k
         assert got[k].shape == v.shape, (k, got[k].shape, v.shape)
     # coarse pass: direct comparison
@@ -158,6 +155,10 @@ def test_render_impl_matches_reference(name, backend):
     assert np.array_equal(got['ray_mask_fine'], out['ray_mask_fine'])
     if 'render_depth' in out:
         np.testing.assert_allclose(got['render_depth'], out['render_depth'], atol=2e-3)
+    if 'hit_prob_self' in out:      # a19, training mode (case d): the coarse one sees identical inputs
+        np.testing.assert_allclose(got['hit_prob_self'], out['hit_prob_self'], atol=TOL_HIT)
+        err_s = np.max(np.abs(got['hit_prob_self_fine'] - out['hit_prob_self_fine']), -1)
+        assert np.mean(err_s <= TOL_HIT) >= 0.9
     if 'pixel_colors_gt' in out:
         np.testing.assert_allclose(got['pixel_colors_gt'], out['pixel_colors_gt'], atol=1e-6)
 
@@ -217,8 +218,6 @@ def test_both_wave_decompositions(name, vpw, backend):
     """views_per_wave = 1 and 2 (odd view counts pad a masked view; rfn 2, 3, 5 exercise OWN = 2 / 4 tiles per
     wave) give the same result up to the summation order of the cross-view reductions."""
     cfg, que, ref, out, mid, extra = load_case(name)
-    if name == 'd_train_vis':
-        cfg = {**cfg, 'use_self_hit_prob': False}
     r, dev = make_renderer(cfg, load_weights(case_uses_vis_weights(name)), backend)
     r.engine(dev).views_per_wave = vpw
     torch.manual_seed(1234)

@@ -185,6 +185,12 @@ def main():
         t_pts = sum(t for t, _ in pts)
         n_pts = sum(n for _, n in pts)
         flops_pt = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False)
+        # HBM/fabric traffic of the point kernel per launch: PMC passes are run separately (rocprofv3 --pmc cannot run
+        # inside this process); the committed summary of the same command is reported here (profiles/README.md)
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if args.fine_samples == 32 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('bytes_per_launch')
         achieved = flops_pt * n_pts / t_pts / 1e12
         line = {
             'metric': 'rays/sec (64 coarse+%d fine samples), lego 800x800 synthetic' % args.fine_samples,
@@ -196,7 +202,8 @@ def main():
                                    % args.fine_samples,
                        'ray_batch': cfg['ray_batch_num'], 'parallelism': 'images sharded over %d GPU(s), no collective' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic,
+                         'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)',
                          'kernel': 'nr::points_kernel', 'launches': len(pts),
                          'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
                          'algorithmic_flops_per_point': flops_pt,

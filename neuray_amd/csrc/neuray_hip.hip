@@ -51,6 +51,7 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     // persistent-style grid: enough workgroups to fill 256 CUs several times over, grid-stride beyond
     int grid = grid_for(npts, 16 * NT, 256 * 16);
     if (const char* e = getenv("NEURAY_MAX_GRID")) grid = grid < atoi(e) ? grid : atoi(e);   // test knob: force grid-stride
+    grid = (grid + 7) / 8 * 8;                         // the XCD-aware tile map needs a multiple of 8
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")
     auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW>;

@@ -32,7 +32,9 @@ __device__ __forceinline__ float softplus(float x) { return x; }
 __device__ __forceinline__ float sigmoidf(float x) { return x; }
 __device__ __forceinline__ float tanh_(float x) { return x; }
 #else
-__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : nr_fast_exp(x) - 1.0f; }
+// ELU(x) = median(x, exp(x) - 1, 0): for x > 0 the order is 0 < x <= exp(x)-1, for x < 0 it is x < exp(x)-1 < 0, so one
+// v_med3_f32 replaces the compare + select (4 instead of 5 VALU per activation; +inf from exp overflow is harmless)
+__device__ __forceinline__ float elu(float x) { return nr_med3(x, nr_fast_exp(x) - 1.0f, 0.0f); }
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : nr_fast_log(1.0f + nr_fast_exp(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return nr_fast_rcp(1.0f + nr_fast_exp(-x)); }
 __device__ __forceinline__ float tanh_(float x) {   // 1 - 2/(exp(2x)+1); saturates cleanly to +-1
@@ -59,12 +61,18 @@ __device__ __forceinline__ float norm_inv_depth(float d, float nearp, float farp
     return rn_div(rn_sub(rn_div(-1.0f, d), nearp), rn_sub(farp, nearp));
 }
 
+// feature-path variant (does not decide any mask or index): one hardware reciprocal, ~1 ulp
+__device__ __forceinline__ float norm_inv_depth_fast(float d, float nearp, float inv_range) {
+    return (-nr_fast_rcp(d) - nearp) * inv_range;
+}
+
 // ---------------------------------------------------------------------------------------------
 // a2  query ray                                                   network/render_ops.py:4-39
 //   qc = query constants: [0..8] K^-1, [9..20] pose, [21..23] centre
 // ---------------------------------------------------------------------------------------------
 struct Ray { float cx, cy, cz, dx, dy, dz, qx, qy, qz; };   // centre, un-normalised dir, que_dir = -dir/|dir|
 
+template <bool EXACT = true>
 __device__ __forceinline__ Ray make_ray(const float* __restrict__ qc, float x, float y) {
     Ray r;
     const float cam0 = dot3(qc[0], qc[1], qc[2], x, y, 1.0f);
@@ -79,7 +87,8 @@ __device__ __forceinline__ Ray make_ray(const float* __restrict__ qc, float x, f
     r.dy = rn_sub(rn_add(w1, r.cy), r.cy);
     r.dz = rn_sub(rn_add(w2, r.cz), r.cz);
     const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(r.dx, r.dx), rn_mul(r.dy, r.dy)), rn_mul(r.dz, r.dz)));
-    r.qx = rn_div(-r.dx, nrm); r.qy = rn_div(-r.dy, nrm); r.qz = rn_div(-r.dz, nrm);
+    if (EXACT) { r.qx = rn_div(-r.dx, nrm); r.qy = rn_div(-r.dy, nrm); r.qz = rn_div(-r.dz, nrm); }
+    else { const float inv = nr_fast_rcp(nrm); r.qx = -r.dx * inv; r.qy = -r.dy * inv; r.qz = -r.dz * inv; }   // direction feature only
     return r;
 }
 
@@ -89,6 +98,7 @@ __device__ __forceinline__ Ray make_ray(const float* __restrict__ qc, float x, f
 // ---------------------------------------------------------------------------------------------
 struct Proj { float u, v, z, mask, dirx, diry, dirz; };
 
+template <bool EXACT = true>
 __device__ __forceinline__ Proj project_point(const float* __restrict__ vc, float px, float py, float pz, float w_img, float h_img) {
     Proj o;
     const float c0 = rn_add(rn_add(rn_add(rn_mul(vc[0], px), rn_mul(vc[1], py)), rn_mul(vc[2], pz)), vc[3]);
@@ -103,7 +113,8 @@ __device__ __forceinline__ Proj project_point(const float* __restrict__ vc, floa
     const float dx = rn_sub(px, vc[12]), dy = rn_sub(py, vc[13]), dz = rn_sub(pz, vc[14]);
     const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(dx, dx), rn_mul(dy, dy)), rn_mul(dz, dz)));
     const float den = fmaxf(nrm, 1e-5f);
-    o.dirx = rn_div(-dx, den); o.diry = rn_div(-dy, den); o.dirz = rn_div(-dz, den);
+    if (EXACT) { o.dirx = rn_div(-dx, den); o.diry = rn_div(-dy, den); o.dirz = rn_div(-dz, den); }
+    else { const float inv = nr_fast_rcp(den); o.dirx = -dx * inv; o.diry = -dy * inv; o.dirz = -dz * inv; }   // feature only
     return o;
 }
 
@@ -121,6 +132,33 @@ __device__ __forceinline__ float texel_coord(float p, float size_full, float siz
 }
 
 struct Taps { int o00, o10, o01, o11; float w00, w10, w01, w11; };   // texel offsets (y*W + x) and weights
+
+// feature-path texel coordinate: p * 1/(size_full-1) instead of the correctly rounded division (<= 1 ulp apart; the
+// bilinear result is continuous in the coordinate, validity masks never depend on it)
+__device__ __forceinline__ float texel_coord_fast(float p, float inv_full_m1, float size_map, bool align) {
+    const float n = p * inv_full_m1 * 2.0f - 1.0f;
+    const float ix = align ? (n + 1.0f) * 0.5f * (size_map - 1.0f) : ((n + 1.0f) * size_map - 1.0f) * 0.5f;
+    return fminf(size_map - 1.0f, fmaxf(ix, 0.0f));
+}
+
+__device__ __forceinline__ Taps taps_from(float ix, float iy, int mw, int mh) {
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + 1 < mw ? x0 + 1 : mw - 1;
+    const int yb = y0 + 1 < mh ? y0 + 1 : mh - 1;
+    const float wx1 = ix - x0f, wy1 = iy - y0f;
+    const float wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
+    Taps t;
+    t.o00 = y0 * mw + x0; t.o10 = y0 * mw + x1; t.o01 = yb * mw + x0; t.o11 = yb * mw + x1;
+    t.w00 = wx0 * wy0; t.w10 = wx1 * wy0; t.w01 = wx0 * wy1; t.w11 = wx1 * wy1;
+    if (x0 + 1 > mw - 1) { t.w10 = 0.0f; t.w11 = 0.0f; }
+    if (y0 + 1 > mh - 1) { t.w01 = 0.0f; t.w11 = 0.0f; }
+    return t;
+}
+
+__device__ __forceinline__ Taps make_taps_fast(float u, float v, float inv_w_m1, float inv_h_m1, int mw, int mh, bool align) {
+    return taps_from(texel_coord_fast(u, inv_w_m1, (float)mw, align), texel_coord_fast(v, inv_h_m1, (float)mh, align), mw, mh);
+}
 
 __device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_full, int mw, int mh) {
     const bool align = (mw == w_full) && (mh == h_full);
@@ -160,6 +198,9 @@ __device__ __forceinline__ float wld1(nr_wbuf W, int voff, int soff) {
 // a staged phase of the packed weights in LDS: same byte offsets as the global buffer, rebased to the phase start
 struct LdsW { const float* base; int begin_bytes; };
 __device__ __forceinline__ float4 wld4(LdsW w, int voff, int soff) {
+#if defined(NR_ABLATE) && (NR_ABLATE & 32)
+    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
+#endif
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
 }
 __device__ __forceinline__ float wld1(LdsW w, int voff, int soff) {
@@ -229,6 +270,10 @@ __device__ __forceinline__ void layer_bias(WS W, int lane, v4f (&acc)[NT][kShape
     }
 }
 
+#ifndef NR_PREFETCH
+#define NR_PREFETCH 2
+#endif
+
 // One quad of A fragments feeds 4 K-steps x NT slots of MFMAs.
 template <int NT, int KQX>
 __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (&xq)[NT][KQX], v4f (&acc)[NT]) {
@@ -288,12 +333,15 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const float (&xq)[NT][
     float s1[MT * K1 > 0 ? MT * K1 : 1];
     NR_PRAGMA_UNROLL
     for (int i = 0; i < MT * K1; ++i) s1[i] = wld1(W, lane * 4, (single_offset(L) + i * 64) * 4);
-    if (KQ > 0) {
-        float4 cur = wld4(W, lane * 16, quads_offset(L) * 4);
+    if constexpr (KQ > 0) {
+        // fragment stream with NR_PREFETCH quads in flight ahead of the one being consumed
+        constexpr int NQ = MT * KQ, PF = NR_PREFETCH < NQ ? NR_PREFETCH : NQ - 1;
+        float4 ring[PF + 1];
         NR_PRAGMA_UNROLL
-        for (int i = 0; i < MT * KQ; ++i) {
-            float4 nxt = cur;
-            if (i + 1 < MT * KQ) nxt = wld4(W, lane * 16, (quads_offset(L) + (i + 1) * 256) * 4);
+        for (int i = 0; i <= PF; ++i) ring[i] = wld4(W, lane * 16, (quads_offset(L) + i * 256) * 4);
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < NQ; ++i) {
+            const float4 cur = ring[i % (PF + 1)];
             NR_PIN();
             const int mo = i / KQ, kq = i % KQ;
             v4f a[NT];
@@ -302,7 +350,7 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const float (&xq)[NT][
             mfma_quad<NT>(cur, kq, xq, a);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
-            cur = nxt;
+            if (i + PF + 1 < NQ) ring[i % (PF + 1)] = wld4(W, lane * 16, (quads_offset(L) + (i + PF + 1) * 256) * 4);
         }
     }
     NR_PRAGMA_UNROLL
@@ -348,6 +396,9 @@ __device__ __forceinline__ LdsW stage_phase(float* wl, nr_wbuf W, int tid, int n
     constexpr int begin = phase_begin(PH), n4 = phase_floats(PH) / 4;
     static_assert(phase_floats(PH) % 4 == 0 && phase_floats(PH) <= kWeightLdsFloats, "phase does not fit the LDS stage");
     float4* dst = reinterpret_cast<float4*>(wl);
+#if defined(NR_ABLATE) && (NR_ABLATE & 64)
+    return LdsW{wl, begin * 4};      // no copy, no barriers
+#endif
     __syncthreads();
     for (int i = tid; i < n4; i += 4 * nthreads) {
         float4 v[4];

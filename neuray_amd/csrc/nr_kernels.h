@@ -26,7 +26,8 @@ __global__ void view_setup_kernel(const float* __restrict__ poses, const float* 
     for (int i = 0; i < 3; ++i) o[12 + i] = dot3(-P[i], -P[4 + i], -P[8 + i], P[3], P[7], P[11]);
     o[15] = rn_div(-1.0f, depth_range[2 * v]);
     o[16] = rn_div(-1.0f, depth_range[2 * v + 1]);
-    o[17] = 0.0f; o[18] = 0.0f; o[19] = 0.0f;
+    o[17] = rn_div(1.0f, rn_sub(o[16], o[15]));   // 1 / (far' - near'): feature-path normalisation
+    o[18] = 0.0f; o[19] = 0.0f;
 }
 
 __global__ void query_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
@@ -37,7 +38,8 @@ __global__ void query_setup_kernel(const float* __restrict__ pose, const float* 
     for (int i = 0; i < 3; ++i) o[21 + i] = dot3(-pose[i], -pose[4 + i], -pose[8 + i], pose[3], pose[7], pose[11]);
     o[24] = rn_div(-1.0f, depth_range[0]);
     o[25] = rn_div(-1.0f, depth_range[1]);
-    o[26] = depth_range[0]; o[27] = depth_range[1];
+    o[26] = depth_range[0];
+    o[27] = rn_div(1.0f, rn_sub(o[25], o[24]));   // 1 / (far' - near')
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -154,7 +156,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     const int tid = threadIdx.x, nthreads = 64 * nw;
     const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
     const float* __restrict__ qc = p.que_const;
-    const float qnearp = qc[24], qfarp = qc[25];
+    const float qnearp = qc[24], qinv = qc[27];
+    const float inv_w_m1 = 1.0f / (float)(p.w - 1), inv_h_m1 = 1.0f / (float)(p.h - 1), inv_rfn = 1.0f / (float)p.rfn;
     const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
     const nr_mbuf rf_map = nr_make_mbuf(p.ray_feats, sizeof(float) * fmap * p.rfn);
     const nr_mbuf if_map = nr_make_mbuf(p.img_feats, sizeof(float) * fmap * p.rfn);
@@ -173,7 +176,11 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     }
 #endif
 
-    for (int base = blockIdx.x * (16 * NT); base < npts; base += gridDim.x * (16 * NT)) {
+    // XCD-aware tile map: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Giving every
+    // XCD a contiguous run of tiles keeps the texels that neighbouring samples / rays share inside one private L2
+    // instead of fetching them into all eight (the grid is a multiple of 8).
+    const int bid = (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8);
+    for (int base = bid * (16 * NT); base < npts; base += gridDim.x * (16 * NT)) {
         // ---------------- geometry + gather (a2-a8) -------------------------------------------
         int pidx[NT]; bool pvalid[NT];
         float mask[NS], dlt[NS][4], fray[NS][8], fimg[NS][8], rgb[NS][3], tref[NS], lo[NT], hi[NT];
@@ -184,15 +191,16 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             pi = pi < npts ? pi : npts - 1;
             pidx[t] = pi;
             const int ray = pi / dn, smp = pi - ray * dn;
-            const Ray r = make_ray(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
+            const Ray r = make_ray<false>(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
             const float* drow = p.depth + (size_t)ray * dn;
             const float d = drow[smp];
-            const float s_c = norm_inv_depth(d, qnearp, qfarp);
-            // half intervals in normalised inverse depth (render_ops.py:46-52, dist_decoder.py:34-38)
-            const float s_n = norm_inv_depth(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qfarp);
-            const float s_p = norm_inv_depth(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp);
-            const float half_c = (smp == dn - 1) ? 500000.0f : rn_div(rn_sub(s_n, s_c), 2.0f);
-            const float half_p = rn_div(rn_sub(s_c, s_p), 2.0f);
+            // half intervals in normalised inverse depth (render_ops.py:46-52, dist_decoder.py:34-38); feature path:
+            // hardware reciprocals (they feed only the logistic CDFs)
+            const float s_c = norm_inv_depth_fast(d, qnearp, qinv);
+            const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qinv);
+            const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qinv);
+            const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
+            const float half_p = (s_c - s_p) * 0.5f;
             hi[t] = half_c;
             lo[t] = (smp == 0) ? half_c : half_p;
             const float px = rn_add(r.cx, rn_mul(r.dx, d));
@@ -205,21 +213,21 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 const bool vok = vraw < p.rfn;                // padding view when rfn % VPW != 0: masked out
                 const int view = vok ? vraw : p.rfn - 1;
                 const float* __restrict__ vc = p.view_const + view * kViewConst;
-                Proj pr = project_point(vc, px, py, pz, (float)p.w, (float)p.h);
+                Proj pr = project_point<false>(vc, px, py, pz, (float)p.w, (float)p.h);   // u, v, z, mask stay exact
                 if (!vok) pr.mask = 0.0f;
                 mask[s] = pr.mask;
                 dlt[s][0] = pr.dirx - r.qx; dlt[s][1] = pr.diry - r.qy; dlt[s][2] = pr.dirz - r.qz;
                 dlt[s][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
-                tref[s] = norm_inv_depth(fmaxf(pr.z, 1e-5f), vc[15], vc[16]);
+                tref[s] = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
                 if (dbg_lane && pvalid[t] && vok) {
                     float* d_ = p.dbg + ((size_t)pi * p.rfn + view) * kDbgFields;
                     d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
                 }
-                const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
+                const Taps tf = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
                 const int fsoff = view * (int)(fmap * sizeof(float)), isoff = view * (int)(imap * sizeof(float));
                 gather8(rf_map, goff, fsoff, tf, pr.mask, fray[s]);
                 gather8(if_map, goff, fsoff, tf, pr.mask, fimg[s]);
-                const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
+                const Taps tc = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.w, p.h, true);
                 gather_rgb(rgb_map, isoff, tc, pr.mask, rgb[s]);
             }
         }
@@ -336,7 +344,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             view_allreduce<NT, VPW, 1, RMAX, RED_SUM>(m1, msum, red, wave, nw, lane);
         }
         NR_PRAGMA_UNROLL
-        for (int s = 0; s < NS; ++s) wv[s] = mask[s] / (msum[s % NT] + 1e-8f);
+        for (int s = 0; s < NS; ++s) wv[s] = mask[s] * nr_fast_rcp(msum[s % NT] + 1e-8f);
 
         v4f accv[NS][4];
         {
@@ -467,8 +475,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
                 const int t = s % NT;
-                wh[s] = vis2[s] / (sums[2 * t] + 1e-8f);
-                const float beta = ev[s] / sums[2 * t + 1];
+                wh[s] = vis2[s] * nr_fast_rcp(sums[2 * t] + 1e-8f);
+                const float beta = ev[s] * nr_fast_rcp(sums[2 * t + 1]);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) b12[s][k] = x[s][k] * wh[s];
                 b12[s][8] = wh[s];
@@ -497,7 +505,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             for (int t = 0; t < NT; ++t) {
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xq[t][k] = big[t * 12 + k];
-                x1[t][0] = sel4(g, big[t * 12 + 8] / (float)p.rfn, 0.0f, 0.0f, 0.0f);
+                x1[t][0] = sel4(g, big[t * 12 + 8] * inv_rfn, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {

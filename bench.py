@@ -63,10 +63,13 @@ def build_case(device, fdn, seed):
     return cfg, renderer, weights, que, ref, tq, tr
 
 
-def render_image(renderer, tq, tr):
+def render_image(renderer, tq, tr, split=False):
     q = dict(tq)
     r = {k: v for k, v in tr.items() if not k.startswith('_')}   # fresh dict: relayout is part of the step
     with torch.no_grad():
+        if split:       # this rank's ray range + all-gather of the tiles (neuray_amd/parallel.py)
+            from neuray_amd import parallel
+            return parallel.render_image_sharded(renderer, q, r)
         return renderer.render(q, r, False)
 
 
@@ -139,6 +142,9 @@ def main():
     ap.add_argument('--cpu-sample-rays', type=int, default=8192)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-baseline', action='store_true')
+    ap.add_argument('--split-image', action='store_true',
+                    help='N > 1: split ONE image over the ranks (contiguous ray ranges) and all-gather the rendered tiles '
+                         '(strong scaling, RCCL all-gather) instead of one image per rank (weak scaling, no collective)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -151,12 +157,13 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=device)
 
-    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=rank)
+    split = args.split_image and world > 1
+    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=0 if split else rank)
     eng = renderer.engine(device)
     nrays = H * W
 
     for _ in range(args.warmup):
-        out = render_image(renderer, tq, tr)
+        out = render_image(renderer, tq, tr, split)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -168,7 +175,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = render_image(renderer, tq, tr)
+        out = render_image(renderer, tq, tr, split)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -178,7 +185,7 @@ def main():
     timing, eng.timing = eng.timing, None
 
     if rank == 0:
-        value = world * args.steps * nrays / dt
+        value = (1 if split else world) * args.steps * nrays / dt
         # dominant kernel: the point kernel.  Duration from HIP events on the launch stream.
         pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in timing if name == 'points']
         rays_k = [e0.elapsed_time(e1) * 1e-3 for name, e0, e1, n in timing if name == 'rays']
@@ -195,12 +202,14 @@ def main():
         line = {
             'metric': 'rays/sec (64 coarse+%d fine samples), lego 800x800 synthetic' % args.fine_samples,
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if split else 'weak',
+            'vs_baseline': None,
             'dtype': 'fp32', 'data': 'synthetic',
             'config': {'workload': 'lego-800 synthetic (nerf_synthetic/lego/black_800 shape): 800x800 = 640000 rays/image, '
                                    '8 ref views, 64 coarse + %d fine samples, maps 200x200x32, 1 image per step per GPU'
                                    % args.fine_samples,
-                       'ray_batch': cfg['ray_batch_num'], 'parallelism': 'images sharded over %d GPU(s), no collective' % world},
+                       'ray_batch': cfg['ray_batch_num'], 'parallelism': ('one image split over %d GPUs, all-gather of tiles' % world) if split else
+                                      ('images sharded over %d GPU(s), no collective' % world)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)',
@@ -216,7 +225,7 @@ def main():
             line['parity'] = parity
         if not args.no_eager_baseline and not args.no_cpu_baseline:
             eb = eager_torch_baseline(cfg, weights, tq, tr, device)
-            eb['speedup_vs_eager'] = value / world / eb['value']
+            eb['speedup_vs_eager'] = value / (1 if split else world) / eb['value']
             line['eager_torch_baseline'] = eb
         print(json.dumps(line))
     if world > 1:

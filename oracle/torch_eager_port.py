@@ -153,16 +153,44 @@ def render_pass(w, cfg, depth, que, ref, is_fine):
     return out
 
 
-def sample_fine(depth, hit, depth_range, fdn):
-    """render_ops.py:172-229, eval mode"""
+def self_hit_prob(w, cfg, depth, que, is_fine):
+    """predict_self_hit_prob (renderer.py:137-155): the query view's own distribution along its rays"""
+    dp = 'fine_dist_decoder.' if is_fine else 'dist_decoder.'
+    _, _, h, wd = que['imgs'].shape
+    f = _grid_gather(que['ray_feats'], que['coords'], h, wd)                       # 1,rn,32
+    sp = F.softplus
+    mean = _mlp(w, dp + 'mean_decoder.', f, [F.elu, F.elu, sp]).unsqueeze(2)
+    var = (_mlp(w, dp + 'var_decoder.', f, [F.elu, F.elu, sp]) + 0.05).unsqueeze(2)
+    aw = _mlp(w, dp + 'aw_decoder.', f, [F.elu, F.elu, torch.sigmoid]).unsqueeze(2)
+    use_vis = cfg['fine_use_vis'] if is_fine else cfg['coarse_use_vis']
+    near_q, far_q = -1 / que['depth_range'][:, 0], -1 / que['depth_range'][:, 1]
+    s = (-1 / depth - near_q[:, None, None]) / (far_q - near_q)[:, None, None]
+    dists = torch.cat([s[..., 1:] - s[..., :-1], torch.full_like(s[..., :1], 1e6)], -1)
+    t = (-1 / depth.clamp_min(1e-5) - near_q[:, None, None]) / (far_q - near_q)[:, None, None]
+    half = dists / 2
+    ext = torch.cat([(t[..., 0] - half[..., 0])[..., None], (t[..., :-1] + t[..., 1:]) / 2, (t[..., -1] + half[..., -1])[..., None]], -1)
+    lo, hi = ext[..., :-1, None], ext[..., 1:, None]
+    c0 = 0.5 + 0.5 * torch.tanh((lo - mean) * var)
+    c1 = 0.5 + 0.5 * torch.tanh((hi - mean) * var)
+    if use_vis:
+        vis_d = _mlp(w, dp + 'vis_decoder.', f, [F.elu, F.elu, torch.sigmoid]).unsqueeze(2)
+        c0, c1 = c0 * vis_d, c1 * vis_d
+    mix = torch.cat([aw, 1 - aw], -1)
+    return ((c1 - c0) * mix).sum(-1)
+
+
+def sample_fine(depth, hit, depth_range, fdn, u=None):
+    """render_ops.py:172-229; u = externally drawn uniforms (training) or None (stratified)"""
     near, far = -1 / depth_range[0, 0], -1 / depth_range[0, 1]
     s = (-1 / depth - near) / (far - near)
     edges = torch.cat([s[..., :1], (s[..., 1:] + s[..., :-1]) / 2, s[..., -1:]], -1)
     pdf = hit + 1e-5
     pdf = pdf / pdf.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
-    interval = 1 / fdn
-    u = (0.5 * interval + torch.arange(fdn, device=depth.device) * interval).expand(list(cdf.shape[:-1]) + [fdn]).contiguous()
+    if u is None:
+        interval = 1 / fdn
+        u = (0.5 * interval + torch.arange(fdn, device=depth.device) * interval).expand(list(cdf.shape[:-1]) + [fdn])
+    u = u.to(depth.device).contiguous()
     idx = torch.searchsorted(cdf, u, right=True)
     lo, hi = (idx - 1).clamp_min(0), idx.clamp_max(cdf.shape[-1] - 1)
     cl, ch = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
@@ -173,8 +201,10 @@ def sample_fine(depth, hit, depth_range, fdn):
     return -1 / (fine * (far - near) + near)
 
 
-def render_impl(w, cfg, que, ref):
-    """coarse + fine (renderer.py:217-226), eval mode; tensors on any device"""
+def render_impl(w, cfg, que, ref, is_train=False, u=None):
+    """coarse + fine (renderer.py:217-226); tensors on any device.  Differentiable: autograd through this function is
+    the gradient oracle for the backward kernels (checked against the reference's own autograd,
+    tests/test_oracle_golden.py::test_torch_eager_port_gradients_match_reference)."""
     rn = que['coords'].shape[1]
     dn = cfg['depth_sample_num']
     near, far = que['depth_range'][:, 0], que['depth_range'][:, 1]
@@ -182,10 +212,16 @@ def render_impl(w, cfg, que, ref):
     ticks[:, -1] = (1 / far - 1 / near)
     depth = (1 / (1 / near[:, None] + ticks))[:, None].expand(-1, rn, -1).contiguous()
     out = render_pass(w, cfg, depth, que, ref, False)
+    self_hp = is_train and cfg.get('use_self_hit_prob', False)
+    if self_hp:
+        out['hit_prob_self'] = self_hit_prob(w, cfg, depth, que, False)
     if cfg.get('use_hierarchical_sampling', False):
-        fd = torch.sort(sample_fine(depth, out['hit_prob_nr'], que['depth_range'], cfg['fine_depth_sample_num']), -1)[0]
+        fd = torch.sort(sample_fine(depth, out['hit_prob_nr'].detach(), que['depth_range'], cfg['fine_depth_sample_num'],
+                                    u if is_train else None), -1)[0]
         if cfg.get('fine_depth_use_all', False):
             fd = torch.sort(torch.cat([depth, fd], -1), -1)[0]
         for k, v in render_pass(w, cfg, fd, que, ref, True).items():
             out[k + '_fine'] = v
+        if self_hp:
+            out['hit_prob_self_fine'] = self_hit_prob(w, cfg, fd, que, True)
     return out

@@ -160,5 +160,64 @@ def main():
     run_case(ns, 'e_use_all', cfg_e, 48, 48, 2, 8, seed=4, is_train=False, integer_coords=True)
 
 
+def gradient_case(ns):
+    """Reference autograd through render_impl (training mode): d(loss)/d(weights, ray_feats, img_feats) for
+    loss = sum(w_c * pixel_colors_nr) + sum(w_f * pixel_colors_nr_fine) + sum(w_s * hit_prob_self[_fine]).
+    Pins the backward kernels (next round) and the autograd of oracle/torch_eager_port.py."""
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'use_self_hit_prob': True,
+           'depth_sample_num': 16, 'fine_depth_sample_num': 16, 'agg_net_cfg': {'sample_num': 16},
+           'fine_agg_net_cfg': {'sample_num': 16}}
+    que, ref = orc.make_scene(48, 48, 3, seed=5, que_imgs=True)
+    rng = np.random.RandomState(55)
+    que['coords'] = coords_for_case(rng, 48, 48, 24, False)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    renderer = build_renderer(ns, cfg, seed=0)
+    renderer.train()
+    tq, tr = to_t(que), to_t(ref)
+    tq.pop('Ks_inv')
+    for k in ('ray_feats', 'img_feats'):
+        tr[k].requires_grad_(True)
+    tq['ray_feats'].requires_grad_(True)
+    lw = {k: torch.from_numpy(rng.randn(*shape).astype(np.float32)) for k, shape in
+          (('pixel_colors_nr', (1, 24, 3)), ('pixel_colors_nr_fine', (1, 24, 3)), ('hit_prob_self', (1, 24, 16)),
+           ('hit_prob_self_fine', (1, 24, 16)))}
+    captured = {}
+    real_rand = torch.rand
+
+    def rand_capture(*a, **k):
+        out = real_rand(*a, **k)
+        captured.setdefault('u', out.clone())
+        return out
+
+    torch.rand = rand_capture
+    try:
+        torch.manual_seed(4321)
+        out = renderer.render_impl(tq, tr, True)
+    finally:
+        torch.rand = real_rand
+    loss = sum((lw[k] * out[k]).sum() for k in lw)
+    loss.backward()
+    save = {'cfg_json': np.array(repr(cfg)), 'u': captured['u'].numpy(), 'loss': loss.detach().numpy()}
+    for k, v in que.items():
+        save['que.' + k] = v
+    for k, v in ref.items():
+        save['ref.' + k] = v
+    for k, v in lw.items():
+        save['lw.' + k] = v.numpy()
+    for k, v in out.items():
+        save['out.' + k] = v.detach().numpy()
+    keep = ('dist_decoder.', 'agg_net.', 'fine_dist_decoder.', 'fine_agg_net.')
+    for k, p_ in renderer.named_parameters():
+        if k.startswith(keep):
+            save['grad.' + k] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy()
+    save['grad.ref.ray_feats'] = tr['ray_feats'].grad.numpy()
+    save['grad.ref.img_feats'] = tr['img_feats'].grad.numpy()
+    save['grad.que.ray_feats'] = tq['ray_feats'].grad.numpy()
+    path = os.path.join(HERE, 'case_g_grads.npz')
+    np.savez_compressed(path, **save)
+    print('wrote', path, 'loss', float(loss))
+
+
 if __name__ == '__main__':
     main()
+    gradient_case(ref_harness.import_reference())

@@ -1,0 +1,90 @@
+"""Edge cases of the render path against the oracle (seeded random weights from the mirror's constructors):
+minimum / maximum sample counts, a single ray, ragged ray counts (not a multiple of the 16-point tile), the maximum
+number of reference views, non-square images whose feature maps are not exactly 1/4 resolution, and argument
+validation of the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from emu_util import emu_lib, to_torch
+from oracle import neuray_oracle as orc
+from neuray_amd import synthetic
+from neuray_amd.network.renderer import NeuralRayBaseRenderer
+
+BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+def build(cfg, backend, seed=0):
+    torch.manual_seed(seed)
+    r = NeuralRayBaseRenderer(cfg).eval()
+    weights = {k: v.detach().numpy().copy() for k, v in r.state_dict().items()}
+    if backend == 'emu':
+        r._engine_test_lib = emu_lib()
+        return r, weights, 'cpu'
+    return r.cuda(), weights, 'cuda:0'
+
+
+def scene(h, w, rfn, rn, seed, fh=None, fw=None):
+    que, ref = synthetic.make_scene(h, w, rfn, seed=seed)
+    if fh is not None:      # feature maps that are not exactly h/4 x w/4
+        rng = np.random.RandomState(seed + 7)
+        ref['ray_feats'] = rng.randn(rfn, 32, fh, fw).astype(np.float32)
+        ref['img_feats'] = rng.randn(rfn, 32, fh, fw).astype(np.float32)
+    rng = np.random.RandomState(seed + 1)
+    que['coords'] = (rng.rand(1, rn, 2) * np.array([w - 1, h - 1])).astype(np.float32)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    return que, ref
+
+
+def check(cfg, que, ref, backend, tol=2e-4):
+    r, weights, dev = build(cfg, backend)
+    with torch.no_grad():
+        got = r.render_impl(to_torch(que, dev), to_torch(ref, dev), False)
+    ocfg = dict(cfg, coarse_use_vis=cfg.get('dist_decoder_cfg', {}).get('use_vis', True), fine_use_vis=True)
+    want = orc.render_impl(weights, ocfg, que, ref)
+    assert np.max(np.abs(got['pixel_colors_nr'].cpu().numpy() - want['pixel_colors_nr'])) <= tol
+    assert np.max(np.abs(got['hit_prob_nr'].cpu().numpy() - want['hit_prob_nr'])) <= 1e-4
+    assert np.array_equal(got['ray_mask'].cpu().numpy(), want['ray_mask'])
+    return got, want
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('dn,rn,rfn', [(3, 1, 1), (5, 7, 2), (17, 33, 3), (128, 5, 2)])
+def test_sample_and_ray_count_extremes(dn, rn, rfn, backend):
+    cfg = {'depth_sample_num': dn, 'agg_net_cfg': {'sample_num': dn}, 'dist_decoder_cfg': {'use_vis': dn % 2 == 1}}
+    que, ref = scene(40, 56, rfn, rn, seed=dn)
+    check(cfg, que, ref, backend)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_sixteen_reference_views(backend):
+    cfg = {'depth_sample_num': 8, 'agg_net_cfg': {'sample_num': 8}, 'dist_decoder_cfg': {'use_vis': False}}
+    que, ref = scene(32, 32, 16, 9, seed=3)
+    check(cfg, que, ref, backend)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_feature_maps_not_quarter_resolution(backend):
+    """ref_pad_interval changes the map / image ratio; the texel mapping must follow interpolate_feats (ops.py:28-29)."""
+    cfg = {'use_hierarchical_sampling': True, 'depth_sample_num': 16, 'fine_depth_sample_num': 16,
+           'agg_net_cfg': {'sample_num': 16}, 'fine_agg_net_cfg': {'sample_num': 16}, 'dist_decoder_cfg': {'use_vis': False}}
+    que, ref = scene(44, 60, 4, 20, seed=5, fh=13, fw=17)
+    got, want = check(cfg, que, ref, backend)
+    err = np.max(np.abs(got['pixel_colors_nr_fine'].cpu().numpy() - want['pixel_colors_nr_fine']), -1)
+    assert np.mean(err <= 2e-4) >= 0.9
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_abi_rejects_bad_arguments(backend):
+    from neuray_amd.engine import RenderEngine
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
+    with pytest.raises(RuntimeError, match='dn'):
+        eng.sample_coarse_depth(torch.tensor([[2.0, 6.0]], device=dev), 4, 2)          # assert(dn > 2), render_ops.py:157
+    que, ref = scene(32, 32, 2, 4, seed=1)
+    with pytest.raises(RuntimeError, match='views'):
+        ref17 = {k: np.repeat(v[:1], 17, 0) for k, v in ref.items()}
+        eng.prepare_views(to_torch(ref17, dev))
+    with pytest.raises(RuntimeError, match='outside'):
+        qc = eng.prepare_query(to_torch(que, dev))
+        eng.sample_fine_depth(qc, torch.ones(4, 200, device=dev), torch.ones(4, 200, device=dev), 16)

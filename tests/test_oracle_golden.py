@@ -105,3 +105,36 @@ def test_torch_eager_port_matches_reference(name):
     assert np.array_equal(got['ray_mask'].numpy(), out['ray_mask'])
     err = np.max(np.abs(got['pixel_colors_nr_fine'].numpy() - out['pixel_colors_nr_fine']), -1)
     assert np.mean(err <= TOL_PIXEL) >= 0.95 and err.max() <= 5e-3
+
+
+def test_torch_eager_port_gradients_match_reference():
+    """Autograd through the eager port against the reference's own autograd (tests/golden/case_g_grads.npz): pins the
+    gradient oracle that the backward kernels (next round) will be checked against."""
+    import os
+    import torch
+    from conftest import GOLDEN_DIR
+    from oracle import torch_eager_port as tep
+    z = np.load(os.path.join(GOLDEN_DIR, 'case_g_grads.npz'))
+    cfg = eval(str(z['cfg_json']))
+    que = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('que.')}
+    ref = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('ref.')}
+    w = {k: torch.from_numpy(v).requires_grad_(True) for k, v in load_weights(False).items()}
+    for t in (ref['ray_feats'], ref['img_feats'], que['ray_feats']):
+        t.requires_grad_(True)
+    out = tep.render_impl(w, {**orc.DEFAULT_CFG, **oracle_cfg(cfg)}, que, ref, is_train=True, u=torch.from_numpy(z['u']))
+    for k in ('pixel_colors_nr', 'hit_prob_self', 'hit_prob_self_fine'):
+        np.testing.assert_allclose(out[k].detach().numpy(), z['out.' + k], atol=1e-4)
+    loss = sum((torch.from_numpy(z['lw.' + k]) * out[k]).sum() for k in ('pixel_colors_nr', 'pixel_colors_nr_fine',
+                                                                         'hit_prob_self', 'hit_prob_self_fine'))
+    assert abs(float(loss) - float(z['loss'])) <= 1e-3
+    loss.backward()
+
+    def close(got, want, name):
+        scale = max(1e-3, float(np.abs(want).max()))
+        assert np.max(np.abs(got - want)) <= 2e-3 * scale, (name, float(np.max(np.abs(got - want))), scale)
+
+    for k, p in w.items():
+        close(p.grad.numpy() if p.grad is not None else np.zeros_like(p.detach().numpy()), z['grad.' + k], k)
+    close(ref['ray_feats'].grad.numpy(), z['grad.ref.ray_feats'], 'ref.ray_feats')
+    close(ref['img_feats'].grad.numpy(), z['grad.ref.img_feats'], 'ref.img_feats')
+    close(que['ray_feats'].grad.numpy(), z['grad.que.ray_feats'], 'que.ray_feats')

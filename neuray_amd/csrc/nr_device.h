@@ -23,11 +23,13 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
 // of ~18 for the libm-exact expf (the precise forms made the point kernel VALU-bound: 10.8 VALU per MFMA).
 #ifdef NR_PRECISE_MATH
 __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+__device__ __forceinline__ float elu_s(float x) { return x > 0.0f ? x : (float)kLog2e * expm1f(x * 0.693147180559945309f); }
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
 #elif defined(NR_ABLATE) && (NR_ABLATE & 2)
 __device__ __forceinline__ float elu(float x) { return x; }
+__device__ __forceinline__ float elu_s(float x) { return x; }
 __device__ __forceinline__ float softplus(float x) { return x; }
 __device__ __forceinline__ float sigmoidf(float x) { return x; }
 __device__ __forceinline__ float tanh_(float x) { return x; }
@@ -35,6 +37,11 @@ __device__ __forceinline__ float tanh_(float x) { return x; }
 // ELU(x) = median(x, exp(x) - 1, 0): for x > 0 the order is 0 < x <= exp(x)-1, for x < 0 it is x < exp(x)-1 < 0, so one
 // v_med3_f32 replaces the compare + select (4 instead of 5 VALU per activation; +inf from exp overflow is harmless)
 __device__ __forceinline__ float elu(float x) { return nr_med3(x, nr_fast_exp(x) - 1.0f, 0.0f); }
+// scaled form (nr_layout.h kOutScaled): argument and result carry the factor L = log2(e).  The same ordering argument
+// holds: y' > 0: 0 < y' <= L(2^y' - 1); y' < 0: y' <= L(2^y' - 1) < 0.
+__device__ __forceinline__ float elu_s(float x) {
+    return nr_med3(x, fmaf(nr_fast_exp2(x), (float)kLog2e, -(float)kLog2e), 0.0f);
+}
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : nr_fast_log(1.0f + nr_fast_exp(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return nr_fast_rcp(1.0f + nr_fast_exp(-x)); }
 __device__ __forceinline__ float tanh_(float x) {   // 1 - 2/(exp(2x)+1); saturates cleanly to +-1
@@ -231,6 +238,33 @@ __device__ __forceinline__ void gather8(nr_mbuf map, int goff, int soff, const T
     out[6] = blend4(a1.z, b1.z, c1.z, d1.z, t) * mask; out[7] = blend4(a1.w, b1.w, c1.w, d1.w, t) * mask;
 }
 
+// split form: tap loads are issued ahead of their blends so that many are in flight together (hipcc otherwise
+// serialises load -> wait -> blend per map and slot to save registers: ~6 dependent round trips per tile)
+__device__ __forceinline__ void issue8(nr_mbuf m, int goff, int soff, const Taps& t, float4 (&q)[8]) {
+    q[0] = mld4(m, t.o00 * 128 + goff, soff); q[1] = mld4(m, t.o00 * 128 + goff, soff + 16);
+    q[2] = mld4(m, t.o10 * 128 + goff, soff); q[3] = mld4(m, t.o10 * 128 + goff, soff + 16);
+    q[4] = mld4(m, t.o01 * 128 + goff, soff); q[5] = mld4(m, t.o01 * 128 + goff, soff + 16);
+    q[6] = mld4(m, t.o11 * 128 + goff, soff); q[7] = mld4(m, t.o11 * 128 + goff, soff + 16);
+}
+
+__device__ __forceinline__ void issue_rgb(nr_mbuf m, int soff, const Taps& t, float4 (&q)[4]) {
+    q[0] = mld4(m, t.o00 * 16, soff); q[1] = mld4(m, t.o10 * 16, soff);
+    q[2] = mld4(m, t.o01 * 16, soff); q[3] = mld4(m, t.o11 * 16, soff);
+}
+
+__device__ __forceinline__ void blend8(const float4 (&q)[8], const Taps& t, float mask, float (&out)[8]) {
+    out[0] = blend4(q[0].x, q[2].x, q[4].x, q[6].x, t) * mask; out[1] = blend4(q[0].y, q[2].y, q[4].y, q[6].y, t) * mask;
+    out[2] = blend4(q[0].z, q[2].z, q[4].z, q[6].z, t) * mask; out[3] = blend4(q[0].w, q[2].w, q[4].w, q[6].w, t) * mask;
+    out[4] = blend4(q[1].x, q[3].x, q[5].x, q[7].x, t) * mask; out[5] = blend4(q[1].y, q[3].y, q[5].y, q[7].y, t) * mask;
+    out[6] = blend4(q[1].z, q[3].z, q[5].z, q[7].z, t) * mask; out[7] = blend4(q[1].w, q[3].w, q[5].w, q[7].w, t) * mask;
+}
+
+__device__ __forceinline__ void blend_rgb(const float4 (&c)[4], const Taps& t, float mask, float (&rgb)[3]) {
+    rgb[0] = blend4(c[0].x, c[1].x, c[2].x, c[3].x, t) * mask;
+    rgb[1] = blend4(c[0].y, c[1].y, c[2].y, c[3].y, t) * mask;
+    rgb[2] = blend4(c[0].z, c[1].z, c[2].z, c[3].z, t) * mask;
+}
+
 __device__ __forceinline__ void gather_rgb(nr_mbuf map, int soff, const Taps& t, float mask, float (&out)[3]) {
     const float4 a = mld4(map, t.o00 * 16, soff), b = mld4(map, t.o10 * 16, soff);
     const float4 c = mld4(map, t.o01 * 16, soff), d = mld4(map, t.o11 * 16, soff);
@@ -363,8 +397,8 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const float (&xq)[NT][
 
 // y = act(W x + b) with D-layout output registers y[t][4*mo + r]
 enum Act { ACT_NONE, ACT_ELU, ACT_RELU };
-template <int A> __device__ __forceinline__ float apply_act(float x) {
-    if (A == ACT_ELU) return elu(x);
+template <int A, int L> __device__ __forceinline__ float apply_act(float x) {
+    if (A == ACT_ELU) return kOutScaled[L] ? elu_s(x) : elu(x);
     if (A == ACT_RELU) return fmaxf(x, 0.0f);
     return x;
 }
@@ -383,7 +417,7 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const float (&xq)[NT][
         NR_PRAGMA_UNROLL
         for (int mo = 0; mo < MT; ++mo)
             NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) y[t][4 * mo + r] = apply_act<A>(acc[t][mo][r]);
+            for (int r = 0; r < 4; ++r) y[t][4 * mo + r] = apply_act<A, L>(acc[t][mo][r]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -184,6 +184,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // ---------------- geometry + gather (a2-a8) -------------------------------------------
         int pidx[NT]; bool pvalid[NT];
         float mask[NS], dlt[NS][4], fray[NS][8], fimg[NS][8], rgb[NS][3], tref[NS], lo[NT], hi[NT];
+        Taps tfs[NS], tcs[NS];
+        int soffs[NS][2];
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) {
             int pi = base + 16 * t + c;
@@ -223,13 +225,25 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     float* d_ = p.dbg + ((size_t)pi * p.rfn + view) * kDbgFields;
                     d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
                 }
-                const Taps tf = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
-                const int fsoff = view * (int)(fmap * sizeof(float)), isoff = view * (int)(imap * sizeof(float));
-                gather8(rf_map, goff, fsoff, tf, pr.mask, fray[s]);
-                gather8(if_map, goff, fsoff, tf, pr.mask, fimg[s]);
-                const Taps tc = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.w, p.h, true);
-                gather_rgb(rgb_map, isoff, tc, pr.mask, rgb[s]);
+                tfs[s] = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
+                tcs[s] = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.w, p.h, true);
+                soffs[s][0] = view * (int)(fmap * sizeof(float)); soffs[s][1] = view * (int)(imap * sizeof(float));
             }
+        }
+        // gathers (a7): the 20 tap loads of a slot are all issued before anything is blended, so they share one memory
+        // round trip (left alone hipcc serialises load -> wait -> blend per map: 3 dependent round trips per slot).
+        // Measured: +5% whole-job; holding two slots' taps (160 registers) or staggering slot s+1's loads into slot s's
+        // blends spills and is slower than this.
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < NS; ++s) {
+            float4 qf[8], qi[8], qc[4];
+            issue8(rf_map, goff, soffs[s][0], tfs[s], qf);
+            issue8(if_map, goff, soffs[s][0], tfs[s], qi);
+            issue_rgb(rgb_map, soffs[s][1], tcs[s], qc);
+            NR_PIN();
+            blend8(qf, tfs[s], mask[s], fray[s]);
+            blend8(qi, tfs[s], mask[s], fimg[s]);
+            blend_rgb(qc, tcs[s], mask[s], rgb[s]);
         }
         float none[NS][1];
         NR_PRAGMA_UNROLL
@@ -417,7 +431,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int mo = 0; mo < 4; ++mo)
                     NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu(accv[s][mo][r]);
+                    for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(accv[s][mo][r]);   // kOutScaled[L_BV]
             layer_fwd<L_B2, NS, ACT_ELU>(W4, lane, h64, none, x);
         }
         {
@@ -530,7 +544,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     NR_PRAGMA_UNROLL
                     for (int t = 0; t < NT; ++t)
                         NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu(accf[j][t][r]);
+                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu_s(accf[j][t][r]);   // kOutScaled[L_GF1]
                 }
             }
         }

@@ -44,6 +44,19 @@ enum LayerId {
     L_COUNT
 };
 
+// ---- scaled ELU ------------------------------------------------------------------------------
+// A hidden ELU layer whose output only feeds another linear layer computes L*ELU(y) with L = log2(e): its weights
+// and bias are packed pre-multiplied by L, so the MFMA result is y' = L*y and
+//     L*ELU(y) = median(y', fma(exp2(y'), L, -L), 0)
+// is 3 VALU instructions (v_exp, v_fma, v_med3) instead of 4; the consuming layer's weights are packed divided by L
+// (ELU -> ELU chains keep their weights untouched: L/L).  Layers whose ELU output is used by non-MFMA arithmetic
+// (ray_dir_fc.2, base_fc.2, vis_fc.2, geometry_fc.2) keep the plain form.
+constexpr double kLog2e = 1.4426950408889634074;
+//                                     DM1 DM2 DV1 DV2 FMS DA1 DA2 FA  DS1 DS2 FAV PE1 PE2 RD1 RD2 NF1 NF2 BG  BV  B2  VF1 VF2 V21 V22 RF1 RF2 RF3 GF1 GF2
+constexpr bool kOutScaled[29] = {       1,  1,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0};
+constexpr bool kInScaled[29] = {        0,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1};
+static_assert(L_COUNT == 29, "kOutScaled / kInScaled follow the LayerId order");
+
 struct LayerShape { int mt_out, kq, k1; };
 
 constexpr LayerShape kShape[L_COUNT] = {

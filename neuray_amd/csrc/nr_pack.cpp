@@ -10,23 +10,27 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
     float* q = dst + quads_offset(layer);
     float* s1 = dst + single_offset(layer);
     float* b = dst + bias_offset(layer);
+    // scaled-ELU bookkeeping (nr_layout.h): rows x L when this layer's activation is the scaled ELU, columns / L when
+    // its input is one; both -> exactly the original weight
+    const double so = kOutScaled[layer] ? kLog2e : 1.0;
+    const double sw = (kOutScaled[layer] == kInScaled[layer]) ? 1.0 : (kOutScaled[layer] ? kLog2e : 1.0 / kLog2e);
     for (int mo = 0; mo < s.mt_out; ++mo) {
         for (int kq = 0; kq < s.kq; ++kq)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j) {
                     const int o = maps.out_map[mo * 16 + (lane & 15)];
                     const int i = maps.in_map[(4 * kq + j) * 4 + (lane >> 4)];
-                    q[((mo * s.kq + kq) * 64 + lane) * 4 + j] = (o >= 0 && i >= 0) ? W[o * ldw + i] : 0.0f;
+                    q[((mo * s.kq + kq) * 64 + lane) * 4 + j] = (o >= 0 && i >= 0) ? (float)(W[o * ldw + i] * sw) : 0.0f;
                 }
         for (int k1 = 0; k1 < s.k1; ++k1)
             for (int lane = 0; lane < 64; ++lane) {
                 const int o = maps.out_map[mo * 16 + (lane & 15)];
                 const int i = maps.in1_map[k1 * 4 + (lane >> 4)];
-                s1[(mo * s.k1 + k1) * 64 + lane] = (o >= 0 && i >= 0) ? W[o * ldw + i] : 0.0f;
+                s1[(mo * s.k1 + k1) * 64 + lane] = (o >= 0 && i >= 0) ? (float)(W[o * ldw + i] * sw) : 0.0f;
             }
         for (int m = 0; m < 16; ++m) {
             const int o = maps.out_map[mo * 16 + m];
-            b[mo * 16 + m] = (o >= 0 && bias) ? bias[o] : 0.0f;
+            b[mo * 16 + m] = (o >= 0 && bias) ? (float)(bias[o] * so) : 0.0f;
         }
     }
 }

@@ -122,12 +122,14 @@ __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32
 // fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32: ~1 ulp each)
 #ifdef NEURAY_EMU
 static inline float nr_fast_exp(float x) { return expf(x); }
+static inline float nr_fast_exp2(float x) { return exp2f(x); }
 static inline float nr_fast_log(float x) { return logf(x); }
 static inline float nr_fast_rcp(float x) { return 1.0f / x; }
 static inline float nr_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 #else
 __device__ __forceinline__ float nr_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 __device__ __forceinline__ float nr_fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float nr_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float nr_fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float nr_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif

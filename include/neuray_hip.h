@@ -149,6 +149,9 @@ int neuray_self_hit_prob(const float* query_const_dev, const float* depth_dev, c
 
 /* ---- hardware self test of the MFMA operand layout the kernels assume (16x4 @ 4x16) ----------------------------- */
 int neuray_mfma_selftest(const float* A_dev, const float* B_dev, float* D_dev, void* stream);
+/* ---- hardware self test of the lane-group sum behind the vector rows (v_permlane16_swap / v_permlane32_swap):
+ * y[l] = (x[c] + x[c+16]) + (x[c+32] + x[c+48]) with c = l % 16, for the 64 lanes of one wave. */
+int neuray_group_sum_selftest(const float* x_dev, float* y_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,7 @@ SYMBOLS = {
     'neuray_self_hit_prob': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     'neuray_mfma_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

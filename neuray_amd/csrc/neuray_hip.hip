@@ -243,4 +243,9 @@ int neuray_mfma_selftest(const float* A, const float* B, float* D, void* stream)
     return check_launch("neuray_mfma_selftest");
 }
 
+int neuray_group_sum_selftest(const float* x, float* y, void* stream) {
+    NR_LAUNCH(nr::group_sum_selftest_kernel, dim3(1), dim3(64), 0, stream, x, y);
+    return check_launch("neuray_group_sum_selftest");
+}
+
 }  // extern "C"

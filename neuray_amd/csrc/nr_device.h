@@ -319,6 +319,11 @@ __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (
     for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
+#if defined(NR_EXTRA_MFMA) && !defined(NEURAY_EMU)          // marginal-cost probe: NR_EXTRA_MFMA dummy MFMAs per quad
+    v4f dacc = {0.f, 0.f, 0.f, 0.f};
+    for (int e_ = 0; e_ < NR_EXTRA_MFMA; ++e_)
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(dacc) : "v"(a.x), "v"(xq[0][4 * kq]));
+#endif
 }
 
 // accumulate a K-slice (quads [KQ0, KQ0+KQN), singles [K10, K10+K1N)) of output tile `mo` (may be a runtime value)
@@ -358,24 +363,86 @@ __device__ __forceinline__ void layer_tile(WS W, int lane, int mo,
     layer_tile_slice<L, NT, 0, kShape[L].kq, 0, kShape[L].k1>(W, lane, mo, xq, x1, acc);
 }
 
+// ---- whole layers ------------------------------------------------------------------------------------------
+// The first fragments of a layer (NR_PREFETCH + 1 quads, the singles, the bias) are loaded into a LayerPre by
+// layer_prefetch; a layer running in the middle of a phase issues the NEXT layer's layer_prefetch two quads before
+// its own MFMA stream ends, so the LDS (or L2) latency of the next layer's first operands hides behind MFMAs and the
+// activation code instead of sitting in front of every layer (hipcc emits ds_read x5 -> s_waitcnt -> first MFMA).
+template <int L> struct LayerPre {
+    static constexpr int MT = kShape[L].mt_out, KQ = kShape[L].kq, K1 = kShape[L].k1, NQ = MT * KQ;
+    static constexpr int NF = NQ < NR_PREFETCH + 1 ? NQ : NR_PREFETCH + 1;
+    float4 q[NF > 0 ? NF : 1];
+    float4 b[MT];
+    float s1[MT * K1 > 0 ? MT * K1 : 1];
+};
+struct NoLayer {};
+
+template <int L, class WS>
+__device__ __forceinline__ void layer_prefetch(WS W, int lane, LayerPre<L>& p) {
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < LayerPre<L>::NF; ++i) p.q[i] = wld4(W, lane * 16, (quads_offset(L) + i * 256) * 4);
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < LayerPre<L>::MT; ++mo) p.b[mo] = wld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < LayerPre<L>::MT * LayerPre<L>::K1; ++i) p.s1[i] = wld1(W, lane * 4, (single_offset(L) + i * 64) * 4);
+}
+template <class WS> __device__ __forceinline__ void layer_prefetch(WS, int, NoLayer&) {}
+
+// ---- vector rows (nr_layout.h kVec): dot products on the VALU for the narrow output rows -------------------
+template <int L> struct VecPre {
+    static constexpr int N = kVec[L].n, TI = kVec[L].tiles;
+    float4 w[N * TI > 0 ? N * TI : 1];
+    float4 b;
+};
+template <int L, class WS>
+__device__ __forceinline__ void layer_prefetch(WS W, int lane, VecPre<L>& p) {
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < VecPre<L>::N * VecPre<L>::TI; ++i) p.w[i] = wld4(W, (lane >> 4) * 16, (vec_offset(L) + i * 16) * 4);
+    p.b = wld4(W, (lane >> 4) * 16, vec_bias_offset(L) * 4);
+}
+// out[t][j] = b_j + sum_f w_j[f] x[t][f], identical in the four lane groups; x in the D layout (4 registers per tile)
+template <int L, int NT, int KX>
+__device__ __forceinline__ void layer_vec(const VecPre<L>& p, const float (&x)[NT][KX], float (&out)[NT][kVec[L].n]) {
+    constexpr int N = kVec[L].n, TI = kVec[L].tiles;
+    static_assert(KX >= 4 * TI, "operand array too small");
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < N; ++j) {
+            float a = p.w[j * TI].x * x[t][0];
+            a = fmaf(p.w[j * TI].y, x[t][1], a); a = fmaf(p.w[j * TI].z, x[t][2], a); a = fmaf(p.w[j * TI].w, x[t][3], a);
+            NR_PRAGMA_UNROLL
+            for (int ti = 1; ti < TI; ++ti) {
+                a = fmaf(p.w[j * TI + ti].x, x[t][4 * ti], a); a = fmaf(p.w[j * TI + ti].y, x[t][4 * ti + 1], a);
+                a = fmaf(p.w[j * TI + ti].z, x[t][4 * ti + 2], a); a = fmaf(p.w[j * TI + ti].w, x[t][4 * ti + 3], a);
+            }
+            const float bj = j == 0 ? p.b.x : (j == 1 ? p.b.y : (j == 2 ? p.b.z : p.b.w));
+            out[t][j] = nr_group_sum(a) + bj;
+        }
+}
+template <int L, int NT, class WS, int KX>
+__device__ __forceinline__ void layer_vec(WS W, int lane, const float (&x)[NT][KX], float (&out)[NT][kVec[L].n]) {
+    VecPre<L> p;
+    layer_prefetch<L>(W, lane, p);
+    layer_vec<L, NT>(p, x, out);
+}
+
 // all output tiles of layer L; the fragment stream (tile-major) is pipelined across tile boundaries too
-template <int L, int NT, class WS, int KQX, int K1X>
-__device__ __forceinline__ void layer_acc(WS W, int lane, const float (&xq)[NT][KQX],
-                                          const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out]) {
+template <int L, int NT, class WS, int KQX, int K1X, class PN>
+__device__ __forceinline__ void layer_acc(WS W, int lane, const LayerPre<L>& pre, const float (&xq)[NT][KQX],
+                                          const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out], PN& next) {
     constexpr int MT = kShape[L].mt_out, KQ = kShape[L].kq, K1 = kShape[L].k1;
     static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
-    float s1[MT * K1 > 0 ? MT * K1 : 1];
-    NR_PRAGMA_UNROLL
-    for (int i = 0; i < MT * K1; ++i) s1[i] = wld1(W, lane * 4, (single_offset(L) + i * 64) * 4);
     if constexpr (KQ > 0) {
         // fragment stream with NR_PREFETCH quads in flight ahead of the one being consumed
         constexpr int NQ = MT * KQ, PF = NR_PREFETCH < NQ ? NR_PREFETCH : NQ - 1;
         float4 ring[PF + 1];
         NR_PRAGMA_UNROLL
-        for (int i = 0; i <= PF; ++i) ring[i] = wld4(W, lane * 16, (quads_offset(L) + i * 256) * 4);
+        for (int i = 0; i <= PF; ++i) ring[i] = pre.q[i];
         NR_PRAGMA_UNROLL
         for (int i = 0; i < NQ; ++i) {
             const float4 cur = ring[i % (PF + 1)];
+            if (i == (NQ >= 2 ? NQ - 2 : 0)) layer_prefetch(W, lane, next);
             NR_PIN();
             const int mo = i / KQ, kq = i % KQ;
             v4f a[NT];
@@ -386,13 +453,16 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const float (&xq)[NT][
             for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
             if (i + PF + 1 < NQ) ring[i % (PF + 1)] = wld4(W, lane * 16, (quads_offset(L) + (i + PF + 1) * 256) * 4);
         }
+    } else {
+        layer_prefetch(W, lane, next);
+        NR_PIN();
     }
     NR_PRAGMA_UNROLL
     for (int mo = 0; mo < MT; ++mo)
         NR_PRAGMA_UNROLL
         for (int k1 = 0; k1 < K1; ++k1)
             NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) acc[t][mo] = nr_mfma16(s1[mo * K1 + k1], x1[t][k1], acc[t][mo]);
+            for (int t = 0; t < NT; ++t) acc[t][mo] = nr_mfma16(pre.s1[mo * K1 + k1], x1[t][k1], acc[t][mo]);
 }
 
 // y = act(W x + b) with D-layout output registers y[t][4*mo + r]
@@ -403,21 +473,44 @@ template <int A, int L> __device__ __forceinline__ float apply_act(float x) {
     return x;
 }
 
-template <int L, int NT, int A, class WS, int KQX, int K1X>
-__device__ __forceinline__ void layer_fwd(WS W, int lane, const float (&xq)[NT][KQX],
-                                          const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {
+// layer L from its prefetched head `pre`; `next` (a LayerPre of the following layer of the same phase, or NoLayer)
+// is filled on the way
+template <int L, int NT, int A, class WS, int KQX, int K1X, class PN>
+__device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre<L>& pre, const float (&xq)[NT][KQX],
+                                          const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4], PN& next) {
     constexpr int MT = kShape[L].mt_out;
     v4f acc[NT][MT];
     NR_SCHED_FENCE();
-    layer_bias<L, NT>(W, lane, acc);
-    layer_acc<L, NT>(W, lane, xq, x1, acc);
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo)
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            acc[t][mo][0] = pre.b[mo].x; acc[t][mo][1] = pre.b[mo].y; acc[t][mo][2] = pre.b[mo].z; acc[t][mo][3] = pre.b[mo].w;
+        }
+    layer_acc<L, NT>(W, lane, pre, xq, x1, acc, next);
     NR_SCHED_FENCE();
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t)
         NR_PRAGMA_UNROLL
         for (int mo = 0; mo < MT; ++mo)
             NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) y[t][4 * mo + r] = apply_act<A, L>(acc[t][mo][r]);
+            for (int r = 0; r < 4; ++r) {
+                y[t][4 * mo + r] = apply_act<A, L>(acc[t][mo][r]);
+#if defined(NR_EXTRA_VALU) && !defined(NEURAY_EMU)      // marginal-cost probe: NR_EXTRA_VALU dummy VALU ops per output register
+                float dummy = y[t][4 * mo + r];
+                for (int e_ = 0; e_ < NR_EXTRA_VALU; ++e_) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(dummy));
+#endif
+            }
+}
+
+// self-contained form: loads its own head (first layer of a phase, stand-alone kernels)
+template <int L, int NT, int A, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_fwd(WS W, int lane, const float (&xq)[NT][KQX],
+                                          const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {
+    LayerPre<L> pre;
+    NoLayer none;
+    layer_prefetch<L>(W, lane, pre);
+    layer_fwd<L, NT, A>(W, lane, pre, xq, x1, y, none);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,7 +526,7 @@ __device__ __forceinline__ LdsW stage_phase(float* wl, nr_wbuf W, int tid, int n
 #if defined(NR_ABLATE) && (NR_ABLATE & 64)
     return LdsW{wl, begin * 4};      // no copy, no barriers
 #endif
-    __syncthreads();
+    NR_BLOCK_SYNC();
     for (int i = tid; i < n4; i += 4 * nthreads) {
         float4 v[4];
         NR_PRAGMA_UNROLL
@@ -447,7 +540,7 @@ __device__ __forceinline__ LdsW stage_phase(float* wl, nr_wbuf W, int tid, int n
             if (j < n4) dst[j] = v[u];
         }
     }
-    __syncthreads();
+    NR_BLOCK_SYNC();
     return LdsW{wl, begin * 4};
 }
 
@@ -465,7 +558,7 @@ __device__ __forceinline__ void block_allreduce(float (&v)[R], float* red, int w
 #endif
     NR_PRAGMA_UNROLL
     for (int r = 0; r < R; ++r) red[(wave * RMAX + r) * 64 + lane] = v[r];
-    __syncthreads();
+    NR_BLOCK_SYNC();
     for (int r = wave; r < R; r += nw) {
         float s = red[r * 64 + lane];
         for (int w = 1; w < nw; ++w) {
@@ -474,7 +567,7 @@ __device__ __forceinline__ void block_allreduce(float (&v)[R], float* red, int w
         }
         red[(nw * RMAX + r) * 64 + lane] = s;
     }
-    __syncthreads();
+    NR_BLOCK_SYNC();
     NR_PRAGMA_UNROLL
     for (int r = 0; r < R; ++r) v[r] = red[(nw * RMAX + r) * 64 + lane];
 }

@@ -252,48 +252,43 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
         float hit[NS], vis[NS];
         {
-            float cat[NS][16], h1[NS][8], h2[NS][8], fin[NS][4];
+            float h1[NS][8], h2[NS][8], fm[NS][2], fv[NS][2], fa[NS][1];
             const LdsW W1 = stage_phase<PH_DIST_MS>(wl, W, tid, nthreads);
-            layer_fwd<L_DM1, NS, ACT_ELU>(W1, lane, fray, none, h1);
-            layer_fwd<L_DM2, NS, ACT_ELU>(W1, lane, h1, none, h2);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
-            layer_fwd<L_DV1, NS, ACT_ELU>(W1, lane, fray, none, h1);
-            layer_fwd<L_DV2, NS, ACT_ELU>(W1, lane, h1, none, h2);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
-            layer_fwd<L_DFIN_MS, NS, ACT_NONE>(W1, lane, cat, none, fin);
+            LayerPre<L_DM1> p_dm1; LayerPre<L_DM2> p_dm2; LayerPre<L_DV1> p_dv1; LayerPre<L_DV2> p_dv2;
+            VecPre<L_DFIN_M> p_fm; VecPre<L_DFIN_V> p_fv;
+            layer_prefetch<L_DM1>(W1, lane, p_dm1);
+            layer_fwd<L_DM1, NS, ACT_ELU>(W1, lane, p_dm1, fray, none, h1, p_dm2);
+            layer_fwd<L_DM2, NS, ACT_ELU>(W1, lane, p_dm2, h1, none, h2, p_fm);
+            layer_prefetch<L_DV1>(W1, lane, p_dv1);
+            layer_vec<L_DFIN_M, NS>(p_fm, h2, fm);
+            layer_fwd<L_DV1, NS, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, p_dv2);
+            layer_fwd<L_DV2, NS, ACT_ELU>(W1, lane, p_dv2, h1, none, h2, p_fv);
+            layer_vec<L_DFIN_V, NS>(p_fv, h2, fv);
             float mu0[NS], mu1[NS], s0[NS], s1[NS], aw[NS], nu[NS];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
-                mu0[s] = softplus(fin[s][0]); mu1[s] = softplus(fin[s][1]);
-                s0[s] = softplus(fin[s][2]) + p.var_bias; s1[s] = softplus(fin[s][3]) + p.var_bias;
+                mu0[s] = softplus(fm[s][0]); mu1[s] = softplus(fm[s][1]);
+                s0[s] = softplus(fv[s][0]) + p.var_bias; s1[s] = softplus(fv[s][1]) + p.var_bias;
             }
             const LdsW W2 = stage_phase<HAS_VIS ? PH_DIST_AV : PH_DIST_A>(wl, W, tid, nthreads);
-            layer_fwd<L_DA1, NS, ACT_ELU>(W2, lane, fray, none, h1);
-            layer_fwd<L_DA2, NS, ACT_ELU>(W2, lane, h1, none, h2);
-            if (HAS_VIS) {
+            LayerPre<L_DA1> p_da1; LayerPre<L_DA2> p_da2; VecPre<L_DFIN_A> p_fa;
+            layer_prefetch<L_DA1>(W2, lane, p_da1);
+            layer_fwd<L_DA1, NS, ACT_ELU>(W2, lane, p_da1, fray, none, h1, p_da2);
+            layer_fwd<L_DA2, NS, ACT_ELU>(W2, lane, p_da2, h1, none, h2, p_fa);
+            if constexpr (HAS_VIS) {
+                LayerPre<L_DS1> p_ds1; LayerPre<L_DS2> p_ds2; VecPre<L_DFIN_S> p_fs;
+                float fs[NS][1];
+                layer_prefetch<L_DS1>(W2, lane, p_ds1);
+                layer_vec<L_DFIN_A, NS>(p_fa, h2, fa);
+                layer_fwd<L_DS1, NS, ACT_ELU>(W2, lane, p_ds1, fray, none, h1, p_ds2);
+                layer_fwd<L_DS2, NS, ACT_ELU>(W2, lane, p_ds2, h1, none, h2, p_fs);
+                layer_vec<L_DFIN_S, NS>(p_fs, h2, fs);
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s)
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
-                layer_fwd<L_DS1, NS, ACT_ELU>(W2, lane, fray, none, h1);
-                layer_fwd<L_DS2, NS, ACT_ELU>(W2, lane, h1, none, h2);
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s)
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
-                layer_fwd<L_DFIN_AV, NS, ACT_NONE>(W2, lane, cat, none, fin);
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fin[s][0]); nu[s] = sigmoidf(fin[s][1]); }
+                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = sigmoidf(fs[s][0]); }
             } else {
-                layer_fwd<L_DFIN_A, NS, ACT_NONE>(W2, lane, h2, none, fin);
+                layer_vec<L_DFIN_A, NS>(p_fa, h2, fa);
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fin[s][0]); nu[s] = 1.0f; }
+                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = 1.0f; }
             }
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
@@ -313,36 +308,42 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
         const LdsW W3 = stage_phase<PH_EMBED>(wl, W, tid, nthreads);
         float e[NS][8];
+        NoLayer last;
+        LayerPre<L_PE1> p_pe1; LayerPre<L_PE2> p_pe2; LayerPre<L_RD1> p_rd1; LayerPre<L_RD2> p_rd2;
+        LayerPre<L_NF1> p_nf1; VecPre<L_RD2> p_rd2v; VecPre<L_NF2> p_nf2;
+        layer_prefetch<L_PE1>(W3, lane, p_pe1);
         {
             float x1[NS][1], h[NS][8];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s)
                 x1[s][0] = sel4(g, (hit[s] - 0.5f) * 2.0f, (vis[s] - 0.5f) * 2.0f, 0.0f, 0.0f);
-            layer_fwd<L_PE1, NS, ACT_RELU>(W3, lane, fray, x1, h);
-            layer_fwd<L_PE2, NS, ACT_NONE>(W3, lane, h, none, e);
+            layer_fwd<L_PE1, NS, ACT_RELU>(W3, lane, p_pe1, fray, x1, h, p_pe2);
+            layer_fwd<L_PE2, NS, ACT_NONE>(W3, lane, p_pe2, h, none, e, p_rd1);
         }
         // ---------------- ray_dir_fc, rgb_feat + direction_feat     ibrnet.py:324-327 -----------------
         float gi[NS][8], gr[NS][3];
         {
-            float x1[NS][1], h[NS][4], df[NS][12];
+            float x1[NS][1], h[NS][4], df[NS][8], dc[NS][3];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) x1[s][0] = sel4(g, dlt[s][0], dlt[s][1], dlt[s][2], dlt[s][3]);
-            layer_fwd<L_RD1, NS, ACT_ELU>(W3, lane, none, x1, h);
-            layer_fwd<L_RD2, NS, ACT_ELU>(W3, lane, h, none, df);
+            layer_fwd<L_RD1, NS, ACT_ELU>(W3, lane, p_rd1, none, x1, h, p_rd2);
+            layer_prefetch<L_RD2>(W3, lane, p_rd2v);
+            layer_fwd<L_RD2, NS, ACT_ELU>(W3, lane, p_rd2, h, none, df, p_nf1);
+            layer_vec<L_RD2, NS>(p_rd2v, h, dc);          // the three rgb rows of ray_dir_fc.2
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) gi[s][k] = fimg[s][k] + df[s][k];
                 NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) gr[s][j] = rgb[s][j] + df[s][8 + j];
+                for (int j = 0; j < 3; ++j) gr[s][j] = rgb[s][j] + elu(dc[s][j]);
             }
         }
         // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
         float sn[NS];
         {
-            float h[NS][4], o[NS][4];
-            layer_fwd<L_NF1, NS, ACT_ELU>(W3, lane, e, none, h);
-            layer_fwd<L_NF2, NS, ACT_NONE>(W3, lane, h, none, o);
+            float h[NS][4], o[NS][1];
+            layer_fwd<L_NF1, NS, ACT_ELU>(W3, lane, p_nf1, e, none, h, p_nf2);
+            layer_vec<L_NF2, NS>(p_nf2, h, o);
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) sn[s] = sigmoidf(o[s][0]);
         }
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = accg[j][t][r];
                 }
             }
-            __syncthreads();
+            NR_BLOCK_SYNC();
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
@@ -425,33 +426,41 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 for (int k = 0; k < 8; ++k) { xq[s][k] = gi[s][k]; xq[s][8 + k] = e[s][k]; }
                 x1[s][0] = sel4(g, gr[s][0], gr[s][1], gr[s][2], 0.0f);
             }
-            layer_acc<L_BV, NS>(W4, lane, xq, x1, accv);
+            LayerPre<L_BV> p_bv; LayerPre<L_B2> p_b2;
+            layer_prefetch<L_BV>(W4, lane, p_bv);
+            layer_acc<L_BV, NS>(W4, lane, p_bv, xq, x1, accv, p_b2);
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
                 for (int mo = 0; mo < 4; ++mo)
                     NR_PRAGMA_UNROLL
                     for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(accv[s][mo][r]);   // kOutScaled[L_BV]
-            layer_fwd<L_B2, NS, ACT_ELU>(W4, lane, h64, none, x);
+            layer_fwd<L_B2, NS, ACT_ELU>(W4, lane, p_b2, h64, none, x, last);
         }
         {
             const LdsW W5 = stage_phase<PH_TAIL>(wl, W, tid, nthreads);
-            float xin[NS][8], h[NS][8], y[NS][12], o[NS][4];
+            float xin[NS][8], h[NS][8], y[NS][8], yv[NS][1], o[NS][1];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xin[s][k] = x[s][k] * wv[s];
-            layer_fwd<L_VF1, NS, ACT_ELU>(W5, lane, xin, none, h);
-            layer_fwd<L_VF2, NS, ACT_ELU>(W5, lane, h, none, y);
+            LayerPre<L_VF1> p_vf1; LayerPre<L_VF2> p_vf2; LayerPre<L_V21> p_v21; LayerPre<L_RF1> p_rf1; LayerPre<L_RF2> p_rf2;
+            VecPre<L_VF2> p_vf2v; VecPre<L_V22> p_v22; VecPre<L_RF3> p_rf3;
+            layer_prefetch<L_VF1>(W5, lane, p_vf1);
+            layer_fwd<L_VF1, NS, ACT_ELU>(W5, lane, p_vf1, xin, none, h, p_vf2);
+            layer_prefetch<L_VF2>(W5, lane, p_vf2v);
+            layer_fwd<L_VF2, NS, ACT_ELU>(W5, lane, p_vf2, h, none, y, p_v21);
+            layer_vec<L_VF2, NS>(p_vf2v, h, yv);          // row 32: the visibility logit
             float visp[NS];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
-                visp[s] = sigmoidf(y[s][8]) * mask[s];      // sigmoid on an ELU output: quirk A.9.4
+                visp[s] = sigmoidf(elu(yv[s][0])) * mask[s];      // sigmoid on an ELU output: quirk A.9.4
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) { x[s][k] = x[s][k] + y[s][k]; xin[s][k] = x[s][k] * visp[s]; }
             }
-            layer_fwd<L_V21, NS, ACT_ELU>(W5, lane, xin, none, h);
-            layer_fwd<L_V22, NS, ACT_NONE>(W5, lane, h, none, o);
+            layer_fwd<L_V21, NS, ACT_ELU>(W5, lane, p_v21, xin, none, h, p_v22);
+            layer_prefetch<L_RF1>(W5, lane, p_rf1);
+            layer_vec<L_V22, NS>(p_v22, h, o);
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) vis2[s] = sigmoidf(o[s][0]) * mask[s];
             float x1[NS][2], h16[NS][4], h8[NS][4];
@@ -460,9 +469,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 x1[s][0] = sel4(g, vis2[s], dlt[s][0], dlt[s][1], dlt[s][2]);
                 x1[s][1] = sel4(g, dlt[s][3], 0.0f, 0.0f, 0.0f);
             }
-            layer_fwd<L_RF1, NS, ACT_ELU>(W5, lane, x, x1, h16);
-            layer_fwd<L_RF2, NS, ACT_ELU>(W5, lane, h16, none, h8);
-            layer_fwd<L_RF3, NS, ACT_NONE>(W5, lane, h8, none, o);
+            layer_fwd<L_RF1, NS, ACT_ELU>(W5, lane, p_rf1, x, x1, h16, p_rf2);
+            layer_fwd<L_RF2, NS, ACT_ELU>(W5, lane, p_rf2, h16, none, h8, p_rf3);
+            layer_vec<L_RF3, NS>(p_rf3, h8, o);
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
                 const int t = s % NT;
@@ -548,7 +557,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 }
             }
         }
-        __syncthreads();
+        NR_BLOCK_SYNC();
         if (wave == 0) {
             float h[NT][16], G[NT][4], nonet[NT][1];
             NR_PRAGMA_UNROLL
@@ -967,48 +976,33 @@ __global__ void __launch_bounds__(256) decoder_rows_kernel(const float* __restri
             const float4 a = ld4(feats + (size_t)r * 32 + 8 * g), b = ld4(feats + (size_t)r * 32 + 8 * g + 4);
             f[s][0] = a.x; f[s][1] = a.y; f[s][2] = a.z; f[s][3] = a.w; f[s][4] = b.x; f[s][5] = b.y; f[s][6] = b.z; f[s][7] = b.w;
         }
-        float cat[NS][16], h1[NS][8], h2[NS][8], fin[NS][4];
+        float h1[NS][8], h2[NS][8], fm[NS][2], fv[NS][2], fa[NS][1];
         layer_fwd<L_DM1, NS, ACT_ELU>(W, lane, f, none, h1);
         layer_fwd<L_DM2, NS, ACT_ELU>(W, lane, h1, none, h2);
-        NR_PRAGMA_UNROLL
-        for (int s = 0; s < NS; ++s)
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
+        layer_vec<L_DFIN_M, NS>(W, lane, h2, fm);
         layer_fwd<L_DV1, NS, ACT_ELU>(W, lane, f, none, h1);
         layer_fwd<L_DV2, NS, ACT_ELU>(W, lane, h1, none, h2);
-        NR_PRAGMA_UNROLL
-        for (int s = 0; s < NS; ++s)
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
-        layer_fwd<L_DFIN_MS, NS, ACT_NONE>(W, lane, cat, none, fin);
+        layer_vec<L_DFIN_V, NS>(W, lane, h2, fv);
         NR_PRAGMA_UNROLL
         for (int s = 0; s < NS; ++s)
             if (ok[s] && g == 0) {
-                mean[2 * row[s]] = softplus(fin[s][0]); mean[2 * row[s] + 1] = softplus(fin[s][1]);
-                var[2 * row[s]] = softplus(fin[s][2]) + var_bias; var[2 * row[s] + 1] = softplus(fin[s][3]) + var_bias;
+                mean[2 * row[s]] = softplus(fm[s][0]); mean[2 * row[s] + 1] = softplus(fm[s][1]);
+                var[2 * row[s]] = softplus(fv[s][0]) + var_bias; var[2 * row[s] + 1] = softplus(fv[s][1]) + var_bias;
             }
         layer_fwd<L_DA1, NS, ACT_ELU>(W, lane, f, none, h1);
         layer_fwd<L_DA2, NS, ACT_ELU>(W, lane, h1, none, h2);
-        if (HAS_VIS) {
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) cat[s][k] = h2[s][k];
+        layer_vec<L_DFIN_A, NS>(W, lane, h2, fa);
+        float fs[NS][1];
+        if constexpr (HAS_VIS) {
             layer_fwd<L_DS1, NS, ACT_ELU>(W, lane, f, none, h1);
             layer_fwd<L_DS2, NS, ACT_ELU>(W, lane, h1, none, h2);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) cat[s][8 + k] = h2[s][k];
-            layer_fwd<L_DFIN_AV, NS, ACT_NONE>(W, lane, cat, none, fin);
-        } else {
-            layer_fwd<L_DFIN_A, NS, ACT_NONE>(W, lane, h2, none, fin);
+            layer_vec<L_DFIN_S, NS>(W, lane, h2, fs);
         }
         NR_PRAGMA_UNROLL
         for (int s = 0; s < NS; ++s)
             if (ok[s] && g == 0) {
-                aw[row[s]] = sigmoidf(fin[s][0]);
-                if (HAS_VIS) vis[row[s]] = sigmoidf(fin[s][1]);
+                aw[row[s]] = sigmoidf(fa[s][0]);
+                if constexpr (HAS_VIS) vis[row[s]] = sigmoidf(fs[s][0]);
             }
     }
 }
@@ -1052,6 +1046,10 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ A /*16x4*/, const
     v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
     acc = nr_mfma16(A[(lane & 15) * 4 + (lane >> 4)], B[(lane >> 4) * 16 + (lane & 15)], acc);
     for (int r = 0; r < 4; ++r) D[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+}
+
+__global__ void group_sum_selftest_kernel(const float* __restrict__ x, float* __restrict__ y) {
+    y[threadIdx.x & 63] = nr_group_sum(x[threadIdx.x & 63]);
 }
 
 }  // namespace nr

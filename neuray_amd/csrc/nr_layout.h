@@ -23,23 +23,24 @@
 namespace nr {
 
 enum LayerId {
-    // dist decoder heads (mean, var, aw, vis): 32 -> 32 -> 32                    dist_decoder.py:64-97
+    // dist decoder heads (mean, var, aw, vis): 32 -> 32 -> 32 -> out                  dist_decoder.py:64-97
     // (order = LDS staging phases, see kPhase below)
     L_DM1, L_DM2, L_DV1, L_DV2,
-    L_DFIN_MS,   // [mu0 mu1 s0 s1] pre-activations from h2(mean) ++ h2(var), replicated in all lane groups
+    L_DFIN_M,    // vector rows: [mu0 mu1] pre-activations from h2(mean)
+    L_DFIN_V,    // vector rows: [s0 s1] from h2(var)
     L_DA1, L_DA2,
-    L_DFIN_A,    // [aw] from h2(aw)                      (decoder without vis head)
+    L_DFIN_A,    // vector row: [aw] from h2(aw)
     L_DS1, L_DS2,
-    L_DFIN_AV,   // [aw vis] from h2(aw) ++ h2(vis)       (decoder with vis head)
+    L_DFIN_S,    // vector row: [vis] from h2(vis)          (decoder with vis head only)
     L_PE1, L_PE2,            // prob_embed 34 -> 32 -> 32                           aggregate_net.py:27-31
-    L_RD1, L_RD2,            // ray_dir_fc 4 -> 16 -> 35                            ibrnet.py:249-252
-    L_NF1, L_NF2,            // neuray_fc 32 -> 8 -> 1                              ibrnet.py:287-291
+    L_RD1, L_RD2,            // ray_dir_fc 4 -> 16 -> 35 (32 image rows on MFMA + 3 rgb vector rows)  ibrnet.py:249-252
+    L_NF1, L_NF2,            // neuray_fc 32 -> 8 -> 1 (vector row)                 ibrnet.py:287-291
     L_BG,                    // base_fc.0 columns [mean0 var0 mean1 var1] (per point) ibrnet.py:254
     L_BV,                    // base_fc.0 columns [rgb_feat neuray_feat]  (per view)
     L_B2,                    // base_fc.2 64 -> 32
-    L_VF1, L_VF2,            // vis_fc 32 -> 32 -> 33                               ibrnet.py:259-263
-    L_V21, L_V22,            // vis_fc2 32 -> 32 -> 1                               ibrnet.py:265-269
-    L_RF1, L_RF2, L_RF3,     // rgb_fc 37 -> 16 -> 8 -> 1                           ibrnet.py:281-285
+    L_VF1, L_VF2,            // vis_fc 32 -> 32 -> 33 (32 MFMA rows + the visibility logit as a vector row)  ibrnet.py:259-263
+    L_V21, L_V22,            // vis_fc2 32 -> 32 -> 1 (vector row)                  ibrnet.py:265-269
+    L_RF1, L_RF2, L_RF3,     // rgb_fc 37 -> 16 -> 8 -> 1 (vector row)              ibrnet.py:281-285
     L_GF1, L_GF2,            // geometry_fc 65 -> 64 -> 16                          ibrnet.py:271-274
     L_COUNT
 };
@@ -52,35 +53,61 @@ enum LayerId {
 // (ELU -> ELU chains keep their weights untouched: L/L).  Layers whose ELU output is used by non-MFMA arithmetic
 // (ray_dir_fc.2, base_fc.2, vis_fc.2, geometry_fc.2) keep the plain form.
 constexpr double kLog2e = 1.4426950408889634074;
-//                                     DM1 DM2 DV1 DV2 FMS DA1 DA2 FA  DS1 DS2 FAV PE1 PE2 RD1 RD2 NF1 NF2 BG  BV  B2  VF1 VF2 V21 V22 RF1 RF2 RF3 GF1 GF2
-constexpr bool kOutScaled[29] = {       1,  1,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0};
-constexpr bool kInScaled[29] = {        0,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1};
-static_assert(L_COUNT == 29, "kOutScaled / kInScaled follow the LayerId order");
+//                                     DM1 DM2 DV1 DV2 FM  FV  DA1 DA2 FA  DS1 DS2 FS  PE1 PE2 RD1 RD2 NF1 NF2 BG  BV  B2  VF1 VF2 V21 V22 RF1 RF2 RF3 GF1 GF2
+constexpr bool kOutScaled[30] = {       1,  1,  1,  1,  0,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0};
+constexpr bool kInScaled[30] = {        0,  1,  0,  1,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1};
+static_assert(L_COUNT == 30, "kOutScaled / kInScaled follow the LayerId order");
 
 struct LayerShape { int mt_out, kq, k1; };
 
 constexpr LayerShape kShape[L_COUNT] = {
     {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0},
-    {1, 4, 0},
+    {0, 0, 0}, {0, 0, 0},
     {2, 2, 0}, {2, 2, 0},
-    {1, 2, 0},
+    {0, 0, 0},
     {2, 2, 0}, {2, 2, 0},
-    {1, 4, 0},
+    {0, 0, 0},
     {2, 2, 1}, {2, 2, 0},
-    {1, 0, 1}, {3, 1, 0},
-    {1, 2, 0}, {1, 1, 0},
+    {1, 0, 1}, {2, 1, 0},
+    {1, 2, 0}, {0, 0, 0},
     {4, 8, 4}, {4, 4, 1}, {2, 4, 0},
-    {2, 2, 0}, {3, 2, 0},
-    {2, 2, 0}, {1, 2, 0},
-    {1, 2, 2}, {1, 1, 0}, {1, 1, 0},
+    {2, 2, 0}, {2, 2, 0},
+    {2, 2, 0}, {0, 0, 0},
+    {1, 2, 2}, {1, 1, 0}, {0, 0, 0},
     {4, 4, 1}, {1, 4, 0},
+};
+
+// ---- vector rows ---------------------------------------------------------------------------------
+// Output rows that would waste most of a 16-row MFMA tile (the 1..4-wide output layers and the odd rows 32..34 of the
+// 35- and 33-wide layers) are evaluated on the VALU instead: the input is in the D layout (lane (c, g) holds features
+// 16t + 4g + r of point c), so each lane multiplies its 4*tiles features with per-lane-group weights and the four lane
+// groups are summed with two permlane swaps; every lane group ends up with the full dot product.
+//   n = output rows (<= 4), tiles = 16-feature input tiles.  Storage: [n][tiles][g][r] weights, then the biases
+//   replicated per lane group, [g][4] (so that every load of a vector layer uses the same per-group address).
+struct VecShape { int n, tiles; };
+constexpr VecShape kVec[L_COUNT] = {
+    {0, 0}, {0, 0}, {0, 0}, {0, 0},
+    {2, 2}, {2, 2},
+    {0, 0}, {0, 0},
+    {1, 2},
+    {0, 0}, {0, 0},
+    {1, 2},
+    {0, 0}, {0, 0},
+    {0, 0}, {3, 1},
+    {0, 0}, {1, 1},
+    {0, 0}, {0, 0}, {0, 0},
+    {0, 0}, {1, 2},
+    {0, 0}, {1, 2},
+    {0, 0}, {0, 0}, {1, 1},
+    {0, 0}, {0, 0},
 };
 
 // sizes in floats
 constexpr int quads_floats(int l) { return kShape[l].mt_out * kShape[l].kq * 64 * 4; }
 constexpr int single_floats(int l) { return kShape[l].mt_out * kShape[l].k1 * 64; }
 constexpr int bias_floats(int l) { return kShape[l].mt_out * 16; }
-constexpr int layer_floats(int l) { return quads_floats(l) + single_floats(l) + bias_floats(l); }
+constexpr int vec_floats(int l) { return kVec[l].n > 0 ? kVec[l].n * kVec[l].tiles * 16 + 16 : 0; }
+constexpr int layer_floats(int l) { return quads_floats(l) + single_floats(l) + bias_floats(l) + vec_floats(l); }
 
 constexpr int layer_offset(int l) {   // float offset of layer l inside the packed pass buffer
     int off = 0;
@@ -90,6 +117,8 @@ constexpr int layer_offset(int l) {   // float offset of layer l inside the pack
 constexpr int quads_offset(int l) { return layer_offset(l); }
 constexpr int single_offset(int l) { return layer_offset(l) + quads_floats(l); }
 constexpr int bias_offset(int l) { return layer_offset(l) + quads_floats(l) + single_floats(l); }
+constexpr int vec_offset(int l) { return bias_offset(l) + bias_floats(l); }               // [n][tiles][16]
+constexpr int vec_bias_offset(int l) { return vec_offset(l) + kVec[l].n * kVec[l].tiles * 16; }
 
 constexpr int kPackedPointFloats = layer_offset(L_COUNT);
 
@@ -98,9 +127,9 @@ constexpr int kPackedPointFloats = layer_offset(L_COUNT);
 enum PhaseId { PH_DIST_MS, PH_DIST_A, PH_DIST_AV, PH_EMBED, PH_BASE, PH_TAIL, PH_COUNT };
 struct PhaseRange { int first, last; };
 constexpr PhaseRange kPhase[PH_COUNT] = {
-    {L_DM1, L_DFIN_MS},      // mean + var heads and their final layer
+    {L_DM1, L_DFIN_V},       // mean + var heads and their output rows
     {L_DA1, L_DFIN_A},       // aw head (decoder without vis head)
-    {L_DA1, L_DFIN_AV},      // aw + vis heads
+    {L_DA1, L_DFIN_S},       // aw + vis heads
     {L_PE1, L_NF2},          // prob_embed, ray_dir_fc, neuray_fc
     {L_BV, L_B2},            // base_fc per-view part + second layer
     {L_VF1, L_RF3},          // vis_fc, vis_fc2, rgb_fc

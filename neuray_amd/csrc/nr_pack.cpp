@@ -35,18 +35,28 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
     }
 }
 
+// vector rows (nr_layout.h kVec): row j of the layer = weight row rows[j], input feature f = column col0 + f of W
+void pack_vec(float* dst, int layer, const float* W, int ldw, const float* bias, const int* rows, int col0, int nfeat) {
+    const VecShape v = kVec[layer];
+    const double sw = kInScaled[layer] ? 1.0 / kLog2e : 1.0;      // vector rows are never scaled-ELU outputs
+    float* w = dst + vec_offset(layer);
+    float* b = dst + vec_bias_offset(layer);
+    for (int j = 0; j < v.n; ++j) {
+        for (int t = 0; t < v.tiles; ++t)
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * t + 4 * g + r;
+                    w[(j * v.tiles + t) * 16 + 4 * g + r] = f < nfeat ? (float)(W[rows[j] * ldw + col0 + f] * sw) : 0.0f;
+                }
+        for (int g = 0; g < 4; ++g) b[4 * g + j] = bias ? bias[rows[j]] : 0.0f;
+    }
+}
+
 namespace {
 
 std::vector<int> out_natural(int mt_out, int n_real) {
     std::vector<int> m(mt_out * 16);
     for (int i = 0; i < mt_out * 16; ++i) m[i] = i < n_real ? i : -1;
-    return m;
-}
-// one tile whose rows 4g+r carry weight row r (r < n_real) in every lane group g
-std::vector<int> out_replicated(int n_real) {
-    std::vector<int> m(16);
-    for (int g = 0; g < 4; ++g)
-        for (int r = 0; r < 4; ++r) m[4 * g + r] = r < n_real ? r : -1;
     return m;
 }
 // 32 gathered channels: k-step s (0..7), lane group g <-> channel 8g + s
@@ -88,29 +98,12 @@ int pack_pass_weights(const float* const* t, float* dst) {
     pack_mlp32(dst, L_DV1, L_DV2, t[T_VAR0_W], t[T_VAR0_B], t[T_VAR2_W], t[T_VAR2_B]);
     pack_mlp32(dst, L_DA1, L_DA2, t[T_AW0_W], t[T_AW0_B], t[T_AW2_W], t[T_AW2_B]);
     if (has_vis) pack_mlp32(dst, L_DS1, L_DS2, t[T_VIS0_W], t[T_VIS0_B], t[T_VIS2_W], t[T_VIS2_B]);
-    {   // [mu0 mu1 s0 s1] = blockdiag(mean.4, var.4) applied to h2(mean) ++ h2(var)
-        float W[4 * 64] = {0}, B[4];
-        for (int r = 0; r < 2; ++r)
-            for (int k = 0; k < 32; ++k) {
-                W[r * 64 + k] = t[T_MEAN4_W][r * 32 + k];
-                W[(2 + r) * 64 + 32 + k] = t[T_VAR4_W][r * 32 + k];
-            }
-        B[0] = t[T_MEAN4_B][0]; B[1] = t[T_MEAN4_B][1]; B[2] = t[T_VAR4_B][0]; B[3] = t[T_VAR4_B][1];
-        LayerMaps m; m.out_map = out_replicated(4);
-        in_dlayout(m.in_map, 0, 32, 2); in_dlayout(m.in_map, 32, 32, 2);
-        pack_layer(dst, L_DFIN_MS, W, 64, B, m);
-    }
-    {
-        LayerMaps m; m.out_map = out_replicated(1); in_dlayout(m.in_map, 0, 32, 2);
-        pack_layer(dst, L_DFIN_A, t[T_AW4_W], 32, t[T_AW4_B], m);
-    }
-    if (has_vis) {
-        float W[2 * 64] = {0}, B[2];
-        for (int k = 0; k < 32; ++k) { W[k] = t[T_AW4_W][k]; W[64 + 32 + k] = t[T_VIS4_W][k]; }
-        B[0] = t[T_AW4_B][0]; B[1] = t[T_VIS4_B][0];
-        LayerMaps m; m.out_map = out_replicated(2);
-        in_dlayout(m.in_map, 0, 32, 2); in_dlayout(m.in_map, 32, 32, 2);
-        pack_layer(dst, L_DFIN_AV, W, 64, B, m);
+    {   // output rows of the heads (vector rows on the D-layout h2 of each head)
+        const int r01[2] = {0, 1}, r0[1] = {0};
+        pack_vec(dst, L_DFIN_M, t[T_MEAN4_W], 32, t[T_MEAN4_B], r01, 0, 32);
+        pack_vec(dst, L_DFIN_V, t[T_VAR4_W], 32, t[T_VAR4_B], r01, 0, 32);
+        pack_vec(dst, L_DFIN_A, t[T_AW4_W], 32, t[T_AW4_B], r0, 0, 32);
+        if (has_vis) pack_vec(dst, L_DFIN_S, t[T_VIS4_W], 32, t[T_VIS4_B], r0, 0, 32);
     }
     // ---- prob_embed: input [ray_feats(32), hit, vis] ---------------------------------------------
     {
@@ -125,21 +118,21 @@ int pack_pass_weights(const float* const* t, float* dst) {
         LayerMaps m; m.out_map = out_natural(1, 16);
         for (int g = 0; g < 4; ++g) m.in1_map.push_back(g);
         pack_layer(dst, L_RD1, t[T_RD0_W], 4, t[T_RD0_B], m);
-        LayerMaps m2; m2.out_map.assign(48, -1);
+        LayerMaps m2; m2.out_map.assign(32, -1);
         for (int tt = 0; tt < 2; ++tt)
             for (int g = 0; g < 4; ++g)
                 for (int r = 0; r < 4; ++r) m2.out_map[tt * 16 + 4 * g + r] = 3 + (8 * g + 4 * tt + r);
-        for (int g = 0; g < 4; ++g)
-            for (int r = 0; r < 3; ++r) m2.out_map[32 + 4 * g + r] = r;
         in_dlayout(m2.in_map, 0, 16, 1);
         pack_layer(dst, L_RD2, t[T_RD2_W], 16, t[T_RD2_B], m2);
+        const int rgb_rows[3] = {0, 1, 2};
+        pack_vec(dst, L_RD2, t[T_RD2_W], 16, t[T_RD2_B], rgb_rows, 0, 16);
     }
     // ---- neuray_fc 32 -> 8 -> 1 ---------------------------------------------------------------------
     {
         LayerMaps m; m.out_map = out_natural(1, 8); in_dlayout(m.in_map, 0, 32, 2);
         pack_layer(dst, L_NF1, t[T_NF0_W], 32, t[T_NF0_B], m);
-        LayerMaps m2; m2.out_map = out_replicated(1); in_dlayout(m2.in_map, 0, 8, 1);
-        pack_layer(dst, L_NF2, t[T_NF2_W], 8, t[T_NF2_B], m2);
+        const int r0[1] = {0};
+        pack_vec(dst, L_NF2, t[T_NF2_W], 8, t[T_NF2_B], r0, 0, 8);
     }
     // ---- base_fc.0 (64 x 207), columns [mean0 var0 mean1 var1 | rgb_feat neuray_feat]   ibrnet.py:340-342
     {
@@ -156,22 +149,21 @@ int pack_pass_weights(const float* const* t, float* dst) {
         LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 64, 4);
         pack_layer(dst, L_B2, t[T_BASE2_W], 64, t[T_BASE2_B], m2);
     }
-    // ---- vis_fc 32 -> 32 -> 33 (row 32 = visibility logit, replicated) -----------------------------
+    // ---- vis_fc 32 -> 32 -> 33 (row 32 = visibility logit: vector row) -----------------------------
     {
         LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 32, 2);
         pack_layer(dst, L_VF1, t[T_VF0_W], 32, t[T_VF0_B], m);
-        LayerMaps m2; m2.out_map.assign(48, -1);
-        for (int i = 0; i < 32; ++i) m2.out_map[i] = i;
-        for (int g = 0; g < 4; ++g) m2.out_map[32 + 4 * g] = 32;
-        in_dlayout(m2.in_map, 0, 32, 2);
+        LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
         pack_layer(dst, L_VF2, t[T_VF2_W], 32, t[T_VF2_B], m2);
+        const int r32[1] = {32};
+        pack_vec(dst, L_VF2, t[T_VF2_W], 32, t[T_VF2_B], r32, 0, 32);
     }
     // ---- vis_fc2 32 -> 32 -> 1 -----------------------------------------------------------------------
     {
         LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 32, 2);
         pack_layer(dst, L_V21, t[T_V20_W], 32, t[T_V20_B], m);
-        LayerMaps m2; m2.out_map = out_replicated(1); in_dlayout(m2.in_map, 0, 32, 2);
-        pack_layer(dst, L_V22, t[T_V22_W], 32, t[T_V22_B], m2);
+        const int r0[1] = {0};
+        pack_vec(dst, L_V22, t[T_V22_W], 32, t[T_V22_B], r0, 0, 32);
     }
     // ---- rgb_fc [x(32), vis(1), ray_diff(4)] -> 16 -> 8 -> 1 -----------------------------------------
     {
@@ -181,8 +173,8 @@ int pack_pass_weights(const float* const* t, float* dst) {
         pack_layer(dst, L_RF1, t[T_RF0_W], 37, t[T_RF0_B], m);
         LayerMaps m2; m2.out_map = out_natural(1, 8); in_dlayout(m2.in_map, 0, 16, 1);
         pack_layer(dst, L_RF2, t[T_RF2_W], 16, t[T_RF2_B], m2);
-        LayerMaps m3; m3.out_map = out_replicated(1); in_dlayout(m3.in_map, 0, 8, 1);
-        pack_layer(dst, L_RF3, t[T_RF4_W], 8, t[T_RF4_B], m3);
+        const int r0[1] = {0};
+        pack_vec(dst, L_RF3, t[T_RF4_W], 8, t[T_RF4_B], r0, 0, 8);
     }
     // ---- geometry_fc [mean(32), var(32), mean weight(1)] -> 64 -> 16 --------------------------------
     {

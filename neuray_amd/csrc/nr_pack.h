@@ -15,6 +15,9 @@ struct LayerMaps {
 // Writes layer `layer` (quads, singles, bias) at its offset inside `dst` (kPackedPassFloats floats).
 void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bias, const LayerMaps& maps);
 
+// Writes the vector rows of `layer` (nr_layout.h kVec): row j = weight row rows[j], features = columns col0.. of W.
+void pack_vec(float* dst, int layer, const float* W, int ldw, const float* bias, const int* rows, int col0, int nfeat);
+
 // tensors: array of T_COUNT host pointers in PassTensor order (vis-head entries may be null).
 // Returns 0 on success, non-zero if a required tensor is missing.
 int pack_pass_weights(const float* const* tensors, float* dst);

@@ -119,6 +119,13 @@ __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32
 #endif
 #endif
 
+// workgroup barrier of the point kernel (timing probe NR_ABLATE & 128: compiler fence only, results are garbage)
+#if defined(NR_ABLATE) && (NR_ABLATE & 128)
+#define NR_BLOCK_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#else
+#define NR_BLOCK_SYNC() __syncthreads()
+#endif
+
 // fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32: ~1 ulp each)
 #ifdef NEURAY_EMU
 static inline float nr_fast_exp(float x) { return expf(x); }
@@ -132,6 +139,25 @@ __device__ __forceinline__ float nr_fast_exp(float x) { return __builtin_amdgcn_
 __device__ __forceinline__ float nr_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float nr_fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float nr_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
+// sum over the four 16-lane groups of a wave (lanes c, c+16, c+32, c+48); every lane receives (g0 + g1) + (g2 + g3)
+#ifdef NEURAY_EMU
+static inline float nr_group_sum(float t) { t = t + __shfl_xor(t, 16); return t + __shfl_xor(t, 32); }
+#else
+__device__ __forceinline__ float nr_group_sum(float t) {
+    // NOTE: bit-cast the WHOLE result vector.  Element-wise `__builtin_bit_cast(float, a.y)` makes hipcc (ROCm 7.2) read
+    // element 0 twice (the IR has `fadd %x, %x`: 4 x own value; same front-end defect as nr_buf_ld4, probe:
+    // tests/hw/permlane_probe.hip).
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const unsigned u = __builtin_bit_cast(unsigned, t);
+    const v2f a = __builtin_bit_cast(v2f, (v2u)__builtin_amdgcn_permlane16_swap(u, u, false, false));  // [r0 r0 r2 r2], [r1 r1 r3 r3]
+    const float s = a.x + a.y;
+    const unsigned v = __builtin_bit_cast(unsigned, s);
+    const v2f b = __builtin_bit_cast(v2f, (v2u)__builtin_amdgcn_permlane32_swap(v, v, false, false));  // [lo lo], [hi hi]
+    return b.x + b.y;
+}
 #endif
 
 // ---- exactly rounded single operations (the "rounding contract") --------------------------------------

@@ -63,6 +63,22 @@ def test_mfma_operand_layout(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_lane_group_sum(backend):
+    """The vector rows sum their partial dot products over the four 16-lane groups with two permlane swaps; the
+    result must be (g0 + g1) + (g2 + g3) bit-exactly, in every lane (hipcc mis-compiles the obvious spelling:
+    neuray_amd/csrc/nr_platform.h nr_group_sum, tests/hw/permlane_probe.hip)."""
+    from neuray_amd.engine import RenderEngine
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
+    x = torch.randn(64, generator=torch.Generator().manual_seed(3))
+    xd, yd = x.to(dev), torch.zeros(64, device=dev)
+    assert eng.lib.neuray_group_sum_selftest(xd.data_ptr(), yd.data_ptr(), eng._stream()) == 0
+    g = x.view(4, 16)
+    want = ((g[0] + g[1]) + (g[2] + g[3])).repeat(4)
+    assert torch.equal(yd.cpu(), want)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('name', ['a_small', 'c_adversarial'])
 def test_coarse_pass_stagewise(name, backend):
     """Every intermediate of the coarse pass against the oracle: geometry bit-exact, MLP stages ~1e-6."""

@@ -514,34 +514,28 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const float (&xq)[NT][
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stage one phase of the packed weights into LDS, cooperatively (every thread copies 16-byte pieces), so that the
-// waves read their MFMA A fragments with ds_read_b128 instead of stalling on an L2 round trip per layer.
-// Barriers: one before the copy (the previous phase's readers are done), one after (the copy is visible).
+// Weight staging (nr_layout.h kPhase): the stage is two LDS regions.  phase_enter<PH> is called by every wave when it
+// is done with the previous phase: one barrier (its fence makes each wave wait for its own DMA pieces first) after
+// which phase PH is complete in its region and nobody reads the other region any more, so the copy of the NEXT phase
+// is issued into that one right away and lands while PH is being computed.
 // ---------------------------------------------------------------------------------------------
 template <int PH>
-__device__ __forceinline__ LdsW stage_phase(float* wl, nr_wbuf W, int tid, int nthreads) {
-    constexpr int begin = phase_begin(PH), n4 = phase_floats(PH) / 4;
-    static_assert(phase_floats(PH) % 4 == 0 && phase_floats(PH) <= kWeightLdsFloats, "phase does not fit the LDS stage");
-    float4* dst = reinterpret_cast<float4*>(wl);
-#if defined(NR_ABLATE) && (NR_ABLATE & 64)
-    return LdsW{wl, begin * 4};      // no copy, no barriers
-#endif
+__device__ __forceinline__ void stage_issue(float* dst, nr_wbuf W, int wave, int nw, int lane) {
+    constexpr int begin = phase_begin(PH) * 4, bytes = phase_floats(PH) * 4, NCH = (bytes + 1023) / 1024;
+    static_assert(bytes % 16 == 0 && bytes <= kStageRegionBytes, "phase does not fit a stage region");
+    // 1 KiB per wave instruction.  The last piece runs past the end of the phase up to the next KiB boundary: the source
+    // bytes exist (later layers of the packed buffer; the buffer descriptor range-checks anyway) and the region is a
+    // whole number of KiB, so no lane needs masking and the only per-lane address is lane * 16.
+    for (int c = wave; c < NCH; c += nw) nr_dma16(W, dst + c * 256, lane, lane * 16, begin + c * 1024);
+}
+
+// seq0 = (tiles this workgroup has finished) * phase_count(VIS): the regions alternate along the phase sequence
+template <int PH, bool VIS>
+__device__ __forceinline__ LdsW phase_enter(float* wl, nr_wbuf W, int seq0, bool issue_next, int wave, int nw, int lane) {
     NR_BLOCK_SYNC();
-    for (int i = tid; i < n4; i += 4 * nthreads) {
-        float4 v[4];
-        NR_PRAGMA_UNROLL
-        for (int u = 0; u < 4; ++u) {
-            const int j = i + u * nthreads;
-            v[u] = nr_buf_ld4(W, (j < n4 ? j : 0) * 16, begin * 4);
-        }
-        NR_PRAGMA_UNROLL
-        for (int u = 0; u < 4; ++u) {
-            const int j = i + u * nthreads;
-            if (j < n4) dst[j] = v[u];
-        }
-    }
-    NR_BLOCK_SYNC();
-    return LdsW{wl, begin * 4};
+    const int r = (seq0 + phase_seq(PH, VIS)) & 1;
+    if (issue_next) stage_issue<phase_next(PH, VIS)>(wl + (r ^ 1) * (kStageRegionBytes / 4), W, wave, nw, lane);
+    return LdsW{wl + r * (kStageRegionBytes / 4), phase_begin(PH) * 4};
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -180,7 +180,15 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     // XCD a contiguous run of tiles keeps the texels that neighbouring samples / rays share inside one private L2
     // instead of fetching them into all eight (the grid is a multiple of 8).
     const int bid = (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8);
-    for (int base = bid * (16 * NT); base < npts; base += gridDim.x * (16 * NT)) {
+    int seq0 = 0;                                       // phases entered so far (selects the stage region)
+    if (bid * (16 * NT) < npts) stage_issue<PH_DIST_M>(wl, W, wave, nw, lane);
+    for (int base = bid * (16 * NT); base < npts; base += gridDim.x * (16 * NT), seq0 += phase_count(HAS_VIS)) {
+        const bool more = base + (int)gridDim.x * (16 * NT) < npts;   // another tile follows: its first phase is prefetched
+        // lane index for the weight loads that go to global memory (L_BG, L_GF1, L_GF2): opaque and re-made per tile,
+        // otherwise hipcc treats these loop-invariant loads as hoistable, keeps ~50 fragment registers alive across the
+        // whole tile loop and spills them (seen as "spills outside, reloads inside the loop" in -Rpass-missed=regalloc)
+        const int glane = lane + nr_opaque_zero();
+        const int gg = glane >> 4;
         // ---------------- geometry + gather (a2-a8) -------------------------------------------
         int pidx[NT]; bool pvalid[NT];
         float mask[NS], dlt[NS][4], fray[NS][8], fimg[NS][8], rgb[NS][3], tref[NS], lo[NT], hi[NT];
@@ -244,6 +252,13 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             blend8(qf, tfs[s], mask[s], fray[s]);
             blend8(qi, tfs[s], mask[s], fimg[s]);
             blend_rgb(qc, tcs[s], mask[s], rgb[s]);
+            // the blends happen HERE: left alone the img / rgb blends are sunk to their first use (ray_dir_fc, two phases
+            // later) and the 48 raw tap registers of the slot are carried - spilled - through the whole dist decoder
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 8; ++k) { NR_KEEP(fray[s][k]); NR_KEEP(fimg[s][k]); }
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 3; ++j) NR_KEEP(rgb[s][j]);
+            NR_PIN();
         }
         float none[NS][1];
         NR_PRAGMA_UNROLL
@@ -253,7 +268,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         float hit[NS], vis[NS];
         {
             float h1[NS][8], h2[NS][8], fm[NS][2], fv[NS][2], fa[NS][1];
-            const LdsW W1 = stage_phase<PH_DIST_MS>(wl, W, tid, nthreads);
+            NoLayer last;      // "no next layer": the following layer belongs to the next phase
+            const LdsW W1 = phase_enter<PH_DIST_M, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
             LayerPre<L_DM1> p_dm1; LayerPre<L_DM2> p_dm2; LayerPre<L_DV1> p_dv1; LayerPre<L_DV2> p_dv2;
             VecPre<L_DFIN_M> p_fm; VecPre<L_DFIN_V> p_fv;
             layer_prefetch<L_DM1>(W1, lane, p_dm1);
@@ -261,8 +277,12 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             layer_fwd<L_DM2, NS, ACT_ELU>(W1, lane, p_dm2, h1, none, h2, p_fm);
             layer_prefetch<L_DV1>(W1, lane, p_dv1);
             layer_vec<L_DFIN_M, NS>(p_fm, h2, fm);
-            layer_fwd<L_DV1, NS, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, p_dv2);
-            layer_fwd<L_DV2, NS, ACT_ELU>(W1, lane, p_dv2, h1, none, h2, p_fv);
+            layer_fwd<L_DV1, NS, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, last);
+            const LdsW W2 = phase_enter<PH_DIST_VA, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
+            layer_prefetch<L_DV2>(W2, lane, p_dv2);
+            layer_fwd<L_DV2, NS, ACT_ELU>(W2, lane, p_dv2, h1, none, h2, p_fv);
+            LayerPre<L_DA1> p_da1; LayerPre<L_DA2> p_da2; VecPre<L_DFIN_A> p_fa;
+            layer_prefetch<L_DA1>(W2, lane, p_da1);
             layer_vec<L_DFIN_V, NS>(p_fv, h2, fv);
             float mu0[NS], mu1[NS], s0[NS], s1[NS], aw[NS], nu[NS];
             NR_PRAGMA_UNROLL
@@ -270,18 +290,16 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 mu0[s] = softplus(fm[s][0]); mu1[s] = softplus(fm[s][1]);
                 s0[s] = softplus(fv[s][0]) + p.var_bias; s1[s] = softplus(fv[s][1]) + p.var_bias;
             }
-            const LdsW W2 = stage_phase<HAS_VIS ? PH_DIST_AV : PH_DIST_A>(wl, W, tid, nthreads);
-            LayerPre<L_DA1> p_da1; LayerPre<L_DA2> p_da2; VecPre<L_DFIN_A> p_fa;
-            layer_prefetch<L_DA1>(W2, lane, p_da1);
             layer_fwd<L_DA1, NS, ACT_ELU>(W2, lane, p_da1, fray, none, h1, p_da2);
             layer_fwd<L_DA2, NS, ACT_ELU>(W2, lane, p_da2, h1, none, h2, p_fa);
             if constexpr (HAS_VIS) {
                 LayerPre<L_DS1> p_ds1; LayerPre<L_DS2> p_ds2; VecPre<L_DFIN_S> p_fs;
                 float fs[NS][1];
-                layer_prefetch<L_DS1>(W2, lane, p_ds1);
                 layer_vec<L_DFIN_A, NS>(p_fa, h2, fa);
-                layer_fwd<L_DS1, NS, ACT_ELU>(W2, lane, p_ds1, fray, none, h1, p_ds2);
-                layer_fwd<L_DS2, NS, ACT_ELU>(W2, lane, p_ds2, h1, none, h2, p_fs);
+                const LdsW W2s = phase_enter<PH_DIST_S, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
+                layer_prefetch<L_DS1>(W2s, lane, p_ds1);
+                layer_fwd<L_DS1, NS, ACT_ELU>(W2s, lane, p_ds1, fray, none, h1, p_ds2);
+                layer_fwd<L_DS2, NS, ACT_ELU>(W2s, lane, p_ds2, h1, none, h2, p_fs);
                 layer_vec<L_DFIN_S, NS>(p_fs, h2, fs);
                 NR_PRAGMA_UNROLL
                 for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = sigmoidf(fs[s][0]); }
@@ -306,7 +324,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         }
 
         // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
-        const LdsW W3 = stage_phase<PH_EMBED>(wl, W, tid, nthreads);
+        const LdsW W3 = phase_enter<PH_EMBED, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
         float e[NS][8];
         NoLayer last;
         LayerPre<L_PE1> p_pe1; LayerPre<L_PE2> p_pe2; LayerPre<L_RD1> p_rd1; LayerPre<L_RD2> p_rd2;
@@ -328,7 +346,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             for (int s = 0; s < NS; ++s) x1[s][0] = sel4(g, dlt[s][0], dlt[s][1], dlt[s][2], dlt[s][3]);
             layer_fwd<L_RD1, NS, ACT_ELU>(W3, lane, p_rd1, none, x1, h, p_rd2);
             layer_prefetch<L_RD2>(W3, lane, p_rd2v);
-            layer_fwd<L_RD2, NS, ACT_ELU>(W3, lane, p_rd2, h, none, df, p_nf1);
+            layer_fwd<L_RD2, NS, ACT_ELU>(W3, lane, p_rd2, h, none, df, last);
             layer_vec<L_RD2, NS>(p_rd2v, h, dc);          // the three rgb rows of ray_dir_fc.2
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
@@ -339,10 +357,13 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             }
         }
         // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
+        // (this phase also holds base_fc.0's per-view rows 0..31, used after the statistics below)
+        const LdsW W4 = phase_enter<PH_NF_BV0, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
         float sn[NS];
         {
             float h[NS][4], o[NS][1];
-            layer_fwd<L_NF1, NS, ACT_ELU>(W3, lane, p_nf1, e, none, h, p_nf2);
+            layer_prefetch<L_NF1>(W4, lane, p_nf1);
+            layer_fwd<L_NF1, NS, ACT_ELU>(W4, lane, p_nf1, e, none, h, p_nf2);
             layer_vec<L_NF2, NS>(p_nf2, h, o);
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) sn[s] = sigmoidf(o[s][0]);
@@ -350,7 +371,6 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // ---------------- cross-view weighted mean / variance       ibrnet.py:334-340 ---------------------
         // Each statistic is all-reduced over the views and immediately consumed by the owner waves as a K-slice of
         // base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
-        const LdsW W4 = stage_phase<PH_BASE>(wl, W, tid, nthreads);   // used after the statistics below
         float msum[NT], wv[NS];
         {
             float m1[NS][1];
@@ -367,7 +387,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
-                const float4 b = wld4(W, g * 16, (bias_offset(L_BG) + (mo < 4 ? mo : 0) * 16) * 4);
+                const float4 b = wld4(W, gg * 16, (bias_offset(L_BG) + (mo < 4 ? mo : 0) * 16) * 4);
                 NR_PRAGMA_UNROLL
                 for (int t = 0; t < NT; ++t) { accg[j][t][0] = b.x; accg[j][t][1] = b.y; accg[j][t][2] = b.z; accg[j][t][3] = b.w; }
             }
@@ -392,11 +412,11 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     NR_PRAGMA_UNROLL
                     for (int j = 0; j < 3; ++j) { const float d_ = gr[s][j] - st[t * 11 + 8 + j]; part[s][8 + j] = wk[s] * (d_ * d_); }
                 }
-                if (k == 0) bg_accumulate<NT, OWN, 0>(W, lane, g, wave, nw, st, accg);
-                else bg_accumulate<NT, OWN, 2>(W, lane, g, wave, nw, st, accg);
+                if (k == 0) bg_accumulate<NT, OWN, 0>(W, glane, g, wave, nw, st, accg);
+                else bg_accumulate<NT, OWN, 2>(W, glane, g, wave, nw, st, accg);
                 view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, sv, red, wave, nw, lane);
-                if (k == 0) bg_accumulate<NT, OWN, 1>(W, lane, g, wave, nw, sv, accg);
-                else bg_accumulate<NT, OWN, 3>(W, lane, g, wave, nw, sv, accg);
+                if (k == 0) bg_accumulate<NT, OWN, 1>(W, glane, g, wave, nw, sv, accg);
+                else bg_accumulate<NT, OWN, 3>(W, glane, g, wave, nw, sv, accg);
             }
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
@@ -418,6 +438,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         }
         // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
         float x[NS][8], vis2[NS], z[NS];
+        LdsW W5;
+        LayerPre<L_VF1> p_vf1;
         {
             float xq[NS][16], x1[NS][1], h64[NS][16];
             NR_PRAGMA_UNROLL
@@ -426,28 +448,44 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 for (int k = 0; k < 8; ++k) { xq[s][k] = gi[s][k]; xq[s][8 + k] = e[s][k]; }
                 x1[s][0] = sel4(g, gr[s][0], gr[s][1], gr[s][2], 0.0f);
             }
-            LayerPre<L_BV> p_bv; LayerPre<L_B2> p_b2;
-            layer_prefetch<L_BV>(W4, lane, p_bv);
-            layer_acc<L_BV, NS>(W4, lane, p_bv, xq, x1, accv, p_b2);
+            LayerPre<L_BV0> p_bv0; LayerPre<L_BV1> p_bv1; LayerPre<L_B2> p_b2;
+            v4f acch[NS][2];
+            layer_prefetch<L_BV0>(W4, lane, p_bv0);
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s) { acch[s][0] = accv[s][0]; acch[s][1] = accv[s][1]; }
+            layer_acc<L_BV0, NS>(W4, lane, p_bv0, xq, x1, acch, last);
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
-                for (int mo = 0; mo < 4; ++mo)
+                for (int mo = 0; mo < 2; ++mo)
                     NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(accv[s][mo][r]);   // kOutScaled[L_BV]
-            layer_fwd<L_B2, NS, ACT_ELU>(W4, lane, p_b2, h64, none, x, last);
+                    for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV0]
+            const LdsW W4b = phase_enter<PH_BV1, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
+            layer_prefetch<L_BV1>(W4b, lane, p_bv1);
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s) { acch[s][0] = accv[s][2]; acch[s][1] = accv[s][3]; }
+            layer_acc<L_BV1, NS>(W4b, lane, p_bv1, xq, x1, acch, last);
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NS; ++s)
+                NR_PRAGMA_UNROLL
+                for (int mo = 0; mo < 2; ++mo)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) h64[s][8 + 4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV1]
+            W5 = phase_enter<PH_B2_VF1, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
+            layer_prefetch<L_B2>(W5, lane, p_b2);
+            layer_fwd<L_B2, NS, ACT_ELU>(W5, lane, p_b2, h64, none, x, p_vf1);
         }
         {
-            const LdsW W5 = stage_phase<PH_TAIL>(wl, W, tid, nthreads);
             float xin[NS][8], h[NS][8], y[NS][8], yv[NS][1], o[NS][1];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s)
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xin[s][k] = x[s][k] * wv[s];
-            LayerPre<L_VF1> p_vf1; LayerPre<L_VF2> p_vf2; LayerPre<L_V21> p_v21; LayerPre<L_RF1> p_rf1; LayerPre<L_RF2> p_rf2;
+            LayerPre<L_VF2> p_vf2; LayerPre<L_V21> p_v21; LayerPre<L_RF1> p_rf1; LayerPre<L_RF2> p_rf2;
             VecPre<L_VF2> p_vf2v; VecPre<L_V22> p_v22; VecPre<L_RF3> p_rf3;
-            layer_prefetch<L_VF1>(W5, lane, p_vf1);
-            layer_fwd<L_VF1, NS, ACT_ELU>(W5, lane, p_vf1, xin, none, h, p_vf2);
+            layer_fwd<L_VF1, NS, ACT_ELU>(W5, lane, p_vf1, xin, none, h, last);
+            W5 = phase_enter<PH_TAIL, HAS_VIS>(wl, W, seq0, more, wave, nw, lane);
+            layer_prefetch<L_VF2>(W5, lane, p_vf2);
             layer_prefetch<L_VF2>(W5, lane, p_vf2v);
             layer_fwd<L_VF2, NS, ACT_ELU>(W5, lane, p_vf2, h, none, y, p_v21);
             layer_vec<L_VF2, NS>(p_vf2v, h, yv);          // row 32: the visibility logit
@@ -513,7 +551,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         NR_PRAGMA_UNROLL
         for (int j = 0; j < OWN; ++j) {
             const int mo = wave + j * nw;
-            const float4 b = wld4(W, g * 16, (bias_offset(L_GF1) + (mo < 4 ? mo : 0) * 16) * 4);
+            const float4 b = wld4(W, gg * 16, (bias_offset(L_GF1) + (mo < 4 ? mo : 0) * 16) * 4);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) { accf[j][t][0] = b.x; accf[j][t][1] = b.y; accf[j][t][2] = b.z; accf[j][t][3] = b.w; }
         }
@@ -533,7 +571,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
-                if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, lane, mo, xq, x1, accf[j]);
+                if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
             }
             view_allreduce<NT, VPW, 8, RMAX, RED_SUM>(v8, var, red, wave, nw, lane);
         }
@@ -549,7 +587,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave + j * nw;
                 if (mo < 4) {
-                    layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, lane, mo, xq, nonet, accf[j]);
+                    layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
                     NR_PRAGMA_UNROLL
                     for (int t = 0; t < NT; ++t)
                         NR_PRAGMA_UNROLL
@@ -566,7 +604,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) h[t][k] = xch[(((k >> 2) * NT + t) * 4 + (k & 3)) * 64 + lane];
             }
-            layer_fwd<L_GF2, NT, ACT_ELU>(W, lane, h, nonet, G);
+            layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, h, nonet, G);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t)
                 if (pvalid[t])

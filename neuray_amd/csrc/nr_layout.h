@@ -25,8 +25,9 @@ namespace nr {
 enum LayerId {
     // dist decoder heads (mean, var, aw, vis): 32 -> 32 -> 32 -> out                  dist_decoder.py:64-97
     // (order = LDS staging phases, see kPhase below)
-    L_DM1, L_DM2, L_DV1, L_DV2,
+    L_DM1, L_DM2,
     L_DFIN_M,    // vector rows: [mu0 mu1] pre-activations from h2(mean)
+    L_DV1, L_DV2,
     L_DFIN_V,    // vector rows: [s0 s1] from h2(var)
     L_DA1, L_DA2,
     L_DFIN_A,    // vector row: [aw] from h2(aw)
@@ -35,13 +36,13 @@ enum LayerId {
     L_PE1, L_PE2,            // prob_embed 34 -> 32 -> 32                           aggregate_net.py:27-31
     L_RD1, L_RD2,            // ray_dir_fc 4 -> 16 -> 35 (32 image rows on MFMA + 3 rgb vector rows)  ibrnet.py:249-252
     L_NF1, L_NF2,            // neuray_fc 32 -> 8 -> 1 (vector row)                 ibrnet.py:287-291
-    L_BG,                    // base_fc.0 columns [mean0 var0 mean1 var1] (per point) ibrnet.py:254
-    L_BV,                    // base_fc.0 columns [rgb_feat neuray_feat]  (per view)
+    L_BV0, L_BV1,            // base_fc.0 columns [rgb_feat neuray_feat] (per view), output rows 0..31 / 32..63  ibrnet.py:254
     L_B2,                    // base_fc.2 64 -> 32
     L_VF1, L_VF2,            // vis_fc 32 -> 32 -> 33 (32 MFMA rows + the visibility logit as a vector row)  ibrnet.py:259-263
     L_V21, L_V22,            // vis_fc2 32 -> 32 -> 1 (vector row)                  ibrnet.py:265-269
     L_RF1, L_RF2, L_RF3,     // rgb_fc 37 -> 16 -> 8 -> 1 (vector row)              ibrnet.py:281-285
-    L_GF1, L_GF2,            // geometry_fc 65 -> 64 -> 16                          ibrnet.py:271-274
+    L_BG,                    // base_fc.0 columns [mean0 var0 mean1 var1] (per point; read from global by the owner waves)
+    L_GF1, L_GF2,            // geometry_fc 65 -> 64 -> 16 (per point)              ibrnet.py:271-274
     L_COUNT
 };
 
@@ -53,27 +54,26 @@ enum LayerId {
 // (ELU -> ELU chains keep their weights untouched: L/L).  Layers whose ELU output is used by non-MFMA arithmetic
 // (ray_dir_fc.2, base_fc.2, vis_fc.2, geometry_fc.2) keep the plain form.
 constexpr double kLog2e = 1.4426950408889634074;
-//                                     DM1 DM2 DV1 DV2 FM  FV  DA1 DA2 FA  DS1 DS2 FS  PE1 PE2 RD1 RD2 NF1 NF2 BG  BV  B2  VF1 VF2 V21 V22 RF1 RF2 RF3 GF1 GF2
-constexpr bool kOutScaled[30] = {       1,  1,  1,  1,  0,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0};
-constexpr bool kInScaled[30] = {        0,  1,  0,  1,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1};
-static_assert(L_COUNT == 30, "kOutScaled / kInScaled follow the LayerId order");
+//                                     DM1 DM2 FM  DV1 DV2 FV  DA1 DA2 FA  DS1 DS2 FS  PE1 PE2 RD1 RD2 NF1 NF2 BV0 BV1 B2  VF1 VF2 V21 V22 RF1 RF2 RF3 BG  GF1 GF2
+constexpr bool kOutScaled[31] = {       1,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  1,  0};
+constexpr bool kInScaled[31] = {        0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  0,  1};
+static_assert(L_COUNT == 31, "kOutScaled / kInScaled follow the LayerId order");
 
 struct LayerShape { int mt_out, kq, k1; };
 
 constexpr LayerShape kShape[L_COUNT] = {
-    {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0},
-    {0, 0, 0}, {0, 0, 0},
-    {2, 2, 0}, {2, 2, 0},
-    {0, 0, 0},
-    {2, 2, 0}, {2, 2, 0},
-    {0, 0, 0},
+    {2, 2, 0}, {2, 2, 0}, {0, 0, 0},
+    {2, 2, 0}, {2, 2, 0}, {0, 0, 0},
+    {2, 2, 0}, {2, 2, 0}, {0, 0, 0},
+    {2, 2, 0}, {2, 2, 0}, {0, 0, 0},
     {2, 2, 1}, {2, 2, 0},
     {1, 0, 1}, {2, 1, 0},
     {1, 2, 0}, {0, 0, 0},
-    {4, 8, 4}, {4, 4, 1}, {2, 4, 0},
+    {2, 4, 1}, {2, 4, 1}, {2, 4, 0},
     {2, 2, 0}, {2, 2, 0},
     {2, 2, 0}, {0, 0, 0},
     {1, 2, 2}, {1, 1, 0}, {0, 0, 0},
+    {4, 8, 4},
     {4, 4, 1}, {1, 4, 0},
 };
 
@@ -86,12 +86,10 @@ constexpr LayerShape kShape[L_COUNT] = {
 //   replicated per lane group, [g][4] (so that every load of a vector layer uses the same per-group address).
 struct VecShape { int n, tiles; };
 constexpr VecShape kVec[L_COUNT] = {
-    {0, 0}, {0, 0}, {0, 0}, {0, 0},
-    {2, 2}, {2, 2},
-    {0, 0}, {0, 0},
-    {1, 2},
-    {0, 0}, {0, 0},
-    {1, 2},
+    {0, 0}, {0, 0}, {2, 2},
+    {0, 0}, {0, 0}, {2, 2},
+    {0, 0}, {0, 0}, {1, 2},
+    {0, 0}, {0, 0}, {1, 2},
     {0, 0}, {0, 0},
     {0, 0}, {3, 1},
     {0, 0}, {1, 1},
@@ -99,6 +97,7 @@ constexpr VecShape kVec[L_COUNT] = {
     {0, 0}, {1, 2},
     {0, 0}, {1, 2},
     {0, 0}, {0, 0}, {1, 1},
+    {0, 0},
     {0, 0}, {0, 0},
 };
 
@@ -122,17 +121,23 @@ constexpr int vec_bias_offset(int l) { return vec_offset(l) + kVec[l].n * kVec[l
 
 constexpr int kPackedPointFloats = layer_offset(L_COUNT);
 
-// ---- LDS staging phases of the point kernel: contiguous layer ranges [first, last] copied into LDS by the whole
-// workgroup before they are used (the per-point layers L_BG, L_GF1, L_GF2 are read from global by their owner waves)
-enum PhaseId { PH_DIST_MS, PH_DIST_A, PH_DIST_AV, PH_EMBED, PH_BASE, PH_TAIL, PH_COUNT };
+// ---- LDS staging phases of the point kernel ------------------------------------------------------------
+// Contiguous layer ranges [first, last] that are copied into LDS before they are used (the per-point layers L_BG,
+// L_GF1, L_GF2 are read from global by their owner waves).  The weight stage is two regions of kStageRegionBytes:
+// while the waves compute phase k out of one region, the LDS-DMA copy of phase k+1 (buffer_load ... lds, no VGPRs)
+// lands in the other, so a phase costs one barrier and no exposed copy latency.  PH_DIST_S exists only for a decoder
+// with a vis head.
+enum PhaseId { PH_DIST_M, PH_DIST_VA, PH_DIST_S, PH_EMBED, PH_NF_BV0, PH_BV1, PH_B2_VF1, PH_TAIL, PH_COUNT };
 struct PhaseRange { int first, last; };
 constexpr PhaseRange kPhase[PH_COUNT] = {
-    {L_DM1, L_DFIN_V},       // mean + var heads and their output rows
-    {L_DA1, L_DFIN_A},       // aw head (decoder without vis head)
-    {L_DA1, L_DFIN_S},       // aw + vis heads
-    {L_PE1, L_NF2},          // prob_embed, ray_dir_fc, neuray_fc
-    {L_BV, L_B2},            // base_fc per-view part + second layer
-    {L_VF1, L_RF3},          // vis_fc, vis_fc2, rgb_fc
+    {L_DM1, L_DV1},          // mean head + its output rows, var.0
+    {L_DV2, L_DFIN_A},       // var.2 + output rows, aw head
+    {L_DS1, L_DFIN_S},       // vis head (HAS_VIS only)
+    {L_PE1, L_RD2},          // prob_embed, ray_dir_fc
+    {L_NF1, L_BV0},          // neuray_fc, base_fc.0 per-view rows 0..31
+    {L_BV1, L_BV1},          // base_fc.0 per-view rows 32..63
+    {L_B2, L_VF1},           // base_fc.2, vis_fc.0
+    {L_VF2, L_RF3},          // vis_fc.2, vis_fc2, rgb_fc
 };
 constexpr int phase_begin(int ph) { return layer_offset(kPhase[ph].first); }
 constexpr int phase_floats(int ph) { return layer_offset(kPhase[ph].last + 1) - layer_offset(kPhase[ph].first); }
@@ -141,7 +146,14 @@ constexpr int max_phase_floats() {
     for (int i = 0; i < PH_COUNT; ++i) m = phase_floats(i) > m ? phase_floats(i) : m;
     return m;
 }
-constexpr int kWeightLdsFloats = max_phase_floats();
+constexpr int kStageRegionBytes = (max_phase_floats() * 4 + 1023) / 1024 * 1024;   // DMA pieces are 1 KiB per wave
+constexpr int kWeightLdsFloats = 2 * kStageRegionBytes / 4;
+// position of a phase in the sequence a kernel variant runs (PH_DIST_S is skipped without a vis head), its successor
+constexpr int phase_count(bool vis) { return vis ? PH_COUNT : PH_COUNT - 1; }
+constexpr int phase_seq(int ph, bool vis) { return (vis || ph < PH_DIST_S) ? ph : ph - 1; }
+constexpr int phase_next(int ph, bool vis) {
+    return ph == PH_COUNT - 1 ? 0 : ((!vis && ph + 1 == PH_DIST_S) ? ph + 2 : ph + 1);
+}
 
 // ---- weights of the ray kernel (attention + sigma head), plain row-major ------------------------
 //   reference: network/ibrnet.py:52-102 (MultiHeadAttention 4 heads x d_k=4, no bias), :276-279

@@ -141,11 +141,14 @@ int pack_pass_weights(const float* const* t, float* dst) {
         for (int j = 0; j < 4; ++j)                       // single k-step j = rgb part of statistic j
             for (int g = 0; g < 4; ++g) m.in1_map.push_back(g < 3 ? 35 * j + g : -1);
         pack_layer(dst, L_BG, t[T_BASE0_W], 207, t[T_BASE0_B], m);
-        LayerMaps v; v.out_map = out_natural(4, 64);
-        in_gathered32(v.in_map, 140 + 3);
-        in_dlayout(v.in_map, 175, 32, 2);
-        for (int g = 0; g < 4; ++g) v.in1_map.push_back(g < 3 ? 140 + g : -1);
-        pack_layer(dst, L_BV, t[T_BASE0_W], 207, nullptr, v);
+        for (int half = 0; half < 2; ++half) {            // per-view columns, output rows 32*half .. 32*half+31
+            LayerMaps v; v.out_map.resize(32);
+            for (int i = 0; i < 32; ++i) v.out_map[i] = 32 * half + i;
+            in_gathered32(v.in_map, 140 + 3);
+            in_dlayout(v.in_map, 175, 32, 2);
+            for (int g = 0; g < 4; ++g) v.in1_map.push_back(g < 3 ? 140 + g : -1);
+            pack_layer(dst, half == 0 ? L_BV0 : L_BV1, t[T_BASE0_W], 207, nullptr, v);
+        }
         LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 64, 4);
         pack_layer(dst, L_B2, t[T_BASE2_W], 64, t[T_BASE2_B], m2);
     }

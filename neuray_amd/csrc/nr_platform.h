@@ -41,6 +41,10 @@ struct nr_buf { const char* p; };
 static inline nr_buf nr_make_buf(const float* p, size_t bytes) { (void)bytes; return nr_buf{(const char*)p}; }
 static inline float4 nr_buf_ld4(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
 static inline float nr_buf_ld1(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
+// LDS-DMA piece (emulation: the copy happens at issue time, a legal completion point)
+static inline void nr_dma16(nr_buf b, float* lds_wave_base, int lane, int voff, int soff) {
+    memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, b.p + voff + soff, 16);
+}
 #else
 // pointer-based variant (debug A/B): same interface, plain global loads
 struct nr_pbuf { const char* p; };
@@ -67,6 +71,14 @@ __device__ __forceinline__ float4 nr_buf_ld4(nr_buf b, int voff, int soff) {
 }
 __device__ __forceinline__ float nr_buf_ld1(nr_buf b, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+// LDS-DMA piece: buffer_load_dwordx4 ... lds.  Every active lane moves 16 bytes from (voff + soff) of the buffer to
+// lds_wave_base + lane * 16 (lds_wave_base is wave-uniform and goes to M0); no VGPRs, completion counted by vmcnt.
+__device__ __forceinline__ void nr_dma16(nr_buf b, float* lds_wave_base, int /*lane*/, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void nr_dma16(nr_pbuf b, float* lds_wave_base, int lane, int voff, int soff) {   // debug A/B
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_wave_base) + lane * 16) = *reinterpret_cast<const float4*>(b.p + voff + soff);
 }
 #endif
 
@@ -98,6 +110,14 @@ typedef nr_buf nr_mbuf;
 static inline int nr_opaque_zero() { return 0; }
 #else
 __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+#endif
+
+// forces a value to be computed HERE (an empty volatile asm that "modifies" it): LLVM's IR-level sinking otherwise moves
+// pure arithmetic down to the block of its first use, across sched_barriers, and keeps the operands alive instead
+#ifdef NEURAY_EMU
+#define NR_KEEP(x) do {} while (0)
+#else
+#define NR_KEEP(x) asm volatile("" : "+v"(x))
 #endif
 
 // pins program order at this point (the machine scheduler otherwise sinks a prefetch load back to its first use)

@@ -648,6 +648,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+    NR_PRAGMA_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
 // y[16] = M[16x16] x[16] with M row-major in LDS (every lane reads the same address: broadcast, conflict-free)
 __device__ __forceinline__ void matvec16(const float* __restrict__ M, const float (&x)[16], float (&y)[16]) {
     NR_PRAGMA_UNROLL
@@ -687,6 +693,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
         // ---- phase 1: K, V of every sample -> LDS
         // (compiler barrier: keeps hipcc from hoisting the uniform LDS weight reads out of the ray loop into SGPRs)
         asm volatile("" ::: "memory");
+        float kn2[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // per head: largest squared key norm of the ray (this lane's samples)
         for (int ch = 0; ch < nch; ++ch) {
             const int i = ch * 64 + lane;
             if (i < dn) {
@@ -698,20 +705,27 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                 }
                 matvec16(RW + RW_WK, G, y);
                 NR_PRAGMA_UNROLL
-                for (int k4 = 0; k4 < 4; ++k4)
+                for (int k4 = 0; k4 < 4; ++k4) {
                     *reinterpret_cast<float4*>(ks + i * 16 + 4 * k4) = make_float4(y[4 * k4], y[4 * k4 + 1], y[4 * k4 + 2], y[4 * k4 + 3]);
+                    kn2[k4] = fmaxf(kn2[k4], fmaf(y[4 * k4 + 3], y[4 * k4 + 3], fmaf(y[4 * k4 + 2], y[4 * k4 + 2],
+                                    fmaf(y[4 * k4 + 1], y[4 * k4 + 1], y[4 * k4] * y[4 * k4]))));
+                }
                 matvec16(RW + RW_WV, G, y);
                 NR_PRAGMA_UNROLL
                 for (int k4 = 0; k4 < 4; ++k4)
                     *reinterpret_cast<float4*>(vs + i * 16 + 4 * k4) = make_float4(y[4 * k4], y[4 * k4 + 1], y[4 * k4 + 2], y[4 * k4 + 3]);
             }
         }
+        NR_PRAGMA_UNROLL
+        for (int hh = 0; hh < 4; ++hh) kn2[hh] = wave_max(kn2[hh]);
         __syncthreads();
         // ---- phase 2: attention row, LayerNorm, sigma, alpha
         for (int ch = 0; ch < nch; ++ch) {
-            const int i = ch * 64 + lane;
+            const int iraw = ch * 64 + lane;
+            const bool act = iraw < dn;               // lanes past the last sample redo sample dn-1 and store nothing, so
+            const int i = act ? iraw : dn - 1;        // that the wave stays converged for the ballot below
             asm volatile("" ::: "memory");
-            if (i < dn) {
+            {
                 float G[16], q[16], o[16];
                 NR_PRAGMA_UNROLL
                 for (int k4 = 0; k4 < 4; ++k4) {
@@ -722,26 +736,57 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                 matvec16(RW + RW_WQ, G, q);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) q[k] = q[k] / 2.0f;      // temperature = sqrt(d_k) = 2 (exact)
-                const bool masked = !(nvalid > 1.0f);   // query-row mask: quirk A.9.3
+                // query-row mask (quirk A.9.3): every score of the row becomes -1e9, i.e. the softmax is uniform - exactly
+                // what a zero query gives, so the row is handled by zeroing q instead of a select per (query, key)
+                if (!(nvalid > 1.0f)) {
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 16; ++k) q[k] = 0.0f;
+                }
+                // softmax shift: any c >= max_j s_ij gives the same softmax; c = |q_i| * max_j |k_j| (Cauchy-Schwarz)
+                // needs no pass over the keys.  exp(s - c) cannot overflow; it could underflow for every key only if
+                // c - max_j s_ij > 87, so rows with c > 40 (never seen with trained or kaiming weights, exercised by
+                // tests/test_edge_cases.py) take the exact two-pass form.
+                float cb[4];
+                bool fast = true;
                 NR_PRAGMA_UNROLL
                 for (int hh = 0; hh < 4; ++hh) {
-                    float mx = -INFINITY;
-                    for (int j = 0; j < dn; ++j) {
-                        const float4 kj = ld4(ks + j * 16 + hh * 4);
-                        float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
-                        s = masked ? -1e9f : s;
-                        mx = fmaxf(mx, s);
+                    const float qn2 = fmaf(q[hh * 4 + 3], q[hh * 4 + 3], fmaf(q[hh * 4 + 2], q[hh * 4 + 2],
+                                           fmaf(q[hh * 4 + 1], q[hh * 4 + 1], q[hh * 4] * q[hh * 4])));
+                    cb[hh] = sqrtf(qn2 * kn2[hh]) * 1.0000005f;      // (rounding slack: the bound must not fall below the max)
+                    fast = fast && (cb[hh] <= 40.0f);
+                }
+                if (__ballot(!fast) == 0ull) {
+                    NR_PRAGMA_UNROLL
+                    for (int hh = 0; hh < 4; ++hh) {
+                        float den = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                        for (int j = 0; j < dn; ++j) {
+                            const float4 kj = ld4(ks + j * 16 + hh * 4);
+                            const float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
+                            const float e_ = nr_fast_exp(s - cb[hh]);
+                            const float4 vj = ld4(vs + j * 16 + hh * 4);
+                            den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
+                        }
+                        o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
                     }
-                    float den = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-                    for (int j = 0; j < dn; ++j) {
-                        const float4 kj = ld4(ks + j * 16 + hh * 4);
-                        float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
-                        s = masked ? -1e9f : s;
-                        const float e_ = nr_fast_exp(s - mx);
-                        const float4 vj = ld4(vs + j * 16 + hh * 4);
-                        den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
+                } else {
+                    NR_PRAGMA_UNROLL
+                    for (int hh = 0; hh < 4; ++hh) {
+                        float mx = -INFINITY;
+                        for (int j = 0; j < dn; ++j) {
+                            const float4 kj = ld4(ks + j * 16 + hh * 4);
+                            const float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
+                            mx = fmaxf(mx, s);
+                        }
+                        float den = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                        for (int j = 0; j < dn; ++j) {
+                            const float4 kj = ld4(ks + j * 16 + hh * 4);
+                            const float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
+                            const float e_ = nr_fast_exp(s - mx);
+                            const float4 vj = ld4(vs + j * 16 + hh * 4);
+                            den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
+                        }
+                        o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
                     }
-                    o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
                 }
                 float y[16], mean = 0.0f;
                 matvec16(RW + RW_FC, o, y);
@@ -761,10 +806,9 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                 for (int k = 0; k < 16; ++k) sg = fmaf(RW[RW_OG2W + k], elu(o[k] + RW[RW_OG0B + k]), sg);
                 sg = fmaxf(sg, 0.0f);
                 if (nvalid < 1.0f) sg = 0.0f;
-                if (p.density && rvalid) p.density[(size_t)ray * dn + i] = sg;
+                if (p.density && rvalid && act) p.density[(size_t)ray * dn + i] = sg;
                 const float alpha = 1.0f - expf(-fmaxf(sg, 0.0f));
-                al[i] = alpha;
-                tr[i] = (1.0f - alpha) + 1e-10f;
+                if (act) { al[i] = alpha; tr[i] = (1.0f - alpha) + 1e-10f; }
             }
         }
         __syncthreads();

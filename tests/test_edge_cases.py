@@ -36,8 +36,12 @@ def scene(h, w, rfn, rn, seed, fh=None, fw=None):
     return que, ref
 
 
-def check(cfg, que, ref, backend, tol=2e-4):
+def check(cfg, que, ref, backend, tol=2e-4, tweak=None):
     r, weights, dev = build(cfg, backend)
+    if tweak is not None:
+        with torch.no_grad():
+            tweak(r)
+        weights = {k: v.detach().cpu().numpy().copy() for k, v in r.state_dict().items()}
     with torch.no_grad():
         got = r.render_impl(to_torch(que, dev), to_torch(ref, dev), False)
     ocfg = dict(cfg, coarse_use_vis=cfg.get('dist_decoder_cfg', {}).get('use_vis', True), fine_use_vis=True)
@@ -54,6 +58,22 @@ def test_sample_and_ray_count_extremes(dn, rn, rfn, backend):
     cfg = {'depth_sample_num': dn, 'agg_net_cfg': {'sample_num': dn}, 'dist_decoder_cfg': {'use_vis': dn % 2 == 1}}
     que, ref = scene(40, 56, rfn, rn, seed=dn)
     check(cfg, que, ref, backend)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('scale', [1.0, 12.0])
+def test_attention_softmax_shift_paths(scale, backend):
+    """The ray kernel shifts the attention softmax by the bound |q| max|k| (one pass over the keys) and falls back to
+    the exact two-pass row maximum when the bound exceeds 40.  scale = 12 on the query / key projections makes the
+    logits ~144x larger (bounds far above 40, near one-hot rows): the fallback must agree with the oracle too."""
+    cfg = {'depth_sample_num': 24, 'agg_net_cfg': {'sample_num': 24}, 'dist_decoder_cfg': {'use_vis': False}}
+    que, ref = scene(40, 56, 3, 19, seed=11)
+
+    def tweak(r):
+        for name, prm in r.named_parameters():
+            if name.endswith('ray_attention.w_qs.weight') or name.endswith('ray_attention.w_ks.weight'):
+                prm.mul_(scale)
+    check(cfg, que, ref, backend, tweak=tweak)
 
 
 @pytest.mark.parametrize('backend', BACKENDS)

@@ -194,10 +194,13 @@ def main():
         flops_pt = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False)
         # HBM/fabric traffic of the point kernel per launch: PMC passes are run separately (rocprofv3 --pmc cannot run
         # inside this process); the committed summary of the same command is reported here (profiles/README.md)
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if args.fine_samples == 32 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('bytes_per_launch')
+        traffic, tsrc = None, None
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')),
+                        key=lambda f: (len(os.path.basename(f)), os.path.basename(f)))   # r01_traffic < r01_e_traffic < r02_...
+        if args.fine_samples == 32 and tfiles:
+            traffic = json.load(open(tfiles[-1])).get('bytes_per_launch')
+            tsrc = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)' % os.path.basename(tfiles[-1])
         achieved = flops_pt * n_pts / t_pts / 1e12
         line = {
             'metric': 'rays/sec (64 coarse+%d fine samples), lego 800x800 synthetic' % args.fine_samples,
@@ -212,7 +215,7 @@ def main():
                                       ('images sharded over %d GPU(s), no collective' % world)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic,
-                         'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)',
+                         'traffic_source': tsrc,
                          'kernel': 'nr::points_kernel', 'launches': len(pts),
                          'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
                          'algorithmic_flops_per_point': flops_pt,

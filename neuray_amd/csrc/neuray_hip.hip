@@ -71,7 +71,7 @@ int launch_points(const nr::PointParams& p, void* stream) {
 }
 
 // Built decompositions (measured on MI355X, DESIGN.md "point kernel tuning"):
-//   views_per_wave = 2, 168 VGPRs, 3 waves per SIMD  - default (1.75 M rays/s on the lego-800 workload)
+//   views_per_wave = 2, 168 VGPRs, 3 waves per SIMD  - default (2.35 M rays/s on the lego-800 workload)
 //   views_per_wave = 1, 128 VGPRs, 4 waves per SIMD  - single reference view, and the A/B reference
 template <bool HAS_VIS>
 int launch_points_cfg(const nr::PointParams& p, int vpw, void* stream) {

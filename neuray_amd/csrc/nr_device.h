@@ -543,27 +543,32 @@ __device__ __forceinline__ LdsW phase_enter(float* wl, nr_wbuf W, int seq0, bool
 //   red: LDS scratch of (nw + 1) * RMAX * 64 floats.  Deterministic (views summed in order 0..nw-1),
 //   identical result in every wave.  Two barriers per round (reduce-scatter, then all-gather).
 // ---------------------------------------------------------------------------------------------
-enum RedOp { RED_SUM, RED_MAX };
-template <int R, int RMAX, int OP>
+// OP = RED_MAX0: rows whose index is a multiple of MAXSTRIDE take the maximum, all other rows the sum
+enum RedOp { RED_SUM, RED_MAX, RED_MAX0 };
+template <int OP, int MAXSTRIDE> __device__ __forceinline__ float red_combine(float a, float b, int row) {
+    if (OP == RED_SUM) return a + b;
+    if (OP == RED_MAX) return fmaxf(a, b);
+    return (row % MAXSTRIDE == 0) ? fmaxf(a, b) : a + b;
+}
+template <int R, int RMAX, int OP, int MAXSTRIDE = 1>
 __device__ __forceinline__ void block_allreduce(float (&v)[R], float* red, int wave, int nw, int lane) {
     static_assert(R <= RMAX, "allreduce scratch too small");
 #if defined(NR_ABLATE) && (NR_ABLATE & 1)
     return;
 #endif
+    NR_PRIO_HI();
     NR_PRAGMA_UNROLL
     for (int r = 0; r < R; ++r) red[(wave * RMAX + r) * 64 + lane] = v[r];
     NR_BLOCK_SYNC();
     for (int r = wave; r < R; r += nw) {
         float s = red[r * 64 + lane];
-        for (int w = 1; w < nw; ++w) {
-            const float o = red[(w * RMAX + r) * 64 + lane];
-            s = (OP == RED_SUM) ? s + o : fmaxf(s, o);
-        }
+        for (int w = 1; w < nw; ++w) s = red_combine<OP, MAXSTRIDE>(s, red[(w * RMAX + r) * 64 + lane], r);
         red[(nw * RMAX + r) * 64 + lane] = s;
     }
     NR_BLOCK_SYNC();
     NR_PRAGMA_UNROLL
     for (int r = 0; r < R; ++r) v[r] = red[(nw * RMAX + r) * 64 + lane];
+    NR_PRIO_LO();
 }
 
 }  // namespace nr

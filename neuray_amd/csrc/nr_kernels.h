@@ -120,7 +120,8 @@ __device__ __forceinline__ void bg_accumulate(nr_wbuf W, int lane, int g, int wa
     }
 }
 
-// sum (or max) over the VPW view slots of each tile, then over the waves of the workgroup
+// sum (or max; RED_MAX0: row 0 of each tile max, the other rows sum) over the VPW view slots of each tile, then over
+// the waves of the workgroup
 template <int NT, int VPW, int R, int RMAX, int OP>
 __device__ __forceinline__ void view_allreduce(const float (&v)[NT * VPW][R], float (&out)[NT * R], float* red, int wave,
                                                int nw, int lane) {
@@ -130,10 +131,10 @@ __device__ __forceinline__ void view_allreduce(const float (&v)[NT * VPW][R], fl
         for (int r = 0; r < R; ++r) {
             float a = v[t][r];
             NR_PRAGMA_UNROLL
-            for (int vv = 1; vv < VPW; ++vv) a = (OP == RED_SUM) ? a + v[vv * NT + t][r] : fmaxf(a, v[vv * NT + t][r]);
+            for (int vv = 1; vv < VPW; ++vv) a = red_combine<OP, R>(a, v[vv * NT + t][r], r);
             out[t * R + r] = a;
         }
-    block_allreduce<NT * R, RMAX, OP>(out, red, wave, nw, lane);
+    block_allreduce<NT * R, RMAX, OP, R>(out, red, wave, nw, lane);
 }
 
 // Point kernel.  One workgroup = ceil(rfn / VPW) waves x NT tiles of 16 sample points; wave w processes the reference
@@ -372,15 +373,6 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // Each statistic is all-reduced over the views and immediately consumed by the owner waves as a K-slice of
         // base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
         float msum[NT], wv[NS];
-        {
-            float m1[NS][1];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) m1[s][0] = mask[s];
-            view_allreduce<NT, VPW, 1, RMAX, RED_SUM>(m1, msum, red, wave, nw, lane);
-        }
-        NR_PRAGMA_UNROLL
-        for (int s = 0; s < NS; ++s) wv[s] = mask[s] * nr_fast_rcp(msum[s % NT] + 1e-8f);
-
         v4f accv[NS][4];
         {
             v4f accg[OWN][NT];
@@ -392,18 +384,45 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 for (int t = 0; t < NT; ++t) { accg[j][t][0] = b.x; accg[j][t][1] = b.y; accg[j][t][2] = b.z; accg[j][t][3] = b.w; }
             }
             float part[NS][11], st[NT * 11], sv[NT * 11], wk[NS];
+            {   // k = 0, first all-reduce: sum(mask) rides along with the un-normalised weighted sum
+                //   weight = mask / (sum(mask) + 1e-8), weight0 = sigmoid(neuray_fc) * weight, mean0 = sum(x * weight0)
+                //   is evaluated as sum(x * sigmoid * mask) / (sum(mask) + 1e-8)
+                float p12[NS][12], o12[NT * 12];
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NS; ++s) {
+                    const float w_ = sn[s] * mask[s];
+                    NR_PRAGMA_UNROLL
+                    for (int q = 0; q < 8; ++q) p12[s][q] = gi[s][q] * w_;
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) p12[s][8 + j] = gr[s][j] * w_;
+                    p12[s][11] = mask[s];
+                }
+                view_allreduce<NT, VPW, 12, RMAX, RED_SUM>(p12, o12, red, wave, nw, lane);
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) {
+                    msum[t] = o12[t * 12 + 11];
+                    const float inv = nr_fast_rcp(msum[t] + 1e-8f);
+                    NR_PRAGMA_UNROLL
+                    for (int q = 0; q < 11; ++q) st[t * 11 + q] = o12[t * 12 + q] * inv;
+                }
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NS; ++s) wv[s] = mask[s] * nr_fast_rcp(msum[s % NT] + 1e-8f);
+            }
             // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0 ;  k = 1: weight -> mean1, var1
             NR_PRAGMA_UNROLL
             for (int k = 0; k < 2; ++k) {
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) {
-                    wk[s] = k == 0 ? sn[s] * wv[s] : wv[s];
+                for (int s = 0; s < NS; ++s) wk[s] = k == 0 ? sn[s] * wv[s] : wv[s];
+                if (k == 1) {
                     NR_PRAGMA_UNROLL
-                    for (int q = 0; q < 8; ++q) part[s][q] = gi[s][q] * wk[s];
-                    NR_PRAGMA_UNROLL
-                    for (int j = 0; j < 3; ++j) part[s][8 + j] = gr[s][j] * wk[s];
+                    for (int s = 0; s < NS; ++s) {
+                        NR_PRAGMA_UNROLL
+                        for (int q = 0; q < 8; ++q) part[s][q] = gi[s][q] * wk[s];
+                        NR_PRAGMA_UNROLL
+                        for (int j = 0; j < 3; ++j) part[s][8 + j] = gr[s][j] * wk[s];
+                    }
+                    view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, st, red, wave, nw, lane);
                 }
-                view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, st, red, wave, nw, lane);
                 NR_PRAGMA_UNROLL
                 for (int s = 0; s < NS; ++s) {
                     const int t = s % NT;
@@ -522,29 +541,34 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             }
         }
         // ---------------- cross-view: blending softmax, visibility-weighted mean/var  ibrnet.py:350-367 ---
-        float zmax[NT], sums[NT * 2], big[NT * 12], wh[NS];
+        // Two all-reduces: {max z, sum vis''} and {sum wh x (8), sum e (1), sum e rgb (3)} with e = exp(z - max z); the
+        // softmax blend sum(rgb * e / sum e) is evaluated as sum(rgb * e) / sum(e), the mean weight sum(wh) / rfn from
+        // sum(vis'') directly.
+        float zv[NT * 2], big[NT * 12], wh[NS], meanw[NT];
         {
-            float z1[NS][1];
+            float z2[NS][2];
             NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) z1[s][0] = z[s];
-            view_allreduce<NT, VPW, 1, RMAX, RED_MAX>(z1, zmax, red, wave, nw, lane);
-            float ev[NS], s2[NS][2];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) { ev[s] = nr_fast_exp(z[s] - zmax[s % NT]); s2[s][0] = vis2[s]; s2[s][1] = ev[s]; }
-            view_allreduce<NT, VPW, 2, RMAX, RED_SUM>(s2, sums, red, wave, nw, lane);
+            for (int s = 0; s < NS; ++s) { z2[s][0] = z[s]; z2[s][1] = vis2[s]; }
+            view_allreduce<NT, VPW, 2, RMAX, RED_MAX0>(z2, zv, red, wave, nw, lane);
             float b12[NS][12];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
                 const int t = s % NT;
-                wh[s] = vis2[s] * nr_fast_rcp(sums[2 * t] + 1e-8f);
-                const float beta = ev[s] * nr_fast_rcp(sums[2 * t + 1]);
+                const float ev = nr_fast_exp(z[s] - zv[2 * t]);
+                wh[s] = vis2[s] * nr_fast_rcp(zv[2 * t + 1] + 1e-8f);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) b12[s][k] = x[s][k] * wh[s];
-                b12[s][8] = wh[s];
+                b12[s][8] = ev;
                 NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) b12[s][9 + j] = rgb[s][j] * beta;
+                for (int j = 0; j < 3; ++j) b12[s][9 + j] = rgb[s][j] * ev;
             }
             view_allreduce<NT, VPW, 12, RMAX, RED_SUM>(b12, big, red, wave, nw, lane);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                const float ie = nr_fast_rcp(big[t * 12 + 8]);
+                big[t * 12 + 9] *= ie; big[t * 12 + 10] *= ie; big[t * 12 + 11] *= ie;
+                meanw[t] = zv[2 * t + 1] * nr_fast_rcp(zv[2 * t + 1] + 1e-8f);
+            }
         }
         // geometry_fc.0 (a14): owner waves stream the mean part, then the variance part   ibrnet.py:353-354
         v4f accf[OWN][NT];
@@ -566,7 +590,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             for (int t = 0; t < NT; ++t) {
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xq[t][k] = big[t * 12 + k];
-                x1[t][0] = sel4(g, big[t * 12 + 8] * inv_rfn, 0.0f, 0.0f, 0.0f);
+                x1[t][0] = sel4(g, meanw[t] * inv_rfn, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {

@@ -120,6 +120,15 @@ __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32
 #define NR_KEEP(x) asm volatile("" : "+v"(x))
 #endif
 
+// wave priority around the short, latency-critical all-reduce sections (+0.2 %; -DNR_NO_PRIO turns it off)
+#if !defined(NR_NO_PRIO) && !defined(NEURAY_EMU)
+#define NR_PRIO_HI() __builtin_amdgcn_s_setprio(3)
+#define NR_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define NR_PRIO_HI() do {} while (0)
+#define NR_PRIO_LO() do {} while (0)
+#endif
+
 // pins program order at this point (the machine scheduler otherwise sinks a prefetch load back to its first use)
 #ifdef NEURAY_EMU
 #define NR_PIN() do {} while (0)

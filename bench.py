@@ -221,12 +221,12 @@ def main():
                          'algorithmic_flops_per_point': flops_pt,
                          'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt},
         }
-        if not args.no_cpu_baseline and args.cpu_sample_rays > 0:
+        if world == 1 and not args.no_cpu_baseline and args.cpu_sample_rays > 0:   # baselines: rank 0 at N = 1 only
             base, parity = cpu_baseline(cfg, weights, que, ref, out['pixel_colors_nr_fine'].cpu().numpy(),
                                         args.cpu_sample_rays, 1024)
             line['cpu_baseline'] = base
             line['parity'] = parity
-        if not args.no_eager_baseline and not args.no_cpu_baseline:
+        if world == 1 and not args.no_eager_baseline and not args.no_cpu_baseline:
             eb = eager_torch_baseline(cfg, weights, tq, tr, device)
             eb['speedup_vs_eager'] = value / (1 if split else world) / eb['value']
             line['eager_torch_baseline'] = eb

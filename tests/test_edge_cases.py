@@ -108,3 +108,44 @@ def test_abi_rejects_bad_arguments(backend):
     with pytest.raises(RuntimeError, match='outside'):
         qc = eng.prepare_query(to_torch(que, dev))
         eng.sample_fine_depth(qc, torch.ones(4, 200, device=dev), torch.ones(4, 200, device=dev), 16)
+
+
+# ---- the shapes of BASELINE.json's other configurations (parity cases, not bench lines) -------------------------
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_config1_shape_coarse_only(backend):
+    """configs[0]: 400x400, 3 reference views, 32 coarse samples, no hierarchical sampling."""
+    cfg = {'use_hierarchical_sampling': False, 'depth_sample_num': 32, 'agg_net_cfg': {'sample_num': 32},
+           'dist_decoder_cfg': {'use_vis': False}}
+    que, ref = synthetic.make_scene(400, 400, 3, seed=21)
+    rng = np.random.RandomState(22)
+    que['coords'] = np.stack([rng.randint(0, 400, 37), rng.randint(0, 400, 37)], -1)[None].astype(np.float32)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    got, want = check(cfg, que, ref, backend)
+    assert 'pixel_colors_nr_fine' not in got and 'pixel_colors_nr_fine' not in want
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_config3_shape_llff_padded_refs(backend):
+    """configs[2] (LLFF fern/high): query 756x1008, reference images padded to 768x1024 (ref_pad_interval 32), feature
+    maps 192x256, 8 views, wide depth range: the query intrinsics / size differ from the reference views'."""
+    cfg = {'use_hierarchical_sampling': True, 'depth_sample_num': 64, 'fine_depth_sample_num': 64,
+           'agg_net_cfg': {'sample_num': 64}, 'fine_agg_net_cfg': {'sample_num': 64}, 'dist_decoder_cfg': {'use_vis': False}}
+    que, ref = synthetic.make_scene(768, 1024, 8, seed=23, depth_range=(1.2, 12.0), radius=5.0)
+    # the query camera keeps the un-padded 756x1008 frame: same focal length, principal point of the smaller image
+    que['Ks'][0, 0, 2] = 1008 / 2.0
+    que['Ks'][0, 1, 2] = 756 / 2.0
+    rng = np.random.RandomState(24)
+    que['coords'] = np.stack([rng.randint(0, 1008, 21), rng.randint(0, 756, 21)], -1)[None].astype(np.float32)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    r, weights, dev = build(cfg, backend)
+    with torch.no_grad():
+        got = r.render_impl(to_torch(que, dev), to_torch(ref, dev), False)
+    ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+    want = orc.render_impl(weights, ocfg, que, ref)
+    # coarse pass on identical inputs: tight; the chained fine pass carries the reference's own resampling
+    # discontinuity (DESIGN.md 2.4), so it is bounded like the other chained comparisons
+    assert np.max(np.abs(got['pixel_colors_nr'].cpu().numpy() - want['pixel_colors_nr'])) <= 2e-4
+    assert np.max(np.abs(got['hit_prob_nr'].cpu().numpy() - want['hit_prob_nr'])) <= 1e-4
+    assert np.array_equal(got['ray_mask'].cpu().numpy(), want['ray_mask'])
+    d = np.abs(got['pixel_colors_nr_fine'].cpu().numpy() - want['pixel_colors_nr_fine'])
+    assert np.median(d) <= 2e-4 and np.mean(d <= 2e-3) >= 0.9

@@ -110,6 +110,39 @@ typedef struct NeurayRaysArgs {
 } NeurayRaysArgs;
 int neuray_render_rays(const NeurayRaysArgs* args, void* stream);
 
+/* ---- backward of neuray_render_rays (autograd of ibrnet.py:52-102,356-360, renderer.py:157-166, render_ops.py:72-80):
+ * gradients of a scalar loss with respect to the per-point records and the ray-part weights, given the gradients of
+ * pixel [rn][3], hit_prob [rn][dn] (NULL = none) and render_depth [rn] (NULL = none).  The forward is recomputed.
+ * d_point_rec [rn][dn][NEURAY_POINT_REC]: [0..15] d geometry feature, [16..18] d blended colour, [19] = 0.
+ * d_ray_weights [NEURAY_PACKED_RAY_FLOATS] is ACCUMULATED into (zero it first); layout = the ray part of the packed
+ * pass, row-major copies at the NEURAY_RW_* offsets: ray_attention.w_qs / w_ks / w_vs / fc .weight (16x16 each),
+ * layer_norm.weight / .bias (16), out_geometry_fc.0.weight (16x16) / .bias (16), out_geometry_fc.2.weight (16) / .bias.
+ * dn <= 64. */
+#define NEURAY_PACKED_RAY_FLOATS 1348
+#define NEURAY_RW_WQ 0
+#define NEURAY_RW_WK 256
+#define NEURAY_RW_WV 512
+#define NEURAY_RW_FC 768
+#define NEURAY_RW_LNW 1024
+#define NEURAY_RW_LNB 1040
+#define NEURAY_RW_OG0W 1056
+#define NEURAY_RW_OG0B 1312
+#define NEURAY_RW_OG2W 1328
+#define NEURAY_RW_OG2B 1344
+typedef struct NeurayRaysBwdArgs {
+    const float* point_rec_dev;       /* [rn][dn][NEURAY_POINT_REC] (forward input) */
+    const float* depth_dev;           /* [rn][dn] */
+    const float* pos_enc_dev;         /* [dn][16] */
+    const float* packed_weights_dev;
+    const float* d_pixel_dev;         /* [rn][3] */
+    const float* d_hit_prob_dev;      /* [rn][dn] or NULL */
+    const float* d_render_depth_dev;  /* [rn] or NULL */
+    float* d_point_rec_dev;           /* [rn][dn][NEURAY_POINT_REC] */
+    float* d_ray_weights_dev;         /* [NEURAY_PACKED_RAY_FLOATS], accumulated */
+    int rn, dn;
+} NeurayRaysBwdArgs;
+int neuray_render_rays_backward(const NeurayRaysBwdArgs* args, void* stream);
+
 /* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
  * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,
  * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)].

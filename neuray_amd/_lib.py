@@ -43,6 +43,26 @@ class NeurayRaysArgs(C.Structure):
     ]
 
 
+class NeurayRaysBwdArgs(C.Structure):
+    _fields_ = [
+        ('point_rec_dev', C.c_void_p), ('depth_dev', C.c_void_p), ('pos_enc_dev', C.c_void_p),
+        ('packed_weights_dev', C.c_void_p), ('d_pixel_dev', C.c_void_p), ('d_hit_prob_dev', C.c_void_p),
+        ('d_render_depth_dev', C.c_void_p), ('d_point_rec_dev', C.c_void_p), ('d_ray_weights_dev', C.c_void_p),
+        ('rn', C.c_int), ('dn', C.c_int),
+    ]
+
+
+PACKED_RAY_FLOATS = 1348
+# (state_dict suffix under agg_net.agg_impl., offset, shape) of the ray-part weights inside d_ray_weights (include/neuray_hip.h)
+RAY_WEIGHT_SLOTS = (
+    ('ray_attention.w_qs.weight', 0, (16, 16)), ('ray_attention.w_ks.weight', 256, (16, 16)),
+    ('ray_attention.w_vs.weight', 512, (16, 16)), ('ray_attention.fc.weight', 768, (16, 16)),
+    ('ray_attention.layer_norm.weight', 1024, (16,)), ('ray_attention.layer_norm.bias', 1040, (16,)),
+    ('out_geometry_fc.0.weight', 1056, (16, 16)), ('out_geometry_fc.0.bias', 1312, (16,)),
+    ('out_geometry_fc.2.weight', 1328, (1, 16)), ('out_geometry_fc.2.bias', 1344, (1,)),
+)
+
+
 # every symbol include/neuray_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     'neuray_abi_version': (C.c_int, []),
@@ -71,6 +91,7 @@ SYMBOLS = {
     'neuray_self_hit_prob': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     'neuray_mfma_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_render_rays_backward': (C.c_int, [C.POINTER(NeurayRaysBwdArgs), C.c_void_p]),
     'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

@@ -2,6 +2,7 @@
 // code lives in nr_kernels.h / nr_device.h.  Built with hipcc --offload-arch=gfx950 (product) or, for the
 // CPU test emulator, g++ -DNEURAY_EMU (tests/emu/build_emu.py).
 #include "nr_kernels.h"
+#include "nr_kernels_bwd.h"
 #include "nr_pack.h"
 #include "../../include/neuray_hip.h"
 
@@ -241,6 +242,31 @@ int neuray_self_hit_prob(const float* query_const, const float* depth, const flo
 int neuray_mfma_selftest(const float* A, const float* B, float* D, void* stream) {
     NR_LAUNCH(nr::mfma_selftest_kernel, dim3(1), dim3(64), 0, stream, A, B, D);
     return check_launch("neuray_mfma_selftest");
+}
+
+static_assert(NEURAY_PACKED_RAY_FLOATS == nr::kPackedRayFloats && NEURAY_RW_WQ == nr::RW_WQ && NEURAY_RW_WK == nr::RW_WK &&
+              NEURAY_RW_WV == nr::RW_WV && NEURAY_RW_FC == nr::RW_FC && NEURAY_RW_LNW == nr::RW_LNW && NEURAY_RW_LNB == nr::RW_LNB &&
+              NEURAY_RW_OG0W == nr::RW_OG0W && NEURAY_RW_OG0B == nr::RW_OG0B && NEURAY_RW_OG2W == nr::RW_OG2W &&
+              NEURAY_RW_OG2B == nr::RW_OG2B, "abi");
+
+int neuray_render_rays_backward(const NeurayRaysBwdArgs* a, void* stream) {
+    if (!a || !a->point_rec_dev || !a->depth_dev || !a->pos_enc_dev || !a->packed_weights_dev || !a->d_pixel_dev ||
+        !a->d_point_rec_dev || !a->d_ray_weights_dev)
+        return fail("neuray_render_rays_backward: null argument");
+    if (a->rn < 1) return fail("neuray_render_rays_backward: rn=%d", a->rn);
+    if (a->dn < 3 || a->dn > 64) return fail("neuray_render_rays_backward: dn=%d outside [3,64]", a->dn);
+    nr::RayBwdParams p;
+    p.point_rec = a->point_rec_dev; p.depth = a->depth_dev; p.pos_enc = a->pos_enc_dev; p.weights = a->packed_weights_dev;
+    p.d_pixel = a->d_pixel_dev; p.d_hit_prob = a->d_hit_prob_dev; p.d_depth = a->d_render_depth_dev;
+    p.d_point_rec = a->d_point_rec_dev; p.d_weights = a->d_ray_weights_dev; p.rn = a->rn; p.dn = a->dn;
+    const size_t smem = nr::ray_bwd_smem_bytes(a->dn);
+    const int grid = grid_for(a->rn, nr::kRayWaves, 256 * 4);
+    auto k = nr::rays_backward_kernel;
+#ifndef NEURAY_EMU
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+    NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+    return check_launch("neuray_render_rays_backward");
 }
 
 int neuray_group_sum_selftest(const float* x, float* y, void* stream) {

@@ -246,6 +246,25 @@ class RenderEngine:
                                                       vis.data_ptr() if vis is not None else None, self._stream()))
         return (mean.view(*lead, 2), var.view(*lead, 2), vis.view(*lead, 1) if vis is not None else None, aw.view(*lead, 1))
 
+    def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None):
+        """Backward of the ray kernel (attention, sigma head, compositing): gradients of a scalar loss w.r.t. the
+        per-point records [rn,dn,POINT_REC] (geometry feature 0..15, colour 16..18) and the ray-part weights.
+        -> (d_point_rec [rn,dn,POINT_REC], {state_dict suffix: grad})   (suffixes under `agg_net.agg_impl.`)"""
+        point_rec, depth, d_pixel = self._f32(point_rec), self._f32(depth), self._f32(d_pixel)
+        rn, dn = depth.shape
+        assert point_rec.shape == (rn, dn, _lib.POINT_REC) and d_pixel.shape == (rn, 3)
+        dh = self._f32(d_hit_prob) if d_hit_prob is not None else None
+        dd = self._f32(d_render_depth) if d_render_depth is not None else None
+        d_rec = self.empty(rn, dn, _lib.POINT_REC)
+        d_w = torch.zeros(_lib.PACKED_RAY_FLOATS, dtype=torch.float32, device=self.device)
+        a = _lib.NeurayRaysBwdArgs(
+            point_rec.data_ptr(), depth.data_ptr(), self.posenc(dn).data_ptr(), packed.dev.data_ptr(), d_pixel.data_ptr(),
+            dh.data_ptr() if dh is not None else None, dd.data_ptr() if dd is not None else None,
+            d_rec.data_ptr(), d_w.data_ptr(), rn, dn)
+        self._check(self.lib.neuray_render_rays_backward(C.byref(a), self._stream()))
+        grads = {name: d_w[off:off + int(np.prod(shape))].view(*shape) for name, off, shape in _lib.RAY_WEIGHT_SLOTS}
+        return d_rec, grads
+
     def self_hit_prob(self, qconst, depth, mean, var, aw, vis):
         depth = self._f32(depth)
         rn, dn = depth.shape

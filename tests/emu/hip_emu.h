@@ -135,6 +135,19 @@ static inline int __shfl(int v, int src) { float f; memcpy(&f, &v, 4); f = emu_s
 static inline int __shfl_xor(int v, int m) { return __shfl(v, emu::my_lane() ^ m); }
 static inline int __shfl_up(int v, int d) { int l = emu::my_lane(); return __shfl(v, l - d < 0 ? l : l - d); }
 static inline int __shfl_down(int v, int d) { int l = emu::my_lane(); return __shfl(v, l + d > 63 ? l : l + d); }
+// float atomicAdd on LDS or global memory (blocks may run on different host threads: compare-and-swap loop)
+static inline float atomicAdd(float* p, float v) {
+    unsigned int* u = reinterpret_cast<unsigned int*>(p);
+    unsigned int old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
+    float f;
+    do {
+        memcpy(&f, &old, 4);
+        const float g = f + v;
+        memcpy(&neu, &g, 4);
+    } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return f;
+}
+
 static inline unsigned long long __ballot(int pred) {
     emu::WaveState& w = emu::my_wave();
     int par = w.gen & 1;

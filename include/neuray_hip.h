@@ -143,6 +143,36 @@ typedef struct NeurayRaysBwdArgs {
 } NeurayRaysBwdArgs;
 int neuray_render_rays_backward(const NeurayRaysBwdArgs* args, void* stream);
 
+/* ---- backward of neuray_render_points (autograd of dist_decoder.py:53-140, renderer.py:67-83,127-135,
+ * aggregate_net.py:34-68, ibrnet.py:315-354,361-367): gradients of a scalar loss with respect to every weight of the pass
+ * and to the ray_feats / img_feats maps, given d_point_rec (the output of neuray_render_rays_backward).
+ * Weights and their gradients use the FLAT NATURAL layout: the NEURAY_PASS_TENSORS tensors, row-major as in the
+ * state_dict, concatenated in the order of neuray_pack_pass_weights (vis-decoder slots always present; zeros without a
+ * vis head); neuray_flat_pass_floats() floats, neuray_flat_tensor_offset(i) = start of tensor i.
+ * d_flat, d_ray_feats_nhwc and d_img_feats_nhwc are ACCUMULATED into (zero them first).  workspace:
+ * neuray_points_backward_workspace_floats(rn * dn, rfn) floats of scratch.  First, correctness-oriented version (no MFMA). */
+size_t neuray_flat_pass_floats(void);
+size_t neuray_flat_tensor_offset(int tensor);
+size_t neuray_points_backward_workspace_floats(int npoints, int rfn);
+typedef struct NeurayPointsBwdArgs {
+    const float* query_const_dev;
+    const float* view_const_dev;
+    const float* coords_dev;          /* [rn][2] */
+    const float* depth_dev;           /* [rn][dn] */
+    const float* ray_feats_nhwc_dev;  /* [rfn][fh][fw][32] */
+    const float* img_feats_nhwc_dev;  /* [rfn][fh][fw][32] */
+    const float* rgba_dev;            /* [rfn][h][w][4] */
+    const float* flat_weights_dev;    /* [neuray_flat_pass_floats()] */
+    const float* d_point_rec_dev;     /* [rn*dn][NEURAY_POINT_REC] */
+    float* d_flat_weights_dev;        /* accumulated */
+    float* d_ray_feats_nhwc_dev;      /* accumulated */
+    float* d_img_feats_nhwc_dev;      /* accumulated */
+    float* workspace_dev;
+    int rfn, rn, dn, h, w, fh, fw, has_vis_head, use_vis;
+    float var_bias;
+} NeurayPointsBwdArgs;
+int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
+
 /* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
  * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,
  * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)].

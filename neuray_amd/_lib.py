@@ -52,6 +52,15 @@ class NeurayRaysBwdArgs(C.Structure):
     ]
 
 
+class NeurayPointsBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'query_const_dev', 'view_const_dev', 'coords_dev', 'depth_dev', 'ray_feats_nhwc_dev', 'img_feats_nhwc_dev',
+        'rgba_dev', 'flat_weights_dev', 'd_point_rec_dev', 'd_flat_weights_dev', 'd_ray_feats_nhwc_dev',
+        'd_img_feats_nhwc_dev', 'workspace_dev')] + \
+        [(n, C.c_int) for n in ('rfn', 'rn', 'dn', 'h', 'w', 'fh', 'fw', 'has_vis_head', 'use_vis')] + \
+        [('var_bias', C.c_float)]
+
+
 PACKED_RAY_FLOATS = 1348
 # (state_dict suffix under agg_net.agg_impl., offset, shape) of the ray-part weights inside d_ray_weights (include/neuray_hip.h)
 RAY_WEIGHT_SLOTS = (
@@ -92,6 +101,10 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p]),
     'neuray_mfma_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_render_rays_backward': (C.c_int, [C.POINTER(NeurayRaysBwdArgs), C.c_void_p]),
+    'neuray_flat_pass_floats': (C.c_size_t, []),
+    'neuray_flat_tensor_offset': (C.c_size_t, [C.c_int]),
+    'neuray_points_backward_workspace_floats': (C.c_size_t, [C.c_int, C.c_int]),
+    'neuray_render_points_backward': (C.c_int, [C.POINTER(NeurayPointsBwdArgs), C.c_void_p]),
     'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

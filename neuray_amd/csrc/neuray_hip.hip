@@ -269,6 +269,41 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* a, void* stream) {
     return check_launch("neuray_render_rays_backward");
 }
 
+size_t neuray_flat_pass_floats(void) { return (size_t)nr::kFlatPassFloats; }
+size_t neuray_flat_tensor_offset(int t) { return (t < 0 || t > nr::T_COUNT) ? (size_t)0 : (size_t)nr::tensor_offset(t); }
+
+namespace {
+int points_bwd_grid(int npoints, int vp) {
+    const int ppw = 64 / vp;
+    return grid_for(npoints, ppw, 1024);
+}
+int pow2_at_least(int n) { int v = 1; while (v < n) v <<= 1; return v; }
+}  // namespace
+
+size_t neuray_points_backward_workspace_floats(int npoints, int rfn) {
+    if (npoints < 1 || rfn < 1 || rfn > NEURAY_MAX_VIEWS) return 0;
+    return (size_t)points_bwd_grid(npoints, pow2_at_least(rfn)) * nr::kBwdRows * 64;
+}
+
+int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
+    if (!a || !a->query_const_dev || !a->view_const_dev || !a->coords_dev || !a->depth_dev || !a->ray_feats_nhwc_dev ||
+        !a->img_feats_nhwc_dev || !a->rgba_dev || !a->flat_weights_dev || !a->d_point_rec_dev || !a->d_flat_weights_dev ||
+        !a->d_ray_feats_nhwc_dev || !a->d_img_feats_nhwc_dev || !a->workspace_dev)
+        return fail("neuray_render_points_backward: null argument");
+    if (a->rfn < 1 || a->rfn > NEURAY_MAX_VIEWS) return fail("neuray_render_points_backward: rfn=%d outside [1,%d]", a->rfn, NEURAY_MAX_VIEWS);
+    if (a->rn < 1 || a->dn < 3 || a->dn > NEURAY_MAX_SAMPLES) return fail("neuray_render_points_backward: rn=%d dn=%d", a->rn, a->dn);
+    nr::PointBwdParams p;
+    p.que_const = a->query_const_dev; p.view_const = a->view_const_dev; p.coords = a->coords_dev; p.depth = a->depth_dev;
+    p.ray_feats = a->ray_feats_nhwc_dev; p.img_feats = a->img_feats_nhwc_dev; p.rgba = a->rgba_dev; p.flat = a->flat_weights_dev;
+    p.d_point_rec = a->d_point_rec_dev; p.d_flat = a->d_flat_weights_dev; p.d_ray_feats = a->d_ray_feats_nhwc_dev;
+    p.d_img_feats = a->d_img_feats_nhwc_dev; p.workspace = a->workspace_dev;
+    p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
+    p.vp = pow2_at_least(a->rfn); p.has_vis_head = a->has_vis_head; p.use_vis = a->use_vis; p.var_bias = a->var_bias;
+    const int grid = points_bwd_grid(a->rn * a->dn, p.vp);
+    NR_LAUNCH(nr::points_backward_kernel, dim3(grid), dim3(64), 0, stream, p);
+    return check_launch("neuray_render_points_backward");
+}
+
 int neuray_group_sum_selftest(const float* x, float* y, void* stream) {
     NR_LAUNCH(nr::group_sum_selftest_kernel, dim3(1), dim3(64), 0, stream, x, y);
     return check_launch("neuray_group_sum_selftest");

@@ -264,4 +264,511 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
     for (int k = threadIdx.x; k < kPackedRayFloats; k += blockDim.x) atomicAdd(p.d_weights + k, WA[k]);
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// points_backward_kernel: gradient of points_kernel (projection -> gathers -> dist decoder -> probabilities ->
+// prob_embed / ray_dir_fc / neuray_fc -> cross-view statistics -> base_fc -> vis_fc -> vis_fc2 -> rgb_fc -> softmax
+// blend + visibility-weighted statistics -> geometry_fc) with respect to every weight of the pass and to the ray_feats
+// and img_feats maps.  Autograd of dist_decoder.py:53-140, renderer.py:67-83,127-135, aggregate_net.py:34-68,
+// ibrnet.py:315-354,361-367 in the reference.
+//
+// First, correctness-oriented version: one wave per workgroup, lane = (point, view) with the views of a point in VP
+// consecutive lanes (VP = power of two >= rfn), so every cross-view reduction is a shuffle.  Activations and
+// gradients live as rows of a per-workgroup arena in global memory (row r, lane l at arena[r*64 + l]); dense layers are
+// runtime loops over natural-layout weights (nr_layout.h "flat natural layout"); a weight gradient
+// dW[o][k] = sum_lanes dY[o][lane] X[k][lane] is computed with one (o,k) per lane and added with one atomicAdd per
+// weight and tile.  The forward is recomputed stage by stage.  (Training batches are ~0.5 M (point, view) pairs per
+// step: this costs a few tens of ms; the MFMA version is future work.)
+// -------------------------------------------------------------------------------------------------
+struct PointBwdParams {
+    const float* que_const;
+    const float* view_const;
+    const float* coords;       // [rn][2]
+    const float* depth;        // [rn][dn]
+    const float* ray_feats;    // [rfn][fh][fw][32]
+    const float* img_feats;    // [rfn][fh][fw][32]
+    const float* rgba;         // [rfn][h][w][4]
+    const float* flat;         // [kFlatPassFloats] natural-layout weights
+    const float* d_point_rec;  // [rn*dn][kPointRec]: [0..15] d geometry feature, [16..18] d colour
+    float* d_flat;             // [kFlatPassFloats], accumulated
+    float* d_ray_feats;        // [rfn][fh][fw][32], accumulated
+    float* d_img_feats;        // [rfn][fh][fw][32], accumulated
+    float* workspace;          // [gridDim.x][kBwdRows][64]
+    int rfn, rn, dn, h, w, fh, fw;
+    int vp;                    // lanes per point: power of two >= rfn
+    int has_vis_head, use_vis;
+    float var_bias;
+};
+
+// arena rows
+constexpr int BR_FR = 0, BR_FI = 32, BR_RGB = 64, BR_DL = 67;
+constexpr int BR_GL = 71, BR_GP = 211, BR_E = 246;                   // base_fc.0 input = [GL(140) GP(35) E(32)] contiguous
+constexpr int BR_X = 278, BR_X2 = 310;
+constexpr int BR_DGL = 342, BR_DGP = 482, BR_DE = 517;               // gradient of the base_fc.0 input, same order
+constexpr int BR_DFR = 549, BR_DX = 581;
+constexpr int BR_S0 = 613, BR_S1 = 677, BR_S2 = 741, BR_S3 = 805;    // 64-row scratch areas
+constexpr int kBwdRows = 869;
+
+enum BwdAct { BA_NONE, BA_ELU, BA_RELU };
+__device__ __forceinline__ float bwd_act(float x, int a) {
+    if (a == BA_ELU) return x > 0.0f ? x : expf(x) - 1.0f;
+    if (a == BA_RELU) return fmaxf(x, 0.0f);
+    return x;
+}
+// derivative of the activation, from its OUTPUT y
+__device__ __forceinline__ float bwd_dact(float y, int a) {
+    if (a == BA_ELU) return y > 0.0f ? 1.0f : y + 1.0f;
+    if (a == BA_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    return 1.0f;
+}
+// Y[o] = act(b[o] + sum_k W[o*ldw + k] X[k]),  rows of this lane's column
+__device__ __forceinline__ void bwd_dense(const float* __restrict__ W, int ldw, const float* __restrict__ b, int O, int K,
+                                          const float* X, float* Y, int act, int lane) {
+    for (int o = 0; o < O; ++o) {
+        float acc = b ? b[o] : 0.0f;
+        for (int k = 0; k < K; ++k) acc = fmaf(W[o * ldw + k], X[k * 64 + lane], acc);
+        Y[o * 64 + lane] = bwd_act(acc, act);
+    }
+}
+// dY[o] *= act'(Y[o])
+__device__ __forceinline__ void bwd_through_act(float* dY, const float* Y, int O, int act, int lane) {
+    for (int o = 0; o < O; ++o) dY[o * 64 + lane] *= bwd_dact(Y[o * 64 + lane], act);
+}
+// dX[k] (+)= sum_o W[o*ldw + k] dY[o]
+__device__ __forceinline__ void bwd_dense_dx(const float* __restrict__ W, int ldw, int O, int K, const float* dY, float* dX,
+                                             bool accumulate, int lane) {
+    for (int k = 0; k < K; ++k) {
+        float acc = accumulate ? dX[k * 64 + lane] : 0.0f;
+        for (int o = 0; o < O; ++o) acc = fmaf(W[o * ldw + k], dY[o * 64 + lane], acc);
+        dX[k * 64 + lane] = acc;
+    }
+}
+// dW[o*ldw + k] += sum_lanes dY[o] X[k],  db[o] += sum_lanes dY[o]   (reads the other lanes' columns)
+__device__ __forceinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, int K, const float* dY, const float* X, int lane) {
+    __syncthreads();
+    for (int idx = lane; idx < O * K; idx += 64) {
+        const int o = idx / K, k = idx - o * K;
+        float sacc = 0.0f;
+        for (int l = 0; l < 64; ++l) sacc = fmaf(dY[o * 64 + l], X[k * 64 + l], sacc);
+        atomicAdd(dW + o * ldw + k, sacc);
+    }
+    if (db)
+        for (int o = lane; o < O; o += 64) {
+            float sacc = 0.0f;
+            for (int l = 0; l < 64; ++l) sacc += dY[o * 64 + l];
+            atomicAdd(db + o, sacc);
+        }
+    __syncthreads();
+}
+// sum / max over the VP lanes of a point (every lane of the group receives the result)
+__device__ __forceinline__ float vp_sum(float v, int vp) {
+    for (int m = 1; m < vp; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float vp_max(float v, int vp) {
+    for (int m = 1; m < vp; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float bwd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float bwd_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// scatter-add of a gathered-feature gradient (32 channels) into the NHWC gradient map: d map[tap] += wt * g
+__device__ __forceinline__ void bwd_scatter32(float* dmap, size_t view_off, const Taps& t, float scale, const float* g, int lane) {
+    if (scale == 0.0f) return;
+    const int offs[4] = {t.o00, t.o10, t.o01, t.o11};
+    const float wts[4] = {t.w00, t.w10, t.w01, t.w11};
+    for (int a = 0; a < 4; ++a) {
+        const float wa = wts[a] * scale;
+        if (wa == 0.0f) continue;
+        float* dst = dmap + view_off + (size_t)offs[a] * 32;
+        for (int c = 0; c < 32; ++c) atomicAdd(dst + c, wa * g[c * 64 + lane]);
+    }
+}
+
+#define FW(T) (p.flat + tensor_offset(T))
+#define DW(T) (p.d_flat + tensor_offset(T))
+
+__global__ void __launch_bounds__(64) points_backward_kernel(PointBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    float* A = p.workspace + (size_t)blockIdx.x * kBwdRows * 64;
+    const int vp = p.vp, ppw = 64 / vp;
+    const int pl = lane / vp, v = lane % vp;
+    const int npts = p.rn * p.dn, dn = p.dn;
+    const float* __restrict__ qc = p.que_const;
+    const float qnearp = qc[24], qinv = qc[27];
+    const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
+    const bool has_vis = p.has_vis_head != 0, use_vis = has_vis && (p.use_vis != 0);
+    float* FR = A + BR_FR * 64; float* FI = A + BR_FI * 64; float* RGB = A + BR_RGB * 64; float* DL = A + BR_DL * 64;
+    float* GL = A + BR_GL * 64; float* GP = A + BR_GP * 64; float* E = A + BR_E * 64;
+    float* X = A + BR_X * 64; float* X2 = A + BR_X2 * 64;
+    float* DGL = A + BR_DGL * 64; float* DGP = A + BR_DGP * 64; float* DE = A + BR_DE * 64;
+    float* DFR = A + BR_DFR * 64; float* DX = A + BR_DX * 64;
+    float* S0 = A + BR_S0 * 64; float* S1 = A + BR_S1 * 64; float* S2 = A + BR_S2 * 64; float* S3 = A + BR_S3 * 64;
+
+    for (int base = blockIdx.x * ppw; base < npts; base += gridDim.x * ppw) {
+        __syncthreads();
+        // ================= geometry, gathers (as points_kernel) =================
+        int pi = base + pl;
+        const bool pvalid = pi < npts;
+        pi = pvalid ? pi : npts - 1;
+        const bool vok = v < p.rfn;
+        const int view = vok ? v : p.rfn - 1;
+        const int ray = pi / dn, smp = pi - ray * dn;
+        const Ray r = make_ray<false>(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
+        const float* drow = p.depth + (size_t)ray * dn;
+        const float d = drow[smp];
+        const float s_c = norm_inv_depth_fast(d, qnearp, qinv);
+        const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qinv);
+        const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qinv);
+        const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
+        const float half_p = (s_c - s_p) * 0.5f;
+        const float hi = half_c, lo = (smp == 0) ? half_c : half_p;
+        const float px = rn_add(r.cx, rn_mul(r.dx, d)), py = rn_add(r.cy, rn_mul(r.dy, d)), pz = rn_add(r.cz, rn_mul(r.dz, d));
+        const float* __restrict__ vc = p.view_const + view * kViewConst;
+        Proj pr = project_point<false>(vc, px, py, pz, (float)p.w, (float)p.h);
+        const float m = vok ? pr.mask : 0.0f;
+        const float tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
+        const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
+        const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
+        {
+            const float* rf = p.ray_feats + (size_t)view * fmap;
+            const float* im = p.img_feats + (size_t)view * fmap;
+            const float* cm = p.rgba + (size_t)view * imap;
+            for (int c = 0; c < 32; ++c) {
+                FR[c * 64 + lane] = m * (tf.w00 * rf[(size_t)tf.o00 * 32 + c] + tf.w10 * rf[(size_t)tf.o10 * 32 + c] +
+                                         tf.w01 * rf[(size_t)tf.o01 * 32 + c] + tf.w11 * rf[(size_t)tf.o11 * 32 + c]);
+                FI[c * 64 + lane] = m * (tf.w00 * im[(size_t)tf.o00 * 32 + c] + tf.w10 * im[(size_t)tf.o10 * 32 + c] +
+                                         tf.w01 * im[(size_t)tf.o01 * 32 + c] + tf.w11 * im[(size_t)tf.o11 * 32 + c]);
+            }
+            for (int c = 0; c < 3; ++c)
+                RGB[c * 64 + lane] = m * (tc.w00 * cm[(size_t)tc.o00 * 4 + c] + tc.w10 * cm[(size_t)tc.o10 * 4 + c] +
+                                          tc.w01 * cm[(size_t)tc.o01 * 4 + c] + tc.w11 * cm[(size_t)tc.o11 * 4 + c]);
+            DL[0 * 64 + lane] = pr.dirx - r.qx; DL[1 * 64 + lane] = pr.diry - r.qy; DL[2 * 64 + lane] = pr.dirz - r.qz;
+            DL[3 * 64 + lane] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
+        }
+        // ================= forward =================
+        // ---- dist decoder heads (dist_decoder.py:64-97): only the outputs are kept
+        float mu0, mu1, sd0, sd1, aw, nu = 1.0f;
+        {
+            bwd_dense(FW(T_MEAN0_W), 32, FW(T_MEAN0_B), 32, 32, FR, S0, BA_ELU, lane);
+            bwd_dense(FW(T_MEAN2_W), 32, FW(T_MEAN2_B), 32, 32, S0, S1, BA_ELU, lane);
+            bwd_dense(FW(T_MEAN4_W), 32, FW(T_MEAN4_B), 2, 32, S1, S2, BA_NONE, lane);
+            mu0 = bwd_softplus(S2[lane]); mu1 = bwd_softplus(S2[64 + lane]);
+            bwd_dense(FW(T_VAR0_W), 32, FW(T_VAR0_B), 32, 32, FR, S0, BA_ELU, lane);
+            bwd_dense(FW(T_VAR2_W), 32, FW(T_VAR2_B), 32, 32, S0, S1, BA_ELU, lane);
+            bwd_dense(FW(T_VAR4_W), 32, FW(T_VAR4_B), 2, 32, S1, S2, BA_NONE, lane);
+            sd0 = bwd_softplus(S2[lane]) + p.var_bias; sd1 = bwd_softplus(S2[64 + lane]) + p.var_bias;
+            bwd_dense(FW(T_AW0_W), 32, FW(T_AW0_B), 32, 32, FR, S0, BA_ELU, lane);
+            bwd_dense(FW(T_AW2_W), 32, FW(T_AW2_B), 32, 32, S0, S1, BA_ELU, lane);
+            bwd_dense(FW(T_AW4_W), 32, FW(T_AW4_B), 1, 32, S1, S2, BA_NONE, lane);
+            aw = bwd_sigmoid(S2[lane]);
+            if (has_vis) {
+                bwd_dense(FW(T_VIS0_W), 32, FW(T_VIS0_B), 32, 32, FR, S0, BA_ELU, lane);
+                bwd_dense(FW(T_VIS2_W), 32, FW(T_VIS2_B), 32, 32, S0, S1, BA_ELU, lane);
+                bwd_dense(FW(T_VIS4_W), 32, FW(T_VIS4_B), 1, 32, S1, S2, BA_NONE, lane);
+                nu = bwd_sigmoid(S2[lane]);
+            }
+        }
+        // ---- probabilities (dist_decoder.py:109-140, renderer.py:79-82)
+        const float nuu = use_vis ? nu : 1.0f;
+        const float a00 = (tref - lo - mu0) * sd0, a01 = (tref - lo - mu1) * sd1;
+        const float a10 = (tref + hi - mu0) * sd0, a11 = (tref + hi - mu1) * sd1;
+        const float t00 = tanhf(a00), t01 = tanhf(a01), t10 = tanhf(a10), t11 = tanhf(a11);
+        const float g00 = 0.5f + 0.5f * t00, g01 = 0.5f + 0.5f * t01, g10 = 0.5f + 0.5f * t10, g11 = 0.5f + 0.5f * t11;
+        const float c00 = g00 * nuu, c01 = g01 * nuu, c10 = g10 * nuu, c11 = g11 * nuu;
+        const float mix0 = aw, mix1 = 1.0f - aw;
+        const float vis_raw = (1.0f - c00) * mix0 + (1.0f - c01) * mix1;
+        const float hit_raw = (c10 - c00) * mix0 + (c11 - c01) * mix1;
+        const float vis = vis_raw * m, hit = hit_raw * m;
+        // ---- prob_embed (aggregate_net.py:43): input [f_ray, 2 hit - 1, 2 vis - 1]; hidden kept in S0 for the backward? no:
+        // recomputed there.  E is kept.
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = FR[c * 64 + lane];
+            S3[32 * 64 + lane] = (hit - 0.5f) * 2.0f; S3[33 * 64 + lane] = (vis - 0.5f) * 2.0f;
+            bwd_dense(FW(T_PE0_W), 34, FW(T_PE0_B), 32, 34, S3, S0, BA_RELU, lane);
+            bwd_dense(FW(T_PE2_W), 32, FW(T_PE2_B), 32, 32, S0, E, BA_NONE, lane);
+        }
+        // ---- ray_dir_fc, rgb_feat + direction feature (ibrnet.py:324-327)
+        {
+            bwd_dense(FW(T_RD0_W), 4, FW(T_RD0_B), 16, 4, DL, S0, BA_ELU, lane);
+            bwd_dense(FW(T_RD2_W), 16, FW(T_RD2_B), 35, 16, S0, S1, BA_ELU, lane);
+            for (int c = 0; c < 3; ++c) GP[c * 64 + lane] = RGB[c * 64 + lane] + S1[c * 64 + lane];
+            for (int c = 0; c < 32; ++c) GP[(3 + c) * 64 + lane] = FI[c * 64 + lane] + S1[(3 + c) * 64 + lane];
+        }
+        // ---- neuray_fc -> sigmoid (ibrnet.py:337)
+        float sn;
+        {
+            bwd_dense(FW(T_NF0_W), 32, FW(T_NF0_B), 8, 32, E, S0, BA_ELU, lane);
+            bwd_dense(FW(T_NF2_W), 8, FW(T_NF2_B), 1, 8, S0, S1, BA_NONE, lane);
+            sn = bwd_sigmoid(S1[lane]);
+        }
+        // ---- cross-view statistics (ibrnet.py:334-340)
+        const float msum = vp_sum(m, vp);
+        const float wv = m / (msum + 1e-8f);
+        const float w0 = sn * wv;
+        const float sa0 = vp_sum(w0, vp), sa1 = vp_sum(wv, vp);
+        for (int f = 0; f < 35; ++f) {
+            const float x = GP[f * 64 + lane];
+            const float mean0 = vp_sum(w0 * x, vp), mean1 = vp_sum(wv * x, vp);
+            const float var0 = vp_sum(w0 * (x - mean0) * (x - mean0), vp), var1 = vp_sum(wv * (x - mean1) * (x - mean1), vp);
+            GL[f * 64 + lane] = mean0; GL[(35 + f) * 64 + lane] = var0; GL[(70 + f) * 64 + lane] = mean1; GL[(105 + f) * 64 + lane] = var1;
+        }
+        // ---- base_fc (ibrnet.py:342): hidden in S0 (64), X kept
+        bwd_dense(FW(T_BASE0_W), 207, FW(T_BASE0_B), 64, 207, GL, S0, BA_ELU, lane);
+        bwd_dense(FW(T_BASE2_W), 64, FW(T_BASE2_B), 32, 64, S0, X, BA_ELU, lane);
+        // ---- vis_fc (ibrnet.py:343-346)
+        float visp, vy32;          // vis' = sigmoid(ELU(.)) * mask; vy32 = the ELU output it is taken from
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X[c * 64 + lane] * wv;
+            bwd_dense(FW(T_VF0_W), 32, FW(T_VF0_B), 32, 32, S3, S0, BA_ELU, lane);
+            bwd_dense(FW(T_VF2_W), 32, FW(T_VF2_B), 33, 32, S0, S1, BA_ELU, lane);
+            vy32 = S1[32 * 64 + lane];
+            visp = bwd_sigmoid(vy32) * m;
+            for (int c = 0; c < 32; ++c) X2[c * 64 + lane] = X[c * 64 + lane] + S1[c * 64 + lane];
+        }
+        // ---- vis_fc2 (ibrnet.py:347-348)
+        float vis2, v2sig;
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane] * visp;
+            bwd_dense(FW(T_V20_W), 32, FW(T_V20_B), 32, 32, S3, S0, BA_ELU, lane);
+            bwd_dense(FW(T_V22_W), 32, FW(T_V22_B), 1, 32, S0, S1, BA_NONE, lane);
+            v2sig = bwd_sigmoid(S1[lane]);
+            vis2 = v2sig * m;
+        }
+        // ---- rgb_fc (ibrnet.py:363-365): input [x, vis, ray_diff]
+        float z;
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane];
+            S3[32 * 64 + lane] = vis2;
+            for (int c = 0; c < 4; ++c) S3[(33 + c) * 64 + lane] = DL[c * 64 + lane];
+            bwd_dense(FW(T_RF0_W), 37, FW(T_RF0_B), 16, 37, S3, S0, BA_ELU, lane);
+            bwd_dense(FW(T_RF2_W), 16, FW(T_RF2_B), 8, 16, S0, S1, BA_ELU, lane);
+            bwd_dense(FW(T_RF4_W), 8, FW(T_RF4_B), 1, 8, S1, S2, BA_NONE, lane);
+            z = m > 0.0f ? S2[lane] : -1e9f;
+        }
+        // ---- softmax blend weights, visibility-weighted statistics (ibrnet.py:350-354,366-367)
+        const float zmax = vp_max(z, vp);
+        const float ez = expf(z - zmax);
+        const float beta = ez / vp_sum(ez, vp);
+        const float svis = vp_sum(vis2, vp);
+        const float wh = vis2 / (svis + 1e-8f);
+        const float swh = vp_sum(wh, vp);
+        // geometry_fc input [mean(32) var(32) mean weight] in S3 rows 0..64 (identical in the VP lanes of a point)
+        for (int f = 0; f < 32; ++f) {
+            const float x = X2[f * 64 + lane];
+            const float mean = vp_sum(wh * x, vp);
+            const float var = vp_sum(wh * (x - mean) * (x - mean), vp);
+            S3[f * 64 + lane] = mean; S3[(32 + f) * 64 + lane] = var;
+        }
+        // wgt.mean(2): mean over the rfn views of the normalised weights (ibrnet.py:354)
+        // (S3 row 64 lives in the next scratch area's first row: S3 has 64 rows -> use DX row 0 temporarily? no: keep in a register
+        //  and write it to a dedicated row of S2 when geometry_fc runs)
+        const float meanw = swh / (float)p.rfn;
+
+        // ================= backward =================
+        const float* up = p.d_point_rec + (size_t)pi * kPointRec;
+        const float gsc = pvalid ? 1.0f : 0.0f;
+        const float own = (v == 0 && pvalid) ? 1.0f : 0.0f;       // per-point layers: one lane of the point carries the gradient
+        // ---- geometry_fc (ibrnet.py:353-354): input rows: S3[0..63] + meanw; hidden S0 (64); output 16
+        float dmean_w;
+        {
+            // forward recompute with the 65-wide input assembled in DGL (free at this point): rows 0..64
+            for (int f = 0; f < 64; ++f) DGL[f * 64 + lane] = S3[f * 64 + lane];
+            DGL[64 * 64 + lane] = meanw;
+            bwd_dense(FW(T_GF0_W), 65, FW(T_GF0_B), 64, 65, DGL, S0, BA_ELU, lane);
+            bwd_dense(FW(T_GF2_W), 64, FW(T_GF2_B), 16, 64, S0, S1, BA_ELU, lane);
+            for (int o = 0; o < 16; ++o) S2[o * 64 + lane] = up[o] * own * bwd_dact(S1[o * 64 + lane], BA_ELU);
+            bwd_dense_dw(DW(T_GF2_W), 64, DW(T_GF2_B), 16, 64, S2, S0, lane);
+            bwd_dense_dx(FW(T_GF2_W), 64, 16, 64, S2, S1, false, lane);          // S1 <- d hidden (64)
+            bwd_through_act(S1, S0, 64, BA_ELU, lane);
+            bwd_dense_dw(DW(T_GF0_W), 65, DW(T_GF0_B), 64, 65, S1, DGL, lane);
+            float* DIN = DGL + 70 * 64;                                          // 65 free rows behind the input copy
+            bwd_dense_dx(FW(T_GF0_W), 65, 64, 65, S1, DIN, false, lane);         // d [mean var meanw] (own lane only)
+            // broadcast the per-point gradient to the VP lanes of the point; S2 <- d mean (0..31), d var (32..63)
+            for (int f = 0; f < 64; ++f) S2[f * 64 + lane] = vp_sum(DIN[f * 64 + lane], vp);
+            dmean_w = vp_sum(DIN[64 * 64 + lane], vp);
+        }
+        // ---- visibility-weighted mean / variance + softmax blend: -> dX2 (DX), dvis2, dz
+        float dvis2, dz;
+        {
+            float dwh = dmean_w / (float)p.rfn;
+            for (int f = 0; f < 32; ++f) {
+                const float x = X2[f * 64 + lane], mean = S3[f * 64 + lane];
+                const float dmean = S2[f * 64 + lane], dvar = S2[(32 + f) * 64 + lane];
+                const float dmt = dmean - 2.0f * dvar * mean * (1.0f - swh);
+                DX[f * 64 + lane] = wh * (dmt + 2.0f * (x - mean) * dvar);
+                dwh += dmt * x + dvar * (x - mean) * (x - mean);
+            }
+            const float sdw = vp_sum(dwh * wh, vp);
+            dvis2 = (dwh - sdw) / (svis + 1e-8f);
+            // colour = sum_v beta_v rgb_in_v
+            const float dbeta = (up[16] * RGB[lane] + up[17] * RGB[64 + lane] + up[18] * RGB[128 + lane]) * gsc;
+            const float sbb = vp_sum(beta * dbeta, vp);
+            dz = beta * (dbeta - sbb);
+            if (!(m > 0.0f)) dz = 0.0f;
+        }
+        // ---- rgb_fc backward
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane];
+            S3[32 * 64 + lane] = vis2;
+            for (int c = 0; c < 4; ++c) S3[(33 + c) * 64 + lane] = DL[c * 64 + lane];
+            bwd_dense(FW(T_RF0_W), 37, FW(T_RF0_B), 16, 37, S3, S0, BA_ELU, lane);
+            bwd_dense(FW(T_RF2_W), 16, FW(T_RF2_B), 8, 16, S0, S1, BA_ELU, lane);
+            S2[lane] = dz;
+            bwd_dense_dw(DW(T_RF4_W), 8, DW(T_RF4_B), 1, 8, S2, S1, lane);
+            float* D8 = S2 + 8 * 64;          // d of the 8-wide hidden
+            bwd_dense_dx(FW(T_RF4_W), 8, 1, 8, S2, D8, false, lane);
+            bwd_through_act(D8, S1, 8, BA_ELU, lane);
+            bwd_dense_dw(DW(T_RF2_W), 16, DW(T_RF2_B), 8, 16, D8, S0, lane);
+            float* D16 = S2 + 16 * 64;
+            bwd_dense_dx(FW(T_RF2_W), 16, 8, 16, D8, D16, false, lane);
+            bwd_through_act(D16, S0, 16, BA_ELU, lane);
+            bwd_dense_dw(DW(T_RF0_W), 37, DW(T_RF0_B), 16, 37, D16, S3, lane);
+            bwd_dense_dx(FW(T_RF0_W), 37, 16, 37, D16, S1, false, lane);         // S1 rows 0..36 <- d [x2, vis2, ray_diff]
+            for (int c = 0; c < 32; ++c) DX[c * 64 + lane] += S1[c * 64 + lane];
+            dvis2 += S1[32 * 64 + lane];
+        }
+        // ---- vis_fc2 backward: vis2 = sigmoid(a) * m
+        float dvisp;
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane] * visp;
+            bwd_dense(FW(T_V20_W), 32, FW(T_V20_B), 32, 32, S3, S0, BA_ELU, lane);
+            S2[lane] = dvis2 * m * v2sig * (1.0f - v2sig);
+            bwd_dense_dw(DW(T_V22_W), 32, DW(T_V22_B), 1, 32, S2, S0, lane);
+            bwd_dense_dx(FW(T_V22_W), 32, 1, 32, S2, S1, false, lane);           // S1 <- d hidden (32)
+            bwd_through_act(S1, S0, 32, BA_ELU, lane);
+            bwd_dense_dw(DW(T_V20_W), 32, DW(T_V20_B), 32, 32, S1, S3, lane);
+            bwd_dense_dx(FW(T_V20_W), 32, 32, 32, S1, S2, false, lane);          // S2 <- d (x2 * vis')
+            dvisp = 0.0f;
+            for (int c = 0; c < 32; ++c) {
+                dvisp = fmaf(S2[c * 64 + lane], X2[c * 64 + lane], dvisp);
+                DX[c * 64 + lane] = fmaf(S2[c * 64 + lane], visp, DX[c * 64 + lane]);
+            }
+        }
+        // ---- vis_fc backward: x2 = x + r, vis' = sigmoid(ELU(.)) * m; DX holds d x2 and becomes d x
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X[c * 64 + lane] * wv;
+            bwd_dense(FW(T_VF0_W), 32, FW(T_VF0_B), 32, 32, S3, S0, BA_ELU, lane);
+            bwd_dense(FW(T_VF2_W), 32, FW(T_VF2_B), 33, 32, S0, S1, BA_ELU, lane);
+            const float sg_ = bwd_sigmoid(vy32);
+            for (int c = 0; c < 32; ++c) S2[c * 64 + lane] = DX[c * 64 + lane];
+            S2[32 * 64 + lane] = dvisp * m * sg_ * (1.0f - sg_);
+            bwd_through_act(S2, S1, 33, BA_ELU, lane);
+            bwd_dense_dw(DW(T_VF2_W), 32, DW(T_VF2_B), 33, 32, S2, S0, lane);
+            bwd_dense_dx(FW(T_VF2_W), 32, 33, 32, S2, S1, false, lane);          // S1 <- d hidden (32)
+            bwd_through_act(S1, S0, 32, BA_ELU, lane);
+            bwd_dense_dw(DW(T_VF0_W), 32, DW(T_VF0_B), 32, 32, S1, S3, lane);
+            bwd_dense_dx(FW(T_VF0_W), 32, 32, 32, S1, S2, false, lane);          // S2 <- d (x * w)
+            for (int c = 0; c < 32; ++c) DX[c * 64 + lane] = fmaf(S2[c * 64 + lane], wv, DX[c * 64 + lane]);
+        }
+        // ---- base_fc backward -> d [GL GP E] (DGL DGP DE contiguous)
+        {
+            bwd_dense(FW(T_BASE0_W), 207, FW(T_BASE0_B), 64, 207, GL, S0, BA_ELU, lane);
+            bwd_through_act(DX, X, 32, BA_ELU, lane);
+            bwd_dense_dw(DW(T_BASE2_W), 64, DW(T_BASE2_B), 32, 64, DX, S0, lane);
+            bwd_dense_dx(FW(T_BASE2_W), 64, 32, 64, DX, S1, false, lane);        // S1 <- d hidden (64)
+            bwd_through_act(S1, S0, 64, BA_ELU, lane);
+            bwd_dense_dw(DW(T_BASE0_W), 207, DW(T_BASE0_B), 64, 207, S1, GL, lane);
+            bwd_dense_dx(FW(T_BASE0_W), 207, 64, 207, S1, DGL, false, lane);
+        }
+        // ---- cross-view statistics backward: d GL (summed over the views) -> d GP, d sigmoid(neuray_fc)
+        float dsn;
+        {
+            float dw0 = 0.0f;
+            for (int f = 0; f < 35; ++f) {
+                const float x = GP[f * 64 + lane];
+                const float mean0 = GL[f * 64 + lane], mean1 = GL[(70 + f) * 64 + lane];
+                const float dmean0 = vp_sum(DGL[f * 64 + lane], vp), dvar0 = vp_sum(DGL[(35 + f) * 64 + lane], vp);
+                const float dmean1 = vp_sum(DGL[(70 + f) * 64 + lane], vp), dvar1 = vp_sum(DGL[(105 + f) * 64 + lane], vp);
+                const float dmt0 = dmean0 - 2.0f * dvar0 * mean0 * (1.0f - sa0);
+                const float dmt1 = dmean1 - 2.0f * dvar1 * mean1 * (1.0f - sa1);
+                DGP[f * 64 + lane] += w0 * (dmt0 + 2.0f * (x - mean0) * dvar0) + wv * (dmt1 + 2.0f * (x - mean1) * dvar1);
+                dw0 += dmt0 * x + dvar0 * (x - mean0) * (x - mean0);
+            }
+            dsn = dw0 * wv;            // weight0 = sigmoid(.) * weight; the masks carry no gradient
+        }
+        // ---- neuray_fc backward -> d E
+        {
+            bwd_dense(FW(T_NF0_W), 32, FW(T_NF0_B), 8, 32, E, S0, BA_ELU, lane);
+            S2[lane] = dsn * sn * (1.0f - sn);
+            bwd_dense_dw(DW(T_NF2_W), 8, DW(T_NF2_B), 1, 8, S2, S0, lane);
+            bwd_dense_dx(FW(T_NF2_W), 8, 1, 8, S2, S1, false, lane);
+            bwd_through_act(S1, S0, 8, BA_ELU, lane);
+            bwd_dense_dw(DW(T_NF0_W), 32, DW(T_NF0_B), 8, 32, S1, E, lane);
+            bwd_dense_dx(FW(T_NF0_W), 32, 8, 32, S1, DE, true, lane);
+        }
+        // ---- ray_dir_fc backward (weights only: the direction difference carries no gradient); d img_feats = d GP[3..34]
+        {
+            bwd_dense(FW(T_RD0_W), 4, FW(T_RD0_B), 16, 4, DL, S0, BA_ELU, lane);
+            bwd_dense(FW(T_RD2_W), 16, FW(T_RD2_B), 35, 16, S0, S1, BA_ELU, lane);
+            for (int c = 0; c < 35; ++c) S2[c * 64 + lane] = DGP[c * 64 + lane] * bwd_dact(S1[c * 64 + lane], BA_ELU);
+            bwd_dense_dw(DW(T_RD2_W), 16, DW(T_RD2_B), 35, 16, S2, S0, lane);
+            bwd_dense_dx(FW(T_RD2_W), 16, 35, 16, S2, S1, false, lane);
+            bwd_through_act(S1, S0, 16, BA_ELU, lane);
+            bwd_dense_dw(DW(T_RD0_W), 4, DW(T_RD0_B), 16, 4, S1, DL, lane);
+        }
+        // ---- prob_embed backward -> d f_ray (DFR), d hit, d vis
+        float dhit, dvis;
+        {
+            for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = FR[c * 64 + lane];
+            S3[32 * 64 + lane] = (hit - 0.5f) * 2.0f; S3[33 * 64 + lane] = (vis - 0.5f) * 2.0f;
+            bwd_dense(FW(T_PE0_W), 34, FW(T_PE0_B), 32, 34, S3, S0, BA_RELU, lane);
+            bwd_dense_dw(DW(T_PE2_W), 32, DW(T_PE2_B), 32, 32, DE, S0, lane);
+            bwd_dense_dx(FW(T_PE2_W), 32, 32, 32, DE, S1, false, lane);
+            bwd_through_act(S1, S0, 32, BA_RELU, lane);
+            bwd_dense_dw(DW(T_PE0_W), 34, DW(T_PE0_B), 32, 34, S1, S3, lane);
+            bwd_dense_dx(FW(T_PE0_W), 34, 32, 34, S1, S2, false, lane);          // S2 rows 0..33
+            for (int c = 0; c < 32; ++c) DFR[c * 64 + lane] = S2[c * 64 + lane];
+            dhit = 2.0f * S2[32 * 64 + lane]; dvis = 2.0f * S2[33 * 64 + lane];
+        }
+        // ---- probabilities backward (dist_decoder.py:109-140)
+        float dmu0, dmu1, dsd0, dsd1, daw, dnu;
+        {
+            const float dh = dhit * m, dv_ = dvis * m;
+            const float dmix0 = dv_ * (1.0f - c00) + dh * (c10 - c00), dmix1 = dv_ * (1.0f - c01) + dh * (c11 - c01);
+            const float dc00 = -mix0 * (dv_ + dh), dc01 = -mix1 * (dv_ + dh), dc10 = mix0 * dh, dc11 = mix1 * dh;
+            dnu = use_vis ? (dc00 * g00 + dc01 * g01 + dc10 * g10 + dc11 * g11) : 0.0f;
+            const float da00 = dc00 * nuu * 0.5f * (1.0f - t00 * t00), da01 = dc01 * nuu * 0.5f * (1.0f - t01 * t01);
+            const float da10 = dc10 * nuu * 0.5f * (1.0f - t10 * t10), da11 = dc11 * nuu * 0.5f * (1.0f - t11 * t11);
+            dmu0 = -sd0 * (da00 + da10); dmu1 = -sd1 * (da01 + da11);
+            dsd0 = (tref - lo - mu0) * da00 + (tref + hi - mu0) * da10;
+            dsd1 = (tref - lo - mu1) * da01 + (tref + hi - mu1) * da11;
+            daw = dmix0 - dmix1;
+        }
+        // ---- dist decoder heads backward -> DFR +=
+        {
+            // head: (w0, b0, w2, b2, w4, b4, n_out, d_out0, d_out1)
+            for (int head = 0; head < (has_vis ? 4 : 3); ++head) {
+                const int t0 = head == 0 ? T_MEAN0_W : (head == 1 ? T_VAR0_W : (head == 2 ? T_AW0_W : T_VIS0_W));
+                const int nout = head < 2 ? 2 : 1;
+                const float* f = p.flat; float* g = p.d_flat;
+                bwd_dense(f + tensor_offset(t0), 32, f + tensor_offset(t0 + 1), 32, 32, FR, S0, BA_ELU, lane);
+                bwd_dense(f + tensor_offset(t0 + 2), 32, f + tensor_offset(t0 + 3), 32, 32, S0, S1, BA_ELU, lane);
+                float d0, d1 = 0.0f;
+                if (head == 0) { d0 = dmu0 * (1.0f - expf(-mu0)); d1 = dmu1 * (1.0f - expf(-mu1)); }
+                else if (head == 1) { d0 = dsd0 * (1.0f - expf(-(sd0 - p.var_bias))); d1 = dsd1 * (1.0f - expf(-(sd1 - p.var_bias))); }
+                else if (head == 2) d0 = daw * aw * (1.0f - aw);
+                else d0 = dnu * nu * (1.0f - nu);
+                S2[lane] = d0; S2[64 + lane] = d1;
+                bwd_dense_dw(g + tensor_offset(t0 + 4), 32, g + tensor_offset(t0 + 5), nout, 32, S2, S1, lane);
+                float* DH = S2 + 8 * 64;      // rows 8..39: d of the 32-wide hiddens
+                bwd_dense_dx(f + tensor_offset(t0 + 4), 32, nout, 32, S2, DH, false, lane);
+                bwd_through_act(DH, S1, 32, BA_ELU, lane);
+                bwd_dense_dw(g + tensor_offset(t0 + 2), 32, g + tensor_offset(t0 + 3), 32, 32, DH, S0, lane);
+                bwd_dense_dx(f + tensor_offset(t0 + 2), 32, 32, 32, DH, S3, false, lane);
+                bwd_through_act(S3, S0, 32, BA_ELU, lane);
+                bwd_dense_dw(g + tensor_offset(t0), 32, g + tensor_offset(t0 + 1), 32, 32, S3, FR, lane);
+                bwd_dense_dx(f + tensor_offset(t0), 32, 32, 32, S3, DFR, true, lane);
+            }
+        }
+        // ---- gathers backward: f_ray = mask * bilinear(ray_feats), f_img = mask * bilinear(img_feats) (render_ops.py:54-70)
+        if (vok && pvalid) {
+            bwd_scatter32(p.d_ray_feats, (size_t)view * fmap, tf, m, DFR, lane);
+            bwd_scatter32(p.d_img_feats, (size_t)view * fmap, tf, m, DGP + 3 * 64, lane);
+        }
+    }
+}
+#undef FW
+#undef DW
+
 }  // namespace nr

@@ -192,4 +192,25 @@ enum PassTensor {
     T_COUNT
 };
 
+// ---- flat natural layout (backward kernels): the T_COUNT tensors of a pass, row-major as in the state_dict, one
+// after the other in PassTensor order (the vis-decoder slots are always present; zero without a vis head).  The
+// gradient buffer of the backward kernels has the same layout.
+constexpr int kTensorRows[T_COUNT] = {
+    32, 32, 32, 32, 2, 2,   32, 32, 32, 32, 2, 2,   32, 32, 32, 32, 1, 1,   32, 32, 32, 32, 1, 1,
+    32, 32, 32, 32,   16, 16, 35, 35,   64, 64, 32, 32,   32, 32, 33, 33,   32, 32, 1, 1,   64, 64, 16, 16,
+    16, 16, 16, 16, 16, 16,   16, 16, 1, 1,   16, 16, 8, 8, 1, 1,   8, 8, 1, 1,
+};
+constexpr int kTensorCols[T_COUNT] = {      // 1 = bias / vector
+    32, 1, 32, 1, 32, 1,   32, 1, 32, 1, 32, 1,   32, 1, 32, 1, 32, 1,   32, 1, 32, 1, 32, 1,
+    34, 1, 32, 1,   4, 1, 16, 1,   207, 1, 64, 1,   32, 1, 32, 1,   32, 1, 32, 1,   65, 1, 64, 1,
+    16, 16, 16, 16, 1, 1,   16, 1, 16, 1,   37, 1, 16, 1, 8, 1,   32, 1, 8, 1,
+};
+constexpr int tensor_floats(int t) { return kTensorRows[t] * kTensorCols[t]; }
+constexpr int tensor_offset(int t) {
+    int off = 0;
+    for (int i = 0; i < t; ++i) off += tensor_floats(i);
+    return off;
+}
+constexpr int kFlatPassFloats = tensor_offset(T_COUNT);
+
 }  // namespace nr

@@ -246,6 +246,49 @@ class RenderEngine:
                                                       vis.data_ptr() if vis is not None else None, self._stream()))
         return (mean.view(*lead, 2), var.view(*lead, 2), vis.view(*lead, 1) if vis is not None else None, aw.view(*lead, 1))
 
+    def flat_pass(self, state_dict, dist_prefix, agg_prefix):
+        """Flat natural-layout weights of a pass (include/neuray_hip.h, backward kernels) -> (device tensor, has_vis)."""
+        keys = pass_tensor_keys(dist_prefix, agg_prefix)
+        n = int(self.lib.neuray_flat_pass_floats())
+        flat = torch.zeros(n, dtype=torch.float32)
+        has_vis = (dist_prefix + 'vis_decoder.0.weight') in state_dict
+        for i, k in enumerate(keys):
+            if k not in state_dict:
+                if '.vis_decoder.' in k and not has_vis:
+                    continue
+                raise KeyError("neuray_amd: missing weight %s" % k)
+            t = torch.as_tensor(state_dict[k]).detach().to('cpu', torch.float32).reshape(-1)
+            off = int(self.lib.neuray_flat_tensor_offset(i))
+            assert off + t.numel() <= n and int(self.lib.neuray_flat_tensor_offset(i + 1)) - off == t.numel(), k
+            flat[off:off + t.numel()] = t
+        return flat.to(self.device), has_vis
+
+    def unflatten_pass_grads(self, d_flat, state_dict, dist_prefix, agg_prefix):
+        """flat gradient buffer -> {state_dict key: grad tensor shaped like the parameter}"""
+        out = {}
+        for i, k in enumerate(pass_tensor_keys(dist_prefix, agg_prefix)):
+            if k in state_dict:
+                shape = tuple(torch.as_tensor(state_dict[k]).shape)
+                off = int(self.lib.neuray_flat_tensor_offset(i))
+                out[k] = d_flat[off:off + int(np.prod(shape))].view(*shape)
+        return out
+
+    def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05):
+        """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC)."""
+        coords, depth, d_point_rec = self._f32(coords), self._f32(depth), self._f32(d_point_rec)
+        rn, dn = depth.shape
+        d_flat = torch.zeros_like(flat)
+        d_rf = torch.zeros_like(views.ray_feats)
+        d_if = torch.zeros_like(views.img_feats)
+        ws = self.empty(int(self.lib.neuray_points_backward_workspace_floats(rn * dn, views.rfn)))
+        a = _lib.NeurayPointsBwdArgs(
+            qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
+            views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_point_rec.data_ptr(), d_flat.data_ptr(),
+            d_rf.data_ptr(), d_if.data_ptr(), ws.data_ptr(), views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
+            int(has_vis_head), int(bool(use_vis)), float(var_bias))
+        self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
+        return d_flat, d_rf, d_if
+
     def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None):
         """Backward of the ray kernel (attention, sigma head, compositing): gradients of a scalar loss w.r.t. the
         per-point records [rn,dn,POINT_REC] (geometry feature 0..15, colour 16..18) and the ray-part weights.

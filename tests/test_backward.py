@@ -88,3 +88,65 @@ def test_rays_backward_rejects_long_rays(backend):
     z = torch.zeros(1, 65, 20, device=dev)
     with pytest.raises(RuntimeError, match='dn=65'):
         eng.render_rays_backward(z, torch.ones(1, 65, device=dev), packed, torch.zeros(1, 3, device=dev))
+
+
+# ---- whole pass: ray backward chained into the point backward, against autograd of the eager port -----------------
+def _pass_case(rfn, rn, dn, use_vis_head, seed):
+    from neuray_amd import synthetic
+    que, ref = synthetic.make_scene(48, 64, rfn, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    que['coords'] = (rng.rand(1, rn, 2) * np.array([63, 47])).astype(np.float32)
+    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    return que, ref, load_weights(use_vis_head), rng
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('rfn,rn,dn,vis_head', [(3, 5, 8, False), (8, 3, 6, True), (2, 4, 5, False)])
+def test_pass_backward_matches_autograd(rfn, rn, dn, vis_head, backend):
+    from neuray_amd.engine import RenderEngine
+    from oracle import neuray_oracle as orc
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
+    que, ref, weights, rng = _pass_case(rfn, rn, dn, vis_head, seed=40 + rfn)
+    lw_pix = rng.randn(rn, 3).astype(np.float32)
+    lw_hit = rng.randn(rn, dn).astype(np.float32)
+    depth = orc.sample_depth(que['depth_range'], rn, dn)                                            # [1,rn,dn]
+    depth = (depth * (1.0 + 0.02 * rng.rand(1, rn, dn))).astype(np.float32); depth.sort(-1)            # de-regularised
+
+    # ---- autograd of the eager port (float32, CPU)
+    w = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in weights.items()
+         if k.startswith(('dist_decoder.', 'agg_net.'))}
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v.copy()) for k, v in ref.items()}
+    tr['ray_feats'].requires_grad_(True); tr['img_feats'].requires_grad_(True)
+    cfg = {'coarse_use_vis': vis_head, 'fine_use_vis': True}
+    out = tep.render_pass(w, cfg, torch.from_numpy(depth), tq, tr, False)
+    loss = (out['pixel_colors_nr'][0] * torch.from_numpy(lw_pix)).sum() + (out['hit_prob_nr'][0] * torch.from_numpy(lw_hit)).sum()
+    loss.backward()
+
+    # ---- ours
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    views = eng.prepare_views({k: t(v) for k, v in ref.items()})
+    qc = eng.prepare_query({k: t(v) for k, v in que.items()})
+    packed = eng.pack_pass(weights, 'dist_decoder.', 'agg_net.')
+    fwd = eng.render_pass(qc, views, t(que['coords'][0]), t(depth[0]), packed, use_vis=vis_head)
+    assert np.abs(fwd['pixel'].cpu().numpy() - out['pixel_colors_nr'][0].detach().numpy()).max() <= 2e-4
+    d_rec, g_ray = eng.render_rays_backward(fwd['point_rec'], t(depth[0]), packed, t(lw_pix), t(lw_hit))
+    flat, has_vis = eng.flat_pass(weights, 'dist_decoder.', 'agg_net.')
+    d_flat, d_rf, d_if = eng.render_points_backward(qc, views, t(que['coords'][0]), t(depth[0]), flat, has_vis, vis_head, d_rec)
+    grads = eng.unflatten_pass_grads(d_flat, weights, 'dist_decoder.', 'agg_net.')
+    for name, g in g_ray.items():
+        grads['agg_net.agg_impl.' + name] = g
+
+    def close(got, want, name, rel=2e-3):
+        want = want.detach().numpy() if torch.is_tensor(want) else want
+        got = got.detach().cpu().numpy()
+        tol = rel * max(1e-3, float(np.abs(want).max()))
+        assert got.shape == want.shape, name
+        assert np.abs(got - want).max() <= tol, (name, float(np.abs(got - want).max()), float(np.abs(want).max()))
+
+    for k, p_ in w.items():
+        want = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        close(grads[k], want, k)
+    close(d_rf.permute(0, 3, 1, 2), tr['ray_feats'].grad, 'ray_feats')
+    close(d_if.permute(0, 3, 1, 2), tr['img_feats'].grad, 'img_feats')

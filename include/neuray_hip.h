@@ -173,6 +173,19 @@ typedef struct NeurayPointsBwdArgs {
 } NeurayPointsBwdArgs;
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
 
+/* ---- backward of the a19 path (renderer.py:137-155): hit_prob_self [rn][dn] as a function of the gathered query-view
+ * features feats [rn][32] (neuray_interpolate_feats of que ray_feats) and the dist decoder weights.
+ * -> d_feats [rn][32]; d_flat (flat natural layout, only the dist decoder tensors are touched) is ACCUMULATED into.
+ * workspace: neuray_self_hit_backward_workspace_floats(rn) floats. */
+size_t neuray_self_hit_backward_workspace_floats(int rn);
+int neuray_self_hit_prob_backward(const float* query_const_dev, const float* depth_dev, const float* feats_dev,
+                                  const float* flat_weights_dev, int has_vis_head, int use_vis, float var_bias,
+                                  const float* d_hit_dev, int rn, int dn, float* d_feats_dev, float* d_flat_weights_dev,
+                                  float* workspace_dev, void* stream);
+/* ---- backward of neuray_interpolate_feats: d_feats [b][c][fh][fw] += bilinear weights * d_out [b][n][c] (accumulated). */
+int neuray_interpolate_feats_backward(const float* d_out_dev, const float* points_dev, const float* mask_dev, int b, int n, int c,
+                                      int fh, int fw, int h_full, int w_full, int align_corners, float* d_feats_dev, void* stream);
+
 /* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
  * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,
  * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)].

@@ -105,6 +105,11 @@ SYMBOLS = {
     'neuray_flat_tensor_offset': (C.c_size_t, [C.c_int]),
     'neuray_points_backward_workspace_floats': (C.c_size_t, [C.c_int, C.c_int]),
     'neuray_render_points_backward': (C.c_int, [C.POINTER(NeurayPointsBwdArgs), C.c_void_p]),
+    'neuray_self_hit_backward_workspace_floats': (C.c_size_t, [C.c_int]),
+    'neuray_self_hit_prob_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_interpolate_feats_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

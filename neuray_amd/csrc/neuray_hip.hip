@@ -304,6 +304,33 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
     return check_launch("neuray_render_points_backward");
 }
 
+size_t neuray_self_hit_backward_workspace_floats(int rn) {
+    if (rn < 1) return 0;
+    return (size_t)grid_for(rn, 64, 1024) * nr::kSelfBwdRows * 64;
+}
+
+int neuray_self_hit_prob_backward(const float* qc, const float* depth, const float* feats, const float* flat, int has_vis_head,
+                                  int use_vis, float var_bias, const float* d_hit, int rn, int dn, float* d_feats, float* d_flat,
+                                  float* workspace, void* stream) {
+    if (!qc || !depth || !feats || !flat || !d_hit || !d_feats || !d_flat || !workspace)
+        return fail("neuray_self_hit_prob_backward: null argument");
+    if (rn < 1 || dn < 3 || dn > NEURAY_MAX_SAMPLES) return fail("neuray_self_hit_prob_backward: rn=%d dn=%d", rn, dn);
+    nr::SelfHitBwdParams p;
+    p.que_const = qc; p.depth = depth; p.feats = feats; p.flat = flat; p.d_hit = d_hit; p.d_feats = d_feats; p.d_flat = d_flat;
+    p.workspace = workspace; p.rn = rn; p.dn = dn; p.has_vis_head = has_vis_head; p.use_vis = use_vis; p.var_bias = var_bias;
+    NR_LAUNCH(nr::self_hit_backward_kernel, dim3(grid_for(rn, 64, 1024)), dim3(64), 0, stream, p);
+    return check_launch("neuray_self_hit_prob_backward");
+}
+
+int neuray_interpolate_feats_backward(const float* d_out, const float* points, const float* mask, int b, int n, int c, int fh,
+                                      int fw, int h_full, int w_full, int align_corners, float* d_feats, void* stream) {
+    if (!d_out || !points || !d_feats) return fail("neuray_interpolate_feats_backward: null argument");
+    if (b < 1 || n < 1 || c < 1 || fh < 1 || fw < 1) return fail("neuray_interpolate_feats_backward: bad shape");
+    NR_LAUNCH(nr::interpolate_backward_kernel, dim3(grid_for((long long)b * n, 256, 4096)), dim3(256), 0, stream, d_out, points,
+              mask, b, n, c, fh, fw, h_full, w_full, align_corners, d_feats);
+    return check_launch("neuray_interpolate_feats_backward");
+}
+
 int neuray_group_sum_selftest(const float* x, float* y, void* stream) {
     NR_LAUNCH(nr::group_sum_selftest_kernel, dim3(1), dim3(64), 0, stream, x, y);
     return check_launch("neuray_group_sum_selftest");

@@ -385,6 +385,85 @@ __device__ __forceinline__ void bwd_scatter32(float* dmap, size_t view_off, cons
     }
 }
 
+
+// backward of the output non-linearities and the three (four) 32->32->32->out MLPs of the dist decoder
+// (dist_decoder.py:64-97): gradients of mu (softplus), s (softplus + bias), aw / nu (sigmoid) -> weight gradients and
+// DFR += d f_ray.  FR: the 32 input rows; S0..S3: 64-row scratch areas.
+__device__ __forceinline__ void bwd_dist_heads(const float* flat, float* d_flat, bool has_vis, float var_bias,
+                                               const float* FR, float* S0, float* S1, float* S2, float* S3, float* DFR,
+                                               float mu0, float mu1, float sd0, float sd1, float aw, float nu,
+                                               float dmu0, float dmu1, float dsd0, float dsd1, float daw, float dnu, int lane) {
+    for (int head = 0; head < (has_vis ? 4 : 3); ++head) {
+        const int t0 = head == 0 ? T_MEAN0_W : (head == 1 ? T_VAR0_W : (head == 2 ? T_AW0_W : T_VIS0_W));
+        const int nout = head < 2 ? 2 : 1;
+        const float* f = flat; float* g = d_flat;
+        bwd_dense(f + tensor_offset(t0), 32, f + tensor_offset(t0 + 1), 32, 32, FR, S0, BA_ELU, lane);
+        bwd_dense(f + tensor_offset(t0 + 2), 32, f + tensor_offset(t0 + 3), 32, 32, S0, S1, BA_ELU, lane);
+        float d0, d1 = 0.0f;
+        if (head == 0) { d0 = dmu0 * (1.0f - expf(-mu0)); d1 = dmu1 * (1.0f - expf(-mu1)); }      // softplus' = sigmoid = 1 - exp(-softplus)
+        else if (head == 1) { d0 = dsd0 * (1.0f - expf(-(sd0 - var_bias))); d1 = dsd1 * (1.0f - expf(-(sd1 - var_bias))); }
+        else if (head == 2) d0 = daw * aw * (1.0f - aw);
+        else d0 = dnu * nu * (1.0f - nu);
+        S2[lane] = d0; S2[64 + lane] = d1;
+        bwd_dense_dw(g + tensor_offset(t0 + 4), 32, g + tensor_offset(t0 + 5), nout, 32, S2, S1, lane);
+        float* DH = S2 + 8 * 64;      // rows 8..39: d of the 32-wide hiddens
+        bwd_dense_dx(f + tensor_offset(t0 + 4), 32, nout, 32, S2, DH, false, lane);
+        bwd_through_act(DH, S1, 32, BA_ELU, lane);
+        bwd_dense_dw(g + tensor_offset(t0 + 2), 32, g + tensor_offset(t0 + 3), 32, 32, DH, S0, lane);
+        bwd_dense_dx(f + tensor_offset(t0 + 2), 32, 32, 32, DH, S3, false, lane);
+        bwd_through_act(S3, S0, 32, BA_ELU, lane);
+        bwd_dense_dw(g + tensor_offset(t0), 32, g + tensor_offset(t0 + 1), 32, 32, S3, FR, lane);
+        bwd_dense_dx(f + tensor_offset(t0), 32, 32, 32, S3, DFR, true, lane);
+    }
+}
+
+// forward of the dist decoder heads on the 32 rows FR (outputs only)
+__device__ __forceinline__ void bwd_dist_heads_fwd(const float* flat, bool has_vis, float var_bias, const float* FR, float* S0,
+                                                   float* S1, float* S2, float& mu0, float& mu1, float& sd0, float& sd1,
+                                                   float& aw, float& nu, int lane) {
+    const float* f = flat;
+    bwd_dense(f + tensor_offset(T_MEAN0_W), 32, f + tensor_offset(T_MEAN0_B), 32, 32, FR, S0, BA_ELU, lane);
+    bwd_dense(f + tensor_offset(T_MEAN2_W), 32, f + tensor_offset(T_MEAN2_B), 32, 32, S0, S1, BA_ELU, lane);
+    bwd_dense(f + tensor_offset(T_MEAN4_W), 32, f + tensor_offset(T_MEAN4_B), 2, 32, S1, S2, BA_NONE, lane);
+    mu0 = bwd_softplus(S2[lane]); mu1 = bwd_softplus(S2[64 + lane]);
+    bwd_dense(f + tensor_offset(T_VAR0_W), 32, f + tensor_offset(T_VAR0_B), 32, 32, FR, S0, BA_ELU, lane);
+    bwd_dense(f + tensor_offset(T_VAR2_W), 32, f + tensor_offset(T_VAR2_B), 32, 32, S0, S1, BA_ELU, lane);
+    bwd_dense(f + tensor_offset(T_VAR4_W), 32, f + tensor_offset(T_VAR4_B), 2, 32, S1, S2, BA_NONE, lane);
+    sd0 = bwd_softplus(S2[lane]) + var_bias; sd1 = bwd_softplus(S2[64 + lane]) + var_bias;
+    bwd_dense(f + tensor_offset(T_AW0_W), 32, f + tensor_offset(T_AW0_B), 32, 32, FR, S0, BA_ELU, lane);
+    bwd_dense(f + tensor_offset(T_AW2_W), 32, f + tensor_offset(T_AW2_B), 32, 32, S0, S1, BA_ELU, lane);
+    bwd_dense(f + tensor_offset(T_AW4_W), 32, f + tensor_offset(T_AW4_B), 1, 32, S1, S2, BA_NONE, lane);
+    aw = bwd_sigmoid(S2[lane]);
+    nu = 1.0f;
+    if (has_vis) {
+        bwd_dense(f + tensor_offset(T_VIS0_W), 32, f + tensor_offset(T_VIS0_B), 32, 32, FR, S0, BA_ELU, lane);
+        bwd_dense(f + tensor_offset(T_VIS2_W), 32, f + tensor_offset(T_VIS2_B), 32, 32, S0, S1, BA_ELU, lane);
+        bwd_dense(f + tensor_offset(T_VIS4_W), 32, f + tensor_offset(T_VIS4_B), 1, 32, S1, S2, BA_NONE, lane);
+        nu = bwd_sigmoid(S2[lane]);
+    }
+}
+
+// gradient of (visibility, hit) of one interval [near, far] (dist_decoder.py:109-140) w.r.t. the mixture parameters,
+// accumulated into dmu*, dsd*, daw, dnu.  nuu = nu if the decoder's use_vis else 1.
+__device__ __forceinline__ void bwd_prob(float nearv, float farv, float mu0, float mu1, float sd0, float sd1, float aw, float nuu,
+                                         bool use_vis, float dv, float dh, float& dmu0, float& dmu1, float& dsd0, float& dsd1,
+                                         float& daw, float& dnu) {
+    const float t00 = tanhf((nearv - mu0) * sd0), t01 = tanhf((nearv - mu1) * sd1);
+    const float t10 = tanhf((farv - mu0) * sd0), t11 = tanhf((farv - mu1) * sd1);
+    const float g00 = 0.5f + 0.5f * t00, g01 = 0.5f + 0.5f * t01, g10 = 0.5f + 0.5f * t10, g11 = 0.5f + 0.5f * t11;
+    const float c00 = g00 * nuu, c01 = g01 * nuu, c10 = g10 * nuu, c11 = g11 * nuu;
+    const float mix0 = aw, mix1 = 1.0f - aw;
+    const float dmix0 = dv * (1.0f - c00) + dh * (c10 - c00), dmix1 = dv * (1.0f - c01) + dh * (c11 - c01);
+    const float dc00 = -mix0 * (dv + dh), dc01 = -mix1 * (dv + dh), dc10 = mix0 * dh, dc11 = mix1 * dh;
+    if (use_vis) dnu += dc00 * g00 + dc01 * g01 + dc10 * g10 + dc11 * g11;
+    const float da00 = dc00 * nuu * 0.5f * (1.0f - t00 * t00), da01 = dc01 * nuu * 0.5f * (1.0f - t01 * t01);
+    const float da10 = dc10 * nuu * 0.5f * (1.0f - t10 * t10), da11 = dc11 * nuu * 0.5f * (1.0f - t11 * t11);
+    dmu0 += -sd0 * (da00 + da10); dmu1 += -sd1 * (da01 + da11);
+    dsd0 += (nearv - mu0) * da00 + (farv - mu0) * da10;
+    dsd1 += (nearv - mu1) * da01 + (farv - mu1) * da11;
+    daw += dmix0 - dmix1;
+}
+
 #define FW(T) (p.flat + tensor_offset(T))
 #define DW(T) (p.d_flat + tensor_offset(T))
 
@@ -722,45 +801,11 @@ __global__ void __launch_bounds__(64) points_backward_kernel(PointBwdParams p) {
             dhit = 2.0f * S2[32 * 64 + lane]; dvis = 2.0f * S2[33 * 64 + lane];
         }
         // ---- probabilities backward (dist_decoder.py:109-140)
-        float dmu0, dmu1, dsd0, dsd1, daw, dnu;
-        {
-            const float dh = dhit * m, dv_ = dvis * m;
-            const float dmix0 = dv_ * (1.0f - c00) + dh * (c10 - c00), dmix1 = dv_ * (1.0f - c01) + dh * (c11 - c01);
-            const float dc00 = -mix0 * (dv_ + dh), dc01 = -mix1 * (dv_ + dh), dc10 = mix0 * dh, dc11 = mix1 * dh;
-            dnu = use_vis ? (dc00 * g00 + dc01 * g01 + dc10 * g10 + dc11 * g11) : 0.0f;
-            const float da00 = dc00 * nuu * 0.5f * (1.0f - t00 * t00), da01 = dc01 * nuu * 0.5f * (1.0f - t01 * t01);
-            const float da10 = dc10 * nuu * 0.5f * (1.0f - t10 * t10), da11 = dc11 * nuu * 0.5f * (1.0f - t11 * t11);
-            dmu0 = -sd0 * (da00 + da10); dmu1 = -sd1 * (da01 + da11);
-            dsd0 = (tref - lo - mu0) * da00 + (tref + hi - mu0) * da10;
-            dsd1 = (tref - lo - mu1) * da01 + (tref + hi - mu1) * da11;
-            daw = dmix0 - dmix1;
-        }
+        float dmu0 = 0.0f, dmu1 = 0.0f, dsd0 = 0.0f, dsd1 = 0.0f, daw = 0.0f, dnu = 0.0f;
+        bwd_prob(tref - lo, tref + hi, mu0, mu1, sd0, sd1, aw, nuu, use_vis, dvis * m, dhit * m, dmu0, dmu1, dsd0, dsd1, daw, dnu);
         // ---- dist decoder heads backward -> DFR +=
-        {
-            // head: (w0, b0, w2, b2, w4, b4, n_out, d_out0, d_out1)
-            for (int head = 0; head < (has_vis ? 4 : 3); ++head) {
-                const int t0 = head == 0 ? T_MEAN0_W : (head == 1 ? T_VAR0_W : (head == 2 ? T_AW0_W : T_VIS0_W));
-                const int nout = head < 2 ? 2 : 1;
-                const float* f = p.flat; float* g = p.d_flat;
-                bwd_dense(f + tensor_offset(t0), 32, f + tensor_offset(t0 + 1), 32, 32, FR, S0, BA_ELU, lane);
-                bwd_dense(f + tensor_offset(t0 + 2), 32, f + tensor_offset(t0 + 3), 32, 32, S0, S1, BA_ELU, lane);
-                float d0, d1 = 0.0f;
-                if (head == 0) { d0 = dmu0 * (1.0f - expf(-mu0)); d1 = dmu1 * (1.0f - expf(-mu1)); }
-                else if (head == 1) { d0 = dsd0 * (1.0f - expf(-(sd0 - p.var_bias))); d1 = dsd1 * (1.0f - expf(-(sd1 - p.var_bias))); }
-                else if (head == 2) d0 = daw * aw * (1.0f - aw);
-                else d0 = dnu * nu * (1.0f - nu);
-                S2[lane] = d0; S2[64 + lane] = d1;
-                bwd_dense_dw(g + tensor_offset(t0 + 4), 32, g + tensor_offset(t0 + 5), nout, 32, S2, S1, lane);
-                float* DH = S2 + 8 * 64;      // rows 8..39: d of the 32-wide hiddens
-                bwd_dense_dx(f + tensor_offset(t0 + 4), 32, nout, 32, S2, DH, false, lane);
-                bwd_through_act(DH, S1, 32, BA_ELU, lane);
-                bwd_dense_dw(g + tensor_offset(t0 + 2), 32, g + tensor_offset(t0 + 3), 32, 32, DH, S0, lane);
-                bwd_dense_dx(f + tensor_offset(t0 + 2), 32, 32, 32, DH, S3, false, lane);
-                bwd_through_act(S3, S0, 32, BA_ELU, lane);
-                bwd_dense_dw(g + tensor_offset(t0), 32, g + tensor_offset(t0 + 1), 32, 32, S3, FR, lane);
-                bwd_dense_dx(f + tensor_offset(t0), 32, 32, 32, S3, DFR, true, lane);
-            }
-        }
+        bwd_dist_heads(p.flat, p.d_flat, has_vis, p.var_bias, FR, S0, S1, S2, S3, DFR, mu0, mu1, sd0, sd1, aw, nu,
+                       dmu0, dmu1, dsd0, dsd1, daw, dnu, lane);
         // ---- gathers backward: f_ray = mask * bilinear(ray_feats), f_img = mask * bilinear(img_feats) (render_ops.py:54-70)
         if (vok && pvalid) {
             bwd_scatter32(p.d_ray_feats, (size_t)view * fmap, tf, m, DFR, lane);
@@ -770,5 +815,82 @@ __global__ void __launch_bounds__(64) points_backward_kernel(PointBwdParams p) {
 }
 #undef FW
 #undef DW
+
+// -------------------------------------------------------------------------------------------------
+// a19 backward: hit_prob_self = compute_prob(is_ref=False) of the decoded query-ray distributions
+// (renderer.py:137-155, dist_decoder.py:39-46,99-140).  lane = ray; feats [rn][32] are the query view's ray_feats
+// gathered at the ray's pixel (neuray_interpolate_feats); -> d_feats [rn][32] and the dist decoder weight gradients.
+// -------------------------------------------------------------------------------------------------
+struct SelfHitBwdParams {
+    const float* que_const;
+    const float* depth;       // [rn][dn]
+    const float* feats;       // [rn][32]
+    const float* flat;
+    const float* d_hit;       // [rn][dn]
+    float* d_feats;           // [rn][32]
+    float* d_flat;            // accumulated
+    float* workspace;         // [gridDim.x][kSelfBwdRows][64]
+    int rn, dn, has_vis_head, use_vis;
+    float var_bias;
+};
+constexpr int kSelfBwdRows = 32 + 4 * 64 + 32;
+
+__global__ void __launch_bounds__(64) self_hit_backward_kernel(SelfHitBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    float* A = p.workspace + (size_t)blockIdx.x * kSelfBwdRows * 64;
+    float* FR = A; float* S0 = A + 32 * 64; float* S1 = S0 + 64 * 64; float* S2 = S1 + 64 * 64; float* S3 = S2 + 64 * 64;
+    float* DFR = S3 + 64 * 64;
+    const float nearp = p.que_const[24], farp = p.que_const[25];
+    const bool has_vis = p.has_vis_head != 0, use_vis = has_vis && (p.use_vis != 0);
+    const int dn = p.dn;
+    for (int base = blockIdx.x * 64; base < p.rn; base += gridDim.x * 64) {
+        __syncthreads();
+        const bool valid = base + lane < p.rn;
+        const int ray = valid ? base + lane : p.rn - 1;
+        for (int c = 0; c < 32; ++c) { FR[c * 64 + lane] = p.feats[(size_t)ray * 32 + c]; DFR[c * 64 + lane] = 0.0f; }
+        float mu0, mu1, sd0, sd1, aw, nu;
+        bwd_dist_heads_fwd(p.flat, has_vis, p.var_bias, FR, S0, S1, S2, mu0, mu1, sd0, sd1, aw, nu, lane);
+        const float nuu = use_vis ? nu : 1.0f;
+        float dmu0 = 0.0f, dmu1 = 0.0f, dsd0 = 0.0f, dsd1 = 0.0f, daw = 0.0f, dnu = 0.0f;
+        const float* drow = p.depth + (size_t)ray * dn;
+        for (int smp = 0; smp < dn; ++smp) {
+            const float t_c = norm_inv_depth(fmaxf(drow[smp], 1e-5f), nearp, farp);
+            float lo, hi;
+            if (smp == 0) lo = t_c - (norm_inv_depth(drow[1], nearp, farp) - norm_inv_depth(drow[0], nearp, farp)) / 2.0f;
+            else lo = (norm_inv_depth(fmaxf(drow[smp - 1], 1e-5f), nearp, farp) + t_c) / 2.0f;
+            if (smp == dn - 1) hi = t_c + 500000.0f;
+            else hi = (t_c + norm_inv_depth(fmaxf(drow[smp + 1], 1e-5f), nearp, farp)) / 2.0f;
+            const float dh = valid ? p.d_hit[(size_t)ray * dn + smp] : 0.0f;
+            bwd_prob(lo, hi, mu0, mu1, sd0, sd1, aw, nuu, use_vis, 0.0f, dh, dmu0, dmu1, dsd0, dsd1, daw, dnu);
+        }
+        bwd_dist_heads(p.flat, p.d_flat, has_vis, p.var_bias, FR, S0, S1, S2, S3, DFR, mu0, mu1, sd0, sd1, aw, nu,
+                       dmu0, dmu1, dsd0, dsd1, daw, dnu, lane);
+        if (valid)
+            for (int c = 0; c < 32; ++c) p.d_feats[(size_t)ray * 32 + c] = DFR[c * 64 + lane];
+    }
+}
+
+// backward of interpolate_kernel (bilinear, border padding; network/ops.py:14-34): d feats[b][c][fh][fw] += w_tap * d out
+__global__ void interpolate_backward_kernel(const float* __restrict__ d_out, const float* __restrict__ points, const float* __restrict__ mask,
+                                            int b, int n, int c, int fh, int fw, int h_full, int w_full, int align,
+                                            float* __restrict__ d_feats) {
+    const long long total = (long long)b * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int bi = (int)(i / n);
+        const float mk = mask ? mask[i] : 1.0f;
+        if (mk == 0.0f) continue;
+        const float ix = texel_coord(points[2 * i], (float)w_full, (float)fw, align != 0);
+        const float iy = texel_coord(points[2 * i + 1], (float)h_full, (float)fh, align != 0);
+        const Taps t = taps_from(ix, iy, fw, fh);
+        const int offs[4] = {t.o00, t.o10, t.o01, t.o11};
+        const float wts[4] = {t.w00, t.w10, t.w01, t.w11};
+        float* dst = d_feats + (size_t)bi * c * fh * fw;
+        for (int ch = 0; ch < c; ++ch) {
+            const float g = d_out[i * c + ch] * mk;
+            for (int a = 0; a < 4; ++a)
+                if (wts[a] != 0.0f) atomicAdd(dst + (size_t)ch * fh * fw + offs[a], wts[a] * g);
+        }
+    }
+}
 
 }  // namespace nr

@@ -289,6 +289,32 @@ class RenderEngine:
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         return d_flat, d_rf, d_if
 
+    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05):
+        """Backward of dist_decoder_rows + self_hit_prob: -> (d_feats [rn,32], d_flat)"""
+        depth, feats, d_hit = self._f32(depth), self._f32(feats), self._f32(d_hit)
+        rn, dn = depth.shape
+        d_feats = self.empty(rn, 32)
+        d_flat = torch.zeros_like(flat)
+        ws = self.empty(int(self.lib.neuray_self_hit_backward_workspace_floats(rn)))
+        self._check(self.lib.neuray_self_hit_prob_backward(qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), flat.data_ptr(),
+                                                           int(has_vis_head), int(bool(use_vis)), float(var_bias), d_hit.data_ptr(),
+                                                           rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), ws.data_ptr(), self._stream()))
+        return d_feats, d_flat
+
+    def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None):
+        """Backward of interpolate_feats w.r.t. the feature maps: -> d_feats [b,c,fh,fw]"""
+        d_out, points = self._f32(d_out), self._f32(points)
+        b, c, fh, fw = feats_shape
+        n = points.shape[1]
+        if h is None and w is None:
+            h, w = fh, fw
+        d_feats = torch.zeros(b, c, fh, fw, dtype=torch.float32, device=self.device)
+        m = self._f32(mask) if mask is not None else None
+        self._check(self.lib.neuray_interpolate_feats_backward(d_out.data_ptr(), points.data_ptr(), m.data_ptr() if m is not None else None,
+                                                               b, n, c, fh, fw, int(h), int(w), int(bool(align_corners)),
+                                                               d_feats.data_ptr(), self._stream()))
+        return d_feats
+
     def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None):
         """Backward of the ray kernel (attention, sigma head, compositing): gradients of a scalar loss w.r.t. the
         per-point records [rn,dn,POINT_REC] (geometry feature 0..15, colour 16..18) and the ray-part weights.

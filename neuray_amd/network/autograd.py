@@ -1,0 +1,80 @@
+"""torch.autograd glue of the HIP render path: the forward runs the forward kernels, the backward the backward kernels
+(include/neuray_hip.h: neuray_render_rays_backward, neuray_render_points_backward, neuray_self_hit_prob_backward,
+neuray_interpolate_feats_backward).  Nothing here computes with PyTorch ops besides layout permutes and slicing."""
+import torch
+
+
+class PassRun:
+    """Everything one render pass needs besides the differentiable tensors."""
+
+    def __init__(self, eng, qconst, views, coords, depth, dist, agg, use_vis, var_bias, mask_view_num, mask_point_num, want_depth):
+        self.eng, self.qconst, self.views, self.coords, self.depth = eng, qconst, views, coords, depth
+        self.dist, self.agg, self.use_vis, self.var_bias = dist, agg, use_vis, var_bias
+        self.mask_view_num, self.mask_point_num, self.want_depth = mask_view_num, mask_point_num, want_depth
+
+    def named_params(self):
+        return [('d.' + k, v) for k, v in self.dist.named_parameters()] + [('a.' + k, v) for k, v in self.agg.named_parameters()]
+
+    def state(self):
+        return {k: v.detach() for k, v in self.named_params()}
+
+
+class RenderPassFn(torch.autograd.Function):
+    """(ray_feats NCHW, img_feats NCHW, *params) -> pixel [rn,3], hit_prob [rn,dn], ray_mask [rn], render_depth [rn]"""
+
+    @staticmethod
+    def forward(ctx, run, packed, ray_feats, img_feats, *params):
+        res = run.eng.render_pass(run.qconst, run.views, run.coords, run.depth, packed, use_vis=run.use_vis,
+                                  var_bias=run.var_bias, ray_mask_view_num=run.mask_view_num,
+                                  ray_mask_point_num=run.mask_point_num, want_depth=True)
+        ctx.run, ctx.packed = run, packed
+        ctx.save_for_backward(res['point_rec'])
+        ctx.mark_non_differentiable(res['ray_mask'])
+        return res['pixel'], res['hit_prob'], res['ray_mask'], res['render_depth']
+
+    @staticmethod
+    def backward(ctx, d_pixel, d_hit, _d_mask, d_depth):
+        run, eng = ctx.run, ctx.run.eng
+        point_rec, = ctx.saved_tensors
+        rn, dn = run.depth.shape
+        if d_pixel is None:
+            d_pixel = torch.zeros(rn, 3, device=point_rec.device)
+        d_rec, g_ray = eng.render_rays_backward(point_rec, run.depth, ctx.packed, d_pixel.contiguous(),
+                                                d_hit.contiguous() if d_hit is not None else None,
+                                                d_depth.contiguous() if d_depth is not None else None)
+        sd = run.state()
+        flat, has_vis = eng.flat_pass(sd, 'd.', 'a.')
+        d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, flat, has_vis,
+                                                        run.use_vis, d_rec, var_bias=run.var_bias)
+        grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
+        for name, g in g_ray.items():
+            grads['a.agg_impl.' + name] = g
+        return (None, None, d_rf.permute(0, 3, 1, 2).contiguous(), d_if.permute(0, 3, 1, 2).contiguous()) + \
+            tuple(grads[k].clone() for k, _ in run.named_params())
+
+
+class SelfHitFn(torch.autograd.Function):
+    """(que ray_feats NCHW [1,32,fh,fw], *dist params) -> hit_prob_self [rn,dn]   (renderer.py:137-155)"""
+
+    @staticmethod
+    def forward(ctx, run, packed, h, w, que_ray_feats, *params):
+        eng = run.eng
+        feats = eng.interpolate_feats(que_ray_feats, run.coords[None], h, w, align_corners=False)      # [1,rn,32]
+        mean, var, vis, aw = eng.dist_decoder_rows(feats[0], packed, run.var_bias)
+        vis = vis if run.use_vis else None
+        out = eng.self_hit_prob(run.qconst, run.depth, mean, var, aw, vis)
+        ctx.run, ctx.hw, ctx.shape = run, (h, w), tuple(que_ray_feats.shape)
+        ctx.save_for_backward(feats)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_hit):
+        run, eng = ctx.run, ctx.run.eng
+        feats, = ctx.saved_tensors
+        sd = {k: v.detach() for k, v in run.named_params()}
+        flat, has_vis = eng.flat_pass(sd, 'd.', 'a.')
+        d_feats, d_flat = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], flat, has_vis, run.use_vis,
+                                                     d_hit.contiguous(), var_bias=run.var_bias)
+        d_map = eng.interpolate_feats_backward(d_feats[None], ctx.shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
+        grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
+        return (None, None, None, None, d_map) + tuple(grads[k].clone() for k, _ in run.named_params())

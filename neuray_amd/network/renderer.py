@@ -5,13 +5,15 @@ Same cfg keys (base_cfg, network/renderer.py:25-52), same state_dict names for t
 What differs is underneath: instead of ~700 small PyTorch kernels per ray batch, each pass is three HIP
 launches (point kernel, ray kernel, fine-sampling kernel) through include/neuray_hip.h.
 
-Round-1 scope: inference (is_train=False, or is_train=True without autograd).  Anything the HIP path does not
-implement raises - it never silently switches to an eager implementation.
+Under autograd (training) each pass is a torch.autograd.Function whose backward runs the backward kernels
+(network/autograd.py).  Anything the HIP path does not implement raises - it never silently switches to an eager
+implementation.
 """
 import torch
 import torch.nn as nn
 
 from ..engine import RenderEngine
+from .autograd import PassRun, RenderPassFn, SelfHitFn
 from .aggregate_net import name2agg_net
 from .dist_decoder import name2dist_decoder
 
@@ -72,9 +74,6 @@ class NeuralRayBaseRenderer(nn.Module):
     # ---- render path ---------------------------------------------------------------------------------
     def render_by_depth(self, que_depth, que_imgs_info, ref_imgs_info, is_train, is_fine):
         """network/renderer.py:168-203.  que_depth [1,rn,dn]."""
-        if is_train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("neuray_amd: the HIP render path is forward-only in this round (no backward "
-                                      "kernels yet); call under torch.no_grad()")
         coords = que_imgs_info['coords']
         assert coords.shape[0] == 1 and que_depth.shape[0] == 1, "one query view per call (qn = 1)"
         eng = self.engine(coords.device)
@@ -84,14 +83,27 @@ class NeuralRayBaseRenderer(nn.Module):
             qconst = eng.prepare_query(que_imgs_info)
             que_imgs_info['_neuray_qconst'] = qconst
         packed = self._packed_pass(eng, is_fine)
-        res = eng.render_pass(qconst, views, coords[0], que_depth[0], packed,
-                              use_vis=self.dist_decoder.cfg['use_vis'],       # renderer.py:75: always the coarse decoder
-                              var_bias=(self.fine_dist_decoder if is_fine else self.dist_decoder).cfg['bias_val'],
-                              ray_mask_view_num=self.cfg['ray_mask_view_num'], ray_mask_point_num=self.cfg['ray_mask_point_num'],
-                              want_depth=self.cfg['render_depth'])
+        dist = self.fine_dist_decoder if is_fine else self.dist_decoder
+        agg = self.fine_agg_net if is_fine else self.agg_net
+        use_vis = self.dist_decoder.cfg['use_vis']                              # renderer.py:75: always the coarse decoder
+        run = PassRun(eng, qconst, views, coords[0].contiguous(), que_depth[0].detach().contiguous(), dist, agg, use_vis,
+                      dist.cfg['bias_val'], self.cfg['ray_mask_view_num'], self.cfg['ray_mask_point_num'], self.cfg['render_depth'])
+        diff = [p for _, p in run.named_params()] + [ref_imgs_info['ray_feats'], ref_imgs_info['img_feats']]
+        self._grad_pass = torch.is_grad_enabled() and any(t.requires_grad for t in diff)
+        if self._grad_pass:
+            if que_depth.shape[-1] > 64:
+                raise NotImplementedError("neuray_amd: the backward kernels take at most 64 samples per ray and pass "
+                                          "(fine_depth_use_all with 64 + 64 is forward-only)")
+            pix, hitp, rmask, rdepth = RenderPassFn.apply(run, packed, ref_imgs_info['ray_feats'], ref_imgs_info['img_feats'],
+                                                          *[p for _, p in run.named_params()])
+            res = {'pixel': pix, 'hit_prob': hitp, 'ray_mask': rmask, 'render_depth': rdepth}
+        else:
+            res = eng.render_pass(qconst, views, run.coords, run.depth, packed, use_vis=use_vis, var_bias=run.var_bias,
+                                  ray_mask_view_num=self.cfg['ray_mask_view_num'], ray_mask_point_num=self.cfg['ray_mask_point_num'],
+                                  want_depth=self.cfg['render_depth'])
         outputs = {'pixel_colors_nr': res['pixel'][None], 'hit_prob_nr': res['hit_prob'][None]}
         if is_train and self.cfg['use_self_hit_prob']:
-            outputs['hit_prob_self'] = self.predict_self_hit_prob(que_imgs_info, que_depth, is_fine)
+            outputs['hit_prob_self'] = self.predict_self_hit_prob(que_imgs_info, que_depth, is_fine, run, packed)
         if 'imgs' in que_imgs_info:
             outputs['pixel_colors_gt'] = eng.interpolate_feats(que_imgs_info['imgs'], coords, align_corners=True)
         if self.cfg['use_ray_mask']:
@@ -100,11 +112,17 @@ class NeuralRayBaseRenderer(nn.Module):
             outputs['render_depth'] = res['render_depth'][None]
         return outputs
 
-    def predict_self_hit_prob(self, que_imgs_info, que_depth, is_fine):
+    def predict_self_hit_prob(self, que_imgs_info, que_depth, is_fine, run=None, packed=None):
         """network/renderer.py:137-155: decode the query view's own visibility feature along its rays."""
         coords = que_imgs_info['coords']
         eng = self.engine(coords.device)
         _, _, h, w = que_imgs_info['imgs'].shape
+        if run is not None and torch.is_grad_enabled() and (
+                que_imgs_info['ray_feats'].requires_grad or any(p.requires_grad for p in run.dist.parameters())):
+            dec = run.dist
+            srun = PassRun(eng, run.qconst, None, run.coords, run.depth, run.dist, run.agg, dec.cfg['use_vis'], dec.cfg['bias_val'],
+                           0, 0, False)
+            return SelfHitFn.apply(srun, packed, h, w, que_imgs_info['ray_feats'], *[p for _, p in srun.named_params()])[None]
         feats = eng.interpolate_feats(que_imgs_info['ray_feats'], coords, h, w, align_corners=False)      # [1,rn,32]
         dec = self.fine_dist_decoder if is_fine else self.dist_decoder
         mean, var, vis, aw = eng.dist_decoder_rows(feats[0], self._packed_pass(eng, is_fine), dec.cfg['bias_val'])

@@ -8,6 +8,9 @@ emulator) - test infrastructure that the package itself never loads.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (first: the library must resolve libamdhip64 to the HIP runtime PyTorch already loaded -
+#                      loaded before torch it binds the system copy and later launches find "no ROCm-capable device")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NEURAY_HIP_LIB', os.path.join(HERE, 'libneuray_hip.so'))   # env override: A/B debugging only
 

@@ -47,6 +47,10 @@ int neuray_is_device_build(void);
  * network/ibrnet.py:249-293. */
 size_t neuray_packed_pass_floats(void);
 int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_host);
+/* The same packing as a gather, for callers that keep the weights on the device (training: they change every step):
+ * packed[i] = flat[index[i]] * scale[i], index -1 = padding (0); flat = the flat natural layout described at
+ * neuray_render_points_backward.  index_host / scale_host: neuray_packed_pass_floats() entries each. */
+int neuray_pack_pass_index_map(int has_vis_head, int* index_host, float* scale_host);
 
 /* ---- camera constants -------------------------------------------------------------------------------
  * view_const[v] = { H = K[R|t] (12), centre -R^T t (3), -1/near, -1/far, pad }   render_ops.py:94,110

@@ -82,6 +82,7 @@ SYMBOLS = {
     'neuray_is_device_build': (C.c_int, []),
     'neuray_packed_pass_floats': (C.c_size_t, []),
     'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    'neuray_pack_pass_index_map': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_setup_views': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_setup_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_relayout_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

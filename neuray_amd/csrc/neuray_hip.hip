@@ -104,6 +104,12 @@ int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_hos
     return 0;
 }
 
+int neuray_pack_pass_index_map(int has_vis_head, int* index_host, float* scale_host) {
+    if (!index_host || !scale_host) return fail("neuray_pack_pass_index_map: null argument");
+    if (nr::pack_pass_index_map(has_vis_head != 0, index_host, scale_host)) return fail("neuray_pack_pass_index_map: internal error");
+    return 0;
+}
+
 int neuray_setup_views(const float* poses, const float* Ks, const float* depth_range, int n, float* out, void* stream) {
     if (n < 1 || n > NEURAY_MAX_VIEWS) return fail("neuray_setup_views: n=%d outside [1,%d]", n, NEURAY_MAX_VIEWS);
     NR_LAUNCH(nr::view_setup_kernel, dim3(1), dim3(64), 0, stream, poses, Ks, depth_range, n, out);
@@ -275,7 +281,7 @@ size_t neuray_flat_tensor_offset(int t) { return (t < 0 || t > nr::T_COUNT) ? (s
 namespace {
 int points_bwd_grid(int npoints, int vp) {
     const int ppw = 64 / vp;
-    return grid_for(npoints, ppw, 1024);
+    return grid_for(npoints, ppw, 2048);      // 2048 x 222 KB of arena; several waves per SIMD hide the L2 latency
 }
 int pow2_at_least(int n) { int v = 1; while (v < n) v <<= 1; return v; }
 }  // namespace

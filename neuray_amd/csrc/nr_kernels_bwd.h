@@ -321,10 +321,24 @@ __device__ __forceinline__ float bwd_dact(float y, int a) {
     if (a == BA_RELU) return y > 0.0f ? 1.0f : 0.0f;
     return 1.0f;
 }
-// Y[o] = act(b[o] + sum_k W[o*ldw + k] X[k]),  rows of this lane's column
+// Y[o] = act(b[o] + sum_k W[o*ldw + k] X[k]),  rows of this lane's column.  Eight output rows per pass over k: one
+// load of X[k] feeds eight independent FMA chains (the weights are wave-uniform scalar loads).
 __device__ __forceinline__ void bwd_dense(const float* __restrict__ W, int ldw, const float* __restrict__ b, int O, int K,
                                           const float* X, float* Y, int act, int lane) {
-    for (int o = 0; o < O; ++o) {
+    int o = 0;
+    for (; o + 8 <= O; o += 8) {
+        float acc[8];
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < 8; ++j) acc[j] = b ? b[o + j] : 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float x = X[k * 64 + lane];
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(W[(o + j) * ldw + k], x, acc[j]);
+        }
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < 8; ++j) Y[(o + j) * 64 + lane] = bwd_act(acc[j], act);
+    }
+    for (; o < O; ++o) {
         float acc = b ? b[o] : 0.0f;
         for (int k = 0; k < K; ++k) acc = fmaf(W[o * ldw + k], X[k * 64 + lane], acc);
         Y[o * 64 + lane] = bwd_act(acc, act);
@@ -334,10 +348,23 @@ __device__ __forceinline__ void bwd_dense(const float* __restrict__ W, int ldw, 
 __device__ __forceinline__ void bwd_through_act(float* dY, const float* Y, int O, int act, int lane) {
     for (int o = 0; o < O; ++o) dY[o * 64 + lane] *= bwd_dact(Y[o * 64 + lane], act);
 }
-// dX[k] (+)= sum_o W[o*ldw + k] dY[o]
+// dX[k] (+)= sum_o W[o*ldw + k] dY[o]   (eight input rows per pass over o)
 __device__ __forceinline__ void bwd_dense_dx(const float* __restrict__ W, int ldw, int O, int K, const float* dY, float* dX,
                                              bool accumulate, int lane) {
-    for (int k = 0; k < K; ++k) {
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        float acc[8];
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < 8; ++j) acc[j] = accumulate ? dX[(k + j) * 64 + lane] : 0.0f;
+        for (int o = 0; o < O; ++o) {
+            const float d = dY[o * 64 + lane];
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(W[o * ldw + k + j], d, acc[j]);
+        }
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < 8; ++j) dX[(k + j) * 64 + lane] = acc[j];
+    }
+    for (; k < K; ++k) {
         float acc = accumulate ? dX[k * 64 + lane] : 0.0f;
         for (int o = 0; o < O; ++o) acc = fmaf(W[o * ldw + k], dY[o * 64 + lane], acc);
         dX[k * 64 + lane] = acc;
@@ -348,14 +375,20 @@ __device__ __forceinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int 
     __syncthreads();
     for (int idx = lane; idx < O * K; idx += 64) {
         const int o = idx / K, k = idx - o * K;
-        float sacc = 0.0f;
-        for (int l = 0; l < 64; ++l) sacc = fmaf(dY[o * 64 + l], X[k * 64 + l], sacc);
-        atomicAdd(dW + o * ldw + k, sacc);
+        const float4* dy4 = reinterpret_cast<const float4*>(dY + o * 64);
+        const float4* x4 = reinterpret_cast<const float4*>(X + k * 64);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        for (int l = 0; l < 16; ++l) {
+            const float4 a = dy4[l], c = x4[l];
+            s0 = fmaf(a.x, c.x, s0); s1 = fmaf(a.y, c.y, s1); s2 = fmaf(a.z, c.z, s2); s3 = fmaf(a.w, c.w, s3);
+        }
+        atomicAdd(dW + o * ldw + k, (s0 + s1) + (s2 + s3));
     }
     if (db)
         for (int o = lane; o < O; o += 64) {
+            const float4* dy4 = reinterpret_cast<const float4*>(dY + o * 64);
             float sacc = 0.0f;
-            for (int l = 0; l < 64; ++l) sacc += dY[o * 64 + l];
+            for (int l = 0; l < 16; ++l) { const float4 a = dy4[l]; sacc += (a.x + a.y) + (a.z + a.w); }
             atomicAdd(db + o, sacc);
         }
     __syncthreads();

@@ -5,6 +5,8 @@
 
 namespace nr {
 
+static bool g_pack_unscaled = false;     // pack_pass_index_map: pack without the scaled-ELU factors
+
 void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bias, const LayerMaps& maps) {
     const LayerShape s = kShape[layer];
     float* q = dst + quads_offset(layer);
@@ -12,8 +14,8 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
     float* b = dst + bias_offset(layer);
     // scaled-ELU bookkeeping (nr_layout.h): rows x L when this layer's activation is the scaled ELU, columns / L when
     // its input is one; both -> exactly the original weight
-    const double so = kOutScaled[layer] ? kLog2e : 1.0;
-    const double sw = (kOutScaled[layer] == kInScaled[layer]) ? 1.0 : (kOutScaled[layer] ? kLog2e : 1.0 / kLog2e);
+    const double so = g_pack_unscaled ? 1.0 : (kOutScaled[layer] ? kLog2e : 1.0);
+    const double sw = g_pack_unscaled ? 1.0 : ((kOutScaled[layer] == kInScaled[layer]) ? 1.0 : (kOutScaled[layer] ? kLog2e : 1.0 / kLog2e));
     for (int mo = 0; mo < s.mt_out; ++mo) {
         for (int kq = 0; kq < s.kq; ++kq)
             for (int lane = 0; lane < 64; ++lane)
@@ -38,7 +40,7 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
 // vector rows (nr_layout.h kVec): row j of the layer = weight row rows[j], input feature f = column col0 + f of W
 void pack_vec(float* dst, int layer, const float* W, int ldw, const float* bias, const int* rows, int col0, int nfeat) {
     const VecShape v = kVec[layer];
-    const double sw = kInScaled[layer] ? 1.0 / kLog2e : 1.0;      // vector rows are never scaled-ELU outputs
+    const double sw = g_pack_unscaled ? 1.0 : (kInScaled[layer] ? 1.0 / kLog2e : 1.0);      // vector rows are never scaled-ELU outputs
     float* w = dst + vec_offset(layer);
     float* b = dst + vec_bias_offset(layer);
     for (int j = 0; j < v.n; ++j) {
@@ -195,6 +197,30 @@ int pack_pass_weights(const float* const* t, float* dst) {
     std::memcpy(r + RW_LNW, t[T_LN_W], 16 * 4); std::memcpy(r + RW_LNB, t[T_LN_B], 16 * 4);
     std::memcpy(r + RW_OG0W, t[T_OG0_W], 256 * 4); std::memcpy(r + RW_OG0B, t[T_OG0_B], 16 * 4);
     std::memcpy(r + RW_OG2W, t[T_OG2_W], 16 * 4); std::memcpy(r + RW_OG2B, t[T_OG2_B], 4);
+    return 0;
+}
+
+// The packing is a gather with a per-element factor: packed[i] = flat[index[i]] * scale[i] (index -1: padding, 0).
+// Obtained from the packer itself: once on tensors whose elements are their own flat position + 1 (scaling off), once
+// on all-ones tensors (scaling on).
+int pack_pass_index_map(bool has_vis, int* index, float* scale) {
+    std::vector<float> pos(kFlatPassFloats), ones(kFlatPassFloats, 1.0f), tmp(kPackedPassFloats);
+    for (int i = 0; i < kFlatPassFloats; ++i) pos[i] = (float)(i + 1);        // < 2^24: exact
+    const float* tp[T_COUNT];
+    const float* to[T_COUNT];
+    for (int t = 0; t < T_COUNT; ++t) {
+        const bool vis_slot = t >= T_VIS0_W && t <= T_VIS4_B;
+        tp[t] = (vis_slot && !has_vis) ? nullptr : pos.data() + tensor_offset(t);
+        to[t] = (vis_slot && !has_vis) ? nullptr : ones.data() + tensor_offset(t);
+    }
+    g_pack_unscaled = true;
+    int rc = pack_pass_weights(tp, tmp.data());
+    g_pack_unscaled = false;
+    if (rc) return rc;
+    for (int i = 0; i < kPackedPassFloats; ++i) index[i] = (int)tmp[i] - 1;
+    rc = pack_pass_weights(to, tmp.data());
+    if (rc) return rc;
+    for (int i = 0; i < kPackedPassFloats; ++i) scale[i] = index[i] >= 0 ? tmp[i] : 0.0f;
     return 0;
 }
 

@@ -22,4 +22,7 @@ void pack_vec(float* dst, int layer, const float* W, int ldw, const float* bias,
 // Returns 0 on success, non-zero if a required tensor is missing.
 int pack_pass_weights(const float* const* tensors, float* dst);
 
+// packed[i] = flat[index[i]] * scale[i] (flat natural layout, nr_layout.h); index -1 = padding.  kPackedPassFloats entries each.
+int pack_pass_index_map(bool has_vis, int* index, float* scale);
+
 }  // namespace nr

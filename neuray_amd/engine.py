@@ -246,6 +246,34 @@ class RenderEngine:
                                                       vis.data_ptr() if vis is not None else None, self._stream()))
         return (mean.view(*lead, 2), var.view(*lead, 2), vis.view(*lead, 1) if vis is not None else None, aw.view(*lead, 1))
 
+    def flat_pass_device(self, named_params, dist_prefix, agg_prefix):
+        """Flat natural-layout weights from DEVICE tensors without a host round trip (training: weights change every step).
+        named_params: dict key -> tensor.  -> (flat device tensor, has_vis)"""
+        keys = pass_tensor_keys(dist_prefix, agg_prefix)
+        has_vis = (dist_prefix + 'vis_decoder.0.weight') in named_params
+        parts = []
+        for i, k in enumerate(keys):
+            if k in named_params:
+                parts.append(named_params[k].detach().reshape(-1).to(device=self.device, dtype=torch.float32))
+            else:
+                if not ('.vis_decoder.' in k and not has_vis):
+                    raise KeyError("neuray_amd: missing weight %s" % k)
+                n = int(self.lib.neuray_flat_tensor_offset(i + 1)) - int(self.lib.neuray_flat_tensor_offset(i))
+                parts.append(torch.zeros(n, dtype=torch.float32, device=self.device))
+        return torch.cat(parts), has_vis
+
+    def pack_pass_device(self, flat, has_vis):
+        """PackedPass from the flat natural layout, on the device: packed = flat[index] * scale (neuray_pack_pass_index_map)."""
+        cache = self.__dict__.setdefault('_pack_maps', {})
+        if has_vis not in cache:
+            n = int(self.lib.neuray_packed_pass_floats())
+            idx = torch.empty(n, dtype=torch.int32)
+            scale = torch.empty(n, dtype=torch.float32)
+            self._check(self.lib.neuray_pack_pass_index_map(int(has_vis), C.c_void_p(idx.data_ptr()), C.c_void_p(scale.data_ptr())))
+            cache[has_vis] = (idx.clamp(min=0).long().to(self.device), scale.to(self.device))
+        idx, scale = cache[has_vis]
+        return PackedPass(flat[idx] * scale, has_vis)
+
     def flat_pass(self, state_dict, dist_prefix, agg_prefix):
         """Flat natural-layout weights of a pass (include/neuray_hip.h, backward kernels) -> (device tensor, has_vis)."""
         keys = pass_tensor_keys(dist_prefix, agg_prefix)

@@ -18,12 +18,19 @@ class PassRun:
     def state(self):
         return {k: v.detach() for k, v in self.named_params()}
 
+    def device_weights(self):
+        """(flat natural-layout weights, packed weights, has_vis) built on the device from the current parameters"""
+        flat, has_vis = self.eng.flat_pass_device(dict(self.named_params()), 'd.', 'a.')
+        return flat, self.eng.pack_pass_device(flat, has_vis), has_vis
+
 
 class RenderPassFn(torch.autograd.Function):
     """(ray_feats NCHW, img_feats NCHW, *params) -> pixel [rn,3], hit_prob [rn,dn], ray_mask [rn], render_depth [rn]"""
 
     @staticmethod
-    def forward(ctx, run, packed, ray_feats, img_feats, *params):
+    def forward(ctx, run, ray_feats, img_feats, *params):
+        flat, packed, has_vis = run.device_weights()
+        ctx.flat, ctx.has_vis = flat, has_vis
         res = run.eng.render_pass(run.qconst, run.views, run.coords, run.depth, packed, use_vis=run.use_vis,
                                   var_bias=run.var_bias, ray_mask_view_num=run.mask_view_num,
                                   ray_mask_point_num=run.mask_point_num, want_depth=True)
@@ -43,13 +50,12 @@ class RenderPassFn(torch.autograd.Function):
                                                 d_hit.contiguous() if d_hit is not None else None,
                                                 d_depth.contiguous() if d_depth is not None else None)
         sd = run.state()
-        flat, has_vis = eng.flat_pass(sd, 'd.', 'a.')
-        d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, flat, has_vis,
+        d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
                                                         run.use_vis, d_rec, var_bias=run.var_bias)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g
-        return (None, None, d_rf.permute(0, 3, 1, 2).contiguous(), d_if.permute(0, 3, 1, 2).contiguous()) + \
+        return (None, d_rf.permute(0, 3, 1, 2).contiguous(), d_if.permute(0, 3, 1, 2).contiguous()) + \
             tuple(grads[k].clone() for k, _ in run.named_params())
 
 
@@ -57,8 +63,10 @@ class SelfHitFn(torch.autograd.Function):
     """(que ray_feats NCHW [1,32,fh,fw], *dist params) -> hit_prob_self [rn,dn]   (renderer.py:137-155)"""
 
     @staticmethod
-    def forward(ctx, run, packed, h, w, que_ray_feats, *params):
+    def forward(ctx, run, h, w, que_ray_feats, *params):
         eng = run.eng
+        flat, packed, has_vis = run.device_weights()
+        ctx.flat, ctx.has_vis = flat, has_vis
         feats = eng.interpolate_feats(que_ray_feats, run.coords[None], h, w, align_corners=False)      # [1,rn,32]
         mean, var, vis, aw = eng.dist_decoder_rows(feats[0], packed, run.var_bias)
         vis = vis if run.use_vis else None
@@ -72,9 +80,8 @@ class SelfHitFn(torch.autograd.Function):
         run, eng = ctx.run, ctx.run.eng
         feats, = ctx.saved_tensors
         sd = {k: v.detach() for k, v in run.named_params()}
-        flat, has_vis = eng.flat_pass(sd, 'd.', 'a.')
-        d_feats, d_flat = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], flat, has_vis, run.use_vis,
+        d_feats, d_flat = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], ctx.flat, ctx.has_vis, run.use_vis,
                                                      d_hit.contiguous(), var_bias=run.var_bias)
         d_map = eng.interpolate_feats_backward(d_feats[None], ctx.shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
-        return (None, None, None, None, d_map) + tuple(grads[k].clone() for k, _ in run.named_params())
+        return (None, None, None, d_map) + tuple(grads[k].clone() for k, _ in run.named_params())

@@ -82,7 +82,7 @@ class NeuralRayBaseRenderer(nn.Module):
         if qconst is None:
             qconst = eng.prepare_query(que_imgs_info)
             que_imgs_info['_neuray_qconst'] = qconst
-        packed = self._packed_pass(eng, is_fine)
+        packed = None
         dist = self.fine_dist_decoder if is_fine else self.dist_decoder
         agg = self.fine_agg_net if is_fine else self.agg_net
         use_vis = self.dist_decoder.cfg['use_vis']                              # renderer.py:75: always the coarse decoder
@@ -94,10 +94,11 @@ class NeuralRayBaseRenderer(nn.Module):
             if que_depth.shape[-1] > 64:
                 raise NotImplementedError("neuray_amd: the backward kernels take at most 64 samples per ray and pass "
                                           "(fine_depth_use_all with 64 + 64 is forward-only)")
-            pix, hitp, rmask, rdepth = RenderPassFn.apply(run, packed, ref_imgs_info['ray_feats'], ref_imgs_info['img_feats'],
+            pix, hitp, rmask, rdepth = RenderPassFn.apply(run, ref_imgs_info['ray_feats'], ref_imgs_info['img_feats'],
                                                           *[p for _, p in run.named_params()])
             res = {'pixel': pix, 'hit_prob': hitp, 'ray_mask': rmask, 'render_depth': rdepth}
         else:
+            packed = self._packed_pass(eng, is_fine)
             res = eng.render_pass(qconst, views, run.coords, run.depth, packed, use_vis=use_vis, var_bias=run.var_bias,
                                   ray_mask_view_num=self.cfg['ray_mask_view_num'], ray_mask_point_num=self.cfg['ray_mask_point_num'],
                                   want_depth=self.cfg['render_depth'])
@@ -122,10 +123,11 @@ class NeuralRayBaseRenderer(nn.Module):
             dec = run.dist
             srun = PassRun(eng, run.qconst, None, run.coords, run.depth, run.dist, run.agg, dec.cfg['use_vis'], dec.cfg['bias_val'],
                            0, 0, False)
-            return SelfHitFn.apply(srun, packed, h, w, que_imgs_info['ray_feats'], *[p for _, p in srun.named_params()])[None]
+            return SelfHitFn.apply(srun, h, w, que_imgs_info['ray_feats'], *[p for _, p in srun.named_params()])[None]
         feats = eng.interpolate_feats(que_imgs_info['ray_feats'], coords, h, w, align_corners=False)      # [1,rn,32]
         dec = self.fine_dist_decoder if is_fine else self.dist_decoder
-        mean, var, vis, aw = eng.dist_decoder_rows(feats[0], self._packed_pass(eng, is_fine), dec.cfg['bias_val'])
+        mean, var, vis, aw = eng.dist_decoder_rows(feats[0], packed if packed is not None else self._packed_pass(eng, is_fine),
+                                                   dec.cfg['bias_val'])
         vis = vis if dec.cfg['use_vis'] else None
         return eng.self_hit_prob(que_imgs_info['_neuray_qconst'], que_depth[0], mean, var, aw, vis)[None]
 

@@ -321,74 +321,99 @@ __device__ __forceinline__ float bwd_dact(float y, int a) {
     if (a == BA_RELU) return y > 0.0f ? 1.0f : 0.0f;
     return 1.0f;
 }
-// Y[o] = act(b[o] + sum_k W[o*ldw + k] X[k]),  rows of this lane's column.  Eight output rows per pass over k: one
-// load of X[k] feeds eight independent FMA chains (the weights are wave-uniform scalar loads).
+// C[r][n] = act(init + sum_q A(r, q) Bm[q][n]) over the wave's 64 columns n, with A(r, q) = W[r*rs + q*qs] taken from
+// the natural-layout weights: fp32 MFMA 16x16x4 per (16 rows, 16 columns) tile, Q/4 K-steps.  init = C (accumulate),
+// the bias, or 0.  A operand: lane (m, kk) -> A(r0+m, 4s+kk); B operand: lane (n, kk) -> Bm[4s+kk][n0+n];
+// D: lane (c, g) -> C[r0+4g+r][n0+c].  Reads and writes other lanes' columns: barriers on entry and exit.
+// (not inlined: one copy with run-time loops; inlined + unrolled at ~90 call sites the kernel grew to 70 k instructions
+// with 3,300 spilled registers)
+__device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs, int R, int Q, const float* __restrict__ Bm, float* __restrict__ C,
+                                       const float* __restrict__ bias, int act, bool accumulate, int lane) {
+    __syncthreads();
+    const int m = lane & 15, kk = lane >> 4;
+    const int nsteps = (Q + 3) >> 2;
+    for (int r0 = 0; r0 < R; r0 += 16) {
+        const bool aok = r0 + m < R;
+        for (int n0 = 0; n0 < 64; n0 += 16) {
+            v4f acc;
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 4 * kk + r;
+                acc[r] = row < R ? (accumulate ? C[row * 64 + n0 + m] : (bias ? bias[row] : 0.0f)) : 0.0f;
+            }
+            for (int s0 = 0; s0 < nsteps; s0 += 8) {          // 16 loads in flight, then 8 MFMAs
+                float a[8], b[8];
+                NR_PRAGMA_UNROLL
+                for (int u = 0; u < 8; ++u) {
+                    const int q = 4 * (s0 + u) + kk;
+                    a[u] = (aok && q < Q) ? W[(r0 + m) * rs + q * qs] : 0.0f;
+                    b[u] = q < Q ? Bm[q * 64 + n0 + m] : 0.0f;
+                }
+                NR_PRAGMA_UNROLL
+                for (int u = 0; u < 8; ++u) acc = nr_mfma16(a[u], b[u], acc);
+            }
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 4 * kk + r;
+                if (row < R) C[row * 64 + n0 + m] = bwd_act(acc[r], act);
+            }
+        }
+    }
+    __syncthreads();
+}
+// Y[o] = act(b[o] + sum_k W[o*ldw + k] X[k])
 __device__ __forceinline__ void bwd_dense(const float* __restrict__ W, int ldw, const float* __restrict__ b, int O, int K,
                                           const float* X, float* Y, int act, int lane) {
-    int o = 0;
-    for (; o + 8 <= O; o += 8) {
-        float acc[8];
-        NR_PRAGMA_UNROLL
-        for (int j = 0; j < 8; ++j) acc[j] = b ? b[o + j] : 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float x = X[k * 64 + lane];
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(W[(o + j) * ldw + k], x, acc[j]);
-        }
-        NR_PRAGMA_UNROLL
-        for (int j = 0; j < 8; ++j) Y[(o + j) * 64 + lane] = bwd_act(acc[j], act);
-    }
-    for (; o < O; ++o) {
-        float acc = b ? b[o] : 0.0f;
-        for (int k = 0; k < K; ++k) acc = fmaf(W[o * ldw + k], X[k * 64 + lane], acc);
-        Y[o * 64 + lane] = bwd_act(acc, act);
-    }
+    bwd_mm(W, ldw, 1, O, K, X, Y, b, act, false, lane);
 }
 // dY[o] *= act'(Y[o])
-__device__ __forceinline__ void bwd_through_act(float* dY, const float* Y, int O, int act, int lane) {
-    for (int o = 0; o < O; ++o) dY[o * 64 + lane] *= bwd_dact(Y[o * 64 + lane], act);
+__device__ __noinline__ void bwd_through_act(float* __restrict__ dY, const float* __restrict__ Y, int O, int act, int lane) {
+    int o = 0;
+    for (; o + 8 <= O; o += 8) {        // eight rows per batch: the loads are issued together
+        float d[8], y[8];
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < 8; ++j) { d[j] = dY[(o + j) * 64 + lane]; y[j] = Y[(o + j) * 64 + lane]; }
+        NR_PRAGMA_UNROLL
+        for (int j = 0; j < 8; ++j) dY[(o + j) * 64 + lane] = d[j] * bwd_dact(y[j], act);
+    }
+    for (; o < O; ++o) dY[o * 64 + lane] *= bwd_dact(Y[o * 64 + lane], act);
 }
-// dX[k] (+)= sum_o W[o*ldw + k] dY[o]   (eight input rows per pass over o)
+// dX[k] (+)= sum_o W[o*ldw + k] dY[o]
 __device__ __forceinline__ void bwd_dense_dx(const float* __restrict__ W, int ldw, int O, int K, const float* dY, float* dX,
                                              bool accumulate, int lane) {
-    int k = 0;
-    for (; k + 8 <= K; k += 8) {
-        float acc[8];
-        NR_PRAGMA_UNROLL
-        for (int j = 0; j < 8; ++j) acc[j] = accumulate ? dX[(k + j) * 64 + lane] : 0.0f;
-        for (int o = 0; o < O; ++o) {
-            const float d = dY[o * 64 + lane];
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(W[o * ldw + k + j], d, acc[j]);
-        }
-        NR_PRAGMA_UNROLL
-        for (int j = 0; j < 8; ++j) dX[(k + j) * 64 + lane] = acc[j];
-    }
-    for (; k < K; ++k) {
-        float acc = accumulate ? dX[k * 64 + lane] : 0.0f;
-        for (int o = 0; o < O; ++o) acc = fmaf(W[o * ldw + k], dY[o * 64 + lane], acc);
-        dX[k * 64 + lane] = acc;
-    }
+    bwd_mm(W, 1, ldw, K, O, dY, dX, nullptr, BA_NONE, accumulate, lane);
 }
-// dW[o*ldw + k] += sum_lanes dY[o] X[k],  db[o] += sum_lanes dY[o]   (reads the other lanes' columns)
-__device__ __forceinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, int K, const float* dY, const float* X, int lane) {
+// dW[o*ldw + k] += sum_lanes dY[o][lane] X[k][lane],  db[o] += sum_lanes dY[o][lane]: a [O x 64] x [64 x K] contraction
+// over the wave's 64 (point, view) columns -> fp32 MFMA 16x16x4 per 16 x 16 tile of dW, 16 K-steps of 4 columns.
+// A[m][kk] = dY[o0 + m][4 s + kk],  B[kk][n] = X[k0 + n][4 s + kk]; D: lane (c, g) holds dW[o0 + 4 g + r][k0 + c].
+__device__ __noinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, int K, const float* dY, const float* X, int lane) {
     __syncthreads();
-    for (int idx = lane; idx < O * K; idx += 64) {
-        const int o = idx / K, k = idx - o * K;
-        const float4* dy4 = reinterpret_cast<const float4*>(dY + o * 64);
-        const float4* x4 = reinterpret_cast<const float4*>(X + k * 64);
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        for (int l = 0; l < 16; ++l) {
-            const float4 a = dy4[l], c = x4[l];
-            s0 = fmaf(a.x, c.x, s0); s1 = fmaf(a.y, c.y, s1); s2 = fmaf(a.z, c.z, s2); s3 = fmaf(a.w, c.w, s3);
+    const int m = lane & 15, kk = lane >> 4;
+    for (int o0 = 0; o0 < O; o0 += 16) {
+        float a[16];
+        const bool aok = o0 + m < O;
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < 16; ++s) a[s] = aok ? dY[(o0 + m) * 64 + 4 * s + kk] : 0.0f;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            const bool bok = k0 + m < K;
+            v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < 16; ++s) {
+                const float b = bok ? X[(k0 + m) * 64 + 4 * s + kk] : 0.0f;
+                acc = nr_mfma16(a[s], b, acc);
+            }
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + 4 * kk + r, k = k0 + m;
+                if (o < O && k < K) atomicAdd(dW + o * ldw + k, acc[r]);
+            }
         }
-        atomicAdd(dW + o * ldw + k, (s0 + s1) + (s2 + s3));
     }
     if (db)
         for (int o = lane; o < O; o += 64) {
             const float4* dy4 = reinterpret_cast<const float4*>(dY + o * 64);
             float sacc = 0.0f;
-            for (int l = 0; l < 16; ++l) { const float4 a = dy4[l]; sacc += (a.x + a.y) + (a.z + a.w); }
+            for (int l = 0; l < 16; ++l) { const float4 a4 = dy4[l]; sacc += (a4.x + a4.y) + (a4.z + a4.w); }
             atomicAdd(db + o, sacc);
         }
     __syncthreads();
@@ -406,7 +431,7 @@ __device__ __forceinline__ float bwd_sigmoid(float x) { return 1.0f / (1.0f + ex
 __device__ __forceinline__ float bwd_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // scatter-add of a gathered-feature gradient (32 channels) into the NHWC gradient map: d map[tap] += wt * g
-__device__ __forceinline__ void bwd_scatter32(float* dmap, size_t view_off, const Taps& t, float scale, const float* g, int lane) {
+__device__ __noinline__ void bwd_scatter32(float* dmap, size_t view_off, const Taps& t, float scale, const float* g, int lane) {
     if (scale == 0.0f) return;
     const int offs[4] = {t.o00, t.o10, t.o01, t.o11};
     const float wts[4] = {t.w00, t.w10, t.w01, t.w11};
@@ -422,7 +447,7 @@ __device__ __forceinline__ void bwd_scatter32(float* dmap, size_t view_off, cons
 // backward of the output non-linearities and the three (four) 32->32->32->out MLPs of the dist decoder
 // (dist_decoder.py:64-97): gradients of mu (softplus), s (softplus + bias), aw / nu (sigmoid) -> weight gradients and
 // DFR += d f_ray.  FR: the 32 input rows; S0..S3: 64-row scratch areas.
-__device__ __forceinline__ void bwd_dist_heads(const float* flat, float* d_flat, bool has_vis, float var_bias,
+__device__ __noinline__ void bwd_dist_heads(const float* flat, float* d_flat, bool has_vis, float var_bias,
                                                const float* FR, float* S0, float* S1, float* S2, float* S3, float* DFR,
                                                float mu0, float mu1, float sd0, float sd1, float aw, float nu,
                                                float dmu0, float dmu1, float dsd0, float dsd1, float daw, float dnu, int lane) {
@@ -451,7 +476,7 @@ __device__ __forceinline__ void bwd_dist_heads(const float* flat, float* d_flat,
 }
 
 // forward of the dist decoder heads on the 32 rows FR (outputs only)
-__device__ __forceinline__ void bwd_dist_heads_fwd(const float* flat, bool has_vis, float var_bias, const float* FR, float* S0,
+__device__ __noinline__ void bwd_dist_heads_fwd(const float* flat, bool has_vis, float var_bias, const float* FR, float* S0,
                                                    float* S1, float* S2, float& mu0, float& mu1, float& sd0, float& sd1,
                                                    float& aw, float& nu, int lane) {
     const float* f = flat;
@@ -500,7 +525,7 @@ __device__ __forceinline__ void bwd_prob(float nearv, float farv, float mu0, flo
 #define FW(T) (p.flat + tensor_offset(T))
 #define DW(T) (p.d_flat + tensor_offset(T))
 
-__global__ void __launch_bounds__(64) points_backward_kernel(PointBwdParams p) {
+__global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p) {
     const int lane = threadIdx.x & 63;
     float* A = p.workspace + (size_t)blockIdx.x * kBwdRows * 64;
     const int vp = p.vp, ppw = 64 / vp;
@@ -510,12 +535,15 @@ __global__ void __launch_bounds__(64) points_backward_kernel(PointBwdParams p) {
     const float qnearp = qc[24], qinv = qc[27];
     const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
     const bool has_vis = p.has_vis_head != 0, use_vis = has_vis && (p.use_vis != 0);
-    float* FR = A + BR_FR * 64; float* FI = A + BR_FI * 64; float* RGB = A + BR_RGB * 64; float* DL = A + BR_DL * 64;
-    float* GL = A + BR_GL * 64; float* GP = A + BR_GP * 64; float* E = A + BR_E * 64;
-    float* X = A + BR_X * 64; float* X2 = A + BR_X2 * 64;
-    float* DGL = A + BR_DGL * 64; float* DGP = A + BR_DGP * 64; float* DE = A + BR_DE * 64;
-    float* DFR = A + BR_DFR * 64; float* DX = A + BR_DX * 64;
-    float* S0 = A + BR_S0 * 64; float* S1 = A + BR_S1 * 64; float* S2 = A + BR_S2 * 64; float* S3 = A + BR_S3 * 64;
+    // (distinct row ranges of the arena: __restrict__ lets the per-row loops overlap their loads and stores)
+    float* __restrict__ FR = A + BR_FR * 64; float* __restrict__ FI = A + BR_FI * 64; float* __restrict__ RGB = A + BR_RGB * 64;
+    float* __restrict__ DL = A + BR_DL * 64;
+    float* __restrict__ GL = A + BR_GL * 64; float* __restrict__ GP = A + BR_GP * 64; float* __restrict__ E = A + BR_E * 64;
+    float* __restrict__ X = A + BR_X * 64; float* __restrict__ X2 = A + BR_X2 * 64;
+    float* __restrict__ DGL = A + BR_DGL * 64; float* __restrict__ DGP = A + BR_DGP * 64; float* __restrict__ DE = A + BR_DE * 64;
+    float* __restrict__ DFR = A + BR_DFR * 64; float* __restrict__ DX = A + BR_DX * 64;
+    float* __restrict__ S0 = A + BR_S0 * 64; float* __restrict__ S1 = A + BR_S1 * 64; float* __restrict__ S2 = A + BR_S2 * 64;
+    float* __restrict__ S3 = A + BR_S3 * 64;
 
     for (int base = blockIdx.x * ppw; base < npts; base += gridDim.x * ppw) {
         __syncthreads();

@@ -39,6 +39,7 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ inline __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 #define __shared__ static thread_local

@@ -196,3 +196,21 @@ def test_training_gradients_match_reference_autograd(backend):
     close(ref['ray_feats'].grad.cpu().numpy(), z['grad.ref.ray_feats'], 'ref.ray_feats')
     close(ref['img_feats'].grad.cpu().numpy(), z['grad.ref.img_feats'], 'ref.img_feats')
     close(que['ray_feats'].grad.cpu().numpy(), z['grad.que.ray_feats'], 'que.ray_feats')
+
+
+@pytest.mark.parametrize('vis_head', [False, True])
+def test_device_packing_matches_host_packer(vis_head):
+    """Training packs the forward weights on the device as packed = flat[index] * scale (neuray_pack_pass_index_map);
+    that must be the host packer's result up to the rounding of one fp32 multiply."""
+    from neuray_amd.engine import RenderEngine
+    eng = RenderEngine('cpu', _test_lib=emu_lib())
+    w = load_weights(vis_head)
+    host = eng.pack_pass(w, 'dist_decoder.', 'agg_net.').dev
+    flat, hv = eng.flat_pass_device({k: torch.from_numpy(v) for k, v in w.items()}, 'dist_decoder.', 'agg_net.')
+    assert hv == vis_head
+    dev = eng.pack_pass_device(flat, hv).dev
+    assert torch.equal(host != 0, dev != 0)
+    rel = ((host - dev).abs() / host.abs().clamp_min(1e-30))[host != 0]
+    assert float(rel.max()) <= 1.2e-7
+    flat_h, _ = eng.flat_pass(w, 'dist_decoder.', 'agg_net.')
+    assert torch.equal(flat_h, flat)

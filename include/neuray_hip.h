@@ -186,6 +186,12 @@ int neuray_self_hit_prob_backward(const float* query_const_dev, const float* dep
                                   const float* flat_weights_dev, int has_vis_head, int use_vis, float var_bias,
                                   const float* d_hit_dev, int rn, int dn, float* d_feats_dev, float* d_flat_weights_dev,
                                   float* workspace_dev, void* stream);
+/* ---- backward of neuray_dist_decoder_rows: gradients w.r.t. the decoder outputs (any of d_mean [n][2], d_var [n][2],
+ * d_aw [n], d_vis [n] may be NULL) -> d_feats [n][32]; d_flat (flat natural layout) ACCUMULATED.  workspace:
+ * neuray_self_hit_backward_workspace_floats(n) floats. */
+int neuray_dist_decoder_rows_backward(const float* feats_dev, const float* flat_weights_dev, int n, int has_vis_head, float var_bias,
+                                      const float* d_mean_dev, const float* d_var_dev, const float* d_aw_dev, const float* d_vis_dev,
+                                      float* d_feats_dev, float* d_flat_weights_dev, float* workspace_dev, void* stream);
 /* ---- backward of neuray_interpolate_feats: d_feats [b][c][fh][fw] += bilinear weights * d_out [b][n][c] (accumulated). */
 int neuray_interpolate_feats_backward(const float* d_out_dev, const float* points_dev, const float* mask_dev, int b, int n, int c,
                                       int fh, int fw, int h_full, int w_full, int align_corners, float* d_feats_dev, void* stream);

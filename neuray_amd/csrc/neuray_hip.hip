@@ -328,6 +328,18 @@ int neuray_self_hit_prob_backward(const float* qc, const float* depth, const flo
     return check_launch("neuray_self_hit_prob_backward");
 }
 
+int neuray_dist_decoder_rows_backward(const float* feats, const float* flat, int n, int has_vis_head, float var_bias,
+                                      const float* d_mean, const float* d_var, const float* d_aw, const float* d_vis,
+                                      float* d_feats, float* d_flat, float* workspace, void* stream) {
+    if (!feats || !flat || !d_feats || !d_flat || !workspace) return fail("neuray_dist_decoder_rows_backward: null argument");
+    if (n < 1) return fail("neuray_dist_decoder_rows_backward: n=%d", n);
+    nr::RowsBwdParams p;
+    p.feats = feats; p.flat = flat; p.d_mean = d_mean; p.d_var = d_var; p.d_aw = d_aw; p.d_vis = d_vis; p.d_feats = d_feats;
+    p.d_flat = d_flat; p.workspace = workspace; p.n = n; p.has_vis_head = has_vis_head; p.var_bias = var_bias;
+    NR_LAUNCH(nr::decoder_rows_backward_kernel, dim3(grid_for(n, 64, 1024)), dim3(64), 0, stream, p);
+    return check_launch("neuray_dist_decoder_rows_backward");
+}
+
 int neuray_interpolate_feats_backward(const float* d_out, const float* points, const float* mask, int b, int n, int c, int fh,
                                       int fw, int h_full, int w_full, int align_corners, float* d_feats, void* stream) {
     if (!d_out || !points || !d_feats) return fail("neuray_interpolate_feats_backward: null argument");

@@ -525,7 +525,7 @@ __device__ __forceinline__ void bwd_prob(float nearv, float farv, float mu0, flo
 #define FW(T) (p.flat + tensor_offset(T))
 #define DW(T) (p.d_flat + tensor_offset(T))
 
-__global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p) {
+__global__ void __launch_bounds__(64, 2) points_backward_kernel(PointBwdParams p) {
     const int lane = threadIdx.x & 63;
     float* A = p.workspace + (size_t)blockIdx.x * kBwdRows * 64;
     const int vp = p.vp, ppw = 64 / vp;
@@ -928,6 +928,44 @@ __global__ void __launch_bounds__(64) self_hit_backward_kernel(SelfHitBwdParams 
                        dmu0, dmu1, dsd0, dsd1, daw, dnu, lane);
         if (valid)
             for (int c = 0; c < 32; ++c) p.d_feats[(size_t)ray * 32 + c] = DFR[c * 64 + lane];
+    }
+}
+
+
+// backward of decoder_rows_kernel (dist decoder on arbitrary rows, dist_decoder.py:99-107,146-151): lane = row.
+// d_mean [n][2], d_var [n][2], d_aw [n], d_vis [n] (any may be null) are the gradients w.r.t. the decoder OUTPUTS.
+struct RowsBwdParams {
+    const float* feats;       // [n][32]
+    const float* flat;
+    const float* d_mean; const float* d_var; const float* d_aw; const float* d_vis;
+    float* d_feats;           // [n][32]
+    float* d_flat;            // accumulated
+    float* workspace;         // [gridDim.x][kSelfBwdRows][64]
+    int n, has_vis_head;
+    float var_bias;
+};
+
+__global__ void __launch_bounds__(64) decoder_rows_backward_kernel(RowsBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    float* A = p.workspace + (size_t)blockIdx.x * kSelfBwdRows * 64;
+    float* FR = A; float* S0 = A + 32 * 64; float* S1 = S0 + 64 * 64; float* S2 = S1 + 64 * 64; float* S3 = S2 + 64 * 64;
+    float* DFR = S3 + 64 * 64;
+    const bool has_vis = p.has_vis_head != 0;
+    for (int base = blockIdx.x * 64; base < p.n; base += gridDim.x * 64) {
+        __syncthreads();
+        const bool valid = base + lane < p.n;
+        const int row = valid ? base + lane : p.n - 1;
+        for (int c = 0; c < 32; ++c) { FR[c * 64 + lane] = p.feats[(size_t)row * 32 + c]; DFR[c * 64 + lane] = 0.0f; }
+        float mu0, mu1, sd0, sd1, aw, nu;
+        bwd_dist_heads_fwd(p.flat, has_vis, p.var_bias, FR, S0, S1, S2, mu0, mu1, sd0, sd1, aw, nu, lane);
+        const float g = valid ? 1.0f : 0.0f;
+        const float dmu0 = p.d_mean ? g * p.d_mean[2 * row] : 0.0f, dmu1 = p.d_mean ? g * p.d_mean[2 * row + 1] : 0.0f;
+        const float dsd0 = p.d_var ? g * p.d_var[2 * row] : 0.0f, dsd1 = p.d_var ? g * p.d_var[2 * row + 1] : 0.0f;
+        const float daw = p.d_aw ? g * p.d_aw[row] : 0.0f, dnu = (p.d_vis && has_vis) ? g * p.d_vis[row] : 0.0f;
+        bwd_dist_heads(p.flat, p.d_flat, has_vis, p.var_bias, FR, S0, S1, S2, S3, DFR, mu0, mu1, sd0, sd1, aw, nu,
+                       dmu0, dmu1, dsd0, dsd1, daw, dnu, lane);
+        if (valid)
+            for (int c = 0; c < 32; ++c) p.d_feats[(size_t)row * 32 + c] = DFR[c * 64 + lane];
     }
 }
 

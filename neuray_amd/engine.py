@@ -246,7 +246,7 @@ class RenderEngine:
                                                       vis.data_ptr() if vis is not None else None, self._stream()))
         return (mean.view(*lead, 2), var.view(*lead, 2), vis.view(*lead, 1) if vis is not None else None, aw.view(*lead, 1))
 
-    def flat_pass_device(self, named_params, dist_prefix, agg_prefix):
+    def flat_pass_device(self, named_params, dist_prefix, agg_prefix, allow_missing_agg=False):
         """Flat natural-layout weights from DEVICE tensors without a host round trip (training: weights change every step).
         named_params: dict key -> tensor.  -> (flat device tensor, has_vis)"""
         keys = pass_tensor_keys(dist_prefix, agg_prefix)
@@ -256,7 +256,7 @@ class RenderEngine:
             if k in named_params:
                 parts.append(named_params[k].detach().reshape(-1).to(device=self.device, dtype=torch.float32))
             else:
-                if not ('.vis_decoder.' in k and not has_vis):
+                if not (('.vis_decoder.' in k and not has_vis) or (allow_missing_agg and k.startswith(agg_prefix))):
                     raise KeyError("neuray_amd: missing weight %s" % k)
                 n = int(self.lib.neuray_flat_tensor_offset(i + 1)) - int(self.lib.neuray_flat_tensor_offset(i))
                 parts.append(torch.zeros(n, dtype=torch.float32, device=self.device))
@@ -327,6 +327,20 @@ class RenderEngine:
         self._check(self.lib.neuray_self_hit_prob_backward(qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), flat.data_ptr(),
                                                            int(has_vis_head), int(bool(use_vis)), float(var_bias), d_hit.data_ptr(),
                                                            rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), ws.data_ptr(), self._stream()))
+        return d_feats, d_flat
+
+    def dist_decoder_rows_backward(self, feats, flat, has_vis_head, var_bias, d_mean=None, d_var=None, d_aw=None, d_vis=None):
+        """Backward of dist_decoder_rows: -> (d_feats [n,32], d_flat)"""
+        feats = self._f32(feats).reshape(-1, 32)
+        n = feats.shape[0]
+        g = [self._f32(t).reshape(-1) if t is not None else None for t in (d_mean, d_var, d_aw, d_vis)]
+        d_feats = self.empty(n, 32)
+        d_flat = torch.zeros_like(flat)
+        ws = self.empty(int(self.lib.neuray_self_hit_backward_workspace_floats(n)))
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self._check(self.lib.neuray_dist_decoder_rows_backward(feats.data_ptr(), flat.data_ptr(), n, int(has_vis_head), float(var_bias),
+                                                               ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), d_feats.data_ptr(),
+                                                               d_flat.data_ptr(), ws.data_ptr(), self._stream()))
         return d_feats, d_flat
 
     def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None):

@@ -214,3 +214,35 @@ def test_device_packing_matches_host_packer(vis_head):
     assert float(rel.max()) <= 1.2e-7
     flat_h, _ = eng.flat_pass(w, 'dist_decoder.', 'agg_net.')
     assert torch.equal(flat_h, flat)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('use_vis', [False, True])
+def test_dist_decoder_module_forward_backward(use_vis, backend):
+    """The mirror MixtureLogisticsDistDecoder called on its own (predict_mean for the Gen renderer's depth loss,
+    renderer.py:280-316): HIP rows kernel + its backward against the module's own nn.Sequential heads in PyTorch."""
+    from neuray_amd.network.dist_decoder import MixtureLogisticsDistDecoder
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    torch.manual_seed(5)
+    dec = MixtureLogisticsDistDecoder({'use_vis': use_vis})
+    if backend == 'emu':
+        dec._engine_test_lib = emu_lib()
+    dec = dec.to(dev)
+    feats = torch.randn(3, 37, 32, device=dev, requires_grad=True)
+    wm, wv, wa = torch.randn(3, 37, 2, device=dev), torch.randn(3, 37, 2, device=dev), torch.randn(3, 37, 1, device=dev)
+    mean, var, vis, aw = dec(feats)
+    loss = (mean * wm).sum() + (var * wv).sum() + (aw * wa).sum() + (vis.sum() * 0.5 if use_vis else 0.0) + dec.predict_mean(feats)[..., 0].sum()
+    loss.backward()
+    got = {k: p_.grad.clone() for k, p_ in dec.named_parameters()}
+    got_f = feats.grad.clone()
+    dec.zero_grad(); feats.grad = None
+    mean_t, var_t, aw_t = dec.mean_decoder(feats), dec.var_decoder(feats), dec.aw_decoder(feats)
+    loss_t = (mean_t * wm).sum() + (var_t * wv).sum() + (aw_t * wa).sum() + mean_t[..., 0].sum()
+    if use_vis:
+        loss_t = loss_t + dec.vis_decoder(feats).sum() * 0.5
+    loss_t.backward()
+    assert torch.allclose(mean, mean_t, atol=1e-5) and torch.allclose(var, var_t, atol=1e-5) and torch.allclose(aw, aw_t, atol=1e-5)
+    for k, p_ in dec.named_parameters():
+        scale = max(1e-3, float(p_.grad.abs().max()))
+        assert float((got[k] - p_.grad).abs().max()) <= 2e-3 * scale, k
+    assert float((got_f - feats.grad).abs().max()) <= 2e-3 * max(1e-3, float(feats.grad.abs().max()))

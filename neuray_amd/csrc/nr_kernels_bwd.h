@@ -307,7 +307,8 @@ constexpr int BR_X = 278, BR_X2 = 310;
 constexpr int BR_DGL = 342, BR_DGP = 482, BR_DE = 517;               // gradient of the base_fc.0 input, same order
 constexpr int BR_DFR = 549, BR_DX = 581;
 constexpr int BR_S0 = 613, BR_S1 = 677, BR_S2 = 741, BR_S3 = 805;    // 64-row scratch areas
-constexpr int kBwdRows = 869;
+constexpr int BR_SC = 869;                                           // 32 rows of per-lane scalars
+constexpr int kBwdRows = 901;
 
 enum BwdAct { BA_NONE, BA_ELU, BA_RELU };
 __device__ __forceinline__ float bwd_act(float x, int a) {
@@ -334,30 +335,35 @@ __device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs,
     const int nsteps = (Q + 3) >> 2;
     for (int r0 = 0; r0 < R; r0 += 16) {
         const bool aok = r0 + m < R;
-        for (int n0 = 0; n0 < 64; n0 += 16) {
-            v4f acc;
+        v4f acc[4];                                        // the four 16-column tiles of the 64 columns
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < 4; ++t)
             NR_PRAGMA_UNROLL
             for (int r = 0; r < 4; ++r) {
                 const int row = r0 + 4 * kk + r;
-                acc[r] = row < R ? (accumulate ? C[row * 64 + n0 + m] : (bias ? bias[row] : 0.0f)) : 0.0f;
+                acc[t][r] = row < R ? (accumulate ? C[row * 64 + 16 * t + m] : (bias ? bias[row] : 0.0f)) : 0.0f;
             }
-            for (int s0 = 0; s0 < nsteps; s0 += 8) {          // 16 loads in flight, then 8 MFMAs
-                float a[8], b[8];
+        for (int s0 = 0; s0 < nsteps; s0 += 8) {          // 8 A + 32 B loads in flight, then 32 MFMAs
+            float a[8], b[4][8];
+            NR_PRAGMA_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int q = 4 * (s0 + u) + kk;
+                a[u] = (aok && q < Q) ? W[(r0 + m) * rs + q * qs] : 0.0f;
                 NR_PRAGMA_UNROLL
-                for (int u = 0; u < 8; ++u) {
-                    const int q = 4 * (s0 + u) + kk;
-                    a[u] = (aok && q < Q) ? W[(r0 + m) * rs + q * qs] : 0.0f;
-                    b[u] = q < Q ? Bm[q * 64 + n0 + m] : 0.0f;
-                }
-                NR_PRAGMA_UNROLL
-                for (int u = 0; u < 8; ++u) acc = nr_mfma16(a[u], b[u], acc);
+                for (int t = 0; t < 4; ++t) b[t][u] = q < Q ? Bm[q * 64 + 16 * t + m] : 0.0f;
             }
             NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 4 * kk + r;
-                if (row < R) C[row * 64 + n0 + m] = bwd_act(acc[r], act);
-            }
+            for (int u = 0; u < 8; ++u)
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < 4; ++t) acc[t] = nr_mfma16(a[u], b[t][u], acc[t]);
         }
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < 4; ++t)
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + 4 * kk + r;
+                if (row < R) C[row * 64 + 16 * t + m] = bwd_act(acc[t][r], act);
+            }
     }
     __syncthreads();
 }
@@ -394,18 +400,24 @@ __device__ __noinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, 
         const bool aok = o0 + m < O;
         NR_PRAGMA_UNROLL
         for (int s = 0; s < 16; ++s) a[s] = aok ? dY[(o0 + m) * 64 + 4 * s + kk] : 0.0f;
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            const bool bok = k0 + m < K;
-            v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
+        for (int k0 = 0; k0 < K; k0 += 32) {               // two 16-column tiles of dW per pass: 32 loads in flight
+            float b[2][16];
             NR_PRAGMA_UNROLL
-            for (int s = 0; s < 16; ++s) {
-                const float b = bok ? X[(k0 + m) * 64 + 4 * s + kk] : 0.0f;
-                acc = nr_mfma16(a[s], b, acc);
+            for (int t = 0; t < 2; ++t) {
+                const bool bok = k0 + 16 * t + m < K;
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 16; ++s) b[t][s] = bok ? X[(k0 + 16 * t + m) * 64 + 4 * s + kk] : 0.0f;
             }
             NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                const int o = o0 + 4 * kk + r, k = k0 + m;
-                if (o < O && k < K) atomicAdd(dW + o * ldw + k, acc[r]);
+            for (int t = 0; t < 2; ++t) {
+                v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < 16; ++s) acc = nr_mfma16(a[s], b[t][s], acc);
+                NR_PRAGMA_UNROLL
+                for (int r = 0; r < 4; ++r) {
+                    const int o = o0 + 4 * kk + r, k = k0 + 16 * t + m;
+                    if (o < O && k < K) atomicAdd(dW + o * ldw + k, acc[r]);
+                }
             }
         }
     }
@@ -530,6 +542,10 @@ __device__ __forceinline__ void bwd_prob(float nearv, float farv, float mu0, flo
 __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p) {
     const int lane = threadIdx.x & 63;
     float* A = p.workspace + (size_t)blockIdx.x * kBwdRows * 64;
+    // per-lane scalars that live from the forward to the backward stages are kept in arena rows, not registers: the
+    // out-of-line dense helpers are called ~90 times and every live register would be saved around each call
+    float* SC = A + BR_SC * 64 + lane;
+#define SCALAR(name, idx) float& name = SC[(idx) * 64]
     const int vp = p.vp, ppw = 64 / vp;
     const int pl = lane / vp, v = lane % vp;
     const int npts = p.rn * p.dn, dn = p.dn;
@@ -564,24 +580,29 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qinv);
         const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
         const float half_p = (s_c - s_p) * 0.5f;
-        const float hi = half_c, lo = (smp == 0) ? half_c : half_p;
+        SCALAR(hi, 0); SCALAR(lo, 1);
+        hi = half_c; lo = (smp == 0) ? half_c : half_p;
         const float px = rn_add(r.cx, rn_mul(r.dx, d)), py = rn_add(r.cy, rn_mul(r.dy, d)), pz = rn_add(r.cz, rn_mul(r.dz, d));
         const float* __restrict__ vc = p.view_const + view * kViewConst;
         Proj pr = project_point<false>(vc, px, py, pz, (float)p.w, (float)p.h);
-        const float m = vok ? pr.mask : 0.0f;
-        const float tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
-        const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
-        const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
+        SCALAR(m, 2); SCALAR(tref, 3); SCALAR(pu, 4); SCALAR(pv, 5);
+        m = vok ? pr.mask : 0.0f;
+        tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
+        pu = pr.u; pv = pr.v;
         {
+            const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);
+            const Taps tc = make_taps(pr.u, pr.v, p.w, p.h, p.w, p.h);
             const float* rf = p.ray_feats + (size_t)view * fmap;
             const float* im = p.img_feats + (size_t)view * fmap;
             const float* cm = p.rgba + (size_t)view * imap;
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) {
                 FR[c * 64 + lane] = m * (tf.w00 * rf[(size_t)tf.o00 * 32 + c] + tf.w10 * rf[(size_t)tf.o10 * 32 + c] +
                                          tf.w01 * rf[(size_t)tf.o01 * 32 + c] + tf.w11 * rf[(size_t)tf.o11 * 32 + c]);
                 FI[c * 64 + lane] = m * (tf.w00 * im[(size_t)tf.o00 * 32 + c] + tf.w10 * im[(size_t)tf.o10 * 32 + c] +
                                          tf.w01 * im[(size_t)tf.o01 * 32 + c] + tf.w11 * im[(size_t)tf.o11 * 32 + c]);
             }
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 3; ++c)
                 RGB[c * 64 + lane] = m * (tc.w00 * cm[(size_t)tc.o00 * 4 + c] + tc.w10 * cm[(size_t)tc.o10 * 4 + c] +
                                           tc.w01 * cm[(size_t)tc.o01 * 4 + c] + tc.w11 * cm[(size_t)tc.o11 * 4 + c]);
@@ -590,7 +611,8 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         }
         // ================= forward =================
         // ---- dist decoder heads (dist_decoder.py:64-97): only the outputs are kept
-        float mu0, mu1, sd0, sd1, aw, nu = 1.0f;
+        SCALAR(mu0, 6); SCALAR(mu1, 7); SCALAR(sd0, 8); SCALAR(sd1, 9); SCALAR(aw, 10); SCALAR(nu, 11);
+        nu = 1.0f;
         {
             bwd_dense(FW(T_MEAN0_W), 32, FW(T_MEAN0_B), 32, 32, FR, S0, BA_ELU, lane);
             bwd_dense(FW(T_MEAN2_W), 32, FW(T_MEAN2_B), 32, 32, S0, S1, BA_ELU, lane);
@@ -612,7 +634,8 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             }
         }
         // ---- probabilities (dist_decoder.py:109-140, renderer.py:79-82)
-        const float nuu = use_vis ? nu : 1.0f;
+        SCALAR(nuu, 12);
+        nuu = use_vis ? nu : 1.0f;
         const float a00 = (tref - lo - mu0) * sd0, a01 = (tref - lo - mu1) * sd1;
         const float a10 = (tref + hi - mu0) * sd0, a11 = (tref + hi - mu1) * sd1;
         const float t00 = tanhf(a00), t01 = tanhf(a01), t10 = tanhf(a10), t11 = tanhf(a11);
@@ -621,10 +644,12 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         const float mix0 = aw, mix1 = 1.0f - aw;
         const float vis_raw = (1.0f - c00) * mix0 + (1.0f - c01) * mix1;
         const float hit_raw = (c10 - c00) * mix0 + (c11 - c01) * mix1;
-        const float vis = vis_raw * m, hit = hit_raw * m;
+        SCALAR(vis, 13); SCALAR(hit, 14);
+        vis = vis_raw * m; hit = hit_raw * m;
         // ---- prob_embed (aggregate_net.py:43): input [f_ray, 2 hit - 1, 2 vis - 1]; hidden kept in S0 for the backward? no:
         // recomputed there.  E is kept.
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = FR[c * 64 + lane];
             S3[32 * 64 + lane] = (hit - 0.5f) * 2.0f; S3[33 * 64 + lane] = (vis - 0.5f) * 2.0f;
             bwd_dense(FW(T_PE0_W), 34, FW(T_PE0_B), 32, 34, S3, S0, BA_RELU, lane);
@@ -634,21 +659,27 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         {
             bwd_dense(FW(T_RD0_W), 4, FW(T_RD0_B), 16, 4, DL, S0, BA_ELU, lane);
             bwd_dense(FW(T_RD2_W), 16, FW(T_RD2_B), 35, 16, S0, S1, BA_ELU, lane);
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 3; ++c) GP[c * 64 + lane] = RGB[c * 64 + lane] + S1[c * 64 + lane];
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) GP[(3 + c) * 64 + lane] = FI[c * 64 + lane] + S1[(3 + c) * 64 + lane];
         }
         // ---- neuray_fc -> sigmoid (ibrnet.py:337)
-        float sn;
+        SCALAR(sn, 15);
         {
             bwd_dense(FW(T_NF0_W), 32, FW(T_NF0_B), 8, 32, E, S0, BA_ELU, lane);
             bwd_dense(FW(T_NF2_W), 8, FW(T_NF2_B), 1, 8, S0, S1, BA_NONE, lane);
             sn = bwd_sigmoid(S1[lane]);
         }
         // ---- cross-view statistics (ibrnet.py:334-340)
-        const float msum = vp_sum(m, vp);
-        const float wv = m / (msum + 1e-8f);
-        const float w0 = sn * wv;
-        const float sa0 = vp_sum(w0, vp), sa1 = vp_sum(wv, vp);
+        SCALAR(wv, 16); SCALAR(w0, 17); SCALAR(sa0, 18); SCALAR(sa1, 19);
+        {
+            const float msum = vp_sum(m, vp);
+            wv = m / (msum + 1e-8f);
+            w0 = sn * wv;
+            sa0 = vp_sum(w0, vp); sa1 = vp_sum(wv, vp);
+        }
+        NR_PRAGMA_UNROLL4
         for (int f = 0; f < 35; ++f) {
             const float x = GP[f * 64 + lane];
             const float mean0 = vp_sum(w0 * x, vp), mean1 = vp_sum(wv * x, vp);
@@ -659,18 +690,21 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         bwd_dense(FW(T_BASE0_W), 207, FW(T_BASE0_B), 64, 207, GL, S0, BA_ELU, lane);
         bwd_dense(FW(T_BASE2_W), 64, FW(T_BASE2_B), 32, 64, S0, X, BA_ELU, lane);
         // ---- vis_fc (ibrnet.py:343-346)
-        float visp, vy32;          // vis' = sigmoid(ELU(.)) * mask; vy32 = the ELU output it is taken from
+        SCALAR(visp, 20); SCALAR(vy32, 21);          // vis' = sigmoid(ELU(.)) * mask; vy32 = the ELU output it is taken from
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X[c * 64 + lane] * wv;
             bwd_dense(FW(T_VF0_W), 32, FW(T_VF0_B), 32, 32, S3, S0, BA_ELU, lane);
             bwd_dense(FW(T_VF2_W), 32, FW(T_VF2_B), 33, 32, S0, S1, BA_ELU, lane);
             vy32 = S1[32 * 64 + lane];
             visp = bwd_sigmoid(vy32) * m;
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) X2[c * 64 + lane] = X[c * 64 + lane] + S1[c * 64 + lane];
         }
         // ---- vis_fc2 (ibrnet.py:347-348)
-        float vis2, v2sig;
+        SCALAR(vis2, 22); SCALAR(v2sig, 23);
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane] * visp;
             bwd_dense(FW(T_V20_W), 32, FW(T_V20_B), 32, 32, S3, S0, BA_ELU, lane);
             bwd_dense(FW(T_V22_W), 32, FW(T_V22_B), 1, 32, S0, S1, BA_NONE, lane);
@@ -678,10 +712,12 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             vis2 = v2sig * m;
         }
         // ---- rgb_fc (ibrnet.py:363-365): input [x, vis, ray_diff]
-        float z;
+        SCALAR(z, 24);
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane];
             S3[32 * 64 + lane] = vis2;
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 4; ++c) S3[(33 + c) * 64 + lane] = DL[c * 64 + lane];
             bwd_dense(FW(T_RF0_W), 37, FW(T_RF0_B), 16, 37, S3, S0, BA_ELU, lane);
             bwd_dense(FW(T_RF2_W), 16, FW(T_RF2_B), 8, 16, S0, S1, BA_ELU, lane);
@@ -689,13 +725,17 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             z = m > 0.0f ? S2[lane] : -1e9f;
         }
         // ---- softmax blend weights, visibility-weighted statistics (ibrnet.py:350-354,366-367)
-        const float zmax = vp_max(z, vp);
-        const float ez = expf(z - zmax);
-        const float beta = ez / vp_sum(ez, vp);
-        const float svis = vp_sum(vis2, vp);
-        const float wh = vis2 / (svis + 1e-8f);
-        const float swh = vp_sum(wh, vp);
+        SCALAR(beta, 25); SCALAR(svis, 26); SCALAR(wh, 27); SCALAR(swh, 28);
+        {
+            const float zmax = vp_max(z, vp);
+            const float ez = expf(z - zmax);
+            beta = ez / vp_sum(ez, vp);
+            svis = vp_sum(vis2, vp);
+            wh = vis2 / (svis + 1e-8f);
+            swh = vp_sum(wh, vp);
+        }
         // geometry_fc input [mean(32) var(32) mean weight] in S3 rows 0..64 (identical in the VP lanes of a point)
+        NR_PRAGMA_UNROLL4
         for (int f = 0; f < 32; ++f) {
             const float x = X2[f * 64 + lane];
             const float mean = vp_sum(wh * x, vp);
@@ -705,7 +745,8 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         // wgt.mean(2): mean over the rfn views of the normalised weights (ibrnet.py:354)
         // (S3 row 64 lives in the next scratch area's first row: S3 has 64 rows -> use DX row 0 temporarily? no: keep in a register
         //  and write it to a dedicated row of S2 when geometry_fc runs)
-        const float meanw = swh / (float)p.rfn;
+        SCALAR(meanw, 29);
+        meanw = swh / (float)p.rfn;
 
         // ================= backward =================
         const float* up = p.d_point_rec + (size_t)pi * kPointRec;
@@ -715,10 +756,12 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         float dmean_w;
         {
             // forward recompute with the 65-wide input assembled in DGL (free at this point): rows 0..64
+            NR_PRAGMA_UNROLL4
             for (int f = 0; f < 64; ++f) DGL[f * 64 + lane] = S3[f * 64 + lane];
             DGL[64 * 64 + lane] = meanw;
             bwd_dense(FW(T_GF0_W), 65, FW(T_GF0_B), 64, 65, DGL, S0, BA_ELU, lane);
             bwd_dense(FW(T_GF2_W), 64, FW(T_GF2_B), 16, 64, S0, S1, BA_ELU, lane);
+            NR_PRAGMA_UNROLL4
             for (int o = 0; o < 16; ++o) S2[o * 64 + lane] = up[o] * own * bwd_dact(S1[o * 64 + lane], BA_ELU);
             bwd_dense_dw(DW(T_GF2_W), 64, DW(T_GF2_B), 16, 64, S2, S0, lane);
             bwd_dense_dx(FW(T_GF2_W), 64, 16, 64, S2, S1, false, lane);          // S1 <- d hidden (64)
@@ -727,6 +770,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             float* DIN = DGL + 70 * 64;                                          // 65 free rows behind the input copy
             bwd_dense_dx(FW(T_GF0_W), 65, 64, 65, S1, DIN, false, lane);         // d [mean var meanw] (own lane only)
             // broadcast the per-point gradient to the VP lanes of the point; S2 <- d mean (0..31), d var (32..63)
+            NR_PRAGMA_UNROLL4
             for (int f = 0; f < 64; ++f) S2[f * 64 + lane] = vp_sum(DIN[f * 64 + lane], vp);
             dmean_w = vp_sum(DIN[64 * 64 + lane], vp);
         }
@@ -734,6 +778,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         float dvis2, dz;
         {
             float dwh = dmean_w / (float)p.rfn;
+            NR_PRAGMA_UNROLL4
             for (int f = 0; f < 32; ++f) {
                 const float x = X2[f * 64 + lane], mean = S3[f * 64 + lane];
                 const float dmean = S2[f * 64 + lane], dvar = S2[(32 + f) * 64 + lane];
@@ -751,8 +796,10 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         }
         // ---- rgb_fc backward
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane];
             S3[32 * 64 + lane] = vis2;
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 4; ++c) S3[(33 + c) * 64 + lane] = DL[c * 64 + lane];
             bwd_dense(FW(T_RF0_W), 37, FW(T_RF0_B), 16, 37, S3, S0, BA_ELU, lane);
             bwd_dense(FW(T_RF2_W), 16, FW(T_RF2_B), 8, 16, S0, S1, BA_ELU, lane);
@@ -767,12 +814,14 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             bwd_through_act(D16, S0, 16, BA_ELU, lane);
             bwd_dense_dw(DW(T_RF0_W), 37, DW(T_RF0_B), 16, 37, D16, S3, lane);
             bwd_dense_dx(FW(T_RF0_W), 37, 16, 37, D16, S1, false, lane);         // S1 rows 0..36 <- d [x2, vis2, ray_diff]
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) DX[c * 64 + lane] += S1[c * 64 + lane];
             dvis2 += S1[32 * 64 + lane];
         }
         // ---- vis_fc2 backward: vis2 = sigmoid(a) * m
         float dvisp;
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X2[c * 64 + lane] * visp;
             bwd_dense(FW(T_V20_W), 32, FW(T_V20_B), 32, 32, S3, S0, BA_ELU, lane);
             S2[lane] = dvis2 * m * v2sig * (1.0f - v2sig);
@@ -782,6 +831,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             bwd_dense_dw(DW(T_V20_W), 32, DW(T_V20_B), 32, 32, S1, S3, lane);
             bwd_dense_dx(FW(T_V20_W), 32, 32, 32, S1, S2, false, lane);          // S2 <- d (x2 * vis')
             dvisp = 0.0f;
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) {
                 dvisp = fmaf(S2[c * 64 + lane], X2[c * 64 + lane], dvisp);
                 DX[c * 64 + lane] = fmaf(S2[c * 64 + lane], visp, DX[c * 64 + lane]);
@@ -789,10 +839,12 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         }
         // ---- vis_fc backward: x2 = x + r, vis' = sigmoid(ELU(.)) * m; DX holds d x2 and becomes d x
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = X[c * 64 + lane] * wv;
             bwd_dense(FW(T_VF0_W), 32, FW(T_VF0_B), 32, 32, S3, S0, BA_ELU, lane);
             bwd_dense(FW(T_VF2_W), 32, FW(T_VF2_B), 33, 32, S0, S1, BA_ELU, lane);
             const float sg_ = bwd_sigmoid(vy32);
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S2[c * 64 + lane] = DX[c * 64 + lane];
             S2[32 * 64 + lane] = dvisp * m * sg_ * (1.0f - sg_);
             bwd_through_act(S2, S1, 33, BA_ELU, lane);
@@ -801,6 +853,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             bwd_through_act(S1, S0, 32, BA_ELU, lane);
             bwd_dense_dw(DW(T_VF0_W), 32, DW(T_VF0_B), 32, 32, S1, S3, lane);
             bwd_dense_dx(FW(T_VF0_W), 32, 32, 32, S1, S2, false, lane);          // S2 <- d (x * w)
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) DX[c * 64 + lane] = fmaf(S2[c * 64 + lane], wv, DX[c * 64 + lane]);
         }
         // ---- base_fc backward -> d [GL GP E] (DGL DGP DE contiguous)
@@ -817,6 +870,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         float dsn;
         {
             float dw0 = 0.0f;
+            NR_PRAGMA_UNROLL4
             for (int f = 0; f < 35; ++f) {
                 const float x = GP[f * 64 + lane];
                 const float mean0 = GL[f * 64 + lane], mean1 = GL[(70 + f) * 64 + lane];
@@ -843,6 +897,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         {
             bwd_dense(FW(T_RD0_W), 4, FW(T_RD0_B), 16, 4, DL, S0, BA_ELU, lane);
             bwd_dense(FW(T_RD2_W), 16, FW(T_RD2_B), 35, 16, S0, S1, BA_ELU, lane);
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 35; ++c) S2[c * 64 + lane] = DGP[c * 64 + lane] * bwd_dact(S1[c * 64 + lane], BA_ELU);
             bwd_dense_dw(DW(T_RD2_W), 16, DW(T_RD2_B), 35, 16, S2, S0, lane);
             bwd_dense_dx(FW(T_RD2_W), 16, 35, 16, S2, S1, false, lane);
@@ -852,6 +907,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         // ---- prob_embed backward -> d f_ray (DFR), d hit, d vis
         float dhit, dvis;
         {
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) S3[c * 64 + lane] = FR[c * 64 + lane];
             S3[32 * 64 + lane] = (hit - 0.5f) * 2.0f; S3[33 * 64 + lane] = (vis - 0.5f) * 2.0f;
             bwd_dense(FW(T_PE0_W), 34, FW(T_PE0_B), 32, 34, S3, S0, BA_RELU, lane);
@@ -860,6 +916,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
             bwd_through_act(S1, S0, 32, BA_RELU, lane);
             bwd_dense_dw(DW(T_PE0_W), 34, DW(T_PE0_B), 32, 34, S1, S3, lane);
             bwd_dense_dx(FW(T_PE0_W), 34, 32, 34, S1, S2, false, lane);          // S2 rows 0..33
+            NR_PRAGMA_UNROLL4
             for (int c = 0; c < 32; ++c) DFR[c * 64 + lane] = S2[c * 64 + lane];
             dhit = 2.0f * S2[32 * 64 + lane]; dvis = 2.0f * S2[33 * 64 + lane];
         }
@@ -871,11 +928,13 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
                        dmu0, dmu1, dsd0, dsd1, daw, dnu, lane);
         // ---- gathers backward: f_ray = mask * bilinear(ray_feats), f_img = mask * bilinear(img_feats) (render_ops.py:54-70)
         if (vok && pvalid) {
+            const Taps tf = make_taps(pu, pv, p.w, p.h, p.fw, p.fh);
             bwd_scatter32(p.d_ray_feats, (size_t)view * fmap, tf, m, DFR, lane);
             bwd_scatter32(p.d_img_feats, (size_t)view * fmap, tf, m, DGP + 3 * 64, lane);
         }
     }
 }
+#undef SCALAR
 #undef FW
 #undef DW
 

@@ -9,6 +9,7 @@
 #include "hip_emu.h"
 #define NR_UNIFORM(x) (x)
 #define NR_PRAGMA_UNROLL
+#define NR_PRAGMA_UNROLL4
 #else
 #include <hip/hip_runtime.h>
 
@@ -24,6 +25,7 @@ __device__ __forceinline__ v4f nr_mfma16(float a, float b, v4f c) {
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define NR_PRAGMA_UNROLL _Pragma("unroll")
+#define NR_PRAGMA_UNROLL4 _Pragma("unroll 4")      // row loops of the backward kernels: some ILP, no full unrolling
 #define NR_DYNAMIC_SMEM(type, name) \
     extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
     type* name = reinterpret_cast<type*>(name##_raw)

@@ -281,7 +281,9 @@ size_t neuray_flat_tensor_offset(int t) { return (t < 0 || t > nr::T_COUNT) ? (s
 namespace {
 int points_bwd_grid(int npoints, int vp) {
     const int ppw = 64 / vp;
-    return grid_for(npoints, ppw, 2048);      // 2048 x 222 KB of arena; several waves per SIMD hide the L2 latency
+    int cap = 2048;                               // 2048 x 230 KB of arena; two waves per SIMD
+    if (const char* e = getenv("NEURAY_BWD_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;     // tuning knob
+    return grid_for(npoints, ppw, cap);
 }
 int pow2_at_least(int n) { int v = 1; while (v < n) v <<= 1; return v; }
 }  // namespace

@@ -154,7 +154,6 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     float* red = smem;
     float* xch = smem + (size_t)(nw + 1) * RMAX * 64;
     float* wl = xch + 16 * NT * 64;                  // staged weights of the current phase
-    const int tid = threadIdx.x, nthreads = 64 * nw;
     const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
     const float* __restrict__ qc = p.que_const;
     const float qnearp = qc[24], qinv = qc[27];

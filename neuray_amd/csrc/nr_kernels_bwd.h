@@ -323,47 +323,53 @@ __device__ __forceinline__ float bwd_dact(float y, int a) {
     return 1.0f;
 }
 // C[r][n] = act(init + sum_q A(r, q) Bm[q][n]) over the wave's 64 columns n, with A(r, q) = W[r*rs + q*qs] taken from
-// the natural-layout weights: fp32 MFMA 16x16x4 per (16 rows, 16 columns) tile, Q/4 K-steps.  init = C (accumulate),
-// the bias, or 0.  A operand: lane (m, kk) -> A(r0+m, 4s+kk); B operand: lane (n, kk) -> Bm[4s+kk][n0+n];
-// D: lane (c, g) -> C[r0+4g+r][n0+c].  Reads and writes other lanes' columns: barriers on entry and exit.
+// the natural-layout weights: fp32 MFMA 16x16x4 per (16 rows, 16 columns) tile.  init = C (accumulate), the bias, or 0.
+// Operand mapping chosen so that every arena access is a 16-byte load / store per lane:
+//   column tiles: tile t of lane column m is arena column 4m + t  (one float4 of row q feeds the four tiles);
+//   contraction: a batch covers 32 values of q, lane group kk contributes q = b0 + 8 kk + u in MFMA step u.
+// D: lane (m, kk), register r of tile t -> C[r0 + 4 kk + r][4 m + t].
+// Reads and writes other lanes' columns: barriers on entry and exit.
 // (not inlined: one copy with run-time loops; inlined + unrolled at ~90 call sites the kernel grew to 70 k instructions
 // with 3,300 spilled registers)
 __device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs, int R, int Q, const float* __restrict__ Bm, float* __restrict__ C,
                                        const float* __restrict__ bias, int act, bool accumulate, int lane) {
     __syncthreads();
     const int m = lane & 15, kk = lane >> 4;
-    const int nsteps = (Q + 3) >> 2;
     for (int r0 = 0; r0 < R; r0 += 16) {
         const bool aok = r0 + m < R;
-        v4f acc[4];                                        // the four 16-column tiles of the 64 columns
+        v4f acc[4];
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < 4; ++t)
-            NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 4 * kk + r;
-                acc[t][r] = row < R ? (accumulate ? C[row * 64 + 16 * t + m] : (bias ? bias[row] : 0.0f)) : 0.0f;
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 4 * kk + r;
+            float4 c4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (row < R) {
+                if (accumulate) c4 = *reinterpret_cast<const float4*>(C + row * 64 + 4 * m);
+                else if (bias) { const float bv = bias[row]; c4 = make_float4(bv, bv, bv, bv); }
             }
-        for (int s0 = 0; s0 < nsteps; s0 += 8) {          // 8 A + 32 B loads in flight, then 32 MFMAs
-            float a[8], b[4][8];
+            acc[0][r] = c4.x; acc[1][r] = c4.y; acc[2][r] = c4.z; acc[3][r] = c4.w;
+        }
+        for (int b0 = 0; b0 < Q; b0 += 32) {               // 8 A + 8 wide B loads in flight, then 32 MFMAs
+            float a[8];
+            float4 b[8];
             NR_PRAGMA_UNROLL
             for (int u = 0; u < 8; ++u) {
-                const int q = 4 * (s0 + u) + kk;
+                const int q = b0 + 8 * kk + u;
                 a[u] = (aok && q < Q) ? W[(r0 + m) * rs + q * qs] : 0.0f;
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < 4; ++t) b[t][u] = q < Q ? Bm[q * 64 + 16 * t + m] : 0.0f;
+                b[u] = q < Q ? *reinterpret_cast<const float4*>(Bm + q * 64 + 4 * m) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
-            for (int u = 0; u < 8; ++u)
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < 4; ++t) acc[t] = nr_mfma16(a[u], b[t][u], acc[t]);
+            for (int u = 0; u < 8; ++u) {
+                acc[0] = nr_mfma16(a[u], b[u].x, acc[0]); acc[1] = nr_mfma16(a[u], b[u].y, acc[1]);
+                acc[2] = nr_mfma16(a[u], b[u].z, acc[2]); acc[3] = nr_mfma16(a[u], b[u].w, acc[3]);
+            }
         }
         NR_PRAGMA_UNROLL
-        for (int t = 0; t < 4; ++t)
-            NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 4 * kk + r;
-                if (row < R) C[row * 64 + 16 * t + m] = bwd_act(acc[t][r], act);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + 4 * kk + r;
+            if (row < R)
+                *reinterpret_cast<float4*>(C + row * 64 + 4 * m) =
+                    make_float4(bwd_act(acc[0][r], act), bwd_act(acc[1][r], act), bwd_act(acc[2][r], act), bwd_act(acc[3][r], act));
+        }
     }
     __syncthreads();
 }
@@ -390,29 +396,37 @@ __device__ __forceinline__ void bwd_dense_dx(const float* __restrict__ W, int ld
     bwd_mm(W, 1, ldw, K, O, dY, dX, nullptr, BA_NONE, accumulate, lane);
 }
 // dW[o*ldw + k] += sum_lanes dY[o][lane] X[k][lane],  db[o] += sum_lanes dY[o][lane]: a [O x 64] x [64 x K] contraction
-// over the wave's 64 (point, view) columns -> fp32 MFMA 16x16x4 per 16 x 16 tile of dW, 16 K-steps of 4 columns.
-// A[m][kk] = dY[o0 + m][4 s + kk],  B[kk][n] = X[k0 + n][4 s + kk]; D: lane (c, g) holds dW[o0 + 4 g + r][k0 + c].
+// over the wave's 64 (point, view) columns -> fp32 MFMA 16x16x4 per 16 x 16 tile of dW.  The contraction index (the
+// column l) is dealt as l = 16 kk + s to lane group kk in MFMA step s, so each lane reads 16 consecutive floats of its
+// row (four 16-byte loads):  A[m][kk] = dY[o0 + m][16 kk + s],  B[kk][n] = X[k0 + n][16 kk + s];
+// D: lane (c, g) holds dW[o0 + 4 g + r][k0 + c].
 __device__ __noinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, int K, const float* dY, const float* X, int lane) {
     __syncthreads();
     const int m = lane & 15, kk = lane >> 4;
     for (int o0 = 0; o0 < O; o0 += 16) {
-        float a[16];
+        float4 a[4];
         const bool aok = o0 + m < O;
         NR_PRAGMA_UNROLL
-        for (int s = 0; s < 16; ++s) a[s] = aok ? dY[(o0 + m) * 64 + 4 * s + kk] : 0.0f;
-        for (int k0 = 0; k0 < K; k0 += 32) {               // two 16-column tiles of dW per pass: 32 loads in flight
-            float b[2][16];
+        for (int j = 0; j < 4; ++j)
+            a[j] = aok ? *reinterpret_cast<const float4*>(dY + (o0 + m) * 64 + 16 * kk + 4 * j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k0 = 0; k0 < K; k0 += 32) {               // two 16-column tiles of dW per pass
+            float4 b[2][4];
             NR_PRAGMA_UNROLL
             for (int t = 0; t < 2; ++t) {
                 const bool bok = k0 + 16 * t + m < K;
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 16; ++s) b[t][s] = bok ? X[(k0 + 16 * t + m) * 64 + 4 * s + kk] : 0.0f;
+                for (int j = 0; j < 4; ++j)
+                    b[t][j] = bok ? *reinterpret_cast<const float4*>(X + (k0 + 16 * t + m) * 64 + 16 * kk + 4 * j)
+                                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
             for (int t = 0; t < 2; ++t) {
                 v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < 16; ++s) acc = nr_mfma16(a[s], b[t][s], acc);
+                for (int j = 0; j < 4; ++j) {
+                    acc = nr_mfma16(a[j].x, b[t][j].x, acc); acc = nr_mfma16(a[j].y, b[t][j].y, acc);
+                    acc = nr_mfma16(a[j].z, b[t][j].z, acc); acc = nr_mfma16(a[j].w, b[t][j].w, acc);
+                }
                 NR_PRAGMA_UNROLL
                 for (int r = 0; r < 4; ++r) {
                     const int o = o0 + 4 * kk + r, k = k0 + 16 * t + m;

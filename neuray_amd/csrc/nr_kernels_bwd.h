@@ -456,20 +456,6 @@ __device__ __forceinline__ float vp_max(float v, int vp) {
 __device__ __forceinline__ float bwd_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float bwd_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
-// scatter-add of a gathered-feature gradient (32 channels) into the NHWC gradient map: d map[tap] += wt * g
-__device__ __noinline__ void bwd_scatter32(float* dmap, size_t view_off, const Taps& t, float scale, const float* g, int lane) {
-    if (scale == 0.0f) return;
-    const int offs[4] = {t.o00, t.o10, t.o01, t.o11};
-    const float wts[4] = {t.w00, t.w10, t.w01, t.w11};
-    for (int a = 0; a < 4; ++a) {
-        const float wa = wts[a] * scale;
-        if (wa == 0.0f) continue;
-        float* dst = dmap + view_off + (size_t)offs[a] * 32;
-        for (int c = 0; c < 32; ++c) atomicAdd(dst + c, wa * g[c * 64 + lane]);
-    }
-}
-
-
 // backward of the output non-linearities and the three (four) 32->32->32->out MLPs of the dist decoder
 // (dist_decoder.py:64-97): gradients of mu (softplus), s (softplus + bias), aw / nu (sigmoid) -> weight gradients and
 // DFR += d f_ray.  FR: the 32 input rows; S0..S3: 64-row scratch areas.
@@ -941,10 +927,33 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         bwd_dist_heads(p.flat, p.d_flat, has_vis, p.var_bias, FR, S0, S1, S2, S3, DFR, mu0, mu1, sd0, sd1, aw, nu,
                        dmu0, dmu1, dsd0, dsd1, daw, dnu, lane);
         // ---- gathers backward: f_ray = mask * bilinear(ray_feats), f_img = mask * bilinear(img_feats) (render_ops.py:54-70)
-        if (vok && pvalid) {
+        // Coalesced scatter: the 32 channels of a texel are contiguous (NHWC), so 32 lanes add one texel's channels
+        // with one instruction; the two halves of the wave take two taps at a time.  Each pair's tap table (byte-free
+        // float offsets + weights, 0 for masked / padded pairs) goes through 9 arena rows and is read back wave-uniformly.
+        {
+            float* TT = S0;                                   // rows 0..3: texel offsets, 4..7: weights, 8: view map offset
             const Taps tf = make_taps(pu, pv, p.w, p.h, p.fw, p.fh);
-            bwd_scatter32(p.d_ray_feats, (size_t)view * fmap, tf, m, DFR, lane);
-            bwd_scatter32(p.d_img_feats, (size_t)view * fmap, tf, m, DGP + 3 * 64, lane);
+            const float sc = (vok && pvalid) ? m : 0.0f;
+            TT[0 * 64 + lane] = __int_as_float(tf.o00); TT[1 * 64 + lane] = __int_as_float(tf.o10);
+            TT[2 * 64 + lane] = __int_as_float(tf.o01); TT[3 * 64 + lane] = __int_as_float(tf.o11);
+            TT[4 * 64 + lane] = tf.w00 * sc; TT[5 * 64 + lane] = tf.w10 * sc; TT[6 * 64 + lane] = tf.w01 * sc; TT[7 * 64 + lane] = tf.w11 * sc;
+            TT[8 * 64 + lane] = __int_as_float(view);
+            __syncthreads();
+            const int c = lane & 31, half = lane >> 5;
+            for (int l = 0; l < 64; ++l) {
+                const float g_r = DFR[c * 64 + l], g_i = DGP[(3 + c) * 64 + l];
+                const size_t voff = (size_t)__float_as_int(TT[8 * 64 + l]) * fmap;
+                NR_PRAGMA_UNROLL
+                for (int tp = 0; tp < 2; ++tp) {
+                    const int tap = 2 * tp + half;
+                    const float wt = TT[(4 + tap) * 64 + l];
+                    if (wt != 0.0f) {
+                        const size_t o = voff + (size_t)__float_as_int(TT[tap * 64 + l]) * 32 + c;
+                        atomicAdd(p.d_ray_feats + o, wt * g_r);
+                        atomicAdd(p.d_img_feats + o, wt * g_i);
+                    }
+                }
+            }
         }
     }
 }

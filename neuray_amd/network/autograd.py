@@ -19,9 +19,17 @@ class PassRun:
         return {k: v.detach() for k, v in self.named_params()}
 
     def device_weights(self):
-        """(flat natural-layout weights, packed weights, has_vis) built on the device from the current parameters"""
-        flat, has_vis = self.eng.flat_pass_device(dict(self.named_params()), 'd.', 'a.')
-        return flat, self.eng.pack_pass_device(flat, has_vis), has_vis
+        """(flat natural-layout weights, packed weights, has_vis) built on the device from the current parameters;
+        cached on the decoder module until a parameter changes (the render pass and the self-hit path of one step,
+        and gradient-accumulation steps, share it)"""
+        named = self.named_params()
+        stamp = tuple((p.data_ptr(), p._version) for _, p in named)
+        hit = getattr(self.dist, '_neuray_devw', None)
+        if hit is None or hit[0] != stamp or hit[1] is not self.agg:
+            flat, has_vis = self.eng.flat_pass_device(dict(named), 'd.', 'a.')
+            hit = (stamp, self.agg, (flat, self.eng.pack_pass_device(flat, has_vis), has_vis))
+            self.dist._neuray_devw = hit
+        return hit[2]
 
 
 class RenderPassFn(torch.autograd.Function):
@@ -56,7 +64,7 @@ class RenderPassFn(torch.autograd.Function):
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g
         return (None, d_rf.permute(0, 3, 1, 2).contiguous(), d_if.permute(0, 3, 1, 2).contiguous()) + \
-            tuple(grads[k].clone() for k, _ in run.named_params())
+            tuple(grads[k] for k, _ in run.named_params())      # views of one buffer: no per-parameter copies
 
 
 class SelfHitFn(torch.autograd.Function):
@@ -84,4 +92,4 @@ class SelfHitFn(torch.autograd.Function):
                                                      d_hit.contiguous(), var_bias=run.var_bias)
         d_map = eng.interpolate_feats_backward(d_feats[None], ctx.shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
-        return (None, None, None, d_map) + tuple(grads[k].clone() for k, _ in run.named_params())
+        return (None, None, None, d_map) + tuple(grads[k] for k, _ in run.named_params())

@@ -136,6 +136,9 @@ static inline int __shfl(int v, int src) { float f; memcpy(&f, &v, 4); f = emu_s
 static inline int __shfl_xor(int v, int m) { return __shfl(v, emu::my_lane() ^ m); }
 static inline int __shfl_up(int v, int d) { int l = emu::my_lane(); return __shfl(v, l - d < 0 ? l : l - d); }
 static inline int __shfl_down(int v, int d) { int l = emu::my_lane(); return __shfl(v, l + d > 63 ? l : l + d); }
+static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+
 // float atomicAdd on LDS or global memory (blocks may run on different host threads: compare-and-swap loop)
 static inline float atomicAdd(float* p, float v) {
     unsigned int* u = reinterpret_cast<unsigned int*>(p);

@@ -246,3 +246,38 @@ def test_dist_decoder_module_forward_backward(use_vis, backend):
         scale = max(1e-3, float(p_.grad.abs().max()))
         assert float((got[k] - p_.grad).abs().max()) <= 2e-3 * scale, k
     assert float((got_f - feats.grad).abs().max()) <= 2e-3 * max(1e-3, float(feats.grad.abs().max()))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_adam_steps_reduce_the_render_loss(backend):
+    """A few optimiser steps through the HIP forward + backward kernels (weights AND the per-view ray_feats, as the
+    reference's fine-tuning does, renderer.py:404-437) must reduce a fixed render loss."""
+    from neuray_amd import synthetic
+    from neuray_amd.network.renderer import NeuralRayBaseRenderer
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 8,
+           'fine_depth_sample_num': 8, 'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 8}}
+    torch.manual_seed(3)
+    r = NeuralRayBaseRenderer(cfg).train()
+    if backend == 'emu':
+        r._engine_test_lib = emu_lib()
+    r = r.to(dev)
+    que, ref = synthetic.make_scene(32, 48, 3, seed=9)
+    rng = np.random.RandomState(9)
+    que['coords'] = (rng.rand(1, 12, 2) * np.array([47, 31])).astype(np.float32)
+    tq = {k: torch.from_numpy(v).to(dev) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v).to(dev) for k, v in ref.items()}
+    ray_feats = torch.nn.Parameter(tr['ray_feats'].clone())
+    target = torch.rand(1, 12, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    opt = torch.optim.Adam(list(r.parameters()) + [ray_feats], lr=2e-3)
+    losses = []
+    for step in range(6):
+        opt.zero_grad(set_to_none=True)
+        torch.manual_seed(100)                      # same fine-sampling uniforms every step: a fixed objective
+        out = r.render_impl(dict(tq), dict(tr, ray_feats=ray_feats), True)
+        loss = ((out['pixel_colors_nr'] - target) ** 2).mean() + ((out['pixel_colors_nr_fine'] - target) ** 2).mean()
+        loss.backward()
+        assert ray_feats.grad is not None and torch.isfinite(ray_feats.grad).all()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.9 * losses[0], losses

@@ -12,7 +12,9 @@ region is bracketed by barrier + synchronize and the max over ranks is taken.
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the MFMA point kernel):
 achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream).
 `cpu_baseline` times the numpy oracle (a port of the reference algorithm) on a bounded sample of the same
-workload on the host cores; it is the only place this file touches oracle/.
+workload on the host cores.  At N = 1 two side measurements ride along (reported baselines, not the metric):
+`eager_torch_baseline` (the eager-PyTorch port of the reference op sequence on the same GPU) and `training_step`
+(forward + backward kernels vs autograd of that port).  These legs are the only places this file touches oracle/.
 """
 import argparse
 import json
@@ -133,6 +135,59 @@ def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch
                     % (batches, rays_per_batch)}
 
 
+def training_step_timing(device, steps=3):
+    """Side measurement (not the headline metric): one render_impl(is_train=True) + backward through the HIP forward and
+    backward kernels on 512 rays x 8 views x 64+64 samples (the shape of BASELINE.json configs[3]/[4]) next to autograd
+    of the eager-PyTorch port on the same GPU."""
+    from oracle import torch_eager_port as tep
+    from oracle import neuray_oracle as orc
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 64,
+           'fine_depth_sample_num': 64, 'agg_net_cfg': {'sample_num': 64}, 'fine_agg_net_cfg': {'sample_num': 64},
+           'use_self_hit_prob': True}
+    torch.manual_seed(0)
+    r = NeuralRayBaseRenderer(cfg).train().to(device)
+    weights = {k: v.detach().cpu().numpy().copy() for k, v in r.state_dict().items()}
+    que, ref = synthetic.make_scene(400, 600, 8, seed=0, que_imgs=True)
+    rng = np.random.RandomState(0)
+    que['coords'] = (rng.rand(1, 512, 2) * np.array([599, 399])).astype(np.float32)
+    tq = {k: torch.from_numpy(v).to(device) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v).to(device) for k, v in ref.items()}
+    for t_ in (tr['ray_feats'], tr['img_feats'], tq['ray_feats']):
+        t_.requires_grad_(True)
+    tgt = torch.rand(1, 512, 3, device=device)
+
+    def loss_of(out):
+        return ((out['pixel_colors_nr'] - tgt) ** 2).mean() + ((out['pixel_colors_nr_fine'] - tgt) ** 2).mean() + \
+            out['hit_prob_self'].mean() + out['hit_prob_self_fine'].mean()
+
+    def ours():
+        r.zero_grad(set_to_none=True)
+        loss_of(r.render_impl(tq, tr, True)).backward()
+
+    w = {k: torch.from_numpy(v).to(device).requires_grad_(True) for k, v in weights.items()}
+    ocfg = {**orc.DEFAULT_CFG, **cfg, 'coarse_use_vis': False, 'fine_use_vis': True}
+    que_t = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in tq.items() if torch.is_tensor(v)}
+    ref_t = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in tr.items() if torch.is_tensor(v)}
+
+    def eager():
+        for p_ in w.values():
+            p_.grad = None
+        loss_of(tep.render_impl(w, ocfg, que_t, ref_t, is_train=True)).backward()
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(device)
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    a, b = timeit(ours), timeit(eager)
+    return {'what': 'forward + backward, 512 rays x 8 views x 64+64 samples, HIP kernels vs autograd of the eager-PyTorch port',
+            'hip_ms_per_step': a, 'eager_torch_ms_per_step': b, 'speedup_vs_eager': b / a}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -230,6 +285,7 @@ def main():
             eb = eager_torch_baseline(cfg, weights, tq, tr, device)
             eb['speedup_vs_eager'] = value / (1 if split else world) / eb['value']
             line['eager_torch_baseline'] = eb
+            line['training_step'] = training_step_timing(device)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

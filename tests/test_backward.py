@@ -101,7 +101,8 @@ def _pass_case(rfn, rn, dn, use_vis_head, seed):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('rfn,rn,dn,vis_head', [(3, 5, 8, False), (8, 3, 6, True), (2, 4, 5, False)])
+@pytest.mark.parametrize('rfn,rn,dn,vis_head', [(3, 5, 8, False), (8, 3, 6, True), (2, 4, 5, False), (1, 3, 5, False),
+                                                  (16, 2, 4, True), (5, 7, 9, True)])
 def test_pass_backward_matches_autograd(rfn, rn, dn, vis_head, backend):
     from neuray_amd.engine import RenderEngine
     from oracle import neuray_oracle as orc

@@ -30,17 +30,26 @@ struct RayBwdParams {
 };
 
 constexpr int kRayBwdPerSample = 16 * 4 + 12 + 3;     // K, V, q~, do | shift, den, D | t, alpha, u
+constexpr int kRayBwdTranspose = 2 * 64 * 17;         // per wave: two [64][17] buffers of wave_outer_add
 inline size_t ray_bwd_smem_bytes(int dn) {
-    return sizeof(float) * (2 * (kPackedRayFloats + 12) + kRayWaves * ((size_t)dn * kRayBwdPerSample));
+    return sizeof(float) * (2 * (kPackedRayFloats + 12) + kRayWaves * ((size_t)dn * kRayBwdPerSample + kRayBwdTranspose));
 }
 
-// acc[o * 16 + k] += sum over the wave of a[o] * b[k]   (acc in LDS, shared by the waves of the workgroup)
-__device__ __forceinline__ void wave_outer_add(float* acc, const float (&a)[16], const float (&b)[16], bool act, int lane) {
-    for (int o = 0; o < 16; ++o)
-        for (int k = 0; k < 16; ++k) {
-            const float s = wave_sum(act ? a[o] * b[k] : 0.0f);
-            if (lane == 0) atomicAdd(acc + o * 16 + k, s);
-        }
+// acc[o * 16 + k] += sum over the wave of a[o] * b[k]   (acc in LDS, shared by the waves of the workgroup).
+// A [16 x 64 samples] x [64 samples x 16] contraction: the per-lane vectors are transposed through LDS (tA, tB: [64][17]
+// per wave) and multiplied on the fp32 MFMA (16 K-steps of 4 samples) instead of 256 wave-wide shuffle reductions.
+__device__ __forceinline__ void wave_outer_add(float* acc, const float (&a)[16], const float (&b)[16], bool act, int lane,
+                                               float* tA, float* tB) {
+    __syncthreads();
+    NR_PRAGMA_UNROLL
+    for (int k = 0; k < 16; ++k) { tA[lane * 17 + k] = act ? a[k] : 0.0f; tB[lane * 17 + k] = act ? b[k] : 0.0f; }
+    __syncthreads();
+    const int m = lane & 15, kk = lane >> 4;
+    v4f d; d[0] = 0.0f; d[1] = 0.0f; d[2] = 0.0f; d[3] = 0.0f;
+    NR_PRAGMA_UNROLL
+    for (int s = 0; s < 16; ++s) d = nr_mfma16(tA[(4 * s + kk) * 17 + m], tB[(4 * s + kk) * 17 + m], d);
+    NR_PRAGMA_UNROLL
+    for (int r = 0; r < 4; ++r) atomicAdd(acc + (4 * kk + r) * 16 + m, d[r]);      // D: row o = 4 kk + r, column k = m
 }
 __device__ __forceinline__ void wave_vec_add(float* acc, const float (&a)[16], bool act, int lane) {
     for (int o = 0; o < 16; ++o) {
@@ -69,10 +78,11 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
     const int dn = p.dn;                               // <= 64: one sample per lane
     float* RW = smem + nr_opaque_zero();
     float* WA = smem + kPackedRayFloats + 12;          // weight-gradient accumulators of the workgroup
-    float* base = smem + 2 * (kPackedRayFloats + 12) + (size_t)wave * (dn * kRayBwdPerSample);
+    float* base = smem + 2 * (kPackedRayFloats + 12) + (size_t)wave * (dn * kRayBwdPerSample + kRayBwdTranspose);
     float* ks = base; float* vs = ks + dn * 16; float* qs = vs + dn * 16; float* dos = qs + dn * 16;
     float* st = dos + dn * 16;                         // [dn][12]: softmax shift (4), denominator (4), D (4)
     float* tr = st + dn * 12; float* al = tr + dn; float* us = al + dn;
+    float* tA = us + dn; float* tB = tA + 64 * 17;
     for (int i = threadIdx.x; i < kPackedRayFloats; i += blockDim.x) { RW[i] = p.weights[kPackedPointFloats + i]; WA[i] = 0.0f; }
     __syncthreads();
     const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
@@ -179,7 +189,7 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
             const float sb = wave_sum(act ? dsg : 0.0f);
             if (lane == 0) atomicAdd(WA + RW_OG2B, sb);
             wave_vec_add(WA + RW_OG0B, dpre1, act, lane);
-            wave_outer_add(WA + RW_OG0W, dpre1, z, act, lane);
+            wave_outer_add(WA + RW_OG0W, dpre1, z, act, lane, tA, tB);
         }
         matvec16_t(RW + RW_OG0W, dpre1, dz);
         // ---- LayerNorm backward
@@ -195,7 +205,7 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
             for (int k = 0; k < 16; ++k) t16[k] = dz[k] * yh[k];
             wave_vec_add(WA + RW_LNW, t16, act, lane);
             wave_vec_add(WA + RW_LNB, dz, act, lane);
-            wave_outer_add(WA + RW_FC, dy, o, act, lane);
+            wave_outer_add(WA + RW_FC, dy, o, act, lane, tA, tB);
         }
         matvec16_t(RW + RW_FC, dy, dO);
         // ---- attention backward, query side (this lane = query i)
@@ -243,9 +253,9 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
             dk[hh * 4] = k0; dk[hh * 4 + 1] = k1; dk[hh * 4 + 2] = k2; dk[hh * 4 + 3] = k3;
             dv[hh * 4] = v0; dv[hh * 4 + 1] = v1; dv[hh * 4 + 2] = v2; dv[hh * 4 + 3] = v3;
         }
-        wave_outer_add(WA + RW_WQ, dq, G, act, lane);
-        wave_outer_add(WA + RW_WK, dk, G, act, lane);
-        wave_outer_add(WA + RW_WV, dv, G, act, lane);
+        wave_outer_add(WA + RW_WQ, dq, G, act, lane, tA, tB);
+        wave_outer_add(WA + RW_WK, dk, G, act, lane, tA, tB);
+        wave_outer_add(WA + RW_WV, dv, G, act, lane, tA, tB);
         float gq[16], gk[16], gv[16];
         matvec16_t(RW + RW_WQ, dq, gq);
         matvec16_t(RW + RW_WK, dk, gk);

@@ -14,6 +14,10 @@ from . import _lib
 _DIST_HEADS = ('mean_decoder', 'var_decoder', 'aw_decoder', 'vis_decoder')
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
 def pass_tensor_keys(dist_prefix, agg_prefix):
     """state_dict keys of one pass in the order of enum nr::PassTensor (csrc/nr_layout.h)."""
     keys = []
@@ -35,7 +39,7 @@ def pass_tensor_keys(dist_prefix, agg_prefix):
     for i in (0, 2):
         keys += ['%sneuray_fc.%d.weight' % (impl, i), '%sneuray_fc.%d.bias' % (impl, i)]
     assert len(keys) == _lib.PASS_TENSORS
-    return keys
+    return tuple(keys)
 
 
 def posenc_table(d_hid, n_samples):
@@ -258,8 +262,8 @@ class RenderEngine:
             else:
                 if not (('.vis_decoder.' in k and not has_vis) or (allow_missing_agg and k.startswith(agg_prefix))):
                     raise KeyError("neuray_amd: missing weight %s" % k)
-                n = int(self.lib.neuray_flat_tensor_offset(i + 1)) - int(self.lib.neuray_flat_tensor_offset(i))
-                parts.append(torch.zeros(n, dtype=torch.float32, device=self.device))
+                off = self._flat_offsets()
+                parts.append(torch.zeros(off[i + 1] - off[i], dtype=torch.float32, device=self.device))
         return torch.cat(parts), has_vis
 
     def pack_pass_device(self, flat, has_vis):
@@ -291,14 +295,19 @@ class RenderEngine:
             flat[off:off + t.numel()] = t
         return flat.to(self.device), has_vis
 
+    def _flat_offsets(self):
+        if '_flat_off' not in self.__dict__:
+            self._flat_off = [int(self.lib.neuray_flat_tensor_offset(i)) for i in range(_lib.PASS_TENSORS + 1)]
+        return self._flat_off
+
     def unflatten_pass_grads(self, d_flat, state_dict, dist_prefix, agg_prefix):
-        """flat gradient buffer -> {state_dict key: grad tensor shaped like the parameter}"""
+        """flat gradient buffer -> {state_dict key: grad tensor shaped like the parameter} (views of d_flat)"""
+        off = self._flat_offsets()
         out = {}
         for i, k in enumerate(pass_tensor_keys(dist_prefix, agg_prefix)):
-            if k in state_dict:
-                shape = tuple(torch.as_tensor(state_dict[k]).shape)
-                off = int(self.lib.neuray_flat_tensor_offset(i))
-                out[k] = d_flat[off:off + int(np.prod(shape))].view(*shape)
+            v = state_dict.get(k)
+            if v is not None:
+                out[k] = d_flat[off[i]:off[i + 1]].view(v.shape)
         return out
 
     def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05):

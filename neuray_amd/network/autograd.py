@@ -13,10 +13,16 @@ class PassRun:
         self.mask_view_num, self.mask_point_num, self.want_depth = mask_view_num, mask_point_num, want_depth
 
     def named_params(self):
-        return [('d.' + k, v) for k, v in self.dist.named_parameters()] + [('a.' + k, v) for k, v in self.agg.named_parameters()]
+        # (the walk over the module tree is cached on the decoder: parameters keep their identity across steps)
+        hit = getattr(self.dist, '_neuray_named', None)
+        if hit is None or hit[0] is not self.agg:
+            named = [('d.' + k, v) for k, v in self.dist.named_parameters()] + [('a.' + k, v) for k, v in self.agg.named_parameters()]
+            hit = (self.agg, named)
+            self.dist._neuray_named = hit
+        return hit[1]
 
     def state(self):
-        return {k: v.detach() for k, v in self.named_params()}
+        return dict(self.named_params())       # only keys and shapes are used (unflatten_pass_grads)
 
     def device_weights(self):
         """(flat natural-layout weights, packed weights, has_vis) built on the device from the current parameters;
@@ -87,7 +93,7 @@ class SelfHitFn(torch.autograd.Function):
     def backward(ctx, d_hit):
         run, eng = ctx.run, ctx.run.eng
         feats, = ctx.saved_tensors
-        sd = {k: v.detach() for k, v in run.named_params()}
+        sd = run.state()
         d_feats, d_flat = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], ctx.flat, ctx.has_vis, run.use_vis,
                                                      d_hit.contiguous(), var_bias=run.var_bias)
         d_map = eng.interpolate_feats_backward(d_feats[None], ctx.shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)

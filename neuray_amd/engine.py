@@ -144,7 +144,7 @@ class RenderEngine:
         """ref_imgs_info: dict with imgs [rfn,3,h,w], poses, Ks, depth_range, ray_feats, img_feats (NCHW)."""
         imgs = self._f32(ref_imgs_info['imgs'])
         rfn, _, h, w = imgs.shape
-        rf, imf = self._f32(ref_imgs_info['ray_feats']), self._f32(ref_imgs_info['img_feats'])
+        rf, imf = ref_imgs_info['ray_feats'], ref_imgs_info['img_feats']
         assert rf.shape == imf.shape and rf.shape[0] == rfn and rf.shape[1] == 32, (rf.shape, imf.shape)
         fh, fw = rf.shape[-2:]
         if rfn > _lib.MAX_VIEWS:
@@ -153,11 +153,21 @@ class RenderEngine:
         vc = self.empty(rfn, _lib.VIEW_CONST)
         poses, Ks, dr = self._f32(ref_imgs_info['poses']), self._f32(ref_imgs_info['Ks']), self._f32(ref_imgs_info['depth_range'])
         self._check(self.lib.neuray_setup_views(poses.data_ptr(), Ks.data_ptr(), dr.data_ptr(), rfn, vc.data_ptr(), s))
-        rf_l, if_l, rgba = self.empty(rfn, fh, fw, 32), self.empty(rfn, fh, fw, 32), self.empty(rfn, h, w, 4)
-        self._check(self.lib.neuray_relayout_nhwc(rf.data_ptr(), rf_l.data_ptr(), rfn, 32, fh, fw, 32, s))
-        self._check(self.lib.neuray_relayout_nhwc(imf.data_ptr(), if_l.data_ptr(), rfn, 32, fh, fw, 32, s))
+        rgba = self.empty(rfn, h, w, 4)
         self._check(self.lib.neuray_relayout_nhwc(imgs.data_ptr(), rgba.data_ptr(), rfn, 3, h, w, 4, s))
-        return ViewSet(vc, rf_l, if_l, rgba, rfn, h, w, fh, fw)
+        return ViewSet(vc, self._nhwc32(rf, s), self._nhwc32(imf, s), rgba, rfn, h, w, fh, fw)
+
+    def _nhwc32(self, t, s):
+        """[n,32,fh,fw] feature maps -> channels-last storage [n,fh,fw,32].  A channels-last tensor (what the encoders of
+        network/encoders.py emit) already IS that storage: no relayout pass."""
+        n, c, fh, fw = t.shape
+        t = t.detach()
+        if t.dtype == torch.float32 and t.device == self.device and t.is_contiguous(memory_format=torch.channels_last):
+            return t.permute(0, 2, 3, 1)
+        t = self._f32(t)
+        out = self.empty(n, fh, fw, 32)
+        self._check(self.lib.neuray_relayout_nhwc(t.data_ptr(), out.data_ptr(), n, 32, fh, fw, 32, s))
+        return out
 
     def prepare_query(self, que_imgs_info):
         """-> query constant block.  K^-1 by torch.inverse exactly as the reference (render_ops.py:20)."""

@@ -218,6 +218,44 @@ def gradient_case(ns):
     print('wrote', path, 'loss', float(loss))
 
 
+def fill_by_name(module, scale=0.25):
+    """Deterministic weights that do not depend on the order in which a module creates its parameters: every tensor is
+    drawn from a generator seeded by the CRC of its name (norm scales around 1)."""
+    import zlib
+    with torch.no_grad():
+        for name, prm in module.named_parameters():
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+            v = torch.randn(prm.shape, generator=g) * scale
+            if name.endswith('.weight') and prm.dim() == 1:     # InstanceNorm scale
+                v = v * 0.4 + 1.0
+            prm.copy_(v)
+
+
+def encoder_case(ns):
+    """image_encoder (ResUNetLight(3,[1,2,6,4],32,inplanes=16), renderer.py:58) and vis_encoder of the reference on a
+    small odd-sized batch, weights from fill_by_name; also the reference base renderer's state_dict surface."""
+    import importlib
+    import json
+    ops, ve = importlib.import_module('network.ops'), importlib.import_module('network.vis_encoder')
+    enc = ops.ResUNetLight(3, [1, 2, 6, 4], 32, inplanes=16).eval()
+    vis = ve.DefaultVisEncoder({}).eval()
+    fill_by_name(enc)
+    fill_by_name(vis)
+    rng = np.random.RandomState(77)
+    imgs = rng.rand(2, 3, 52, 70).astype(np.float32)
+    with torch.no_grad():
+        feats = enc(torch.from_numpy(imgs))            # odd sizes: the decoder's upsampled size (16 x 20), not h/4 x w/4
+        ray_in = rng.randn(*feats.shape).astype(np.float32)
+        out = vis(torch.from_numpy(ray_in), feats)
+    np.savez_compressed(os.path.join(HERE, 'case_enc.npz'), imgs=imgs, ray_in=ray_in, img_feats=feats.numpy(), ray_feats=out.numpy())
+    full = ns.renderer.NeuralRayBaseRenderer({'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': True}})
+    json.dump({k: list(v.shape) for k, v in full.state_dict().items()},
+              open(os.path.join(HERE, 'ref_base_renderer_state_dict.json'), 'w'), indent=0, sort_keys=True)
+    print('wrote case_enc.npz', feats.shape, out.shape)
+
+
 if __name__ == '__main__':
     main()
-    gradient_case(ref_harness.import_reference())
+    ns_ = ref_harness.import_reference()
+    gradient_case(ns_)
+    encoder_case(ns_)

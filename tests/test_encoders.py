@@ -63,8 +63,8 @@ def test_render_from_images_equals_render_from_precomputed_features(backend):
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 8,
            'fine_depth_sample_num': 8, 'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 8},
            'build_encoders': True, 'ray_batch_num': 16}
-    torch.manual_seed(2)
     r = NeuralRayBaseRenderer(cfg).eval()
+    fill_by_name(r)
     if backend == 'emu':
         r._engine_test_lib = emu_lib()
     r = r.to(dev)
@@ -83,8 +83,33 @@ def test_render_from_images_equals_render_from_precomputed_features(backend):
         # same feature tensors, once channels-last (consumed in place) and once as plain NCHW copies (relayout kernel)
         b = r.render(dict(tq), dict(tr, ray_feats=ray_feats, img_feats=img_feats), False)
         c = r.render(dict(tq), dict(tr, ray_feats=ray_feats.contiguous().clone(), img_feats=img_feats.contiguous().clone()), False)
-    assert a['pixel_colors_nr_fine'].shape == (1, 23, 3)
+    assert a['pixel_colors_nr_fine'].shape == (1, 23, 3) and float(a['pixel_colors_nr_fine'].abs().max()) > 1e-3
     for k in b:
         assert torch.equal(b[k], c[k]), k
         # (a ran the encoders itself: bitwise equal on CPU; MIOpen convolutions need not repeat bit for bit)
         assert torch.allclose(a[k].float(), b[k].float(), atol=1e-4), k
+
+
+def test_gradients_reach_the_encoders():
+    """Training from images: the map gradients of the HIP backward kernels flow on into image_encoder / vis_encoder
+    (and into the initial ray_feats, the learnable per-view parameters of the reference's fine-tuning)."""
+    from neuray_amd import synthetic
+    from neuray_amd.network.renderer import NeuralRayBaseRenderer
+    cfg = {'use_hierarchical_sampling': False, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 6,
+           'agg_net_cfg': {'sample_num': 6}, 'build_encoders': True, 'use_self_hit_prob': True}
+    r = NeuralRayBaseRenderer(cfg).train()
+    fill_by_name(r)      # (a default-initialised sigma head can sit in its dead ReLU half: zero hit_prob, zero gradients)
+    r._engine_test_lib = emu_lib()
+    que, ref = synthetic.make_scene(32, 48, 2, seed=8, que_imgs=True)
+    que['coords'] = (np.random.RandomState(8).rand(1, 9, 2) * np.array([47, 31])).astype(np.float32)
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v) for k, v in ref.items()}
+    tr.pop('img_feats')
+    init = torch.nn.Parameter(tr.pop('ray_feats'))
+    out = r.render(tq, dict(tr, ray_feats=init), True)
+    assert float(out['hit_prob_nr'].sum()) > 0.1
+    (out['pixel_colors_nr'].square().sum() + out['hit_prob_self'].sum()).backward()
+    for name in ('image_encoder.conv1.weight', 'image_encoder.out_conv.weight', 'vis_encoder.out_conv.0.weight'):
+        g = dict(r.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name
+    assert init.grad is not None and float(init.grad.abs().max()) > 0

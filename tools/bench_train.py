@@ -1,6 +1,7 @@
 """Training-step timing (not the contract bench): one render_impl(is_train=True) + backward on 512 rays, 8 reference
-views, 64 + 64 samples (the shape of BASELINE.json configs[3]/[4]), HIP kernels vs the eager-PyTorch port of the
-reference's op sequence on the same GPU.      python tools/bench_train.py [--rays 512] [--steps 5]"""
+views, 64 + 64 samples (the shape of BASELINE.json configs[3]/[4]) through the HIP forward + backward kernels.
+The baseline beside it (the eager-PyTorch port of the reference's op sequence on the same GPU) is bench.py's
+`training_step` leg - this tool never touches oracle/.      python tools/bench_train.py [--rays 512] [--steps 5]"""
 import argparse
 import json
 import os
@@ -20,7 +21,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rays', type=int, default=512)
     ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--no-eager', action='store_true')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 64,
@@ -28,7 +28,6 @@ def main():
            'use_self_hit_prob': True}
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).train().to(dev)
-    weights = {k: v.detach().cpu().numpy().copy() for k, v in r.state_dict().items()}
     que, ref = synthetic.make_scene(400, 600, 8, seed=0, que_imgs=True)
     rng = np.random.RandomState(0)
     que['coords'] = (rng.rand(1, args.rays, 2) * np.array([599, 399])).astype(np.float32)
@@ -54,23 +53,6 @@ def main():
         return (time.perf_counter() - t0) / args.steps
 
     res = {'rays': args.rays, 'views': 8, 'samples': '64+64', 'hip_ms_per_step': 1e3 * timeit(step_ours)}
-    if not args.no_eager:
-        from oracle import torch_eager_port as tep
-        from oracle import neuray_oracle as orc
-        w = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in weights.items()}
-        ocfg = {**orc.DEFAULT_CFG, **cfg, 'coarse_use_vis': False, 'fine_use_vis': True}
-        que_t = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in tq.items() if torch.is_tensor(v)}
-        ref_t = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in tr.items() if torch.is_tensor(v)}
-
-        def step_eager():
-            for p_ in w.values():
-                p_.grad = None
-            out = tep.render_impl(w, ocfg, que_t, ref_t, is_train=True)
-            loss = ((out['pixel_colors_nr'] - tgt) ** 2).mean() + ((out['pixel_colors_nr_fine'] - tgt) ** 2).mean() + \
-                out['hit_prob_self'].mean() + out['hit_prob_self_fine'].mean()
-            loss.backward()
-        res['eager_torch_ms_per_step'] = 1e3 * timeit(step_eager)
-        res['speedup'] = res['eager_torch_ms_per_step'] / res['hip_ms_per_step']
     print(json.dumps(res))
 
 

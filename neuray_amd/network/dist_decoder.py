@@ -68,6 +68,9 @@ class MixtureLogisticsDistDecoder(nn.Module):
 
     def _engine(self, device):
         from ..engine import RenderEngine
+        from . import render_ops
+        if self._engine_test_lib is None:
+            return render_ops.engine_for(device)       # one engine per device, shared with the free functions
         if self._eng is None or self._eng.device != torch.device(device):
             self._eng = RenderEngine(device, _test_lib=self._engine_test_lib)
         return self._eng

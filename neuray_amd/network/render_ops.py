@@ -56,12 +56,33 @@ def depth2inv_dists(depth, depth_range):
     return torch.stack([eng.depth_dists(depth[q], depth_range[q]) for q in range(depth.shape[0])], 0)
 
 
+class _InterpFn(torch.autograd.Function):
+    """interpolate_feats with the gradient w.r.t. the feature map (the coordinates are constants on every call site of the
+    render / depth-loss path, renderer.py:127-155,282-300)."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, mask, h, w, align):
+        eng = engine_for(feats.device)
+        ctx.save_for_backward(coords, mask)
+        ctx.meta = (eng, tuple(feats.shape), h, w, align)
+        return eng.interpolate_feats(feats, coords, h, w, align_corners=align, mask=mask)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        coords, mask = ctx.saved_tensors
+        eng, shape, h, w, align = ctx.meta
+        return eng.interpolate_feats_backward(d_out.contiguous(), shape, coords, h, w, align_corners=align, mask=mask), \
+            None, None, None, None, None
+
+
 def interpolate_feature_map(ray_feats, coords, mask, h, w, border_type='border'):
     if border_type != 'border':
         raise NotImplementedError("neuray_amd: only padding_mode='border' is on the render path")
     fh, fw = ray_feats.shape[-2:]
-    return engine_for(ray_feats.device).interpolate_feats(ray_feats, coords, h, w, align_corners=(fh == h and fw == w),
-                                                          mask=mask.float())
+    align = (fh == h and fw == w)
+    if torch.is_grad_enabled() and ray_feats.requires_grad:
+        return _InterpFn.apply(ray_feats, coords, mask.float(), h, w, align)
+    return engine_for(ray_feats.device).interpolate_feats(ray_feats, coords, h, w, align_corners=align, mask=mask.float())
 
 
 def alpha_values2hit_prob(alpha_values):

@@ -9,6 +9,7 @@ Under autograd (training) each pass is a torch.autograd.Function whose backward 
 (network/autograd.py).  Anything the HIP path does not implement raises - it never silently switches to an eager
 implementation.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -196,4 +197,274 @@ class NeuralRayBaseRenderer(nn.Module):
         return {k: torch.cat(v, 1) for k, v in render_info_all.items()}
 
 
-name2network = {'neuray_base': NeuralRayBaseRenderer}
+# ---- generalisation renderer ----------------------------------------------------------------------------
+name2init_net = {}
+"""Registry of initial-visibility-feature networks (`init_net_type` -> class(cfg)), the reference's `name2init_net`
+(network/init_net.py:163-166).  DepthInitNet / CostVolumeInitNet are SURVEY.md 8(f) rows f-2 / f-3 and are not built
+here: register a module under the reference's name, pass one as `init_net=`, or hand the initial `ray_feats` over in
+`ref_imgs_info` (they are consumed exactly where the reference consumes init_net's output)."""
+
+
+class NeuralRayGenRenderer(NeuralRayBaseRenderer):
+    """network/renderer.py:256-326: init_net -> encoders -> render, plus the mean-depth readout of the depth loss."""
+    default_cfg = {'init_net_type': 'depth', 'init_net_cfg': {}, 'use_depth_loss': False, 'depth_loss_coords_num': 8192}
+
+    def __init__(self, cfg, init_net=None):
+        super().__init__({**self.default_cfg, **cfg, 'build_encoders': True})
+        if init_net is None and self.cfg['init_net_type'] in name2init_net:
+            init_net = name2init_net[self.cfg['init_net_type']](self.cfg['init_net_cfg'])
+        if init_net is not None:
+            self.init_net = init_net
+        else:
+            self.init_net = None      # plain attribute: no parameters, not in the state_dict
+
+    def render_call(self, que_imgs_info, ref_imgs_info, is_train, src_imgs_info=None):
+        if self.init_net is not None:
+            ref_imgs_info['ray_feats'] = self.init_net(ref_imgs_info, src_imgs_info, is_train)
+        elif 'ray_feats' not in ref_imgs_info:
+            raise NotImplementedError(
+                "neuray_amd: no init_net for init_net_type=%r (SURVEY.md 8(f) f-2/f-3 are not built) and no initial "
+                "ref_imgs_info['ray_feats'] was handed over" % self.cfg['init_net_type'])
+        return self.render(que_imgs_info, ref_imgs_info, is_train)
+
+    def gen_depth_loss_coords(self, h, w, device):
+        """renderer.py:272-278 (quirk kept: the pairs are (row, col) although the gather reads them as (x, y))."""
+        num = self.cfg['depth_loss_coords_num']
+        pick = torch.randperm(h * w)[:num]
+        return torch.stack([pick // w, pick % w], -1).to(device)
+
+    def predict_mean_for_depth_loss(self, ref_imgs_info):
+        """renderer.py:280-316: decoded mixture means of every reference view at random pixels of that view."""
+        from . import render_ops
+        ray_feats = ref_imgs_info['ray_feats']
+        rfn, _, h, w = ref_imgs_info['imgs'].shape
+        coords = self.gen_depth_loss_coords(h, w, ray_feats.device)[None].repeat(rfn, 1, 1)
+        ones = torch.ones(coords.shape[:2], dtype=torch.float32, device=ray_feats.device)
+        feats = render_ops.interpolate_feature_map(ray_feats, coords.float(), ones, h, w)      # rfn,pn,f
+        mean = self.dist_decoder.predict_mean(feats)
+        outputs = {'depth_mean': mean[..., 0], 'depth_coords': coords, 'depth_mean_2': mean[..., 1]}
+        if self.cfg['use_hierarchical_sampling']:
+            fine = self.fine_dist_decoder.predict_mean(feats)
+            outputs['depth_mean_fine'], outputs['depth_mean_fine_2'] = fine[..., 0], fine[..., 1]
+        return outputs
+
+    def forward(self, data):
+        ref_imgs_info, que_imgs_info = data['ref_imgs_info'].copy(), data['que_imgs_info'].copy()
+        is_train = 'eval' not in data
+        src_imgs_info = data['src_imgs_info'].copy() if 'src_imgs_info' in data else None
+        outputs = self.render_call(que_imgs_info, ref_imgs_info, is_train, src_imgs_info)
+        if (self.cfg['use_depth_loss'] and 'true_depth' in ref_imgs_info) or not is_train:
+            outputs.update(self.predict_mean_for_depth_loss(ref_imgs_info))
+        return outputs
+
+
+# ---- per-scene fine-tuning renderer --------------------------------------------------------------------
+def camera_centres(poses):
+    """[n,3,4] world->camera poses -> [n,3] centres  -R^T t"""
+    poses = np.asarray(poses, np.float64)
+    return -np.einsum('nji,nj->ni', poses[:, :, :3], poses[:, :, 3])
+
+
+def nearest_view_table(que_poses, ref_poses):
+    """utils/view_select.py:7-16: for every query camera the reference cameras ordered by centre distance -> [qn,rfn] int"""
+    d = np.linalg.norm(camera_centres(ref_poses)[None] - camera_centres(que_poses)[:, None], 2, 2)
+    return np.argsort(d, 1)
+
+
+def sample_train_coords(fg_mask, ray_num, foreground_ratio):
+    """utils/base_utils.py:585-603: `ray_num` pixel coordinates (x, y) of one image, at least
+    int(ray_num * foreground_ratio) of them drawn from the foreground mask (when it has that many), the rest from the
+    remaining pixels; two np.random.shuffle draws in the reference's order."""
+    want_fg = int(ray_num * foreground_ratio)
+    ys, xs = np.nonzero(fg_mask)
+    fg = np.stack([xs, ys], 1).astype(np.float32)
+    ys, xs = np.nonzero(~fg_mask)
+    bg = np.stack([xs, ys], 1).astype(np.float32)
+    order = np.arange(fg.shape[0])
+    np.random.shuffle(order)
+    fg = fg[order]
+    picked = fg[:want_fg]
+    if want_fg >= ray_num:
+        return picked
+    pool = np.concatenate([bg, fg[want_fg:]], 0)
+    order = np.arange(pool.shape[0])
+    np.random.shuffle(order)
+    return np.concatenate([picked, pool[order[:ray_num - want_fg]]], 0)
+
+
+def pad_views(info, interval):
+    """utils/imgs_info.py:60-75: reflect-pad imgs / depth / masks (/ true_depth) at the bottom and right to multiples of
+    `interval` (the encoders halve the resolution four times)."""
+    h, w = info['imgs'].shape[-2:]
+    ph, pw = (-h) % interval, (-w) % interval
+    if ph or pw:
+        for k in ('imgs', 'depth', 'masks', 'true_depth'):
+            if k in info:
+                info[k] = np.pad(np.asarray(info[k]), ((0, 0), (0, 0), (0, ph), (0, pw)), 'reflect')
+    return info
+
+
+def _as_torch(info):
+    return {k: torch.from_numpy(v) if isinstance(v, np.ndarray) else v for k, v in info.items()}
+
+
+def _take(info, idx):
+    idx = torch.as_tensor(np.asarray(idx)).long()
+    return {k: v[idx] for k, v in info.items()}
+
+
+class NeuralRayFtRenderer(NeuralRayBaseRenderer):
+    """network/renderer.py:328-545: the per-scene renderer.  Every reference view owns a learnable visibility feature
+    map (`ray_feats`, an nn.ParameterList of [1,32,h/4,w/4]); a step renders rays of one view from its neighbours.
+
+    The reference constructor reads the scene through its dataset layer (`parse_database_name`, `build_imgs_info`:
+    file I/O, SURVEY.md 8(f) f-4, not built) and initialises `ray_feats` by running a generalisation checkpoint's
+    init_net (f-2/f-3).  Here both enter as data:
+      scene = {'ref_imgs_info': imgs_info of all reference views (imgs, masks, depth, poses, Ks, depth_range; numpy or
+               torch, host memory), 'val_imgs_info': the same for the validation views (optional), 'database': anything}
+      init_ray_feats = per-view initial maps (list of [1,dim,fh,fw]) or None for the reference's "init from scratch"
+    and `load_gen_state_dict` copies the shared networks from a generalisation state_dict (renderer.py:466-475)."""
+    default_cfg = {
+        'database_name': None, 'database_split': 'val_all', 'ref_pad_interval': 16, 'use_consistent_depth_range': True,
+        'gen_cfg': None, 'use_validation': True, 'validate_initialization': True, 'init_view_num': 8, 'init_src_view_num': 3,
+        'include_self_prob': 0.01, 'neighbor_view_num': 8, 'neighbor_pool_ratio': 2, 'train_ray_num': 512,
+        'foreground_ratio': 0.5, 'ray_feats_res': [200, 200], 'ray_feats_dim': 32,
+    }
+
+    def __init__(self, cfg, scene=None, init_ray_feats=None):
+        super().__init__({**self.default_cfg, **cfg, 'build_encoders': True})
+        if scene is None:
+            raise NotImplementedError("neuray_amd: NeuralRayFtRenderer needs scene={'ref_imgs_info': ..., ['val_imgs_info': ...]} - "
+                                      "the dataset layer behind cfg['database_name'] is host I/O outside the render path")
+        self.database = scene.get('database')
+        ref = pad_views({k: np.asarray(v) if not torch.is_tensor(v) else v.numpy() for k, v in scene['ref_imgs_info'].items()},
+                        self.cfg['ref_pad_interval'])
+        if self.cfg['use_consistent_depth_range']:
+            ref['depth_range'] = np.array(ref['depth_range'], np.float32)
+            ref['depth_range'][:, 0], ref['depth_range'][:, 1] = ref['depth_range'].min(), ref['depth_range'].max()
+        self.ref_imgs_info = _as_torch(ref)
+        self.ref_ids = np.arange(ref['imgs'].shape[0])
+        self.ref_dist_idx = nearest_view_table(ref['poses'], ref['poses'])          # rfn,rfn (column 0: the view itself)
+        self.val_imgs_info = None
+        if self.cfg['use_validation'] and 'val_imgs_info' in scene:
+            val = {k: np.asarray(v) if not torch.is_tensor(v) else v.numpy() for k, v in scene['val_imgs_info'].items()}
+            self.val_imgs_info = _as_torch(val)
+            self.val_dist_idx = nearest_view_table(val['poses'], ref['poses'])
+            self.val_num = val['imgs'].shape[0]
+        self.ray_feats = nn.ParameterList()
+        n = len(self.ref_ids)
+        if init_ray_feats is None:          # renderer.py:476-482
+            fh, fw = self.cfg['ray_feats_res']
+            init_ray_feats = [torch.randn(1, self.cfg['ray_feats_dim'], fh, fw) for _ in range(n)]
+        assert len(init_ray_feats) == n
+        for t in init_ray_feats:
+            self.ray_feats.append(nn.Parameter(torch.as_tensor(t).detach().clone().float()))
+        self.touched_views = []             # reference-view indices whose ray_feats the last train_step used
+        self._scene_dev, self._enc_cache = {}, {}
+
+    def load_gen_state_dict(self, state_dict):
+        """renderer.py:466-475: take the shared networks of a generalisation model (everything but its init_net)."""
+        own = self.state_dict()
+        picked = {k: v for k, v in state_dict.items() if k in own and not k.startswith('ray_feats.')}
+        missing = [k for k in own if not k.startswith('ray_feats.') and k not in picked]
+        if missing:
+            raise KeyError("generalisation state_dict lacks %s" % missing[:4])
+        self.load_state_dict(picked, strict=False)
+
+    def _device(self):
+        return self.ray_feats[0].device
+
+    def _resident(self, which):
+        """The scene's views stay resident in HBM (a 100-view 800x800 scene is 0.8 GB of 288): moved once per device
+        instead of the reference's per-step `to_cuda(imgs_info_slice(...))` (renderer.py:487)."""
+        dev = self._device()
+        hit = self._scene_dev.get(which)
+        if hit is None or hit[0] != dev:
+            src = self.ref_imgs_info if which == 'ref' else self.val_imgs_info
+            self._scene_dev[which] = (dev, {k: v.to(dev) if torch.is_tensor(v) else v for k, v in src.items()})
+        return self._scene_dev[which][1]
+
+    def _encoded(self, ref_idx):
+        """eval only: per-view encoder outputs, reused while the encoders and that view's ray_feats are unchanged
+        (neighbouring poses share most of their reference views) -> (img_feats, ray_feats)"""
+        enc_stamp = tuple(p._version for p in self.image_encoder.parameters()) + tuple(p._version for p in self.vis_encoder.parameters())
+        imgs = self._resident('ref')['imgs']
+        out = []
+        for i in (int(i) for i in ref_idx):
+            stamp = (enc_stamp, self.ray_feats[i]._version, self._device())
+            hit = self._enc_cache.get(i)
+            if hit is None or hit[0] != stamp:
+                with torch.no_grad():
+                    f = self.image_encoder(imgs[i:i + 1])
+                    hit = (stamp, f, self.vis_encoder(self.ray_feats[i], f))
+                self._enc_cache[i] = hit
+            out.append(hit)
+        return torch.cat([h[1] for h in out], 0), torch.cat([h[2] for h in out], 0)
+
+    def _ref_views(self, ref_idx, is_train):
+        ref_imgs_info = _take(self._resident('ref'), ref_idx)
+        if is_train:
+            ref_imgs_info['ray_feats'] = torch.cat([self.ray_feats[int(i)] for i in ref_idx], 0)
+        else:
+            ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'] = self._encoded(ref_idx)
+        return ref_imgs_info
+
+    def slice_imgs_info(self, ref_idx, val_idx, is_train):
+        """renderer.py:484-507"""
+        ref_imgs_info = self._ref_views(ref_idx, is_train)
+        if is_train:
+            fg = self.ref_imgs_info['masks'][val_idx, 0].numpy() > 0
+            que = _take(self._resident('ref'), [val_idx])
+            coords = sample_train_coords(fg, self.cfg['train_ray_num'], self.cfg['foreground_ratio']).reshape(1, -1, 2)
+        else:
+            que = _take(self._resident('val'), [val_idx])
+            hn, wn = que['imgs'].shape[-2:]
+            coords = np.stack(np.meshgrid(np.arange(wn), np.arange(hn)), -1).reshape(1, -1, 2).astype(np.float32)
+        que['coords'] = torch.from_numpy(coords).to(self._device())
+        if is_train and self.cfg['use_self_hit_prob']:
+            que['ray_feats'] = self.ray_feats[int(val_idx)]
+        return ref_imgs_info, que
+
+    def validate_step(self, val_idx):
+        """renderer.py:509-519"""
+        ref_idx = self.val_dist_idx[val_idx][:self.cfg['neighbor_view_num']]
+        ref_imgs_info, que_imgs_info = self.slice_imgs_info(ref_idx, val_idx, False)
+        with torch.no_grad():
+            outputs = self.render(que_imgs_info, ref_imgs_info, False)
+        for k in ('ray_feats', 'img_feats', '_neuray_views'):
+            ref_imgs_info.pop(k, None)
+        outputs.update({'ref_imgs_info': ref_imgs_info, 'que_imgs_info': que_imgs_info})
+        return outputs
+
+    def train_step(self):
+        """renderer.py:521-543: a random view as the query, 8 of its 16 nearest other views (itself with 1 % probability)."""
+        que_i = np.random.randint(0, len(self.ref_ids))
+        ref_idx = self.ref_dist_idx[que_i]
+        if np.random.random() > self.cfg['include_self_prob']:
+            ref_idx = ref_idx[1:]
+        ref_idx = ref_idx[:self.cfg['neighbor_view_num'] * self.cfg['neighbor_pool_ratio']].copy()
+        np.random.shuffle(ref_idx)
+        ref_idx = ref_idx[:self.cfg['neighbor_view_num']]
+        ref_imgs_info, que_imgs_info = self.slice_imgs_info(ref_idx, que_i, True)
+        self.touched_views = sorted(set(int(i) for i in ref_idx) | ({int(que_i)} if self.cfg['use_self_hit_prob'] else set()))
+        outputs = self.render(que_imgs_info.copy(), ref_imgs_info.copy(), True)
+        for k in ('ray_feats', 'img_feats', '_neuray_qconst'):
+            que_imgs_info.pop(k, None)
+        outputs['que_imgs_info'] = que_imgs_info
+        return outputs
+
+    def render_pose(self, render_imgs_info):
+        """renderer.py:545-555: render an arbitrary pose from its nearest reference views (the nearest one is skipped,
+        as in the reference's `select_working_views(..., exclude_self=True)`)."""
+        order = nearest_view_table(render_imgs_info['poses'].cpu().numpy(), self.ref_imgs_info['poses'].numpy())[0]
+        ref_idx = order[1:self.cfg['neighbor_view_num'] + 1]
+        with torch.no_grad():
+            return self.render(render_imgs_info, self._ref_views(ref_idx, False), False)
+
+    def forward(self, data):
+        if 'eval' not in data:
+            return self.train_step()
+        return self.validate_step(data['index'])
+
+
+name2network = {'neuray_base': NeuralRayBaseRenderer, 'neuray_gen': NeuralRayGenRenderer, 'neuray_ft': NeuralRayFtRenderer}

@@ -76,3 +76,36 @@ def allreduce_gradients(parameters, average=True, group=None):
         else:
             p.grad.copy_(g)
         off += n
+
+
+def allreduce_scene_feature_gradients(ray_feats, touched, max_touched, average=True, group=None):
+    """Fine-tuning mode (SURVEY.md 8(e) caveat): `ray_feats` is the per-view nn.ParameterList of NeuralRayFtRenderer
+    (100 views x 5 MB on lego-800) and a step gives gradients to the <= neighbor_view_num + 1 views this rank rendered
+    from (`touched`: their indices, e.g. renderer.touched_views).  Instead of reducing all 512 MB (or marking unused
+    parameters), the ranks all-gather their touched ids (fixed length `max_touched`, padded with -1) and all-reduce only
+    the union's maps in one flattened buffer (<= world * 9 x 5 MB).  Afterwards every rank holds the same gradient for
+    every view of the union and `grad is None` for all others, so per-parameter Adam state advances identically on all
+    ranks (torch.optim skips parameters without a gradient, as the reference's single-GPU training does).
+    -> sorted list of the union's view indices"""
+    world = dist.get_world_size(group)
+    dev = ray_feats[0].device
+    ids = torch.full((max_touched,), -1, dtype=torch.int64, device=dev)
+    assert len(touched) <= max_touched
+    ids[:len(touched)] = torch.as_tensor(sorted(touched), dtype=torch.int64)
+    gathered = [torch.empty_like(ids) for _ in range(world)]
+    dist.all_gather(gathered, ids, group=group)
+    union = sorted(set(int(i) for g in gathered for i in g.tolist() if i >= 0))
+    if not union:
+        return union
+    flat = torch.cat([(ray_feats[i].grad if ray_feats[i].grad is not None else torch.zeros_like(ray_feats[i])).reshape(-1).float()
+                      for i in union])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= world
+    off = 0
+    for i in union:
+        p = ray_feats[i]
+        g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+        p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
+        off += p.numel()
+    return union

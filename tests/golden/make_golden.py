@@ -254,8 +254,119 @@ def encoder_case(ns):
     print('wrote case_enc.npz', feats.shape, out.shape)
 
 
+def scene_case(ns):
+    """The scene-level renderers of the reference (network/renderer.py:256-545) on a tiny synthetic scene:
+      gen:  NeuralRayGenRenderer.forward(data) in eval with a pass-through init_net (the real ones need depth maps / MVSNet)
+      ft:   NeuralRayFtRenderer.train_step / validate_step / render_pose on an instance whose scene attributes are set
+            directly (its constructor reads a dataset from disk), `to_cuda` patched to the identity
+      helpers: get_coords_mask, compute_nearest_camera_indices, select_working_views, pad_imgs_info
+    Weights: fill_by_name (reproducible from the parameter names)."""
+    import importlib
+    import torch.nn as nn
+    from neuray_amd import synthetic
+    R = ns.renderer
+    out = {}
+    # ---- helpers
+    vs, bu, ii = importlib.import_module('utils.view_select'), importlib.import_module('utils.base_utils'), importlib.import_module('utils.imgs_info')
+    rng = np.random.RandomState(21)
+    poses = np.stack([synthetic.look_at_pose(synthetic.sphere_pos(4.0, a, e)) for a, e in rng.rand(7, 2) * np.array([360, 60])]).astype(np.float32)
+    qposes = np.stack([synthetic.look_at_pose(synthetic.sphere_pos(4.0, a, e)) for a, e in rng.rand(3, 2) * np.array([360, 60])]).astype(np.float32)
+
+    class DB:
+        def get_pose(self, i):
+            return (poses if i >= 0 else qposes)[i if i >= 0 else -i - 1]
+    out['h_poses'], out['h_qposes'] = poses, qposes
+    out['h_nearest_self'] = vs.compute_nearest_camera_indices(DB(), list(range(7)))
+    out['h_nearest_que'] = vs.compute_nearest_camera_indices(DB(), [-1, -2, -3], list(range(7)))
+    out['h_working'] = vs.select_working_views(poses, qposes, 4, True)
+    mask = rng.rand(20, 30) > 0.7
+    out['h_mask'] = mask
+    for tag, (num, ratio) in {'a': (64, 0.5), 'b': (16, 1.0), 'c': (400, 0.5)}.items():
+        np.random.seed(5)
+        out['h_coords_' + tag] = bu.get_coords_mask(mask, num, ratio)
+    info = {'imgs': rng.rand(2, 3, 21, 35).astype(np.float32), 'depth': rng.rand(2, 1, 21, 35).astype(np.float32),
+            'masks': (rng.rand(2, 1, 21, 35) > 0.5).astype(np.float32)}
+    out['h_pad_in_imgs'], out['h_pad_in_depth'], out['h_pad_in_masks'] = info['imgs'], info['depth'], info['masks']
+    padded = ii.pad_imgs_info(dict(info), 16)
+    out['h_pad_imgs'], out['h_pad_depth'], out['h_pad_masks'] = padded['imgs'], padded['depth'], padded['masks']
+
+    # ---- gen
+    class PassThrough(nn.Module):
+        def __init__(self, cfg):
+            super().__init__()
+
+        def forward(self, ref_imgs_info, src_imgs_info, is_train):
+            return ref_imgs_info['ray_feats']
+    R.name2init_net['passthrough'] = PassThrough
+    small = {'use_hierarchical_sampling': True, 'depth_sample_num': 8, 'fine_depth_sample_num': 8,
+             'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 8}, 'ray_batch_num': 16}
+    gen = R.NeuralRayGenRenderer({**small, 'init_net_type': 'passthrough', 'depth_loss_coords_num': 40}).eval()
+    fill_by_name(gen)
+    que, ref = synthetic.make_scene(48, 64, 3, seed=5)
+    que['coords'] = (np.random.RandomState(6).rand(1, 23, 2) * np.array([63, 47])).astype(np.float32)
+    ref.pop('img_feats')
+    torch.manual_seed(11)
+    with torch.no_grad():
+        g = gen({'que_imgs_info': to_t(que), 'ref_imgs_info': to_t(ref), 'eval': True})
+    for k, v in g.items():
+        out['gen_' + k] = v.numpy()
+
+    # ---- ft
+    h, w, n = 48, 64, 6
+    _, sref = synthetic.make_scene(h, w, n, seed=9)
+    sref.pop('img_feats')
+    init = sref.pop('ray_feats')
+    srng = np.random.RandomState(10)
+    sref['masks'] = (srng.rand(n, 1, h, w) > 0.6).astype(np.float32)
+    sref['depth'] = (2 + 4 * srng.rand(n, 1, h, w)).astype(np.float32)
+    sval = {'imgs': srng.rand(2, 3, h, w).astype(np.float32), 'masks': np.ones((2, 1, h, w), np.float32),
+            'poses': np.stack([synthetic.look_at_pose(synthetic.sphere_pos(4.03, 33.0, 22.0)),
+                               synthetic.look_at_pose(synthetic.sphere_pos(4.03, 20.0, 30.0))]).astype(np.float32),
+            'Ks': sref['Ks'][:2].copy(), 'depth_range': sref['depth_range'][:2].copy()}
+    ft_cfg = {**small, 'use_self_hit_prob': True, 'neighbor_view_num': 3, 'neighbor_pool_ratio': 1, 'train_ray_num': 12,
+              'foreground_ratio': 0.5, 'include_self_prob': 0.01, 'use_validation': True}
+    ft = R.NeuralRayFtRenderer.__new__(R.NeuralRayFtRenderer)
+    R.NeuralRayBaseRenderer.__init__(ft, {**R.NeuralRayFtRenderer.default_cfg, **ft_cfg})
+    fill_by_name(ft)
+    R.to_cuda = lambda d: d
+    ft.ref_ids = np.arange(n)
+    ft.ref_imgs_info, ft.val_imgs_info = to_t(sref), to_t(sval)
+    cen = lambda P: np.asarray([-p[:, :3].T @ p[:, 3] for p in P])
+    ft.ref_dist_idx = np.argsort(np.linalg.norm(cen(sref['poses'])[None] - cen(sref['poses'])[:, None], 2, 2), 1)
+    ft.val_dist_idx = np.argsort(np.linalg.norm(cen(sref['poses'])[None] - cen(sval['poses'])[:, None], 2, 2), 1)
+    ft.ray_feats = nn.ParameterList([nn.Parameter(torch.from_numpy(init[i:i + 1].copy())) for i in range(n)])
+    for k, v in {'ref': sref, 'val': sval}.items():
+        for kk, vv in v.items():
+            out['ft_%s_%s' % (k, kk)] = vv
+    out['ft_init_ray_feats'] = init
+    ft.eval()
+    v = ft.validate_step(1)
+    out['ft_val_pixel_colors_nr_fine'] = v['pixel_colors_nr_fine'].numpy()
+    out['ft_val_ray_mask_fine'] = v['ray_mask_fine'].numpy()
+    pose_info = {'poses': torch.from_numpy(sval['poses'][:1]), 'Ks': torch.from_numpy(sval['Ks'][:1]),
+                 'depth_range': torch.from_numpy(sval['depth_range'][:1]),
+                 'coords': torch.from_numpy((np.random.RandomState(12).rand(1, 19, 2) * np.array([63, 47])).astype(np.float32))}
+    out['ft_pose_coords'] = pose_info['coords'].numpy()
+    out['ft_pose_pixel_colors_nr_fine'] = ft.render_pose(pose_info)['pixel_colors_nr_fine'].numpy()
+    ft.train()
+    np.random.seed(3)
+    torch.manual_seed(4)
+    t = ft.train_step()
+    out['ft_train_coords'] = t['que_imgs_info']['coords'].numpy()
+    for k in ('pixel_colors_nr', 'pixel_colors_nr_fine', 'hit_prob_self', 'hit_prob_self_fine', 'pixel_colors_gt'):
+        out['ft_train_' + k] = t[k].detach().numpy()
+    loss = ((t['pixel_colors_nr_fine'] - t['pixel_colors_gt']) ** 2).mean() + t['hit_prob_self_fine'].mean()
+    loss.backward()
+    out['ft_train_touched'] = np.array([i for i in range(n) if ft.ray_feats[i].grad is not None and float(ft.ray_feats[i].grad.abs().max()) > 0])
+    for i in out['ft_train_touched'][:2]:
+        out['ft_train_grad_%d' % i] = ft.ray_feats[int(i)].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'case_scene.npz'), **out)
+    print('wrote case_scene.npz', out['ft_train_touched'], out['gen_depth_mean'].shape)
+
+
 if __name__ == '__main__':
     main()
     ns_ = ref_harness.import_reference()
     gradient_case(ns_)
     encoder_case(ns_)
+    scene_case(ns_)

@@ -108,3 +108,52 @@ def test_two_rank_training_step_matches_reference_gradients(tmp_path):
         want = z['grad.' + k]
         scale = max(1e-3, float(np.abs(want).max()))
         assert np.max(np.abs(got[k] - want)) <= 5e-3 * scale, k
+
+
+# ---- fine-tuning mode: per-view feature maps get gradients on the ranks that rendered from them -------------------
+def _ft_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NEURAY_EMU_THREADS='2')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from conftest import GOLDEN_DIR
+    from test_scene_renderers import make_ft
+    gold = np.load(os.path.join(GOLDEN_DIR, 'case_scene.npz'))
+    ft = make_ft(gold, 'cpu').train()                    # identical replicas on every rank
+    shared = [p for n, p in ft.named_parameters() if not n.startswith('ray_feats.')]
+    opt = torch.optim.Adam(ft.parameters(), lr=1e-2)
+    log = []
+    for step in range(2):
+        np.random.seed(100 * step + rank)                # every rank draws its own query view / neighbours / rays
+        torch.manual_seed(100 * step + rank)
+        opt.zero_grad(set_to_none=True)
+        t = ft.train_step()
+        (((t['pixel_colors_nr_fine'] - t['pixel_colors_gt']) ** 2).mean() + t['hit_prob_self_fine'].mean()).backward()
+        mine = list(ft.touched_views)
+        parallel.allreduce_gradients(shared)
+        union = parallel.allreduce_scene_feature_gradients(ft.ray_feats, mine, ft.cfg['neighbor_view_num'] + 1)
+        with_grad = [i for i, p in enumerate(ft.ray_feats) if p.grad is not None]
+        log.append((mine, union, with_grad))
+        opt.step()
+    state = torch.cat([p.detach().reshape(-1) for p in ft.parameters()])
+    torch.save({'log': log, 'state': state}, os.path.join(out_dir, 'ft_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_finetuning_exchanges_only_touched_feature_maps(tmp_path):
+    """SURVEY.md 8(e) caveat: in ft mode each rank touches <= neighbor_view_num + 1 of the scene's per-view maps; the
+    ranks exchange the union's gradients only, views outside it keep grad None (so Adam skips them on every rank), and
+    the replicas stay bit-identical after the optimiser steps."""
+    emu_lib()
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_ft_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'ft_rank0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'ft_rank1.pt'))
+    assert torch.equal(a['state'], b['state'])
+    differed = False
+    for (mine_a, union_a, grad_a), (mine_b, union_b, grad_b) in zip(a['log'], b['log']):
+        assert union_a == union_b == sorted(set(mine_a) | set(mine_b)) == grad_a == grad_b
+        assert len(union_a) < 6 or mine_a != mine_b
+        differed |= mine_a != mine_b
+    assert differed            # the ranks did render from different views

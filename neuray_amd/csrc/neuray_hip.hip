@@ -281,7 +281,7 @@ size_t neuray_flat_tensor_offset(int t) { return (t < 0 || t > nr::T_COUNT) ? (s
 namespace {
 int points_bwd_grid(int npoints, int vp) {
     const int ppw = 64 / vp;
-    int cap = 2048;                               // 2048 x 230 KB of arena; two waves per SIMD
+    int cap = 4096;                               // 4096 x 230 KB of arena; four waves per SIMD
     if (const char* e = getenv("NEURAY_BWD_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;     // tuning knob
     return grid_for(npoints, ppw, cap);
 }

@@ -340,10 +340,18 @@ __device__ __forceinline__ float bwd_dact(float y, int a) {
 // D: lane (m, kk), register r of tile t -> C[r0 + 4 kk + r][4 m + t].
 // Reads and writes other lanes' columns: barriers on entry and exit.
 // (not inlined: one copy with run-time loops; inlined + unrolled at ~90 call sites the kernel grew to 70 k instructions
-// with 3,300 spilled registers)
-__device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs, int R, int Q, const float* __restrict__ Bm, float* __restrict__ C,
-                                       const float* __restrict__ bias, int act, bool accumulate, int lane) {
+// with 3,300 spilled registers.  The pointer arguments are cast to the global address space - a non-inlined function
+// cannot see where they point and would use FLAT accesses - and the sizes are made wave-uniform, they arrive in VGPRs.
+// Tried and measured slower, 15.1 vs 11.1 ms per training step: all row blocks of C in one pass over Bm, 64 accumulator
+// registers, so that Bm is read once per call - the re-reads it saves hit in L2 anyway.)
+__device__ __noinline__ void bwd_mm(const float* __restrict__ W_, int rs, int qs, int R, int Q, const float* __restrict__ Bm_, float* __restrict__ C_,
+                                       const float* __restrict__ bias_, int act, bool accumulate, int lane) {
     __syncthreads();
+    NR_GLOBAL_PTR(const float) W = NR_TO_GLOBAL(const float, W_);
+    NR_GLOBAL_PTR(const float) Bm = NR_TO_GLOBAL(const float, Bm_);
+    NR_GLOBAL_PTR(const float) bias = NR_TO_GLOBAL(const float, bias_);
+    NR_GLOBAL_PTR(float) C = NR_TO_GLOBAL(float, C_);
+    R = NR_UNIFORM(R); Q = NR_UNIFORM(Q); rs = NR_UNIFORM(rs); qs = NR_UNIFORM(qs); act = NR_UNIFORM(act);
     const int m = lane & 15, kk = lane >> 4;
     for (int r0 = 0; r0 < R; r0 += 16) {
         const bool aok = r0 + m < R;
@@ -353,8 +361,8 @@ __device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs,
             const int row = r0 + 4 * kk + r;
             float4 c4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (row < R) {
-                if (accumulate) c4 = *reinterpret_cast<const float4*>(C + row * 64 + 4 * m);
-                else if (bias) { const float bv = bias[row]; c4 = make_float4(bv, bv, bv, bv); }
+                if (accumulate) c4 = nr_gld4(C + row * 64 + 4 * m);
+                else if (bias_) { const float bv = bias[row]; c4 = make_float4(bv, bv, bv, bv); }
             }
             acc[0][r] = c4.x; acc[1][r] = c4.y; acc[2][r] = c4.z; acc[3][r] = c4.w;
         }
@@ -365,7 +373,7 @@ __device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs,
             for (int u = 0; u < 8; ++u) {
                 const int q = b0 + 8 * kk + u;
                 a[u] = (aok && q < Q) ? W[(r0 + m) * rs + q * qs] : 0.0f;
-                b[u] = q < Q ? *reinterpret_cast<const float4*>(Bm + q * 64 + 4 * m) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                b[u] = q < Q ? nr_gld4(Bm + q * 64 + 4 * m) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
             for (int u = 0; u < 8; ++u) {
@@ -377,8 +385,7 @@ __device__ __noinline__ void bwd_mm(const float* __restrict__ W, int rs, int qs,
         for (int r = 0; r < 4; ++r) {
             const int row = r0 + 4 * kk + r;
             if (row < R)
-                *reinterpret_cast<float4*>(C + row * 64 + 4 * m) =
-                    make_float4(bwd_act(acc[0][r], act), bwd_act(acc[1][r], act), bwd_act(acc[2][r], act), bwd_act(acc[3][r], act));
+                nr_gst4(C + row * 64 + 4 * m, make_float4(bwd_act(acc[0][r], act), bwd_act(acc[1][r], act), bwd_act(acc[2][r], act), bwd_act(acc[3][r], act)));
         }
     }
     __syncthreads();
@@ -389,7 +396,9 @@ __device__ __forceinline__ void bwd_dense(const float* __restrict__ W, int ldw, 
     bwd_mm(W, ldw, 1, O, K, X, Y, b, act, false, lane);
 }
 // dY[o] *= act'(Y[o])
-__device__ __noinline__ void bwd_through_act(float* __restrict__ dY, const float* __restrict__ Y, int O, int act, int lane) {
+__device__ __noinline__ void bwd_through_act(float* __restrict__ dY_, const float* __restrict__ Y_, int O, int act, int lane) {
+    NR_GLOBAL_PTR(float) dY = NR_TO_GLOBAL(float, dY_);
+    NR_GLOBAL_PTR(const float) Y = NR_TO_GLOBAL(const float, Y_);
     int o = 0;
     for (; o + 8 <= O; o += 8) {        // eight rows per batch: the loads are issued together
         float d[8], y[8];
@@ -410,15 +419,20 @@ __device__ __forceinline__ void bwd_dense_dx(const float* __restrict__ W, int ld
 // column l) is dealt as l = 16 kk + s to lane group kk in MFMA step s, so each lane reads 16 consecutive floats of its
 // row (four 16-byte loads):  A[m][kk] = dY[o0 + m][16 kk + s],  B[kk][n] = X[k0 + n][16 kk + s];
 // D: lane (c, g) holds dW[o0 + 4 g + r][k0 + c].
-__device__ __noinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, int K, const float* dY, const float* X, int lane) {
+__device__ __noinline__ void bwd_dense_dw(float* dW_, int ldw, float* db_, int O, int K, const float* dY_, const float* X_, int lane) {
     __syncthreads();
+    NR_GLOBAL_PTR(float) dW = NR_TO_GLOBAL(float, dW_);
+    NR_GLOBAL_PTR(float) db = NR_TO_GLOBAL(float, db_);
+    NR_GLOBAL_PTR(const float) dY = NR_TO_GLOBAL(const float, dY_);
+    NR_GLOBAL_PTR(const float) X = NR_TO_GLOBAL(const float, X_);
+    O = NR_UNIFORM(O); K = NR_UNIFORM(K); ldw = NR_UNIFORM(ldw);
     const int m = lane & 15, kk = lane >> 4;
     for (int o0 = 0; o0 < O; o0 += 16) {
         float4 a[4];
         const bool aok = o0 + m < O;
         NR_PRAGMA_UNROLL
         for (int j = 0; j < 4; ++j)
-            a[j] = aok ? *reinterpret_cast<const float4*>(dY + (o0 + m) * 64 + 16 * kk + 4 * j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            a[j] = aok ? nr_gld4(dY + (o0 + m) * 64 + 16 * kk + 4 * j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int k0 = 0; k0 < K; k0 += 32) {               // two 16-column tiles of dW per pass
             float4 b[2][4];
             NR_PRAGMA_UNROLL
@@ -426,7 +440,7 @@ __device__ __noinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, 
                 const bool bok = k0 + 16 * t + m < K;
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < 4; ++j)
-                    b[t][j] = bok ? *reinterpret_cast<const float4*>(X + (k0 + 16 * t + m) * 64 + 16 * kk + 4 * j)
+                    b[t][j] = bok ? nr_gld4(X + (k0 + 16 * t + m) * 64 + 16 * kk + 4 * j)
                                   : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
             NR_PRAGMA_UNROLL
@@ -440,17 +454,16 @@ __device__ __noinline__ void bwd_dense_dw(float* dW, int ldw, float* db, int O, 
                 NR_PRAGMA_UNROLL
                 for (int r = 0; r < 4; ++r) {
                     const int o = o0 + 4 * kk + r, k = k0 + 16 * t + m;
-                    if (o < O && k < K) atomicAdd(dW + o * ldw + k, acc[r]);
+                    if (o < O && k < K) atomicAdd(NR_FROM_GLOBAL(float, dW + o * ldw + k), acc[r]);
                 }
             }
         }
     }
-    if (db)
+    if (db_)
         for (int o = lane; o < O; o += 64) {
-            const float4* dy4 = reinterpret_cast<const float4*>(dY + o * 64);
             float sacc = 0.0f;
-            for (int l = 0; l < 16; ++l) { const float4 a4 = dy4[l]; sacc += (a4.x + a4.y) + (a4.z + a4.w); }
-            atomicAdd(db + o, sacc);
+            for (int l = 0; l < 16; ++l) { const float4 a4 = nr_gld4(dY + o * 64 + 4 * l); sacc += (a4.x + a4.y) + (a4.z + a4.w); }
+            atomicAdd(NR_FROM_GLOBAL(float, db + o), sacc);
         }
     __syncthreads();
 }
@@ -547,8 +560,10 @@ __device__ __forceinline__ void bwd_prob(float nearv, float farv, float mu0, flo
 #define FW(T) (p.flat + tensor_offset(T))
 #define DW(T) (p.d_flat + tensor_offset(T))
 
-// (waves-per-EU 4 is a request the register allocator only half meets - 2 waves per SIMD at ~195 VGPRs - but asking for
-// 2 lets it take all 512 registers and run 1 wave per SIMD: 28 ms instead of 23 ms per training step)
+// waves-per-EU 4: the kernel body fits 128 VGPRs (with spills) and the AMDGPU attributor hands the same bound to the
+// non-inlined helpers ONLY if every kernel that calls them asks for it - the two small kernels below carry (64, 4) for
+// that reason (with plain (64) the helpers took up to 213 VGPRs and this kernel ran at 2 waves per SIMD).  Asking for 2
+// lets the allocator take all 512 registers and run 1 wave per SIMD (28 ms instead of 23 ms per training step).
 __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p) {
     const int lane = threadIdx.x & 63;
     float* A = p.workspace + (size_t)blockIdx.x * kBwdRows * 64;
@@ -990,7 +1005,7 @@ struct SelfHitBwdParams {
 };
 constexpr int kSelfBwdRows = 32 + 4 * 64 + 32;
 
-__global__ void __launch_bounds__(64) self_hit_backward_kernel(SelfHitBwdParams p) {
+__global__ void __launch_bounds__(64, 4) self_hit_backward_kernel(SelfHitBwdParams p) {
     const int lane = threadIdx.x & 63;
     float* A = p.workspace + (size_t)blockIdx.x * kSelfBwdRows * 64;
     float* FR = A; float* S0 = A + 32 * 64; float* S1 = S0 + 64 * 64; float* S2 = S1 + 64 * 64; float* S3 = S2 + 64 * 64;
@@ -1039,7 +1054,7 @@ struct RowsBwdParams {
     float var_bias;
 };
 
-__global__ void __launch_bounds__(64) decoder_rows_backward_kernel(RowsBwdParams p) {
+__global__ void __launch_bounds__(64, 4) decoder_rows_backward_kernel(RowsBwdParams p) {
     const int lane = threadIdx.x & 63;
     float* A = p.workspace + (size_t)blockIdx.x * kSelfBwdRows * 64;
     float* FR = A; float* S0 = A + 32 * 64; float* S1 = S0 + 64 * 64; float* S2 = S1 + 64 * 64; float* S3 = S2 + 64 * 64;

@@ -8,6 +8,11 @@
 #ifdef NEURAY_EMU
 #include "hip_emu.h"
 #define NR_UNIFORM(x) (x)
+#define NR_GLOBAL_PTR(T) T*
+#define NR_TO_GLOBAL(T, p) (p)
+#define NR_FROM_GLOBAL(T, p) (p)
+static inline float4 nr_gld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+static inline void nr_gst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #define NR_PRAGMA_UNROLL
 #define NR_PRAGMA_UNROLL4
 #else
@@ -25,6 +30,18 @@ __device__ __forceinline__ v4f nr_mfma16(float a, float b, v4f c) {
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define NR_PRAGMA_UNROLL _Pragma("unroll")
+// pointer known to address global memory (generic pointers in non-inlined device functions compile to FLAT accesses)
+#define NR_GLOBAL_PTR(T) __attribute__((address_space(1))) T*
+#define NR_TO_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define NR_FROM_GLOBAL(T, p) ((T*)(p))
+__device__ __forceinline__ float4 nr_gld4(NR_GLOBAL_PTR(const float) p) {         // global_load_dwordx4
+    const v4f v = *reinterpret_cast<NR_GLOBAL_PTR(const v4f)>(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nr_gst4(NR_GLOBAL_PTR(float) p, float4 v) {
+    v4f w; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    *reinterpret_cast<NR_GLOBAL_PTR(v4f)>(p) = w;
+}
 #define NR_PRAGMA_UNROLL4 _Pragma("unroll 4")      // row loops of the backward kernels: some ILP, no full unrolling
 #define NR_DYNAMIC_SMEM(type, name) \
     extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \

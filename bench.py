@@ -188,6 +188,40 @@ def training_step_timing(device, steps=3):
             'hip_ms_per_step': a, 'eager_torch_ms_per_step': b, 'speedup_vs_eager': b / a}
 
 
+def init_net_timing(device, reps=10):
+    """Side measurement: the depth init net front end on 8 views of 800 x 800 - get_diff_feats as the
+    fused neuray_diff_feats kernel next to the eager tensor formulation of the reference (oracle/torch_eager_port.py),
+    and the whole DepthInitNet forward."""
+    from oracle import torch_eager_port as tep
+    from neuray_amd.network import init_net
+    h = w = 800
+    _, ref = synthetic.make_scene(h, w, 8, seed=0)
+    info = {k: torch.from_numpy(ref[k]).to(device) for k in ('imgs', 'poses', 'Ks', 'depth_range')}
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    info['depth'] = torch.from_numpy(np.stack([3.6 + 0.7 * np.sin(xx / 90.0 + v) * np.cos(yy / 70.0 - v)
+                                               for v in range(8)])[:, None].astype(np.float32)).to(device)
+    net = init_net.DepthInitNet({}).eval().to(device)
+
+    def timeit(fn, n):
+        fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(device)
+        return 1e3 * (time.perf_counter() - t0) / n
+    with torch.no_grad():
+        dn = init_net.extract_depth_for_init(info)
+        got, want = init_net.get_diff_feats(info, dn), tep.get_diff_feats(info, dn)
+        res = {'what': 'depth init net front end, 8 x 800 x 800: 41 M lift-project-gather pairs',
+               'hip_get_diff_feats_ms': timeit(lambda: init_net.get_diff_feats(info, dn), reps),
+               'eager_torch_get_diff_feats_ms': timeit(lambda: tep.get_diff_feats(info, dn), 3),
+               'depth_init_net_ms': timeit(lambda: net(info, None, False), reps),
+               'frac_within_1e-4_of_eager': float(((got - want).abs() <= 1e-4).float().mean())}
+    res['speedup_vs_eager'] = res['eager_torch_get_diff_feats_ms'] / res['hip_get_diff_feats_ms']
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -286,6 +320,7 @@ def main():
             eb['speedup_vs_eager'] = value / (1 if split else world) / eb['value']
             line['eager_torch_baseline'] = eb
             line['training_step'] = training_step_timing(device)
+            line['init_net'] = init_net_timing(device)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -203,6 +203,15 @@ int neuray_interpolate_feats_backward(const float* d_out_dev, const float* point
 int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_dev, const float* hit_prob_dev,
                              const float* u_dev, int rn, int dn, int fdn, int use_all, float* out_dev, void* stream);
 
+/* ---- get_diff_feats of the depth init net (network/init_net.py:30-61, with depth2pts3d :13-28,
+ * project_points_ref_views render_ops.py:117-130, interpolate_feats ops.py:14-34 and masked_mean_var ops.py:36-41 fused):
+ * every pixel of every view lifted with its depth, projected into all rfn views, |rgb| and inverse-depth differences
+ * reduced to masked mean / variance.  view_const_dev: neuray_setup_views; lift_const_dev [rfn][NEURAY_QUERY_CONST]:
+ * neuray_setup_query of every view; rgbd_dev [rfn][h][w][4] = rgb + metric depth;
+ * out_dev [rfn][h][w][8] = [rgb_mean 3, rgb_var 3, dpt_mean, dpt_var] (channels-last storage of the reference's [rfn,8,h,w]). */
+int neuray_diff_feats(const float* view_const_dev, const float* lift_const_dev, const float* rgbd_dev, int rfn, int h, int w,
+                      float* out_dev, void* stream);
+
 /* ---- a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
  * render_ops.py:54-70): bilinear, padding_mode='border'.  feats [b][c][fh][fw], points [b][n][2] pixel (x,y) in
  * units of the (w_full, h_full) image, mask [b][n] or NULL, out [b][n][c]. */

@@ -197,6 +197,16 @@ int neuray_interpolate_feats(const float* feats, const float* points, const floa
     return check_launch("neuray_interpolate_feats");
 }
 
+int neuray_diff_feats(const float* view_const, const float* lift_const, const float* rgbd, int rfn, int h, int w, float* out, void* stream) {
+    if (!view_const || !lift_const || !rgbd || !out) return fail("neuray_diff_feats: null pointer");
+    if (rfn < 1 || rfn > NEURAY_MAX_VIEWS || h < 2 || w < 2) return fail("neuray_diff_feats: bad shape rfn=%d h=%d w=%d", rfn, h, w);
+    nr::DiffFeatsParams p;
+    p.view_const = view_const; p.lift_const = lift_const; p.rgbd = rgbd; p.out = out; p.rfn = rfn; p.h = h; p.w = w;
+    const int grid = grid_for((long long)rfn * h * w, 256, 256 * 32);
+    NR_LAUNCH(nr::diff_feats_kernel, dim3(grid), dim3(256), 0, stream, p);
+    return check_launch("neuray_diff_feats");
+}
+
 int neuray_rays_points(const float* query_const, const float* coords, const float* depth, int rn, int dn, float* centers,
                        float* dirs, float* pts, float* que_dir, void* stream) {
     if (rn < 1 || (pts && (dn < 1 || !depth || !que_dir))) return fail("neuray_rays_points: bad arguments rn=%d dn=%d", rn, dn);

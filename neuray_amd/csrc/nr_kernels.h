@@ -958,6 +958,88 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// cross-view consistency features of the depth init net   network/init_net.py:13-61
+// Every pixel of every view t is lifted with its depth (depth2pts3d, :13-28), projected into every view s (a4-a6 of the
+// render path), the (rgb, depth) map of s is read there (bilinear, border, align_corners=True) and
+//   rgb_diff = |rgb_s(uv) - rgb_t(pixel)|,   dpt_diff = min(|-1/max(d_s(uv),1e-5) + 1/max(z,1e-5)| / (far'_s - near'_s), 1.5)
+// are reduced over s to a masked mean and variance (ops.py:36-41, the mask sum clamped to 1e-4):
+//   out[t][y][x] = [rgb_mean 3, rgb_var 3, dpt_mean, dpt_var]   (NHWC, i.e. the channels-last storage of [rfn,8,h,w]).
+// rgbd: [rfn][h][w][4] = rgb + metric depth: one 16-byte load per tap.  The reference materialises
+// [rfn, rfn*h*w, {2,1,1,3,3}] tensors for this (41 M projections at 8 x 800 x 800); here it is one pass, one thread per
+// pixel, the per-view values of a pixel kept in registers for the two-pass variance.
+// lift_const: per view the query constants of neuray_setup_query (K^-1, pose, centre).
+// -------------------------------------------------------------------------------------------------
+struct DiffFeatsParams {
+    const float* view_const;   // [rfn][kViewConst]
+    const float* lift_const;   // [rfn][kQueryConst]
+    const float* rgbd;         // [rfn][h][w][4]
+    float* out;                // [rfn][h][w][8]
+    int rfn, h, w;
+};
+
+__global__ void __launch_bounds__(256) diff_feats_kernel(DiffFeatsParams p) {
+    const long long hw = (long long)p.h * p.w, total = hw * p.rfn;
+    const float wf = (float)p.w, hf = (float)p.h;
+    const float4* maps = reinterpret_cast<const float4*>(p.rgbd);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / hw);
+        const int pix = (int)(i - t * hw);
+        const int y = pix / p.w, x = pix - y * p.w;
+        const float* lc = p.lift_const + t * kQueryConst;
+        const float4 own = maps[i];
+        // depth * [x, y, 1] -> K^-1 -> R^T (.) + t',  t' = -R^T t (the camera centre)
+        const float sx = rn_mul(own.w, (float)x), sy = rn_mul(own.w, (float)y), sz = own.w;
+        const float c0 = dot3(lc[0], lc[1], lc[2], sx, sy, sz);
+        const float c1 = dot3(lc[3], lc[4], lc[5], sx, sy, sz);
+        const float c2 = dot3(lc[6], lc[7], lc[8], sx, sy, sz);
+        const float* P = lc + 9;
+        const float X = rn_add(dot3(P[0], P[4], P[8], c0, c1, c2), lc[21]);
+        const float Y = rn_add(dot3(P[1], P[5], P[9], c0, c1, c2), lc[22]);
+        const float Z = rn_add(dot3(P[2], P[6], P[10], c0, c1, c2), lc[23]);
+        float val[kMaxViews][4], msk[kMaxViews];
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < kMaxViews; ++s) {
+            val[s][0] = 0.0f; val[s][1] = 0.0f; val[s][2] = 0.0f; val[s][3] = 0.0f; msk[s] = 0.0f;
+            if (s < p.rfn) {
+                const float* vc = p.view_const + s * kViewConst;
+                const Proj pr = project_point<false>(vc, X, Y, Z, wf, hf);
+                const Taps tp = taps_from(texel_coord(pr.u, wf, wf, true), texel_coord(pr.v, hf, hf, true), p.w, p.h);
+                const float4* m = maps + (long long)s * hw;
+                const float4 a = m[tp.o00], b = m[tp.o10], c = m[tp.o01], d = m[tp.o11];
+                const float gr = a.x * tp.w00 + b.x * tp.w10 + c.x * tp.w01 + d.x * tp.w11;
+                const float gg = a.y * tp.w00 + b.y * tp.w10 + c.y * tp.w01 + d.y * tp.w11;
+                const float gb = a.z * tp.w00 + b.z * tp.w10 + c.z * tp.w01 + d.z * tp.w11;
+                const float gd = a.w * tp.w00 + b.w * tp.w10 + c.w * tp.w01 + d.w * tp.w11;
+                val[s][0] = fabsf(gr - own.x); val[s][1] = fabsf(gg - own.y); val[s][2] = fabsf(gb - own.z);
+                const float dd = fabsf(rn_add(rn_div(-1.0f, fmaxf(gd, 1e-5f)), rn_div(1.0f, fmaxf(pr.z, 1e-5f))));
+                val[s][3] = fminf(rn_div(dd, rn_sub(vc[16], vc[15])), 1.5f);
+                msk[s] = pr.mask;
+            }
+        }
+        float msum = 0.0f, mean[4] = {0.0f, 0.0f, 0.0f, 0.0f}, var[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < kMaxViews; ++s) {
+            msum += msk[s];
+            NR_PRAGMA_UNROLL
+            for (int c = 0; c < 4; ++c) mean[c] += val[s][c] * msk[s];
+        }
+        msum = fmaxf(msum, 1e-4f);
+        NR_PRAGMA_UNROLL
+        for (int c = 0; c < 4; ++c) mean[c] = rn_div(mean[c], msum);
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < kMaxViews; ++s) {
+            NR_PRAGMA_UNROLL
+            for (int c = 0; c < 4; ++c) { const float e = val[s][c] - mean[c]; var[c] += e * e * msk[s]; }
+        }
+        NR_PRAGMA_UNROLL
+        for (int c = 0; c < 4; ++c) var[c] = rn_div(var[c], msum);
+        float4* o = reinterpret_cast<float4*>(p.out) + 2 * i;
+        o[0] = make_float4(mean[0], mean[1], mean[2], var[0]);
+        o[1] = make_float4(var[1], var[2], mean[3], var[3]);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
 // render_ops.py:54-70).  One thread per (batch, point); used for pixel_colors_gt and the auxiliary
 // (non per-sample) gathers.  points [b][n][2] pixel (x,y) in units of the (w_full, h_full) image.

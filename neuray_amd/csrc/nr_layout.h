@@ -170,6 +170,7 @@ constexpr int kPointRec = 20;
 // ---- per-view constants produced by the view-setup kernel ---------------------------------------
 //   [0..11] H = K [R|t] (row major 3x4), [12..14] camera centre -R^T t, [15] -1/near, [16] -1/far
 constexpr int kViewConst = 20;
+constexpr int kMaxViews = 16;          // NEURAY_MAX_VIEWS of include/neuray_hip.h
 // query constants: [0..8] K^-1, [9..20] pose 3x4, [21..23] centre, [24] -1/near, [25] -1/far
 constexpr int kQueryConst = 28;
 

@@ -169,6 +169,29 @@ class RenderEngine:
         self._check(self.lib.neuray_relayout_nhwc(t.data_ptr(), out.data_ptr(), n, 32, fh, fw, 32, s))
         return out
 
+    def diff_feats(self, ref_imgs_info, depth):
+        """network/init_net.py:30-61 `get_diff_feats` given the metric depth maps [rfn,1,h,w] (the clamped depths the
+        reference recovers from its normalised input): -> [rfn,8,h,w] (channels-last storage) of
+        [rgb_mean 3, rgb_var 3, dpt_mean, dpt_var]."""
+        imgs = self._f32(ref_imgs_info['imgs'])
+        rfn, _, h, w = imgs.shape
+        if rfn > _lib.MAX_VIEWS:
+            raise RuntimeError("neuray_amd: %d views > %d" % (rfn, _lib.MAX_VIEWS))
+        s = self._stream()
+        poses, Ks, dr = self._f32(ref_imgs_info['poses']), self._f32(ref_imgs_info['Ks']), self._f32(ref_imgs_info['depth_range'])
+        vc = self.empty(rfn, _lib.VIEW_CONST)
+        self._check(self.lib.neuray_setup_views(poses.data_ptr(), Ks.data_ptr(), dr.data_ptr(), rfn, vc.data_ptr(), s))
+        kinv = self._f32(torch.inverse(Ks))                   # as depth2pts3d (init_net.py:23)
+        lift = self.empty(rfn, _lib.QUERY_CONST)
+        for v in range(rfn):
+            self._check(self.lib.neuray_setup_query(poses[v].data_ptr(), kinv[v].data_ptr(), dr[v].data_ptr(), lift[v].data_ptr(), s))
+        rgbd_nchw = torch.cat([imgs, self._f32(depth)], 1).contiguous()
+        rgbd = self.empty(rfn, h, w, 4)
+        self._check(self.lib.neuray_relayout_nhwc(rgbd_nchw.data_ptr(), rgbd.data_ptr(), rfn, 4, h, w, 4, s))
+        out = self.empty(rfn, h, w, 8)
+        self._check(self.lib.neuray_diff_feats(vc.data_ptr(), lift.data_ptr(), rgbd.data_ptr(), rfn, h, w, out.data_ptr(), s))
+        return out.permute(0, 3, 1, 2)
+
     def prepare_query(self, que_imgs_info):
         """-> query constant block.  K^-1 by torch.inverse exactly as the reference (render_ops.py:20)."""
         pose = self._f32(que_imgs_info['poses'])

@@ -198,11 +198,9 @@ class NeuralRayBaseRenderer(nn.Module):
 
 
 # ---- generalisation renderer ----------------------------------------------------------------------------
-name2init_net = {}
-"""Registry of initial-visibility-feature networks (`init_net_type` -> class(cfg)), the reference's `name2init_net`
-(network/init_net.py:163-166).  DepthInitNet / CostVolumeInitNet are SURVEY.md 8(f) rows f-2 / f-3 and are not built
-here: register a module under the reference's name, pass one as `init_net=`, or hand the initial `ray_feats` over in
-`ref_imgs_info` (they are consumed exactly where the reference consumes init_net's output)."""
+from .init_net import name2init_net      # noqa: E402  'depth' (f-2) is built; 'cost_volume' (MVSNet, f-3) is not: register a
+#                                                        module under that name, pass one as `init_net=`, or hand the
+#                                                        initial `ray_feats` over in ref_imgs_info
 
 
 class NeuralRayGenRenderer(NeuralRayBaseRenderer):
@@ -223,7 +221,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
             ref_imgs_info['ray_feats'] = self.init_net(ref_imgs_info, src_imgs_info, is_train)
         elif 'ray_feats' not in ref_imgs_info:
             raise NotImplementedError(
-                "neuray_amd: no init_net for init_net_type=%r (SURVEY.md 8(f) f-2/f-3 are not built) and no initial "
+                "neuray_amd: no init_net for init_net_type=%r (the MVSNet init net, SURVEY.md 8(f) f-3, is not built) and no initial "
                 "ref_imgs_info['ray_feats'] was handed over" % self.cfg['init_net_type'])
         return self.render(que_imgs_info, ref_imgs_info, is_train)
 

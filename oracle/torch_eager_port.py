@@ -225,3 +225,42 @@ def render_impl(w, cfg, que, ref, is_train=False, u=None):
         if self_hp:
             out['hit_prob_self_fine'] = self_hit_prob(w, cfg, fd, que, True)
     return out
+
+
+def get_diff_feats(info, depth_in):
+    """The tensor formulation of network/init_net.py:13-61 (depth2pts3d, project_points_ref_views, two grid_samples on
+    [rfn, rfn*h*w, .] tensors, masked_mean_var) - the eager baseline beside the fused neuray_diff_feats kernel."""
+    imgs, dr, Ks, poses = info['imgs'], info['depth_range'], info['Ks'], info['poses']
+    rfn, _, h, w = imgs.shape
+    dev = imgs.device
+    near, far = dr[:, 0][:, None, None], dr[:, 1][:, None, None]
+    near_inv, far_inv = -1 / near[..., None], -1 / far[..., None]
+    depth = -1 / (depth_in * (far_inv - near_inv) + near_inv)
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')
+    coords = torch.stack([xs, ys, torch.ones_like(xs)], -1).float()[None, :, :, None, :]          # 1,h,w,1,3
+    pts = (depth.permute(0, 2, 3, 1).unsqueeze(-1) * coords).reshape(rfn, h * w, 3).permute(0, 2, 1)
+    pts = torch.inverse(Ks) @ pts
+    R = poses[:, :, :3].permute(0, 2, 1)
+    pts = (R @ pts + (-R @ poses[:, :, 3:])).permute(0, 2, 1).reshape(-1, 3)                      # rfn*h*w,3
+    hom = torch.cat([pts, torch.ones_like(pts[:, :1])], 1)
+    cam = hom[None] @ (Ks @ poses).permute(0, 2, 1)                                               # rfn,N,3
+    z = cam[..., 2:]
+    bad = z.abs() < 1e-4
+    z = torch.where(bad, torch.full_like(z, 1e-3), z)
+    uv = cam[..., :2] / z
+    valid = (~bad[..., 0]) & (uv[..., 0] >= -0.5) & (uv[..., 0] < w - 0.5) & (uv[..., 1] >= -0.5) & (uv[..., 1] < h - 0.5)
+    d_int = _grid_gather(depth, uv, h, w)
+    c_int = _grid_gather(imgs, uv, h, w)
+    rgb_diff = (c_int - imgs.permute(0, 2, 3, 1).reshape(1, rfn * h * w, 3)).abs()
+    dpt_diff = (-1 / d_int.clamp(min=1e-5) + 1 / z.clamp(min=1e-5)).abs() / ((-1 / far) - (-1 / near))
+    dpt_diff = dpt_diff.clamp(max=1.5)
+    m = valid.float().unsqueeze(-1)
+
+    def mean_var(x):
+        msum = m.sum(0, keepdim=True).clamp_min(1e-4)
+        mean = (x * m).sum(0, keepdim=True) / msum
+        return mean, ((x - mean) ** 2 * m).sum(0, keepdim=True) / msum
+    dm, dv = mean_var(dpt_diff)
+    rm, rv = mean_var(rgb_diff)
+    to_map = lambda t, c: t.reshape(rfn, h, w, c).permute(0, 3, 1, 2)
+    return torch.cat([to_map(rm, 3), to_map(rv, 3), to_map(dm, 1), to_map(dv, 1)], 1)

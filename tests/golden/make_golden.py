@@ -364,9 +364,42 @@ def scene_case(ns):
     print('wrote case_scene.npz', out['ft_train_touched'], out['gen_depth_mean'].shape)
 
 
+def init_net_case(ns):
+    """extract_depth_for_init, get_diff_feats and the whole DepthInitNet (network/init_net.py:13-112)
+    of the reference on a small scene with depth maps (smooth surface + noise + a few out-of-range values for the clamps)."""
+    import importlib
+    from neuray_amd import synthetic
+    init_net = importlib.import_module('network.init_net')
+    h, w, n = 48, 64, 3
+    _, ref = synthetic.make_scene(h, w, n, seed=13)
+    rng = np.random.RandomState(14)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    depth = np.stack([3.6 + 0.7 * np.sin(xx / 9.0 + v) * np.cos(yy / 7.0 - v) + 0.05 * rng.randn(h, w) for v in range(n)])[:, None]
+    depth[0, 0, :2, :5] = 0.0
+    depth[1, 0, 5, 5:9] = 9.0
+    depth[2, 0, -1, -4:] = 1.0
+    depth = depth.astype(np.float32)
+    info = {k: torch.from_numpy(ref[k]) for k in ('imgs', 'poses', 'Ks', 'depth_range')}
+    info['depth'] = torch.from_numpy(depth)
+    net = init_net.DepthInitNet({}).eval()
+    fill_by_name(net)
+    with torch.no_grad():
+        dn = init_net.extract_depth_for_init(info)
+        diff = init_net.get_diff_feats(info, dn)
+        out = net(info, None, False)
+    np.savez_compressed(os.path.join(HERE, 'case_init_depth.npz'), imgs=ref['imgs'], poses=ref['poses'], Ks=ref['Ks'],
+                        depth_range=ref['depth_range'], depth=depth, depth_norm=dn.numpy(), diff_feats=diff.numpy(),
+                        ray_feats=out.numpy())
+    import json
+    json.dump({k: list(v.shape) for k, v in net.state_dict().items()},
+              open(os.path.join(HERE, 'ref_depth_init_net_state_dict.json'), 'w'), indent=0, sort_keys=True)
+    print('wrote case_init_depth.npz', diff.shape, out.shape, float(diff.abs().max()))
+
+
 if __name__ == '__main__':
     main()
     ns_ = ref_harness.import_reference()
     gradient_case(ns_)
     encoder_case(ns_)
     scene_case(ns_)
+    init_net_case(ns_)

@@ -219,6 +219,23 @@ def init_net_timing(device, reps=10):
                'depth_init_net_ms': timeit(lambda: net(info, None, False), reps),
                'frac_within_1e-4_of_eager': float(((got - want).abs() <= 1e-4).float().mean())}
     res['speedup_vs_eager'] = res['eager_torch_get_diff_feats_ms'] / res['hip_get_diff_feats_ms']
+    # f-3: plane-sweep variance volume of the cost-volume init net, one reference view of the 800 x 800 evaluation path
+    # (built at 640 x 640: 160 x 160 x 64 planes, 3 source views), and the whole CostVolumeInitNet forward
+    from neuray_amd.network import render_ops
+    eng = render_ops.engine_for(device)
+    info['nn_ids'] = torch.tensor([[(v + 1) % 8, (v + 2) % 8, (v + 3) % 8] for v in range(8)], device=device)
+    cv = init_net.CostVolumeInitNet({}).eval().to(device)
+    with torch.no_grad():
+        f = torch.randn(8, 32, 160, 160, generator=torch.Generator().manual_seed(0)).to(device)
+        prj = init_net.construct_project_matrix(0.2, 0.2, info['Ks'], info['poses'])
+        dv = init_net.get_depth_vals(info['depth_range'], 64)
+        ids = info['nn_ids'][:1]
+        got, want = eng.warp_variance(f[:1], f, ids, prj[:1], prj, dv[:1]), tep.variance_volume(f[:1], f, ids, prj[:1], prj, dv[:1])
+        res.update({'hip_warp_variance_ms_per_ref_view': timeit(lambda: eng.warp_variance(f[:1], f, ids, prj[:1], prj, dv[:1]), reps),
+                    'eager_torch_warp_variance_ms_per_ref_view': timeit(lambda: tep.variance_volume(f[:1], f, ids, prj[:1], prj, dv[:1]), 3),
+                    'warp_variance_frac_within_1e-3_of_eager': float(((got - want).abs() <= 1e-3).float().mean()),
+                    'cost_volume_init_net_ms': timeit(lambda: cv(info, info, False), 3)})
+    res['warp_variance_speedup_vs_eager'] = res['eager_torch_warp_variance_ms_per_ref_view'] / res['hip_warp_variance_ms_per_ref_view']
     return res
 
 

@@ -212,6 +212,17 @@ int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_de
 int neuray_diff_feats(const float* view_const_dev, const float* lift_const_dev, const float* rgbd_dev, int rfn, int h, int w,
                       float* out_dev, void* stream);
 
+/* ---- plane-sweep variance volume of the cost-volume init net (network/mvsnet/mvsnet.py:186-203
+ * `construct_cost_volume_with_src` with `homo_warp`, network/mvsnet/modules.py:25-64, fused): for every reference view r,
+ * depth plane d and feature pixel, the 32-channel features of the n_num source views nn_ids[r][j] (rows of src_feats,
+ * all < sn) are read at the homography  transforms[r][j] = (src_proj_j @ inverse(ref_proj_r))[:3] (3x4 row-major,
+ * computed by the caller as the reference does) - bilinear, zero padding, align_corners=True - and reduced together
+ * with the reference's own feature to the per-channel variance.
+ * ref_feats_dev [rfn][fh][fw][32], src_feats_dev [sn][fh][fw][32] (NHWC), depth_vals_dev [rfn][dn],
+ * out_dev [rfn][32][dn][fh][fw]. */
+int neuray_warp_variance(const float* ref_feats_dev, const float* src_feats_dev, const int* nn_ids_dev, const float* transforms_dev,
+                         const float* depth_vals_dev, int rfn, int sn, int n_num, int dn, int fh, int fw, float* out_dev, void* stream);
+
 /* ---- a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
  * render_ops.py:54-70): bilinear, padding_mode='border'.  feats [b][c][fh][fw], points [b][n][2] pixel (x,y) in
  * units of the (w_full, h_full) image, mask [b][n] or NULL, out [b][n][c]. */

@@ -117,6 +117,8 @@ SYMBOLS = {
     'neuray_interpolate_feats_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_warp_variance': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_diff_feats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

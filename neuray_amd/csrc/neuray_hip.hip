@@ -207,6 +207,19 @@ int neuray_diff_feats(const float* view_const, const float* lift_const, const fl
     return check_launch("neuray_diff_feats");
 }
 
+int neuray_warp_variance(const float* ref_feats, const float* src_feats, const int* nn_ids, const float* transforms, const float* depth_vals,
+                         int rfn, int sn, int n_num, int dn, int fh, int fw, float* out, void* stream) {
+    if (!ref_feats || !src_feats || !nn_ids || !transforms || !depth_vals || !out) return fail("neuray_warp_variance: null pointer");
+    if (rfn < 1 || sn < 1 || n_num < 1 || dn < 1 || fh < 2 || fw < 2)
+        return fail("neuray_warp_variance: bad shape rfn=%d sn=%d n_num=%d dn=%d fh=%d fw=%d", rfn, sn, n_num, dn, fh, fw);
+    nr::WarpVarParams p;
+    p.ref_feats = ref_feats; p.src_feats = src_feats; p.nn_ids = nn_ids; p.transforms = transforms; p.depth_vals = depth_vals; p.out = out;
+    p.rfn = rfn; p.n_num = n_num; p.dn = dn; p.fh = fh; p.fw = fw;
+    const int grid = grid_for((long long)rfn * dn * fh * fw, 256, 256 * 64);
+    NR_LAUNCH(nr::warp_variance_kernel, dim3(grid), dim3(256), 0, stream, p);
+    return check_launch("neuray_warp_variance");
+}
+
 int neuray_rays_points(const float* query_const, const float* coords, const float* depth, int rn, int dn, float* centers,
                        float* dirs, float* pts, float* que_dir, void* stream) {
     if (rn < 1 || (pts && (dn < 1 || !depth || !que_dir))) return fail("neuray_rays_points: bad arguments rn=%d dn=%d", rn, dn);

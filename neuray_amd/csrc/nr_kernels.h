@@ -958,6 +958,91 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// plane-sweep variance volume of the cost-volume init net
+//   network/mvsnet/mvsnet.py:186-203 (construct_cost_volume_with_src) with homo_warp, mvsnet/modules.py:25-64, fused:
+// for reference view r, depth plane d and feature pixel (x, y):  p = M_rj (x d, y d, d, 1),  M_rj = (src_proj_j ref_proj_r^-1)[:3]
+// (computed by the caller as the reference computes it), z clamped to >= 1e-4, the 32-channel feature of source view j
+// read at (p.x/z, p.y/z) (bilinear, ZERO padding, align_corners=True), and over the n_num sources plus the reference's
+// own feature   var_c = sum_sq_c / V - (sum_c / V)^2,  V = n_num + 1.
+// The reference materialises a [B,32,D,h,w] volume per source view plus the two running sums (the memory peak of the
+// whole pipeline); here a thread owns one (r, d, y, x), keeps the 2 x 32 sums in registers and writes the variance once.
+// feats are NHWC (8 x 16-byte loads per tap); out is NCDHW for the 3-D convolutions that follow.
+// -------------------------------------------------------------------------------------------------
+struct WarpVarParams {
+    const float* ref_feats;    // [rfn][fh][fw][32]
+    const float* src_feats;    // [sn][fh][fw][32]
+    const int* nn_ids;         // [rfn][n_num] rows of src_feats
+    const float* transforms;   // [rfn][n_num][12]: 3x4, row-major
+    const float* depth_vals;   // [rfn][dn]
+    float* out;                // [rfn][32][dn][fh][fw]
+    int rfn, n_num, dn, fh, fw;
+};
+
+__global__ void __launch_bounds__(256) warp_variance_kernel(WarpVarParams p) {
+    const long long hw = (long long)p.fh * p.fw, per_view = hw * p.dn, total = per_view * p.rfn;
+    const float wm1 = (float)(p.fw - 1), hm1 = (float)(p.fh - 1);
+    const float half_w = rn_div(wm1, 2.0f), half_h = rn_div(hm1, 2.0f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per_view);
+        const long long rem = i - (long long)r * per_view;
+        const int d = (int)(rem / hw), pix = (int)(rem - (long long)d * hw);
+        const int y = pix / p.fw, x = pix - y * p.fw;
+        const float dv = p.depth_vals[r * p.dn + d];
+        const float gx = rn_mul((float)x, dv), gy = rn_mul((float)y, dv), gz = dv;
+        float sum[32], sq[32];
+        {
+            const float4* own = reinterpret_cast<const float4*>(p.ref_feats + ((long long)r * hw + pix) * 32);
+            NR_PRAGMA_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = own[q];
+                sum[4 * q] = v.x; sum[4 * q + 1] = v.y; sum[4 * q + 2] = v.z; sum[4 * q + 3] = v.w;
+                sq[4 * q] = v.x * v.x; sq[4 * q + 1] = v.y * v.y; sq[4 * q + 2] = v.z * v.z; sq[4 * q + 3] = v.w * v.w;
+            }
+        }
+        for (int j = 0; j < p.n_num; ++j) {
+            const float* M = p.transforms + ((long long)r * p.n_num + j) * 12;
+            const float X = rn_add(dot3(M[0], M[1], M[2], gx, gy, gz), M[3]);
+            const float Y = rn_add(dot3(M[4], M[5], M[6], gx, gy, gz), M[7]);
+            float Z = rn_add(dot3(M[8], M[9], M[10], gx, gy, gz), M[11]);
+            if (Z < 1e-4f) Z = 1e-4f;
+            // grid_sample(align_corners=True) un-normalisation of  g = s / ((size-1)/2) - 1
+            const float ix = rn_mul(rn_div(rn_add(rn_sub(rn_div(rn_div(X, Z), half_w), 1.0f), 1.0f), 2.0f), wm1);
+            const float iy = rn_mul(rn_div(rn_add(rn_sub(rn_div(rn_div(Y, Z), half_h), 1.0f), 1.0f), 2.0f), hm1);
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
+            // (NaN / huge coordinates fail every bounds test below: zero contribution, as in grid_sample)
+            const bool okx0 = x0f >= 0.0f && x0f <= wm1, okx1 = x0f + 1.0f >= 0.0f && x0f + 1.0f <= wm1;
+            const bool oky0 = y0f >= 0.0f && y0f <= hm1, oky1 = y0f + 1.0f >= 0.0f && y0f + 1.0f <= hm1;
+            const int x0 = okx0 ? (int)x0f : 0, x1 = okx1 ? (int)x0f + 1 : 0, y0 = oky0 ? (int)y0f : 0, y1 = oky1 ? (int)y0f + 1 : 0;
+            const float w00 = (okx0 && oky0) ? wx0 * wy0 : 0.0f, w10 = (okx1 && oky0) ? wx1 * wy0 : 0.0f;
+            const float w01 = (okx0 && oky1) ? wx0 * wy1 : 0.0f, w11 = (okx1 && oky1) ? wx1 * wy1 : 0.0f;
+            const float4* m = reinterpret_cast<const float4*>(p.src_feats + (long long)p.nn_ids[r * p.n_num + j] * hw * 32);
+            const float4* t00 = m + ((long long)y0 * p.fw + x0) * 8;
+            const float4* t10 = m + ((long long)y0 * p.fw + x1) * 8;
+            const float4* t01 = m + ((long long)y1 * p.fw + x0) * 8;
+            const float4* t11 = m + ((long long)y1 * p.fw + x1) * 8;
+            NR_PRAGMA_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                const float4 a = t00[q], b = t10[q], c = t01[q], e = t11[q];
+                const float v0 = a.x * w00 + b.x * w10 + c.x * w01 + e.x * w11;
+                const float v1 = a.y * w00 + b.y * w10 + c.y * w01 + e.y * w11;
+                const float v2 = a.z * w00 + b.z * w10 + c.z * w01 + e.z * w11;
+                const float v3 = a.w * w00 + b.w * w10 + c.w * w01 + e.w * w11;
+                sum[4 * q] += v0; sum[4 * q + 1] += v1; sum[4 * q + 2] += v2; sum[4 * q + 3] += v3;
+                sq[4 * q] += v0 * v0; sq[4 * q + 1] += v1 * v1; sq[4 * q + 2] += v2 * v2; sq[4 * q + 3] += v3 * v3;
+            }
+        }
+        const float V = (float)(p.n_num + 1);
+        float* o = p.out + (long long)r * 32 * per_view + (long long)d * hw + pix;
+        NR_PRAGMA_UNROLL
+        for (int c = 0; c < 32; ++c) {
+            const float mean = rn_div(sum[c], V);
+            o[(long long)c * per_view] = rn_sub(rn_div(sq[c], V), rn_mul(mean, mean));
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // cross-view consistency features of the depth init net   network/init_net.py:13-61
 // Every pixel of every view t is lifted with its depth (depth2pts3d, :13-28), projected into every view s (a4-a6 of the
 // render path), the (rgb, depth) map of s is read there (bilinear, border, align_corners=True) and

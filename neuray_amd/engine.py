@@ -192,6 +192,26 @@ class RenderEngine:
         self._check(self.lib.neuray_diff_feats(vc.data_ptr(), lift.data_ptr(), rgbd.data_ptr(), rfn, h, w, out.data_ptr(), s))
         return out.permute(0, 3, 1, 2)
 
+    def warp_variance(self, ref_feats, src_feats, nn_ids, ref_prjs, src_prjs, depth_vals):
+        """network/mvsnet/mvsnet.py:186-203: feature maps [n,32,fh,fw], nn_ids [rfn,n_num] (rows of src_feats), 4x4
+        projections, depth_vals [rfn,dn] -> variance volume [rfn,32,dn,fh,fw]."""
+        rfn, c, fh, fw = ref_feats.shape
+        assert c == 32 and src_feats.shape[1:] == ref_feats.shape[1:]
+        sn, n_num, dn = src_feats.shape[0], nn_ids.shape[1], depth_vals.shape[1]
+        assert int(nn_ids.max()) < sn and int(nn_ids.min()) >= 0
+        s = self._stream()
+        nhwc = lambda t: self._f32(t).permute(0, 2, 3, 1).contiguous()
+        rf, sf = nhwc(ref_feats), nhwc(src_feats)
+        ids = nn_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        # transform = src_proj @ ref_proj_inv, per (reference view, neighbour) as homo_warp computes it (modules.py:36)
+        inv = torch.inverse(self._f32(ref_prjs))
+        tr = torch.stack([self._f32(src_prjs)[nn_ids[:, j].to(self.device).long()] @ inv for j in range(n_num)], 1)[:, :, :3, :].contiguous()
+        dv = self._f32(depth_vals)
+        out = self.empty(rfn, 32, dn, fh, fw)
+        self._check(self.lib.neuray_warp_variance(rf.data_ptr(), sf.data_ptr(), ids.data_ptr(), tr.data_ptr(), dv.data_ptr(),
+                                                  rfn, sn, n_num, dn, fh, fw, out.data_ptr(), s))
+        return out
+
     def prepare_query(self, que_imgs_info):
         """-> query constant block.  K^-1 by torch.inverse exactly as the reference (render_ops.py:20)."""
         pose = self._f32(que_imgs_info['poses'])

@@ -1,0 +1,124 @@
+"""MVSNet as the cost-volume init net uses it (reference network/mvsnet/mvsnet.py,
+network/mvsnet/modules.py): frozen, eval mode, `construct_cost_volume_with_src` only.
+
+  feature            8 conv + activated-batch-norm layers, 3 -> 32 channels at 1/4 resolution (mvsnet.py:7-30)
+  variance volume    ONE HIP kernel (neuray_warp_variance) instead of a [B,32,D,h,w] warp per source view plus two
+                     running sums (mvsnet.py:186-203, modules.py:25-64)
+  cost_regularization  3-D U-Net, 32 -> 1 channel (mvsnet.py:32-75): PyTorch Conv3d / ConvTranspose3d (MIOpen)
+
+The reference builds it with `inplace_abn.ABN` (network/init_net.py:121): F.batch_norm with the running statistics
+followed by leaky_relu(0.01); `ActivatedBatchNorm` below has that module's parameter and buffer names (`weight`, `bias`,
+`running_mean`, `running_var`), so `mvsnet_pl.ckpt` loads through `load_ckpt` as in the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ActivatedBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, slope=0.01):
+        super().__init__()
+        self.eps, self.slope = eps, slope
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+
+    def forward(self, x):
+        x = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, 0.1, self.eps)
+        return F.leaky_relu(x, self.slope)
+
+
+class _ConvAbn(nn.Module):
+    def __init__(self, conv, cout):
+        super().__init__()
+        self.conv, self.bn = conv, ActivatedBatchNorm(cout)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+def _c2(cin, cout, k=3, stride=1, pad=1):
+    return _ConvAbn(nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False), cout)
+
+
+def _c3(cin, cout, stride=1):
+    return _ConvAbn(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False), cout)
+
+
+def _up3(cin, cout):
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                         ActivatedBatchNorm(cout))
+
+
+class FeatureNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv0, self.conv1 = _c2(3, 8), _c2(8, 8)
+        self.conv2, self.conv3, self.conv4 = _c2(8, 16, 5, 2, 2), _c2(16, 16), _c2(16, 16)
+        self.conv5, self.conv6 = _c2(16, 32, 5, 2, 2), _c2(32, 32)
+        self.feature = nn.Conv2d(32, 32, 3, 1, 1)
+
+    def forward(self, x):
+        x = self.conv1(self.conv0(x))
+        x = self.conv4(self.conv3(self.conv2(x)))
+        return self.feature(self.conv6(self.conv5(x)))
+
+
+class CostRegNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv0 = _c3(32, 8)
+        self.conv1, self.conv2 = _c3(8, 16, 2), _c3(16, 16)
+        self.conv3, self.conv4 = _c3(16, 32, 2), _c3(32, 32)
+        self.conv5, self.conv6 = _c3(32, 64, 2), _c3(64, 64)
+        self.conv7, self.conv9, self.conv11 = _up3(64, 32), _up3(32, 16), _up3(16, 8)
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        x = c4 + self.conv7(self.conv6(self.conv5(c4)))
+        x = c2 + self.conv9(x)
+        x = c0 + self.conv11(x)
+        return self.prob(x)
+
+
+class MVSNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.feature = FeatureNet()
+        self.cost_regularization = CostRegNet()
+
+    def variance_volume(self, ref_feats, src_feats, ref_nn_idx, ref_prjs, src_prjs, depth_values):
+        from . import render_ops
+        return render_ops.engine_for(ref_feats.device).warp_variance(ref_feats, src_feats, ref_nn_idx, ref_prjs, src_prjs, depth_values)
+
+    def construct_cost_volume_with_src(self, ref_imgs, src_imgs, ref_nn_idx, ref_prjs, src_prjs, depth_values, batch_num=2):
+        """mvsnet.py:186-203 -> cost_reg [rfn,dn,h/4,w/4].  `batch_num` reference views go through the 3-D U-Net at a
+        time, as in the reference (it bounds the activation memory, not the result)."""
+        ref_feats, src_feats = self.feature(ref_imgs), self.feature(src_imgs)
+        out = []
+        for r0 in range(0, ref_feats.shape[0], batch_num):
+            sl = slice(r0, r0 + batch_num)
+            var = self.variance_volume(ref_feats[sl], src_feats, ref_nn_idx[sl], ref_prjs[sl], src_prjs, depth_values[sl])
+            out.append(self.cost_regularization(var).squeeze(1))
+        return torch.cat(out, 0)
+
+
+def extract_model_state_dict(ckpt_path, prefixes_to_ignore=()):
+    """mvsnet.py:205-229: a pytorch-lightning checkpoint ('state_dict' with a 'model.' prefix) or bare model weights"""
+    ckpt = torch.load(ckpt_path, map_location='cpu')
+    if 'state_dict' in ckpt:
+        items = ((k[6:], v) for k, v in ckpt['state_dict'].items() if k.startswith('model.'))
+    else:
+        items = ckpt.items()
+    return {k: v for k, v in items if not any(k.startswith(p) for p in prefixes_to_ignore)}
+
+
+def load_ckpt(model, ckpt_path, prefixes_to_ignore=()):
+    """mvsnet.py:231-235"""
+    sd = model.state_dict()
+    sd.update(extract_model_state_dict(ckpt_path, prefixes_to_ignore))
+    model.load_state_dict(sd)

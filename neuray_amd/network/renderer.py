@@ -198,9 +198,7 @@ class NeuralRayBaseRenderer(nn.Module):
 
 
 # ---- generalisation renderer ----------------------------------------------------------------------------
-from .init_net import name2init_net      # noqa: E402  'depth' (f-2) is built; 'cost_volume' (MVSNet, f-3) is not: register a
-#                                                        module under that name, pass one as `init_net=`, or hand the
-#                                                        initial `ray_feats` over in ref_imgs_info
+from .init_net import name2init_net      # noqa: E402  'depth'  and 'cost_volume' (f-3)
 
 
 class NeuralRayGenRenderer(NeuralRayBaseRenderer):
@@ -221,7 +219,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
             ref_imgs_info['ray_feats'] = self.init_net(ref_imgs_info, src_imgs_info, is_train)
         elif 'ray_feats' not in ref_imgs_info:
             raise NotImplementedError(
-                "neuray_amd: no init_net for init_net_type=%r (the MVSNet init net, SURVEY.md 8(f) f-3, is not built) and no initial "
+                "neuray_amd: no init_net registered for init_net_type=%r (pass one as init_net=) and no initial "
                 "ref_imgs_info['ray_feats'] was handed over" % self.cfg['init_net_type'])
         return self.render(que_imgs_info, ref_imgs_info, is_train)
 

@@ -673,3 +673,54 @@ def get_diff_feats(ref, depth_norm, Ks_inv=None):
     rm, rv = mean_var(rgb_diff)
     to_map = lambda t, c: t.reshape(rfn, h, w, c).transpose(0, 3, 1, 2)
     return np.concatenate([to_map(rm, 3), to_map(rv, 3), to_map(dm, 1), to_map(dv, 1)], 1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# plane-sweep warp + variance     network/mvsnet/modules.py:25-64, mvsnet.py:186-203
+# --------------------------------------------------------------------------------------
+def homo_warp(src_feat, src_proj, ref_proj_inv, depth_values):
+    """src_feat [B,C,H,W], 4x4 projections [B,4,4], depth_values [B,D] -> warped [B,C,D,H,W]
+    (bilinear, zero padding, align_corners=True; z clamped to >= 1e-4)"""
+    src_feat = f32(src_feat)
+    B, C, H, W = src_feat.shape
+    D = depth_values.shape[1]
+    out = np.zeros([B, C, D, H, W], np.float32)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    for b in range(B):
+        M = (f32(src_proj[b]) @ f32(ref_proj_inv[b]))[:3]
+        for d in range(D):
+            dv = F32(depth_values[b, d])
+            gx, gy, gz = xx * dv, yy * dv, np.full_like(xx, dv)
+            X = dot3(M[0, 0], M[0, 1], M[0, 2], gx, gy, gz) + M[0, 3]
+            Y = dot3(M[1, 0], M[1, 1], M[1, 2], gx, gy, gz) + M[1, 3]
+            Z = dot3(M[2, 0], M[2, 1], M[2, 2], gx, gy, gz) + M[2, 3]
+            Z = np.where(Z < F32(1e-4), F32(1e-4), Z)
+            ix = ((X / Z) / F32((W - 1) / 2) - F32(1) + F32(1)) / F32(2) * F32(W - 1)
+            iy = ((Y / Z) / F32((H - 1) / 2) - F32(1) + F32(1)) / F32(2) * F32(H - 1)
+            x0f, y0f = np.floor(ix), np.floor(iy)
+            wx1, wy1 = ix - x0f, iy - y0f
+            wx0, wy0 = (x0f + F32(1)) - ix, (y0f + F32(1)) - iy
+            acc = np.zeros([C, H, W], np.float32)
+            for (xf, yf, ww) in ((x0f, y0f, wx0 * wy0), (x0f + 1, y0f, wx1 * wy0), (x0f, y0f + 1, wx0 * wy1), (x0f + 1, y0f + 1, wx1 * wy1)):
+                ok = (xf >= 0) & (xf <= W - 1) & (yf >= 0) & (yf <= H - 1)
+                xi = np.where(ok, xf, 0).astype(np.int64)
+                yi = np.where(ok, yf, 0).astype(np.int64)
+                acc += src_feat[b][:, yi, xi] * np.where(ok, ww, F32(0))[None]
+            out[b, :, d] = acc
+    return out
+
+
+def variance_volume(ref_feats, src_feats, nn_ids, ref_prjs, src_prjs, depth_values):
+    """mvsnet.py:186-203 without the U-Net: [rfn,32,dn,h,w]"""
+    ref_feats, src_feats = f32(ref_feats), f32(src_feats)
+    rfn, n_num = nn_ids.shape
+    inv = np.stack([np.linalg.inv(f32(p).astype(np.float64)).astype(np.float32) for p in ref_prjs])
+    dn = depth_values.shape[1]
+    s = np.repeat(ref_feats[:, :, None], dn, 2)
+    sq = s * s
+    for j in range(n_num):
+        wv = homo_warp(src_feats[nn_ids[:, j]], f32(src_prjs)[nn_ids[:, j]], inv, depth_values)
+        s = s + wv
+        sq = sq + wv * wv
+    V = F32(n_num + 1)
+    return (sq / V - (s / V) ** 2).astype(np.float32)

@@ -264,3 +264,32 @@ def get_diff_feats(info, depth_in):
     rm, rv = mean_var(rgb_diff)
     to_map = lambda t, c: t.reshape(rfn, h, w, c).permute(0, 3, 1, 2)
     return torch.cat([to_map(rm, 3), to_map(rv, 3), to_map(dm, 1), to_map(dv, 1)], 1)
+
+
+def variance_volume(ref_feats, src_feats, nn_ids, ref_prjs, src_prjs, depth_values):
+    """The tensor formulation of network/mvsnet/mvsnet.py:186-203 + modules.py:25-64 (one [B,32,D,h,w] grid_sample per
+    source view, two running sums) - the eager baseline beside the fused neuray_warp_variance kernel."""
+    B, C, H, W = ref_feats.shape
+    D = depth_values.shape[1]
+    dev = ref_feats.device
+    inv = torch.inverse(ref_prjs)
+    s = ref_feats.unsqueeze(2).repeat(1, 1, D, 1, 1)
+    sq = s ** 2
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing='ij')
+    grid = torch.stack([xs, ys, torch.ones_like(xs)], 0).reshape(1, 3, H * W).expand(B, -1, -1)
+    n_num = nn_ids.shape[1]
+    for j in range(n_num):
+        tr = src_prjs[nn_ids[:, j]] @ inv
+        R, T = tr[:, :3, :3], tr[:, :3, 3:]
+        g = (grid.unsqueeze(2) * depth_values.view(B, 1, D, 1)).reshape(B, 3, D * H * W)
+        p = R @ g + T
+        z = p[:, 2:].clamp(min=1e-4)
+        xy = p[:, :2] / z
+        gx = xy[:, 0] / ((W - 1) / 2) - 1
+        gy = xy[:, 1] / ((H - 1) / 2) - 1
+        samp = torch.stack([gx, gy], -1).view(B, D, H * W, 2)
+        wv = F.grid_sample(src_feats[nn_ids[:, j]], samp, mode='bilinear', padding_mode='zeros', align_corners=True).view(B, C, D, H, W)
+        s = s + wv
+        sq = sq + wv ** 2
+    V = n_num + 1
+    return sq / V - (s / V) ** 2

@@ -39,8 +39,45 @@ def _stub(name, **attrs):
     return m
 
 
+def _abn_class():
+    """Restatement of inplace_abn.ABN (mapillary/inplace_abn 1.x, the activated batch norm the reference's MVSNet is built
+    with: network/init_net.py:5,121 `MVSNet(ABN)`; requirements.txt lists `inplace-abn` unpinned): F.batch_norm with the
+    module's running statistics followed by leaky_relu(0.01); parameters weight / bias, buffers running_mean /
+    running_var (no num_batches_tracked); any number of trailing dimensions (it is used on 4-D and 5-D tensors)."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class ABN(nn.Module):
+        def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu", activation_param=0.01):
+            super().__init__()
+            self.num_features, self.eps, self.momentum = num_features, eps, momentum
+            self.activation, self.activation_param = activation, activation_param
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+            self.register_buffer('running_mean', torch.zeros(num_features))
+            self.register_buffer('running_var', torch.ones(num_features))
+
+        def forward(self, x):
+            x = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, self.momentum, self.eps)
+            return F.leaky_relu(x, negative_slope=self.activation_param)
+    return ABN
+
+
+def create_meshgrid(height, width, normalized_coordinates=True, device=None, dtype=None):
+    """Restatement of kornia.utils.create_meshgrid for the one way the reference calls it (mvsnet/modules.py:42,
+    normalized_coordinates=False): [1, H, W, 2] pixel coordinates, (x, y) order."""
+    import torch
+    assert not normalized_coordinates
+    xs = torch.linspace(0, width - 1, width, device=device, dtype=dtype)
+    ys = torch.linspace(0, height - 1, height, device=device, dtype=dtype)
+    gy, gx = torch.meshgrid(ys, xs, indexing='ij')
+    return torch.stack([gx, gy], -1)[None]
+
+
 def install_stubs():
     import torch.nn as nn
+    ABN = _abn_class()
     if "easydict" not in sys.modules:
         _stub("easydict", EasyDict=dict)
     for n in ["skimage", "skimage.io", "skimage.metrics", "h5py", "plyfile", "transforms3d",
@@ -54,8 +91,8 @@ def install_stubs():
         _stub("cv2", INTER_LINEAR=1, INTER_NEAREST=0, INTER_AREA=3, INTER_CUBIC=2,
               SOLVEPNP_ITERATIVE=0, SOLVEPNP_EPNP=1, BORDER_CONSTANT=0)
     if "inplace_abn" not in sys.modules:
-        _stub("inplace_abn", ABN=nn.BatchNorm2d, InPlaceABN=nn.BatchNorm2d)
-    sys.modules["kornia.utils"].create_meshgrid = lambda *a, **k: None
+        _stub("inplace_abn", ABN=ABN, InPlaceABN=ABN)
+    sys.modules["kornia.utils"].create_meshgrid = create_meshgrid
 
 
 def import_reference():

@@ -42,8 +42,21 @@ def main():
         dn = init_net.extract_depth_for_init(info)
         t_diff = timeit(lambda: init_net.get_diff_feats(info, dn))
         t_net = timeit(lambda: net(info, None, False))
+    # cost-volume init net, evaluation path: 800 x 800 is built at 640 x 640 -> 160 x 160 x 64 planes, 3 source views each
+    cv = init_net.CostVolumeInitNet({}).eval().to(dev)
+    info['nn_ids'] = torch.tensor([[(v + 1) % a.views, (v + 2) % a.views, (v + 3) % a.views] for v in range(a.views)], device=dev)
+    with torch.no_grad():
+        t_cv = timeit(lambda: cv(info, info, False)) if a.size in (800,) else None
+        from neuray_amd.network import render_ops
+        eng = render_ops.engine_for(dev)
+        f = torch.randn(a.views, 32, 160, 160, device=dev)
+        prj = init_net.construct_project_matrix(0.2, 0.2, info['Ks'], info['poses'])
+        dv = init_net.get_depth_vals(info['depth_range'], 64)
+        t_var = timeit(lambda: eng.warp_variance(f[:1], f, info['nn_ids'][:1], prj[:1], prj, dv[:1]))
     pairs = a.views * a.views * h * w
     print(json.dumps({'views': a.views, 'size': a.size, 'get_diff_feats_ms': t_diff, 'depth_init_net_ms': t_net,
+                      'cost_volume_init_net_ms': t_cv, 'warp_variance_ms_per_ref_view_160x160x64x3src': t_var,
+                      'warp_variance_out_GB': 32 * 64 * 160 * 160 * 4 / 1e9,
                       'projections': pairs, 'gather_demand_GB': pairs * 64 / 1e9,
                       'gather_demand_GBps': pairs * 64 / 1e9 / (t_diff * 1e-3)}))
 

@@ -64,3 +64,41 @@ def psnr_uint8(a, b):
     qb = np.clip(np.round(b * 255), 0, 255)
     mse = np.mean((qa - qb) ** 2)
     return float('inf') if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse))
+
+
+class MemoryDatabase:
+    """An in-memory scene with the accessor methods of the reference's BaseDatabase (dataset/database.py:14-50):
+    seeded random uint8 images, masks, depth maps, cameras on a sphere.  `ragged`: views of slightly different sizes."""
+
+    def __init__(self, n, h, w, seed=0, ragged=False, radius=4.03, depth_range=(2.0, 6.0)):
+        rng = np.random.RandomState(seed)
+        self.ids = list(range(n))
+        self.sizes = [(h - (i % 3) * 2, w - (i % 2) * 3) if ragged else (h, w) for i in range(n)]
+        self.images = [rng.randint(0, 256, size=(hh, ww, 3)).astype(np.uint8) for hh, ww in self.sizes]
+        self.masks = [rng.rand(hh, ww) > 0.4 for hh, ww in self.sizes]
+        self.depths = [(depth_range[0] + (depth_range[1] - depth_range[0]) * rng.rand(hh, ww)).astype(np.float32) for hh, ww in self.sizes]
+        self.poses = [look_at_pose(sphere_pos(radius, 360.0 * i / n + 5.0 * rng.rand(), 20.0 + 15.0 * rng.rand())).astype(np.float32) for i in range(n)]
+        f = 0.5 * w / np.tan(0.5 * 0.6911112070083618)
+        self.K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+        self.depth_range = np.asarray(depth_range, np.float32)
+
+    def get_img_ids(self):
+        return list(self.ids)
+
+    def get_image(self, i):
+        return self.images[i]
+
+    def get_mask(self, i):
+        return self.masks[i]
+
+    def get_depth(self, i):
+        return self.depths[i]
+
+    def get_pose(self, i):
+        return self.poses[i]
+
+    def get_K(self, i):
+        return self.K.copy()
+
+    def get_depth_range(self, i):
+        return self.depth_range.copy()

@@ -454,6 +454,37 @@ def cost_volume_case(ns):
     print('wrote case_cost_volume.npz', cost_reg.shape, depth.shape, feats.shape)
 
 
+def pipeline_case(ns):
+    """build_imgs_info / build_render_imgs_info / select_working_views_db / colour mapping of the
+    reference (utils/imgs_info.py, utils/view_select.py, utils/base_utils.py) on an in-memory database."""
+    import importlib
+    from neuray_amd import synthetic
+    ii, vs, bu = importlib.import_module('utils.imgs_info'), importlib.import_module('utils.view_select'), importlib.import_module('utils.base_utils')
+    db = synthetic.MemoryDatabase(7, 37, 53, seed=31)
+    out = {}
+    ids = [4, 0, 6]
+    a = ii.build_imgs_info(db, ids, 16, True, False, True, True)
+    for k, v in a.items():
+        out['aligned_' + k] = v
+    b = ii.build_imgs_info(db, ids, -1, True, True, False)
+    for k, v in b.items():
+        out['nodepth_' + k] = v
+    ragged = synthetic.MemoryDatabase(3, 30, 41, seed=32, ragged=True)
+    c = ii.build_imgs_info(ragged, [0, 1, 2], -1, False)
+    for k, v in c.items():
+        out['ragged_' + k] = v
+    r = ii.build_render_imgs_info(db.get_pose(2), db.get_K(2), (37, 53), (2.0, 6.0))
+    for k in ('poses', 'Ks', 'coords', 'depth_range'):
+        out['render_' + k] = r[k]
+    qp = np.stack([db.get_pose(1), db.get_pose(5)])
+    out['working'] = vs.select_working_views_db(db, None, qp, 3, False)
+    out['working_excl'] = vs.select_working_views_db(db, [6, 5, 4, 3, 2], qp, 2, True)
+    x = np.random.RandomState(33).rand(5, 7, 3).astype(np.float32) * 1.2 - 0.1
+    out['cmap_in'], out['cmap_back'] = x, bu.color_map_backward(x)
+    np.savez_compressed(os.path.join(HERE, 'case_pipeline.npz'), **out)
+    print('wrote case_pipeline.npz', a['imgs'].shape, c['imgs'].shape)
+
+
 if __name__ == '__main__':
     main()
     ns_ = ref_harness.import_reference()
@@ -462,3 +493,4 @@ if __name__ == '__main__':
     scene_case(ns_)
     init_net_case(ns_)
     cost_volume_case(ns_)
+    pipeline_case(ns_)

@@ -92,7 +92,7 @@ class DeviceViewCache:
         self.uploaded_bytes = 0
 
     def _load(self, view_id):
-        img = database_image = self.database.get_image(view_id)            # uint8 [h,w,3]
+        img = self.database.get_image(view_id)                             # uint8 [h,w,3]
         mask = np.asarray(self.database.get_mask(view_id), np.float32)
         depth = self.database.get_depth(view_id) if self.has_depth else None
         if self.has_depth and depth is None:
@@ -114,7 +114,6 @@ class DeviceViewCache:
             t = torch.from_numpy(v).to(self.device, non_blocking=True)
             self.uploaded_bytes += v.nbytes
             dev[k] = t.float() / 255 if k == 'imgs' else t            # color_map_forward on the device
-        del database_image
         return dev
 
     def view(self, view_id):
@@ -130,9 +129,9 @@ class DeviceViewCache:
 
 def render_poses(renderer, database, que_poses, que_Ks, que_shapes, que_depth_ranges, ref_ids_list, pad_interval=16,
                  cache=None, key=None, save_fn=None):
-    """render.py:124-141 for a generalisation renderer: one image per query pose from its working views; yields nothing,
-    returns the list of uint8 [h,w,3] images (numpy) - or hands each one to `save_fn(qi, image)` (file formats are the
-    caller's business).  `cache`: a DeviceViewCache to keep across calls."""
+    """render.py:124-141 for a generalisation renderer: one image per query pose from its working views.  Returns the list
+    of uint8 [h,w,3] images (numpy), or hands each one to `save_fn(qi, image)` instead (file formats are the caller's
+    business).  `cache`: a DeviceViewCache to keep across calls."""
     dev = next(renderer.parameters()).device
     cache = cache or DeviceViewCache(database, dev, pad_interval)
     images = []

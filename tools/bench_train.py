@@ -17,12 +17,42 @@ from neuray_amd import synthetic                                   # noqa: E402
 from neuray_amd.network.renderer import NeuralRayBaseRenderer      # noqa: E402
 
 
+def ft_step(args, dev):
+    from neuray_amd import pipeline
+    from neuray_amd.network.renderer import NeuralRayFtRenderer
+    db = synthetic.MemoryDatabase(24, 800, 800, seed=0)
+    scene = {'ref_imgs_info': pipeline.build_imgs_info(db, db.get_img_ids(), -1, True, False, True, True)}
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'use_self_hit_prob': True, 'use_validation': False,
+           'train_ray_num': args.rays}
+    ft = NeuralRayFtRenderer(cfg, scene=scene).train().to(dev)
+    opt = torch.optim.Adam(ft.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = ft.train_step()
+        loss = ((out['pixel_colors_nr'] - out['pixel_colors_gt']) ** 2).mean() + ((out['pixel_colors_nr_fine'] - out['pixel_colors_gt']) ** 2).mean() + \
+            out['hit_prob_self'].mean() + out['hit_prob_self_fine'].mean()
+        loss.backward()
+        opt.step()
+    step(); step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    print(json.dumps({'what': 'NeuralRayFtRenderer.train_step + backward + Adam, %d rays, 8 of 24 views of 800 x 800, 64+64 samples' % args.rays,
+                      'ms_per_step': 1e3 * (time.perf_counter() - t0) / args.steps}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rays', type=int, default=512)
     ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--ft', action='store_true', help='a NeuralRayFtRenderer.train_step on a 24-view 800 x 800 in-memory scene '
+                                                      '(per-view learnable ray_feats, encoders trained) instead of the bare render_impl step')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
+    if args.ft:
+        return ft_step(args, dev)
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 64,
            'fine_depth_sample_num': 64, 'agg_net_cfg': {'sample_num': 64}, 'fine_agg_net_cfg': {'sample_num': 64},
            'use_self_hit_prob': True}

@@ -151,13 +151,27 @@ class NeuralRayBaseRenderer(nn.Module):
         u = None
         if is_train:   # the reference draws the uniforms on the CPU (render_ops.py:205)
             u = torch.rand(list(depth.shape[:-1]) + [fdn])[0]
-        que_depth = eng.sample_fine_depth(que_imgs_info['_neuray_qconst'], depth[0].contiguous(), hit[0].detach().contiguous(),
+        qconst = que_imgs_info['_neuray_qconst']
+        if '_neuray_fine_range' in que_imgs_info:            # view q > 0 of a multi-view query: view 0's range (quirk A.9.6)
+            qconst = eng.prepare_query({**que_imgs_info, 'depth_range': que_imgs_info['_neuray_fine_range']})
+        que_depth = eng.sample_fine_depth(qconst, depth[0].contiguous(), hit[0].detach().contiguous(),
                                           fdn, use_all=self.cfg['fine_depth_use_all'], u=u)
         return self.render_by_depth(que_depth[None], que_imgs_info, ref_imgs_info, is_train, True)
 
     def render_impl(self, que_imgs_info, ref_imgs_info, is_train):
-        """network/renderer.py:217-226"""
+        """network/renderer.py:217-226.  qn > 1 query views (no shipped caller has them, the tensors carry the dimension) go
+        through the fused kernels one view at a time; the fine sampling of every view is normalised with view 0's depth
+        range, as in the reference (render_ops.py:183,225)."""
         coords = que_imgs_info['coords']
+        qn = coords.shape[0]
+        if qn > 1:
+            per_view = [k for k, v in que_imgs_info.items() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == qn]
+            outs = []
+            for q in range(qn):
+                sub = {k: (v[q:q + 1] if k in per_view else v) for k, v in que_imgs_info.items() if not k.startswith('_')}
+                sub['_neuray_fine_range'] = que_imgs_info['depth_range'][0:1]
+                outs.append(self.render_impl(sub, ref_imgs_info, is_train))
+            return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         eng = self.engine(coords.device)
         rn = coords.shape[1]
         que_depth = eng.sample_coarse_depth(que_imgs_info['depth_range'], rn, self.cfg['depth_sample_num'])[None]

@@ -485,6 +485,36 @@ def pipeline_case(ns):
     print('wrote case_pipeline.npz', a['imgs'].shape, c['imgs'].shape)
 
 
+def multi_query_case(ns):
+    """qn = 2 query views in one render_impl call (every shipped caller uses qn = 1; the tensors carry the dimension):
+    second view with its own pose / intrinsics / depth range - the fine sampling normalises every view with view 0's
+    range (quirk A.9.6, render_ops.py:183,225).  Weights: weights_seed0.npz (the default-cfg renderer under seed 0)."""
+    from neuray_amd import synthetic
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 8, 'fine_depth_sample_num': 8,
+           'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 8}, 'use_self_hit_prob': True, 'render_depth': True}
+    que, ref = orc.make_scene(40, 56, 3, seed=21, que_imgs=True)
+    pose2 = synthetic.look_at_pose(synthetic.sphere_pos(4.03, 41.0, 17.0)).astype(np.float32)
+    rng = np.random.RandomState(22)
+    q2 = {'poses': np.stack([que['poses'][0], pose2]), 'Ks': np.stack([que['Ks'][0], que['Ks'][0] * np.array([[1.1], [1.05], [1.0]], np.float32)]),
+          'depth_range': np.array([[2.0, 6.0], [2.5, 5.0]], np.float32),
+          'coords': (rng.rand(2, 19, 2) * np.array([55, 39])).astype(np.float32),
+          'imgs': rng.rand(2, 3, 40, 56).astype(np.float32), 'ray_feats': rng.randn(2, 32, 10, 14).astype(np.float32)}
+    renderer = build_renderer(ns, cfg, seed=0)
+    with torch.no_grad():
+        out = renderer.render_impl(to_t(q2), to_t(ref), False)
+    save = {'cfg_json': np.array(repr(cfg))}
+    for k, v in q2.items():
+        save['que.' + k] = v
+    for k, v in ref.items():
+        save['ref.' + k] = v
+    for k, v in out.items():
+        save['out.' + k] = v.numpy()
+    for k, v in hot_weights(renderer).items():
+        save['w.' + k] = v
+    np.savez_compressed(os.path.join(HERE, 'case_h_two_queries.npz'), **save)
+    print('wrote case_h_two_queries.npz', {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == '__main__':
     main()
     ns_ = ref_harness.import_reference()
@@ -494,3 +524,4 @@ if __name__ == '__main__':
     init_net_case(ns_)
     cost_volume_case(ns_)
     pipeline_case(ns_)
+    multi_query_case(ns_)

@@ -2,6 +2,8 @@
 minimum / maximum sample counts, a single ray, ragged ray counts (not a multiple of the 16-point tile), the maximum
 number of reference views, non-square images whose feature maps are not exactly 1/4 resolution, and argument
 validation of the C ABI."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -149,3 +151,30 @@ def test_config3_shape_llff_padded_refs(backend):
     assert np.array_equal(got['ray_mask'].cpu().numpy(), want['ray_mask'])
     d = np.abs(got['pixel_colors_nr_fine'].cpu().numpy() - want['pixel_colors_nr_fine'])
     assert np.median(d) <= 2e-4 and np.mean(d <= 2e-3) >= 0.9
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_two_query_views_in_one_call(backend):
+    """qn = 2 against the reference (tests/golden/case_h_two_queries.npz): per-view pose / intrinsics / depth range, fine
+    sampling normalised with view 0's range for both (render_ops.py:183,225)."""
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'case_h_two_queries.npz'))
+    cfg = eval(str(z['cfg_json']))
+    r = NeuralRayBaseRenderer(cfg).eval()
+    r.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w.')}, strict=True)
+    if backend == 'emu':
+        r._engine_test_lib = emu_lib()
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    r = r.to(dev)
+    tq = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith('que.')}
+    tr = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith('ref.')}
+    with torch.no_grad():
+        out = r.render_impl(tq, tr, False)
+    want = {k[4:]: z[k] for k in z.files if k.startswith('out.')}
+    assert set(out) == set(want)
+    for k in ('pixel_colors_nr', 'pixel_colors_gt', 'render_depth'):
+        assert out[k].shape == want[k].shape and np.max(np.abs(out[k].cpu().numpy() - want[k])) <= 2e-4, k
+    assert np.max(np.abs(out['hit_prob_nr'].cpu().numpy() - want['hit_prob_nr'])) <= 1e-4
+    assert np.array_equal(out['ray_mask'].cpu().numpy(), want['ray_mask'])
+    d = np.abs(out['pixel_colors_nr_fine'].cpu().numpy() - want['pixel_colors_nr_fine']).max(-1)
+    assert np.mean(d <= 2e-4) >= 0.9 and d.max() < 0.1            # chained coarse -> fine (DESIGN.md 2.4)

@@ -110,6 +110,17 @@ def test_abi_rejects_bad_arguments(backend):
     with pytest.raises(RuntimeError, match='outside'):
         qc = eng.prepare_query(to_torch(que, dev))
         eng.sample_fine_depth(qc, torch.ones(4, 200, device=dev), torch.ones(4, 200, device=dev), 16)
+    # the init-net kernels
+    lib, f = eng.lib, torch.zeros(64, device=dev)
+    assert lib.neuray_diff_feats(f.data_ptr(), f.data_ptr(), f.data_ptr(), 17, 8, 8, f.data_ptr(), None) != 0
+    assert b'rfn=17' in lib.neuray_last_error()
+    assert lib.neuray_diff_feats(f.data_ptr(), None, f.data_ptr(), 2, 8, 8, f.data_ptr(), None) != 0
+    assert b'null' in lib.neuray_last_error()
+    assert lib.neuray_warp_variance(f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), 1, 1, 0, 8, 4, 4, f.data_ptr(), None) != 0
+    assert b'n_num=0' in lib.neuray_last_error()
+    with pytest.raises(AssertionError):            # a neighbour index beyond the source views never reaches the kernel
+        eng.warp_variance(torch.zeros(1, 32, 4, 4, device=dev), torch.zeros(2, 32, 4, 4, device=dev), torch.tensor([[0, 2]], device=dev),
+                          torch.eye(4, device=dev)[None], torch.eye(4, device=dev)[None].repeat(2, 1, 1), torch.ones(1, 8, device=dev))
 
 
 # ---- the shapes of BASELINE.json's other configurations (parity cases, not bench lines) -------------------------

@@ -68,6 +68,10 @@ int neuray_relayout_nhwc(const float* src_dev, float* dst_dev, int n, int c, int
 
 /* ---- a1: sample_depth (network/render_ops.py:146-170, random_sample=False) -> depth [rn][dn] ------------ */
 int neuray_sample_coarse_depth(const float* que_depth_range_dev /*[2]*/, int rn, int dn, float* depth_dev, void* stream);
+/* the random_sample=True branch (render_ops.py:160-161): uniforms_dev [rn][dn-2] in [0,1), drawn by the caller with
+ * torch.rand as the reference does; interior tick i becomes i + (u - 0.5) * 0.999.  NULL = neuray_sample_coarse_depth. */
+int neuray_sample_coarse_depth_jittered(const float* depth_range_dev, const float* uniforms_dev, int rn, int dn, float* depth_dev,
+                                        void* stream);
 
 /* ---- a2-a14: one render pass over the sample points of a ray batch ------------------------------------------
  * Replaces, fused: depth2inv_dists, depth2points, project_points_dict (render_ops.py:27-52,82-144),
@@ -199,7 +203,8 @@ int neuray_interpolate_feats_backward(const float* d_out_dev, const float* point
 /* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
  * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,
  * render_ops.py:205) or NULL for the deterministic stratified samples.  out [rn][fdn (+ dn if use_all)].
- * use_all: bit 0 = merge the coarse depths (fine_depth_use_all), bit 1 = skip the sort (the bare render_ops function). */
+ * use_all: bit 0 = merge the coarse depths (fine_depth_use_all), bit 1 = skip the sort (the bare render_ops function),
+ * bit 2 = inv_mode=False (interpolate the metric depths instead of the normalised inverse depths). */
 int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_dev, const float* hit_prob_dev,
                              const float* u_dev, int rn, int dn, int fdn, int use_all, float* out_dev, void* stream);
 

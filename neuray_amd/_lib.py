@@ -87,6 +87,7 @@ SYMBOLS = {
     'neuray_setup_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_relayout_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'neuray_sample_coarse_depth': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_sample_coarse_depth_jittered': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_render_points': (C.c_int, [C.POINTER(NeurayPointsArgs), C.c_void_p]),
     'neuray_render_rays': (C.c_int, [C.POINTER(NeurayRaysArgs), C.c_void_p]),
     'neuray_sample_fine_depth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -129,9 +129,13 @@ int neuray_relayout_nhwc(const float* src, float* dst, int n, int c, int h, int 
 }
 
 int neuray_sample_coarse_depth(const float* depth_range, int rn, int dn, float* depth, void* stream) {
+    return neuray_sample_coarse_depth_jittered(depth_range, nullptr, rn, dn, depth, stream);
+}
+
+int neuray_sample_coarse_depth_jittered(const float* depth_range, const float* uniforms, int rn, int dn, float* depth, void* stream) {
     if (dn <= 2) return fail("neuray_sample_coarse_depth: dn=%d must be > 2 (render_ops.py:157)", dn);
     const int grid = grid_for((long long)rn * dn, 256, 256 * 8);
-    NR_LAUNCH(nr::coarse_depth_kernel, dim3(grid), dim3(256), 0, stream, depth_range, rn, dn, depth);
+    NR_LAUNCH(nr::coarse_depth_kernel, dim3(grid), dim3(256), 0, stream, depth_range, uniforms, rn, dn, depth);
     return check_launch("neuray_sample_coarse_depth");
 }
 
@@ -182,7 +186,7 @@ int neuray_sample_fine_depth(const float* query_const, const float* depth, const
         return fail("neuray_sample_fine_depth: dn=%d fdn=%d outside [2,%d]", dn, fdn, NEURAY_MAX_SAMPLES);
     nr::FineParams p;
     p.que_const = query_const; p.depth = depth; p.hit_prob = hit_prob; p.u = u; p.out = out;
-    p.rn = rn; p.dn = dn; p.fdn = fdn; p.use_all = use_all & 1; p.no_sort = (use_all >> 1) & 1;
+    p.rn = rn; p.dn = dn; p.fdn = fdn; p.use_all = use_all & 1; p.no_sort = (use_all >> 1) & 1; p.linear = (use_all >> 2) & 1;
     const int grid = grid_for(rn, nr::kRayWaves, 256 * 16);
     NR_LAUNCH(nr::fine_kernel, dim3(grid), dim3(64 * nr::kRayWaves), 0, stream, p);
     return check_launch("neuray_sample_fine_depth");

@@ -59,11 +59,23 @@ __global__ void relayout_kernel(const float* __restrict__ src, float* __restrict
 // -------------------------------------------------------------------------------------------------
 // a1: coarse depths [rn][dn]
 // -------------------------------------------------------------------------------------------------
-__global__ void coarse_depth_kernel(const float* __restrict__ depth_range, int rn, int dn, float* __restrict__ out) {
+// rnd: null, or the uniforms of sample_depth(random_sample=True) [rn][dn-2] (render_ops.py:160-161): interior tick i
+// becomes i + (r - 0.5) * 0.999
+__global__ void coarse_depth_kernel(const float* __restrict__ depth_range, const float* __restrict__ rnd, int rn, int dn,
+                                    float* __restrict__ out) {
     const float near = depth_range[0], far = depth_range[1];
     const long long total = (long long)rn * dn;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-        out[i] = coarse_depth(near, far, (int)(i % dn), dn);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % dn);
+        if (rnd && k > 0 && k < dn - 1) {
+            const float inv_near = rn_div(1.0f, near);
+            const float step = rn_div(rn_sub(rn_div(1.0f, far), inv_near), (float)(dn - 1));
+            const float val = rn_add((float)k, rn_mul(rn_sub(rnd[(i / dn) * (dn - 2) + (k - 1)], 0.5f), 0.999f));
+            out[i] = rn_div(1.0f, rn_add(inv_near, rn_mul(step, val)));
+        } else {
+            out[i] = coarse_depth(near, far, k, dn);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -873,6 +885,7 @@ struct FineParams {
     const float* u;          // [rn][fdn] or null -> stratified (k + 0.5)/fdn
     float* out;              // [rn][nout], nout = fdn (+ dn when use_all)
     int rn, dn, fdn, use_all, no_sort;
+    int linear;              // sample_fine_depth(inv_mode=False): interpolate the metric depths themselves
 };
 
 constexpr int kMaxSamples = 128;   // dn, fdn <= 128
@@ -902,7 +915,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
         float tot = 0.0f;
         for (int i = lane; i < ((dn + 63) & ~63); i += 64) {
             float hp = 0.0f;
-            if (i < dn) { ss[i] = norm_inv_depth(drow[i], nearp, farp); hp = hrow[i] + 1e-5f; pdf[i] = hp; }
+            if (i < dn) { ss[i] = p.linear ? drow[i] : norm_inv_depth(drow[i], nearp, farp); hp = hrow[i] + 1e-5f; pdf[i] = hp; }
             tot += hp;
         }
         tot = wave_sum(tot);
@@ -930,8 +943,12 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
                 if (denom < 1e-5f) denom = 1.0f;
                 const float tt = rn_div(rn_sub(uu, cdf[below]), denom);
                 float sf = rn_add(edge[below], rn_mul(tt, rn_sub(edge[above], edge[below])));
-                sf = rn_add(rn_mul(sf, rn_sub(farp, nearp)), nearp);
-                val = rn_div(-1.0f, sf);
+                if (p.linear) {
+                    val = sf;
+                } else {
+                    sf = rn_add(rn_mul(sf, rn_sub(farp, nearp)), nearp);
+                    val = rn_div(-1.0f, sf);
+                }
             } else if (k < nout) {
                 val = drow[k - fdn];
             }

@@ -225,13 +225,18 @@ class RenderEngine:
         return qc
 
     # ------------------------------------------------------------------------------------------
-    def sample_coarse_depth(self, que_depth_range, rn, dn):
+    def sample_coarse_depth(self, que_depth_range, rn, dn, uniforms=None):
+        """uniforms: None, or the [rn, dn-2] draws of sample_depth(random_sample=True) (render_ops.py:160-161)"""
         dr = self._f32(que_depth_range).reshape(-1)[:2].contiguous()
         depth = self.empty(rn, dn)
-        self._check(self.lib.neuray_sample_coarse_depth(dr.data_ptr(), rn, dn, depth.data_ptr(), self._stream()))
+        if uniforms is None:
+            self._check(self.lib.neuray_sample_coarse_depth(dr.data_ptr(), rn, dn, depth.data_ptr(), self._stream()))
+        else:
+            uniforms = self._f32(uniforms).reshape(rn, dn - 2)
+            self._check(self.lib.neuray_sample_coarse_depth_jittered(dr.data_ptr(), uniforms.data_ptr(), rn, dn, depth.data_ptr(), self._stream()))
         return depth
 
-    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None, sort=True):
+    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None, sort=True, inv_mode=True):
         rn, dn = depth.shape
         out = self.empty(rn, fdn + (dn if use_all else 0))
         u_ptr = None
@@ -239,7 +244,7 @@ class RenderEngine:
             u = self._f32(u).reshape(rn, fdn)
             u_ptr = u.data_ptr()
         self._check(self.lib.neuray_sample_fine_depth(qconst.data_ptr(), depth.data_ptr(), hit_prob.data_ptr(), u_ptr,
-                                                      rn, dn, fdn, int(use_all) | (0 if sort else 2), out.data_ptr(),
+                                                      rn, dn, fdn, int(use_all) | (0 if sort else 2) | (0 if inv_mode else 4), out.data_ptr(),
                                                       self._stream()))
         return out
 

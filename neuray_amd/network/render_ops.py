@@ -123,19 +123,17 @@ def project_points_dict(ref_imgs_info, que_pts):
 
 
 def sample_depth(depth_range, coords, sample_num, random_sample):
-    if random_sample:
-        raise NotImplementedError("neuray_amd: sample_depth(random_sample=True) is never used by the renderer "
-                                  "(network/renderer.py:219)")
     eng = engine_for(coords.device)
     qn, rn, _ = coords.shape
-    depth = torch.stack([eng.sample_coarse_depth(depth_range[q], rn, sample_num) for q in range(qn)], 0)
+    # random_sample: the jitter uniforms are drawn exactly as render_ops.py:161 draws them (same shape, dtype and device,
+    # hence the same generator stream)
+    u = torch.rand(qn, rn, sample_num - 2, dtype=torch.float32, device=coords.device) if random_sample else None
+    depth = torch.stack([eng.sample_coarse_depth(depth_range[q], rn, sample_num, None if u is None else u[q]) for q in range(qn)], 0)
     dists = torch.cat([depth[..., 1:], torch.full_like(depth[..., :1], 1e6)], -1) - depth
     return depth, dists
 
 
 def sample_fine_depth(depth, hit_prob, depth_range, sample_num, random_sample, inv_mode=True):
-    if not inv_mode:
-        raise NotImplementedError("neuray_amd: sample_fine_depth(inv_mode=False) is not on the render path")
     eng = engine_for(depth.device)
     qn, rn, dn = depth.shape
     u = torch.rand([qn, rn, sample_num]) if random_sample else None      # CPU generator, as render_ops.py:205
@@ -143,5 +141,5 @@ def sample_fine_depth(depth, hit_prob, depth_range, sample_num, random_sample, i
     for q in range(qn):
         qc = _query_const(eng, torch.eye(3, 4, device=depth.device), torch.eye(3, device=depth.device), depth_range[0])
         outs.append(eng.sample_fine_depth(qc, depth[q].contiguous(), hit_prob[q].contiguous(), sample_num,
-                                          u=None if u is None else u[q], sort=False))
+                                          u=None if u is None else u[q], sort=False, inv_mode=inv_mode))
     return torch.stack(outs, 0)

@@ -515,6 +515,30 @@ def multi_query_case(ns):
     print('wrote case_h_two_queries.npz', {k: tuple(v.shape) for k, v in out.items()})
 
 
+def sampling_branches_case(ns):
+    """the two branches of network/render_ops.py the renderer never takes: sample_depth(random_sample=True) (:160-161) and
+    sample_fine_depth(inv_mode=False) (:181-186,224-228), for the render_ops module surface"""
+    ro = ns.render_ops
+    rng = np.random.RandomState(41)
+    dr = torch.tensor([[2.0, 6.0], [1.5, 9.0]])
+    coords = torch.zeros(2, 11, 2)
+    torch.manual_seed(77)
+    u = torch.rand(2, 11, 14)
+    torch.manual_seed(77)
+    depth, dists = ro.sample_depth(dr, coords, 16, True)
+    hit = torch.from_numpy((rng.rand(2, 11, 16) ** 3).astype(np.float32))
+    sorted_depth = torch.sort(depth, -1)[0]
+    fine_lin = ro.sample_fine_depth(sorted_depth, hit, dr, 12, False, inv_mode=False)
+    torch.manual_seed(78)
+    uf = torch.rand(2, 11, 12)
+    torch.manual_seed(78)
+    fine_lin_rand = ro.sample_fine_depth(sorted_depth, hit, dr, 12, True, inv_mode=False)
+    np.savez_compressed(os.path.join(HERE, 'case_sampling_branches.npz'), depth_range=dr.numpy(), u=u.numpy(), depth=depth.numpy(),
+                        dists=dists.numpy(), hit=hit.numpy(), sorted_depth=sorted_depth.numpy(), fine_lin=fine_lin.numpy(),
+                        uf=uf.numpy(), fine_lin_rand=fine_lin_rand.numpy())
+    print('wrote case_sampling_branches.npz', depth.shape, fine_lin.shape)
+
+
 if __name__ == '__main__':
     main()
     ns_ = ref_harness.import_reference()
@@ -525,3 +549,4 @@ if __name__ == '__main__':
     cost_volume_case(ns_)
     pipeline_case(ns_)
     multi_query_case(ns_)
+    sampling_branches_case(ns_)

@@ -1,10 +1,12 @@
 """Function-level parity of the network.render_ops mirror against the oracle,
 on the emulator (CPU) and on the MI355X (gpu)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_case
+from conftest import GOLDEN_DIR, load_case
 from emu_util import emu_lib, to_torch
 from oracle import neuray_oracle as orc
 from neuray_amd.network import render_ops as ro
@@ -70,8 +72,6 @@ def test_compositing_and_fine_sampling_functions(dev):
     fine = ro.sample_fine_depth(depth, torch.from_numpy(out['hit_prob_nr']).to(dev), tq['depth_range'], 16, False)
     want = orc.sample_fine_depth(mid['que_depth'], out['hit_prob_nr'], que['depth_range'], 16)
     np.testing.assert_allclose(fine.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
-    with pytest.raises(NotImplementedError):
-        ro.sample_depth(tq['depth_range'], tq['coords'], 16, True)
 
 
 def test_dist_decoder_rows(dev):
@@ -92,3 +92,28 @@ def test_dist_decoder_rows(dev):
         assert (v is None) == (ovis is None)
         if v is not None:
             np.testing.assert_allclose(v.cpu().numpy(), ovis, atol=2e-6)
+
+
+def test_sampling_branches_the_renderer_never_takes(dev):
+    """sample_depth(random_sample=True) and sample_fine_depth(inv_mode=False) against the reference
+    (tests/golden/case_sampling_branches.npz); the uniforms are drawn as the reference draws them, so a seeded call
+    consumes the generator identically (checked on the CPU generator)."""
+    z = np.load(os.path.join(GOLDEN_DIR, 'case_sampling_branches.npz'))
+    dr = torch.from_numpy(z['depth_range']).to(dev)
+    coords = torch.zeros(2, 11, 2, device=dev)
+    if dev == 'cpu':
+        torch.manual_seed(77)
+        depth, dists = ro.sample_depth(dr, coords, 16, True)
+    else:                      # the device generator differs from the CPU one the golden was drawn with: feed the draws
+        eng = ro.engine_for(dev)
+        u = torch.from_numpy(z['u']).to(dev)
+        depth = torch.stack([eng.sample_coarse_depth(dr[q], 11, 16, u[q]) for q in range(2)], 0)
+        dists = torch.cat([depth[..., 1:], torch.full_like(depth[..., :1], 1e6)], -1) - depth
+    assert np.max(np.abs(depth.cpu().numpy() - z['depth']) / z['depth']) <= 2e-7
+    assert np.max(np.abs(dists.cpu().numpy()[..., :-1] - z['dists'][..., :-1])) <= 2e-6 and float(dists[..., -1].min()) > 9e5
+    sd, hit = torch.from_numpy(z['sorted_depth']).to(dev), torch.from_numpy(z['hit']).to(dev)
+    fine = ro.sample_fine_depth(sd, hit, dr, 12, False, inv_mode=False)
+    assert fine.shape == (2, 11, 12) and np.max(np.abs(fine.cpu().numpy() - z['fine_lin']) / z['fine_lin']) <= 1e-5
+    torch.manual_seed(78)
+    fine_r = ro.sample_fine_depth(sd, hit, dr, 12, True, inv_mode=False)        # (these uniforms are CPU draws on every device)
+    assert np.max(np.abs(fine_r.cpu().numpy() - z['fine_lin_rand']) / z['fine_lin_rand']) <= 1e-5

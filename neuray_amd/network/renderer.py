@@ -76,12 +76,28 @@ class NeuralRayBaseRenderer(nn.Module):
             self._packed[is_fine] = (stamp, eng.pack_pass(sd, 'd.', 'a.'))
         return self._packed[is_fine][1]
 
+    @staticmethod
+    def _same_tensors(entry, info, keys):
+        """cache validity: the very same tensor objects (the entry holds references, so an id cannot be recycled) at the
+        same in-place version"""
+        return entry is not None and all(info.get(k) is t and (t is None or t._version == v) for k, (t, v) in zip(keys, entry))
+
     def _views(self, eng, ref_imgs_info):
-        key = tuple((id(ref_imgs_info[k]), ref_imgs_info[k]._version) for k in ('imgs', 'ray_feats', 'img_feats', 'poses', 'Ks'))
+        keys = ('imgs', 'ray_feats', 'img_feats', 'poses', 'Ks', 'depth_range')
         hit = ref_imgs_info.get('_neuray_views')
-        if hit is None or hit[0] != key:
-            ref_imgs_info['_neuray_views'] = (key, eng.prepare_views(ref_imgs_info))
+        if hit is None or not self._same_tensors(hit[0], ref_imgs_info, keys):
+            stamp = [(ref_imgs_info.get(k), None if ref_imgs_info.get(k) is None else ref_imgs_info[k]._version) for k in keys]
+            ref_imgs_info['_neuray_views'] = (stamp, eng.prepare_views(ref_imgs_info))
         return ref_imgs_info['_neuray_views'][1]
+
+    def _query(self, eng, que_imgs_info):
+        keys = ('poses', 'Ks', 'depth_range', 'Ks_inv')
+        hit = que_imgs_info.get('_neuray_qconst_entry')
+        if hit is None or not self._same_tensors(hit[0], que_imgs_info, keys):
+            stamp = [(que_imgs_info.get(k), None if que_imgs_info.get(k) is None else que_imgs_info[k]._version) for k in keys]
+            que_imgs_info['_neuray_qconst_entry'] = (stamp, eng.prepare_query(que_imgs_info))
+        que_imgs_info['_neuray_qconst'] = que_imgs_info['_neuray_qconst_entry'][1]
+        return que_imgs_info['_neuray_qconst']
 
     # ---- render path ---------------------------------------------------------------------------------
     def render_by_depth(self, que_depth, que_imgs_info, ref_imgs_info, is_train, is_fine):
@@ -90,10 +106,7 @@ class NeuralRayBaseRenderer(nn.Module):
         assert coords.shape[0] == 1 and que_depth.shape[0] == 1, "one query view per call (qn = 1)"
         eng = self.engine(coords.device)
         views = self._views(eng, ref_imgs_info)
-        qconst = que_imgs_info.get('_neuray_qconst')
-        if qconst is None:
-            qconst = eng.prepare_query(que_imgs_info)
-            que_imgs_info['_neuray_qconst'] = qconst
+        qconst = self._query(eng, que_imgs_info)
         packed = None
         dist = self.fine_dist_decoder if is_fine else self.dist_decoder
         agg = self.fine_agg_net if is_fine else self.agg_net
@@ -458,7 +471,7 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
         ref_imgs_info, que_imgs_info = self.slice_imgs_info(ref_idx, que_i, True)
         self.touched_views = sorted(set(int(i) for i in ref_idx) | ({int(que_i)} if self.cfg['use_self_hit_prob'] else set()))
         outputs = self.render(que_imgs_info.copy(), ref_imgs_info.copy(), True)
-        for k in ('ray_feats', 'img_feats', '_neuray_qconst'):
+        for k in ('ray_feats', 'img_feats', '_neuray_qconst', '_neuray_qconst_entry'):
             que_imgs_info.pop(k, None)
         outputs['que_imgs_info'] = que_imgs_info
         return outputs

@@ -256,3 +256,20 @@ def test_single_reference_view(backend):
     want = orc.render_impl(weights, oracle_cfg(cfg), que, ref1)
     assert np.max(np.abs(got['pixel_colors_nr'].cpu().numpy() - want['pixel_colors_nr'])) <= 1e-5
     assert np.max(np.abs(got['hit_prob_nr'].cpu().numpy() - want['hit_prob_nr'])) <= 1e-5
+
+
+def test_per_dict_caches_follow_their_tensors():
+    """the view / query constant blocks cached inside the imgs_info dicts are rebuilt when a source tensor is replaced or
+    modified in place (they are keyed by tensor identity + in-place version, with the entry holding the references)"""
+    cfg, que, ref, out, mid, extra, weights, full, (r, tq, tr) = run_case('a_small', 'emu')
+    with torch.no_grad():
+        a = r.render_impl(tq, tr, False)['pixel_colors_nr'].clone()
+        assert torch.equal(r.render_impl(tq, tr, False)['pixel_colors_nr'], a)             # cached blocks reused
+        views_before = tr['_neuray_views'][1]
+        tq['poses'][0, 0, 3] += 0.05                                                        # in place: version bump
+        b = r.render_impl(tq, tr, False)['pixel_colors_nr'].clone()
+        assert not torch.equal(a, b) and tr['_neuray_views'][1] is views_before            # only the query block was rebuilt
+        tq['poses'][0, 0, 3] -= 0.05
+        tr['ray_feats'] = tr['ray_feats'] * 1.0 + 0.25                                      # replaced by a new tensor
+        c = r.render_impl(tq, tr, False)['pixel_colors_nr']
+        assert not torch.equal(a, c) and tr['_neuray_views'][1] is not views_before

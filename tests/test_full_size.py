@@ -92,7 +92,7 @@ def test_reference_view_order_does_not_matter(case):
     perm = torch.tensor([3, 7, 0, 5, 1, 6, 2, 4], device=coords.device)
     tr2 = {k: (v[perm] if torch.is_tensor(v) and v.shape[0] == 8 else v) for k, v in tr.items() if not k.startswith('_')}
     b = render(renderer, tq, tr2, coords, is_train=False)
-    assert float((a['pixel_colors_nr'] - b['pixel_colors_nr']).abs().max()) <= 2e-5
+    assert float((a['pixel_colors_nr'] - b['pixel_colors_nr']).abs().max()) <= 1e-4
     d = (a['pixel_colors_nr_fine'] - b['pixel_colors_nr_fine']).abs().max(-1)[0]
     assert float((d <= 2e-4).float().mean()) >= 0.97            # chained coarse -> fine: DESIGN.md 2.4
 

@@ -188,6 +188,34 @@ def training_step_timing(device, steps=3):
             'hip_ms_per_step': a, 'eager_torch_ms_per_step': b, 'speedup_vs_eager': b / a}
 
 
+def bf16_variant_timing(device, fdn, tq, tr, fp32_pixels, steps=2):
+    """Side measurement, reported SEPARATELY from the headline (which stays fp32, the reference's arithmetic): the same
+    workload through libneuray_hip_bf16.so - bf16 MFMA operands (weights and activations rounded to bf16 in the quad
+    K-steps of every layer), fp32 accumulation, everything else fp32 - with its distance from the fp32 render."""
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': DN_COARSE,
+           'fine_depth_sample_num': fdn, 'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
+           'ray_batch_num': 32768, 'hip_variant': 'bf16'}
+    torch.manual_seed(0)
+    r = NeuralRayBaseRenderer(cfg).eval().to(device)
+    eng = r.engine(device)
+    out = render_image(r, tq, tr)
+    eng.timing = []
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = render_image(r, tq, tr)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    pts = [e0.elapsed_time(e1) for name, e0, e1, n in eng.timing if name == 'points']
+    eng.timing = None
+    got = out['pixel_colors_nr_fine'].cpu().numpy()
+    err = np.abs(got - fp32_pixels).max(-1).reshape(-1)
+    return {'what': 'same workload, bf16 MFMA operands / fp32 accumulate (libneuray_hip_bf16.so); NOT the headline', 'dtype': 'bf16 operands, fp32 accumulate',
+            'value': steps * H * W / dt, 'unit': 'rays/s', 'point_kernel_ms_per_launch': float(np.mean(pts)),
+            'psnr_vs_fp32_render_db': synthetic.psnr_uint8(np.clip(got, 0, 1), np.clip(fp32_pixels, 0, 1)),
+            'max_abs_err_vs_fp32_render': float(err.max()), 'frac_rays_within_1e-2': float(np.mean(err <= 1e-2))}
+
+
 def init_net_timing(device, reps=10):
     """Side measurement: the depth init net front end on 8 views of 800 x 800 - get_diff_feats as the
     fused neuray_diff_feats kernel next to the eager tensor formulation of the reference (oracle/torch_eager_port.py),
@@ -338,6 +366,7 @@ def main():
             line['eager_torch_baseline'] = eb
             line['training_step'] = training_step_timing(device)
             line['init_net'] = init_net_timing(device)
+            line['bf16_variant'] = bf16_variant_timing(device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -34,6 +34,10 @@ int neuray_abi_version(void);
 const char* neuray_last_error(void);
 /* 1 if the library was built for the GPU (hipcc, gfx950); 0 for the CPU test emulator build */
 int neuray_is_device_build(void);
+/* 32: the library computes with fp32 MFMA operands (the product, libneuray_hip.so).  16: the separately built and separately
+ * reported bf16-operand variant (libneuray_hip_bf16.so: the quad K-steps of every MFMA layer take bf16 weights and
+ * bf16-rounded activations, fp32 accumulation; inference only). */
+int neuray_operand_precision(void);
 
 /* ---- weights --------------------------------------------------------------------------------------
  * Packs the state_dict tensors of ONE pass (dist_decoder + agg_net, or fine_dist_decoder + fine_agg_net;

@@ -13,6 +13,7 @@ import torch  # noqa: F401  (first: the library must resolve libamdhip64 to the 
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NEURAY_HIP_LIB', os.path.join(HERE, 'libneuray_hip.so'))   # env override: A/B debugging only
+BF16_LIB_PATH = os.path.join(HERE, 'libneuray_hip_bf16.so')     # the separately reported bf16-operand variant (inference only)
 
 PASS_TENSORS = 68
 POINT_REC = 20
@@ -80,6 +81,7 @@ SYMBOLS = {
     'neuray_abi_version': (C.c_int, []),
     'neuray_last_error': (C.c_char_p, []),
     'neuray_is_device_build': (C.c_int, []),
+    'neuray_operand_precision': (C.c_int, []),
     'neuray_packed_pass_floats': (C.c_size_t, []),
     'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_index_map': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
@@ -138,22 +140,25 @@ def bind(path):
     return lib
 
 
-_LIB = None
+_LIBS = {}
 
 
-def load():
-    """The product library (HIP, gfx950).  Raises loudly if it has not been built."""
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+def load(variant='fp32'):
+    """The product library (HIP, gfx950), or with variant='bf16' the bf16-operand build.  Raises loudly if it has not
+    been built."""
+    if variant not in _LIBS:
+        path = {'fp32': LIB_PATH, 'bf16': BF16_LIB_PATH}[variant]
+        if not os.path.exists(path):
             raise NeurayLibError(
                 "neuray_amd: %s not found - build it with `python -m neuray_amd.build` (hipcc, gfx950). "
-                "There is no CPU/eager fallback for the render path." % LIB_PATH)
-        lib = bind(LIB_PATH)
+                "There is no CPU/eager fallback for the render path." % path)
+        lib = bind(path)
         if lib.neuray_is_device_build() != 1:
-            raise NeurayLibError("neuray_amd: %s is not a device build" % LIB_PATH)
-        _LIB = lib
-    return _LIB
+            raise NeurayLibError("neuray_amd: %s is not a device build" % path)
+        if lib.neuray_operand_precision() != {'fp32': 32, 'bf16': 16}[variant]:
+            raise NeurayLibError("neuray_amd: %s is not the %s build" % (path, variant))
+        _LIBS[variant] = lib
+    return _LIBS[variant]
 
 
 def check(lib, rc):

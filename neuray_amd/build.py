@@ -20,17 +20,22 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp
          '-Wno-comment']
 
 
-def needs_build():
-    return not os.path.exists(OUT) or any(os.path.getmtime(OUT) < os.path.getmtime(d) for d in DEPS)
+OUT_BF16 = os.path.join(HERE, 'libneuray_hip_bf16.so')      # same sources with -DNR_BF16_QUADS (bf16 MFMA operands)
+
+
+def needs_build(out=OUT):
+    return not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in DEPS)
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
-    cmd = [HIPCC] + FLAGS + SOURCES + ['-o', OUT]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    """-> path of the product library; also (re)builds the bf16-operand variant next to it"""
+    for out, extra in ((OUT, []), (OUT_BF16, ['-DNR_BF16_QUADS'])):
+        if not force and not needs_build(out):
+            continue
+        cmd = [HIPCC] + FLAGS + extra + SOURCES + ['-o', out]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
     return OUT
 
 

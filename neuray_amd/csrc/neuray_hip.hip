@@ -104,8 +104,19 @@ int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_hos
     return 0;
 }
 
+int neuray_operand_precision(void) {
+#ifdef NR_BF16_QUADS
+    return 16;
+#else
+    return 32;
+#endif
+}
+
 int neuray_pack_pass_index_map(int has_vis_head, int* index_host, float* scale_host) {
     if (!index_host || !scale_host) return fail("neuray_pack_pass_index_map: null argument");
+#ifdef NR_BF16_QUADS
+    return fail("neuray_pack_pass_index_map: the bf16-operand build packs on the host only (inference variant, no training path)");
+#endif
     if (nr::pack_pass_index_map(has_vis_head != 0, index_host, scale_host)) return fail("neuray_pack_pass_index_map: internal error");
     return 0;
 }

@@ -311,6 +311,12 @@ __device__ __forceinline__ void layer_bias(WS W, int lane, v4f (&acc)[NT][kShape
 // One quad of A fragments feeds 4 K-steps x NT slots of MFMAs.
 template <int NT, int KQX>
 __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (&xq)[NT][KQX], v4f (&acc)[NT]) {
+#ifdef NR_BF16_QUADS      // the bf16-operand library: (a.x, a.y) hold the quad's four weights as bf16, one MFMA per slot
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        acc[t] = nr_mfma16_bf16q(a.x, a.y, xq[t][4 * kq + 0], xq[t][4 * kq + 1], xq[t][4 * kq + 2], xq[t][4 * kq + 3], acc[t]);
+    return;
+#endif
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.x, xq[t][4 * kq + 0], acc[t]);
     NR_PRAGMA_UNROLL

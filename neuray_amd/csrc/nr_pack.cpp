@@ -7,6 +7,15 @@ namespace nr {
 
 static bool g_pack_unscaled = false;     // pack_pass_index_map: pack without the scaled-ELU factors
 
+#ifdef NR_BF16_QUADS
+static unsigned short to_bf16(float f) {          // round to nearest even, as v_cvt_pk_bf16_f32
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+#endif
+
 void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bias, const LayerMaps& maps) {
     const LayerShape s = kShape[layer];
     float* q = dst + quads_offset(layer);
@@ -22,7 +31,13 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
                 for (int j = 0; j < 4; ++j) {
                     const int o = maps.out_map[mo * 16 + (lane & 15)];
                     const int i = maps.in_map[(4 * kq + j) * 4 + (lane >> 4)];
-                    q[((mo * s.kq + kq) * 64 + lane) * 4 + j] = (o >= 0 && i >= 0) ? (float)(W[o * ldw + i] * sw) : 0.0f;
+                    const float v = (o >= 0 && i >= 0) ? (float)(W[o * ldw + i] * sw) : 0.0f;
+                    float* slot = q + ((mo * s.kq + kq) * 64 + lane) * 4;
+#ifdef NR_BF16_QUADS      // the four weights of the quad as bf16 in the slot's first two dwords (the rest stays zero)
+                    reinterpret_cast<unsigned short*>(slot)[j] = to_bf16(v);
+#else
+                    slot[j] = v;
+#endif
                 }
         for (int k1 = 0; k1 < s.k1; ++k1)
             for (int lane = 0; lane < 64; ++lane) {

@@ -27,6 +27,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f nr_mfma16(float a, float b, v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+#ifdef NR_BF16_QUADS
+// bf16-operand variant (separately built and reported library): one v_mfma_f32_16x16x16_bf16 does the
+// four K-steps of a quad.  lane l supplies A[m = l&15][k = 4*(l>>4) + j] and B[k = 4*(l>>4) + j][n = l&15], j = 0..3, as
+// four bf16 (two registers each); fp32 accumulation, same D layout.  The A values arrive packed (the packer stores them
+// as bf16 pairs in the first two dwords of the quad's slot); the B values are rounded here (v_cvt_pk_bf16_f32, RNE).
+typedef short nr_v4s __attribute__((ext_vector_type(4)));
+typedef __bf16 nr_v2bf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nr_pk_bf16(float lo, float hi) {
+    nr_v2bf v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ v4f nr_mfma16_bf16q(float a01, float a23, float b0, float b1, float b2, float b3, v4f c) {
+    const uint2 ap = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+    const uint2 bp = make_uint2(nr_pk_bf16(b0, b1), nr_pk_bf16(b2, b3));
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(nr_v4s, ap), __builtin_bit_cast(nr_v4s, bp), c, 0, 0, 0);
+}
+#endif
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define NR_PRAGMA_UNROLL _Pragma("unroll")

@@ -69,15 +69,17 @@ class ViewSet:
 
 
 class RenderEngine:
-    def __init__(self, device, _test_lib=None, views_per_wave=0):
+    def __init__(self, device, _test_lib=None, views_per_wave=0, variant='fp32'):
         """device: torch device of the HIP GPU.  `_test_lib` is for the CPU test-suite only (binds the
-        emulator build of the same kernels); the product path always uses libneuray_hip.so."""
+        emulator build of the same kernels); the product path always uses libneuray_hip.so.
+        variant: 'fp32' (the product) or 'bf16' (libneuray_hip_bf16.so: bf16 MFMA operands, fp32 accumulation;
+        inference only, reported separately - DESIGN.md section 4.8)."""
         self.device = torch.device(device)
         if _test_lib is None:
             if self.device.type != 'cuda':
                 raise RuntimeError("neuray_amd.RenderEngine needs a HIP device (got %s): the render path has no CPU "
                                    "fallback" % self.device)
-            self.lib = _lib.load()
+            self.lib = _lib.load(variant)
         else:
             self.lib = _test_lib
         self.views_per_wave = views_per_wave

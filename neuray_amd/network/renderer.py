@@ -33,6 +33,9 @@ class NeuralRayBaseRenderer(nn.Module):
         # not a reference key: also build image_encoder / vis_encoder (network/encoders.py), which makes the state_dict
         # equal to the reference base renderer's and lets render() start from images + initial ray_feats
         'build_encoders': False,
+        # not a reference key: 'fp32' = the product library; 'bf16' = the separately built bf16-operand variant of the
+        # kernels (libneuray_hip_bf16.so; inference only, never the default)
+        'hip_variant': 'fp32',
     }
 
     def __init__(self, cfg):
@@ -60,7 +63,7 @@ class NeuralRayBaseRenderer(nn.Module):
     # ---- engine / weight plumbing ---------------------------------------------------------------
     def engine(self, device):
         if self._engine is None or self._engine.device != torch.device(device):
-            self._engine = RenderEngine(device, _test_lib=self._engine_test_lib)
+            self._engine = RenderEngine(device, _test_lib=self._engine_test_lib, variant=self.cfg['hip_variant'])
             self._packed = {}
         return self._engine
 

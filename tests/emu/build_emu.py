@@ -14,16 +14,20 @@ DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bw
     [os.path.join(HERE, 'hip_emu.h'), os.path.join(ROOT, 'include', 'neuray_hip.h')]
 
 
-def build(force=False):
+def build(force=False, variant='fp32'):
+    """variant 'bf16': the same sources with -DNR_BF16_QUADS (the bf16-operand library on the emulator)"""
     os.makedirs(OUT_DIR, exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
+    out = OUT if variant == 'fp32' else OUT.replace('.so', '_bf16.so')
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
     cmd = ['g++', '-std=c++17', '-O2', '-g', '-rdynamic', '-fPIC', '-shared', '-DNEURAY_EMU', '-ffp-contract=off',
-           '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', OUT]
+           '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', out]
+    if variant == 'bf16':
+        cmd.append('-DNR_BF16_QUADS')
     for s in SOURCES:
         cmd += ['-x', 'c++', s]
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == '__main__':

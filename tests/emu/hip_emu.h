@@ -182,6 +182,32 @@ static inline v4f nr_mfma16(float a, float b, v4f c) {
     return d;
 }
 
+// ---- bf16-operand quad MFMA 16x16x16 (NR_BF16_QUADS builds): A values arrive as packed bf16 pairs, B values are rounded
+// to bf16 (round to nearest even) here; fp32 accumulation over k = 4*(lane>>4) + j in ascending order.
+static inline float emu_bf16_round(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    float r; memcpy(&r, &u, 4); return r;
+}
+static inline void emu_bf16_unpack(float packed, float& lo, float& hi) {
+    unsigned u; memcpy(&u, &packed, 4);
+    unsigned l = u << 16, h = u & 0xffff0000u;
+    memcpy(&lo, &l, 4); memcpy(&hi, &h, 4);
+}
+static inline v4f nr_mfma16_bf16q(float a01, float a23, float b0, float b1, float b2, float b3, v4f c) {
+    float a[4];
+    emu_bf16_unpack(a01, a[0], a[1]); emu_bf16_unpack(a23, a[2], a[3]);
+    const float b[4] = {emu_bf16_round(b0), emu_bf16_round(b1), emu_bf16_round(b2), emu_bf16_round(b3)};
+    v4f d = c;
+    for (int j = 0; j < 4; ++j) {       // four K-steps with k = 4*kk + j: every (m, n) sums all 16 products; order differs
+        v4f z = {0.0f, 0.0f, 0.0f, 0.0f};                                  // from the hardware's only in rounding noise
+        v4f t = nr_mfma16(a[j], b[j], z);
+        for (int r = 0; r < 4; ++r) d[r] += t[r];
+    }
+    return d;
+}
+
 // ---- exact-rounding helpers (same names as the HIP device intrinsics) --------------------------
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }

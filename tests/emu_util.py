@@ -21,6 +21,20 @@ def emu_lib():
     return _EMU
 
 
+_EMU_BF16 = None
+
+
+def emu_lib_bf16():
+    """the bf16-operand variant of the kernels on the emulator"""
+    global _EMU_BF16
+    if _EMU_BF16 is None:
+        import build_emu
+        from neuray_amd import _lib
+        _EMU_BF16 = _lib.bind(build_emu.build(variant='bf16'))
+        assert _EMU_BF16.neuray_is_device_build() == 0 and _EMU_BF16.neuray_operand_precision() == 16
+    return _EMU_BF16
+
+
 def emu_engine(**kw):
     from neuray_amd.engine import RenderEngine
     return RenderEngine('cpu', _test_lib=emu_lib(), **kw)

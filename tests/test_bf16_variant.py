@@ -1,0 +1,56 @@
+"""The separately built bf16-operand variant of the kernels (libneuray_hip_bf16.so, cfg['hip_variant'] = 'bf16'; DESIGN.md
+4.8): same sources with -DNR_BF16_QUADS - bf16 weights and bf16-rounded activations in the quad K-steps of every MFMA
+layer, fp32 accumulation, fp32 everywhere else.  It is NOT the product path and never the default; these tests pin how
+far it is from the fp32 path (and through it from the reference) and that it cannot be picked up by accident."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_case, load_weights
+from emu_util import emu_lib, emu_lib_bf16, to_torch
+from neuray_amd import synthetic
+from neuray_amd.network.renderer import NeuralRayBaseRenderer
+
+BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+def renderer_for(cfg, variant, backend):
+    r = NeuralRayBaseRenderer({**cfg, 'hip_variant': variant}).eval()
+    r.load_state_dict({k: torch.from_numpy(v) for k, v in load_weights(False).items()}, strict=False)
+    if backend == 'emu':
+        r._engine_test_lib = emu_lib() if variant == 'fp32' else emu_lib_bf16()
+        return r, 'cpu'
+    return r.cuda(), 'cuda:0'
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('name', ['a_small', 'b_default'])
+def test_bf16_variant_stays_close_to_the_fp32_path(name, backend):
+    cfg, que, ref, out, mid, extra = load_case(name)
+    res = {}
+    for variant in ('fp32', 'bf16'):
+        r, dev = renderer_for(cfg, variant, backend)
+        assert r.engine(dev).lib.neuray_operand_precision() == (32 if variant == 'fp32' else 16)
+        with torch.no_grad():
+            res[variant] = {k: v.cpu().numpy() for k, v in r.render_impl(to_torch(que, dev), to_torch(ref, dev), False).items()}
+    a, b = res['fp32'], res['bf16']
+    assert np.abs(a['pixel_colors_nr'] - out['pixel_colors_nr']).max() <= 2e-4            # the fp32 path is untouched
+    assert np.abs(b['pixel_colors_nr'] - a['pixel_colors_nr']).max() <= 2e-2 and np.abs(b['hit_prob_nr'] - a['hit_prob_nr']).max() <= 1e-2
+    assert not np.array_equal(b['pixel_colors_nr'], a['pixel_colors_nr'])                  # it really is another arithmetic
+    assert synthetic.psnr_uint8(np.clip(a['pixel_colors_nr'], 0, 1), np.clip(b['pixel_colors_nr'], 0, 1)) >= 48.0
+    assert synthetic.psnr_uint8(np.clip(a['pixel_colors_nr_fine'], 0, 1), np.clip(b['pixel_colors_nr_fine'], 0, 1)) >= 38.0
+
+
+def test_bf16_variant_is_inference_only_and_never_the_default():
+    from neuray_amd import _lib
+    assert NeuralRayBaseRenderer({}).cfg['hip_variant'] == 'fp32'
+    lib = emu_lib_bf16()
+    idx, sc = np.zeros(_lib.PACKED_RAY_FLOATS + 200000, np.int32), np.zeros(_lib.PACKED_RAY_FLOATS + 200000, np.float32)
+    assert lib.neuray_pack_pass_index_map(0, idx.ctypes.data, sc.ctypes.data) != 0 and b'bf16' in lib.neuray_last_error()
+    cfg, que, ref, out, mid, extra = load_case('a_small')
+    r, dev = renderer_for({**cfg, 'use_self_hit_prob': False}, 'bf16', 'emu')
+    r.train()
+    tq, tr = to_torch(que, dev), to_torch(ref, dev)
+    tr['ray_feats'].requires_grad_(True)
+    with pytest.raises(RuntimeError, match='bf16'):
+        r.render_impl(tq, tr, True)

@@ -210,8 +210,21 @@ __device__ __forceinline__ float4 wld4(LdsW w, int voff, int soff) {
 #endif
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
 }
+__device__ __forceinline__ float2 wld2(nr_wbuf W, int voff, int soff) { return nr_buf_ld2(W, voff, soff); }
+__device__ __forceinline__ float2 wld2(LdsW w, int voff, int soff) {
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
 __device__ __forceinline__ float wld1(LdsW w, int voff, int soff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
+// one quad fragment (nr_layout.h): 16 bytes per lane; in the bf16-operand build only the first 8 carry data
+template <class WS> __device__ __forceinline__ float4 wldq(WS W, int voff, int soff) {
+#ifdef NR_BF16_QUADS
+    const float2 h = wld2(W, voff, soff);
+    return make_float4(h.x, h.y, 0.0f, 0.0f);
+#else
+    return wld4(W, voff, soff);
+#endif
 }
 __device__ __forceinline__ float4 mld4(nr_mbuf M, int voff, int soff) {
 #if defined(NR_ABLATE) && (NR_ABLATE & 16)
@@ -346,11 +359,11 @@ __device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
     NR_PRAGMA_UNROLL
     for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, lane * 4, (single_offset(L) + (mo * K1 + K10 + k1) * 64) * 4);
     if (KQN > 0) {
-        float4 cur = wld4(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0) * 256) * 4);
+        float4 cur = wldq(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0) * 256) * 4);
         NR_PRAGMA_UNROLL
         for (int kq = 0; kq < KQN; ++kq) {
             float4 nxt = cur;
-            if (kq + 1 < KQN) nxt = wld4(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0 + kq + 1) * 256) * 4);
+            if (kq + 1 < KQN) nxt = wldq(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0 + kq + 1) * 256) * 4);
             NR_PIN();
             mfma_quad<NT>(cur, kq, xq, acc);
             cur = nxt;
@@ -386,7 +399,7 @@ struct NoLayer {};
 template <int L, class WS>
 __device__ __forceinline__ void layer_prefetch(WS W, int lane, LayerPre<L>& p) {
     NR_PRAGMA_UNROLL
-    for (int i = 0; i < LayerPre<L>::NF; ++i) p.q[i] = wld4(W, lane * 16, (quads_offset(L) + i * 256) * 4);
+    for (int i = 0; i < LayerPre<L>::NF; ++i) p.q[i] = wldq(W, lane * 16, (quads_offset(L) + i * 256) * 4);
     NR_PRAGMA_UNROLL
     for (int mo = 0; mo < LayerPre<L>::MT; ++mo) p.b[mo] = wld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
     NR_PRAGMA_UNROLL
@@ -457,7 +470,7 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const LayerPre<L>& pre
             mfma_quad<NT>(cur, kq, xq, a);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
-            if (i + PF + 1 < NQ) ring[i % (PF + 1)] = wld4(W, lane * 16, (quads_offset(L) + (i + PF + 1) * 256) * 4);
+            if (i + PF + 1 < NQ) ring[i % (PF + 1)] = wldq(W, lane * 16, (quads_offset(L) + (i + PF + 1) * 256) * 4);
         }
     } else {
         layer_prefetch(W, lane, next);

@@ -77,6 +77,7 @@ struct nr_buf { const char* p; };
 static inline nr_buf nr_make_buf(const float* p, size_t bytes) { (void)bytes; return nr_buf{(const char*)p}; }
 static inline float4 nr_buf_ld4(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
 static inline float nr_buf_ld1(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
+static inline float2 nr_buf_ld2(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float2*>(b.p + voff + soff); }
 // LDS-DMA piece (emulation: the copy happens at issue time, a legal completion point)
 static inline void nr_dma16(nr_buf b, float* lds_wave_base, int lane, int voff, int soff) {
     memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, b.p + voff + soff, 16);
@@ -87,6 +88,7 @@ struct nr_pbuf { const char* p; };
 __device__ __forceinline__ nr_pbuf nr_make_pbuf(const float* p, size_t) { return nr_pbuf{(const char*)p}; }
 __device__ __forceinline__ float4 nr_buf_ld4(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
 __device__ __forceinline__ float nr_buf_ld1(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
+__device__ __forceinline__ float2 nr_buf_ld2(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float2*>(b.p + voff + soff); }
 struct nr_buf { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ nr_buf nr_make_buf(const float* p, size_t bytes) {
     nr_buf b;
@@ -107,6 +109,13 @@ __device__ __forceinline__ float4 nr_buf_ld4(nr_buf b, int voff, int soff) {
 }
 __device__ __forceinline__ float nr_buf_ld1(nr_buf b, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+__device__ __forceinline__ float2 nr_buf_ld2(nr_buf b, int voff, int soff) {       // (whole-vector cast, as in nr_buf_ld4)
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const v2u u = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
+    const v2f_ f = __builtin_bit_cast(v2f_, u);
+    return make_float2(f.x, f.y);
 }
 // LDS-DMA piece: buffer_load_dwordx4 ... lds.  Every active lane moves 16 bytes from (voff + soff) of the buffer to
 // lds_wave_base + lane * 16 (lds_wave_base is wave-uniform and goes to M0); no VGPRs, completion counted by vmcnt.

@@ -265,17 +265,33 @@ __device__ __forceinline__ void issue_rgb(nr_mbuf m, int soff, const Taps& t, fl
     q[2] = mld4(m, t.o01 * 16, soff); q[3] = mld4(m, t.o11 * 16, soff);
 }
 
-__device__ __forceinline__ void blend8(const float4 (&q)[8], const Taps& t, float mask, float (&out)[8]) {
-    out[0] = blend4(q[0].x, q[2].x, q[4].x, q[6].x, t) * mask; out[1] = blend4(q[0].y, q[2].y, q[4].y, q[6].y, t) * mask;
-    out[2] = blend4(q[0].z, q[2].z, q[4].z, q[6].z, t) * mask; out[3] = blend4(q[0].w, q[2].w, q[4].w, q[6].w, t) * mask;
-    out[4] = blend4(q[1].x, q[3].x, q[5].x, q[7].x, t) * mask; out[5] = blend4(q[1].y, q[3].y, q[5].y, q[7].y, t) * mask;
-    out[6] = blend4(q[1].z, q[3].z, q[5].z, q[7].z, t) * mask; out[7] = blend4(q[1].w, q[3].w, q[5].w, q[7].w, t) * mask;
+// bilinear blend of channel PAIRS (v_pk_mul_f32 / v_pk_fma_f32: two channels per instruction); the validity mask is folded
+// into the four weights (mask is 0 or 1, so w * mask is exact and the chain equals blend4(...) * mask)
+struct TapW2 { nr_v2 w00, w10, w01, w11; };
+__device__ __forceinline__ TapW2 tap_weights2(const Taps& t, float mask) {
+    const float a = t.w00 * mask, b = t.w10 * mask, c = t.w01 * mask, d = t.w11 * mask;
+    TapW2 w; w.w00 = nr_v2_make(a, a); w.w10 = nr_v2_make(b, b); w.w01 = nr_v2_make(c, c); w.w11 = nr_v2_make(d, d);
+    return w;
 }
-
+__device__ __forceinline__ nr_v2 blend4_2(nr_v2 a, nr_v2 b, nr_v2 c, nr_v2 d, const TapW2& w) {
+    return nr_v2_fma(d, w.w11, nr_v2_fma(c, w.w01, nr_v2_fma(b, w.w10, nr_v2_mul(a, w.w00))));
+}
+__device__ __forceinline__ void blend8(const float4 (&q)[8], const Taps& t, float mask, float (&out)[8]) {
+    const TapW2 w = tap_weights2(t, mask);
+    NR_PRAGMA_UNROLL
+    for (int h = 0; h < 2; ++h) {            // q[h], q[2+h], q[4+h], q[6+h]: the four taps of channels 4h .. 4h+3
+        const nr_v2 lo = blend4_2(nr_v2_make(q[h].x, q[h].y), nr_v2_make(q[2 + h].x, q[2 + h].y), nr_v2_make(q[4 + h].x, q[4 + h].y),
+                                  nr_v2_make(q[6 + h].x, q[6 + h].y), w);
+        const nr_v2 hi = blend4_2(nr_v2_make(q[h].z, q[h].w), nr_v2_make(q[2 + h].z, q[2 + h].w), nr_v2_make(q[4 + h].z, q[4 + h].w),
+                                  nr_v2_make(q[6 + h].z, q[6 + h].w), w);
+        out[4 * h] = lo.x; out[4 * h + 1] = lo.y; out[4 * h + 2] = hi.x; out[4 * h + 3] = hi.y;
+    }
+}
 __device__ __forceinline__ void blend_rgb(const float4 (&c)[4], const Taps& t, float mask, float (&rgb)[3]) {
-    rgb[0] = blend4(c[0].x, c[1].x, c[2].x, c[3].x, t) * mask;
-    rgb[1] = blend4(c[0].y, c[1].y, c[2].y, c[3].y, t) * mask;
-    rgb[2] = blend4(c[0].z, c[1].z, c[2].z, c[3].z, t) * mask;
+    const TapW2 w = tap_weights2(t, mask);
+    const nr_v2 rg = blend4_2(nr_v2_make(c[0].x, c[0].y), nr_v2_make(c[1].x, c[1].y), nr_v2_make(c[2].x, c[2].y), nr_v2_make(c[3].x, c[3].y), w);
+    const nr_v2 bb = blend4_2(nr_v2_make(c[0].z, c[0].w), nr_v2_make(c[1].z, c[1].w), nr_v2_make(c[2].z, c[2].w), nr_v2_make(c[3].z, c[3].w), w);
+    rgb[0] = rg.x; rgb[1] = rg.y; rgb[2] = bb.x;
 }
 
 __device__ __forceinline__ void gather_rgb(nr_mbuf map, int soff, const Taps& t, float mask, float (&out)[3]) {
@@ -492,6 +508,22 @@ template <int A, int L> __device__ __forceinline__ float apply_act(float x) {
     return x;
 }
 
+// two activations at a time: the multiply-add around the exponentials is one packed instruction for the pair (bitwise the
+// scalar result); exp2 and med3 have no packed form
+template <int A, int L> __device__ __forceinline__ void apply_act2(float x0, float x1, float& y0, float& y1) {
+#if !defined(NR_PRECISE_MATH) && !(defined(NR_ABLATE) && (NR_ABLATE & 2))
+    if (A == ACT_ELU) {
+        if (kOutScaled[L]) {       // L(2^x - 1)
+            const nr_v2 f = nr_v2_fma(nr_v2_make(nr_fast_exp2(x0), nr_fast_exp2(x1)), nr_v2_make((float)kLog2e, (float)kLog2e),
+                                      nr_v2_make(-(float)kLog2e, -(float)kLog2e));
+            y0 = nr_med3(x0, f.x, 0.0f); y1 = nr_med3(x1, f.y, 0.0f);
+            return;
+        }
+    }
+#endif
+    y0 = apply_act<A, L>(x0); y1 = apply_act<A, L>(x1);
+}
+
 // layer L from its prefetched head `pre`; `next` (a LayerPre of the following layer of the same phase, or NoLayer)
 // is filled on the way
 template <int L, int NT, int A, class WS, int KQX, int K1X, class PN>
@@ -513,11 +545,11 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre<L>& pre
         NR_PRAGMA_UNROLL
         for (int mo = 0; mo < MT; ++mo)
             NR_PRAGMA_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                y[t][4 * mo + r] = apply_act<A, L>(acc[t][mo][r]);
+            for (int r = 0; r < 4; r += 2) {
+                apply_act2<A, L>(acc[t][mo][r], acc[t][mo][r + 1], y[t][4 * mo + r], y[t][4 * mo + r + 1]);
 #if defined(NR_EXTRA_VALU) && !defined(NEURAY_EMU)      // marginal-cost probe: NR_EXTRA_VALU dummy VALU ops per output register
                 float dummy = y[t][4 * mo + r];
-                for (int e_ = 0; e_ < NR_EXTRA_VALU; ++e_) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(dummy));
+                for (int e_ = 0; e_ < 2 * NR_EXTRA_VALU; ++e_) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(dummy));
 #endif
             }
 }

@@ -69,6 +69,20 @@ __device__ __forceinline__ void nr_gst4(NR_GLOBAL_PTR(float) p, float4 v) {
 
 #define NR_WAVE 64
 
+// ---- two fp32 values per instruction (v_pk_mul_f32 / v_pk_fma_f32: full-rate on CDNA3/4, i.e. twice the scalar VALU
+// throughput).  Each half is the IEEE result of the scalar operation, so packed and scalar code are bitwise equal.
+#ifdef NEURAY_EMU
+struct nr_v2 { float x, y; };
+static inline nr_v2 nr_v2_make(float a, float b) { return nr_v2{a, b}; }
+static inline nr_v2 nr_v2_mul(nr_v2 a, nr_v2 b) { return nr_v2{__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)}; }
+static inline nr_v2 nr_v2_fma(nr_v2 a, nr_v2 b, nr_v2 c) { return nr_v2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float nr_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ nr_v2 nr_v2_make(float a, float b) { nr_v2 v; v.x = a; v.y = b; return v; }
+__device__ __forceinline__ nr_v2 nr_v2_mul(nr_v2 a, nr_v2 b) { return a * b; }
+__device__ __forceinline__ nr_v2 nr_v2_fma(nr_v2 a, nr_v2 b, nr_v2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+
 // ---- read-only buffers addressed as {SGPR descriptor, one per-lane byte offset VGPR, scalar byte offset} --------
 // buffer_load needs no per-load 64-bit address register pair; with plain pointers hipcc hoisted ~150 loop-invariant
 // fragment addresses out of the point loop and spilled them.

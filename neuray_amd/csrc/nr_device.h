@@ -444,13 +444,15 @@ __device__ __forceinline__ void layer_vec(const VecPre<L>& p, const float (&x)[N
     for (int t = 0; t < NT; ++t)
         NR_PRAGMA_UNROLL
         for (int j = 0; j < N; ++j) {
-            float a = p.w[j * TI].x * x[t][0];
-            a = fmaf(p.w[j * TI].y, x[t][1], a); a = fmaf(p.w[j * TI].z, x[t][2], a); a = fmaf(p.w[j * TI].w, x[t][3], a);
+            // two products per instruction (v_pk_mul / v_pk_fma over register pairs), the halves added at the end
+            nr_v2 a2 = nr_v2_mul(nr_v2_make(p.w[j * TI].x, p.w[j * TI].y), nr_v2_make(x[t][0], x[t][1]));
+            a2 = nr_v2_fma(nr_v2_make(p.w[j * TI].z, p.w[j * TI].w), nr_v2_make(x[t][2], x[t][3]), a2);
             NR_PRAGMA_UNROLL
             for (int ti = 1; ti < TI; ++ti) {
-                a = fmaf(p.w[j * TI + ti].x, x[t][4 * ti], a); a = fmaf(p.w[j * TI + ti].y, x[t][4 * ti + 1], a);
-                a = fmaf(p.w[j * TI + ti].z, x[t][4 * ti + 2], a); a = fmaf(p.w[j * TI + ti].w, x[t][4 * ti + 3], a);
+                a2 = nr_v2_fma(nr_v2_make(p.w[j * TI + ti].x, p.w[j * TI + ti].y), nr_v2_make(x[t][4 * ti], x[t][4 * ti + 1]), a2);
+                a2 = nr_v2_fma(nr_v2_make(p.w[j * TI + ti].z, p.w[j * TI + ti].w), nr_v2_make(x[t][4 * ti + 2], x[t][4 * ti + 3]), a2);
             }
+            const float a = a2.x + a2.y;
             const float bj = j == 0 ? p.b.x : (j == 1 ? p.b.y : (j == 2 ? p.b.z : p.b.w));
             out[t][j] = nr_group_sum(a) + bj;
         }

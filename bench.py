@@ -267,6 +267,14 @@ def init_net_timing(device, reps=10):
     return res
 
 
+def side(fn, *a, **k):
+    """a side measurement must never cost the headline line: report its failure instead"""
+    try:
+        return fn(*a, **k)
+    except Exception as e:                          # noqa: BLE001
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -364,9 +372,9 @@ def main():
             eb = eager_torch_baseline(cfg, weights, tq, tr, device)
             eb['speedup_vs_eager'] = value / (1 if split else world) / eb['value']
             line['eager_torch_baseline'] = eb
-            line['training_step'] = training_step_timing(device)
-            line['init_net'] = init_net_timing(device)
-            line['bf16_variant'] = bf16_variant_timing(device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
+            line['training_step'] = side(training_step_timing, device)
+            line['init_net'] = side(init_net_timing, device)
+            line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -73,21 +73,21 @@ def test_render_loop_equals_direct_renderer_calls(backend):
         if backend == 'emu':
             gen._engine_test_lib = emu_lib()
         gen = gen.to(dev)
-        db = synthetic.MemoryDatabase(6, 32, 48, seed=7)
+        db = synthetic.MemoryDatabase(6, 32, 32, seed=7)
         qposes = np.stack([db.get_pose(0), db.get_pose(3)])
         ref_ids = pipeline.select_working_views_db(db, None, qposes, 3, True)
         cache = pipeline.DeviceViewCache(db, dev, pad_interval=16)
         saved = {}
-        imgs = pipeline.render_poses(gen, db, qposes, [db.get_K(0)] * 2, [(32, 48)] * 2, [(2.0, 6.0)] * 2, ref_ids, cache=cache,
+        imgs = pipeline.render_poses(gen, db, qposes, [db.get_K(0)] * 2, [(32, 32)] * 2, [(2.0, 6.0)] * 2, ref_ids, cache=cache,
                                      save_fn=lambda qi, im: saved.__setitem__(qi, im))
-        assert imgs == [] and sorted(saved) == [0, 1] and saved[0].shape == (32, 48, 3) and saved[0].dtype == np.uint8
+        assert imgs == [] and sorted(saved) == [0, 1] and saved[0].shape == (32, 32, 3) and saved[0].dtype == np.uint8
         # the same image through the reference-style host build + a plain renderer call
         ref = {k: torch.from_numpy(v).to(dev) for k, v in pipeline.build_imgs_info(db, list(ref_ids[1]), 16, True, False, True, True).items()}
-        que = pipeline.build_render_imgs_info(qposes[1], db.get_K(0), (32, 48), (2.0, 6.0))
+        que = pipeline.build_render_imgs_info(qposes[1], db.get_K(0), (32, 32), (2.0, 6.0))
         que.pop('shape')
         with torch.no_grad():
             out = gen({'que_imgs_info': {k: torch.from_numpy(v).to(dev) for k, v in que.items()}, 'ref_imgs_info': ref, 'eval': True})
-        want = pipeline.color_map_backward(out['pixel_colors_nr_fine'].reshape(32, 48, 3).cpu().numpy())
+        want = pipeline.color_map_backward(out['pixel_colors_nr_fine'].reshape(32, 32, 3).cpu().numpy())
         diff = np.abs(saved[1].astype(np.int32) - want.astype(np.int32))
         if backend == 'emu':
             assert diff.max() == 0

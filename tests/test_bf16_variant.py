@@ -54,3 +54,22 @@ def test_bf16_variant_is_inference_only_and_never_the_default():
     tr['ray_feats'].requires_grad_(True)
     with pytest.raises(RuntimeError, match='bf16'):
         r.render_impl(tq, tr, True)
+
+
+def test_bf16_packing_is_the_rounded_fp32_packing():
+    """every quad slot of the bf16 build holds the round-to-nearest-even bf16 of the four fp32 weights the product build
+    holds there (first two dwords; the other two are zero); biases, singles and vector rows are identical fp32"""
+    from neuray_amd.engine import RenderEngine
+    w = {k: torch.from_numpy(v) for k, v in load_weights(False).items()}
+    p32 = RenderEngine('cpu', _test_lib=emu_lib()).pack_pass(w, 'dist_decoder.', 'agg_net.').dev.numpy()
+    p16 = RenderEngine('cpu', _test_lib=emu_lib_bf16()).pack_pass(w, 'dist_decoder.', 'agg_net.').dev.numpy()
+    assert p32.shape == p16.shape
+    same = p32.view(np.uint32) == p16.view(np.uint32)
+    differs = np.flatnonzero(~same)
+    assert differs.size > 10000                                       # the quad regions
+    slots = np.unique(differs // 4)                                   # 16-byte slots that differ are quad slots
+    a = p32.reshape(-1, 4)[slots]
+    b = p16.reshape(-1, 4)[slots].copy().view(np.uint16).reshape(-1, 8)
+    assert not b[:, 4:].any()
+    want = torch.from_numpy(a.copy()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(b[:, :4], want)

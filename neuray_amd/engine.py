@@ -52,6 +52,11 @@ def posenc_table(d_hid, n_samples):
     return torch.from_numpy(t.astype(np.float32))
 
 
+def host_inverse(Ks):
+    """torch.inverse of [n,3,3] intrinsics on the host in fp32 (see RenderEngine.prepare_query)"""
+    return torch.inverse(torch.as_tensor(Ks).detach().to('cpu', torch.float32))
+
+
 class PackedPass:
     """Device-resident packed weights of one pass (dist decoder + aggregation net)."""
 
@@ -87,6 +92,7 @@ class RenderEngine:
         # optional kernel timing: set to a list and every point/ray launch appends
         # (name, start_event, end_event, n_points) recorded on the launch stream (HIP events)
         self.timing = None
+        self.max_backward_samples = _lib.MAX_BACKWARD_SAMPLES
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -183,7 +189,7 @@ class RenderEngine:
         poses, Ks, dr = self._f32(ref_imgs_info['poses']), self._f32(ref_imgs_info['Ks']), self._f32(ref_imgs_info['depth_range'])
         vc = self.empty(rfn, _lib.VIEW_CONST)
         self._check(self.lib.neuray_setup_views(poses.data_ptr(), Ks.data_ptr(), dr.data_ptr(), rfn, vc.data_ptr(), s))
-        kinv = self._f32(torch.inverse(Ks))                   # as depth2pts3d (init_net.py:23)
+        kinv = self._f32(host_inverse(Ks))                    # as depth2pts3d (init_net.py:23)
         lift = self.empty(rfn, _lib.QUERY_CONST)
         for v in range(rfn):
             self._check(self.lib.neuray_setup_query(poses[v].data_ptr(), kinv[v].data_ptr(), dr[v].data_ptr(), lift[v].data_ptr(), s))
@@ -215,12 +221,15 @@ class RenderEngine:
         return out
 
     def prepare_query(self, que_imgs_info):
-        """-> query constant block.  K^-1 by torch.inverse exactly as the reference (render_ops.py:20)."""
+        """-> query constant block.  K^-1 is `torch.inverse(Ks)` as in the reference (render_ops.py:20), evaluated on the
+        HOST (LAPACK, fp32) wherever the tensor lives: a 3x3 LU on the GPU goes through a different solver whose last bits
+        differ, and the reference-generated golden vectors (and the bit-exact geometry contract) are pinned
+        to the CPU result.  36 bytes D2H once per query view (cached by HipRenderPath._query); a caller that wants no host
+        round trip at all hands `Ks_inv` over."""
         pose = self._f32(que_imgs_info['poses'])
         assert pose.shape[0] == 1, "one query view per render() call (qn = 1)"
-        Ks = self._f32(que_imgs_info['Ks'])
         # torch.inverse returns a column-major tensor: make it contiguous and keep it bound until the launch
-        kinv = self._f32(que_imgs_info['Ks_inv'] if 'Ks_inv' in que_imgs_info else torch.inverse(Ks))
+        kinv = self._f32(que_imgs_info['Ks_inv'] if 'Ks_inv' in que_imgs_info else host_inverse(que_imgs_info['Ks']))
         dr = self._f32(que_imgs_info['depth_range'])
         qc = self.empty(_lib.QUERY_CONST)
         self._check(self.lib.neuray_setup_query(pose.data_ptr(), kinv.data_ptr(), dr.data_ptr(), qc.data_ptr(), self._stream()))

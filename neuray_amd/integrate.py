@@ -1,0 +1,88 @@
+"""Drop the HIP render path into the REFERENCE's own classes.
+
+The reference has no FFI layer: its "operator API" for the per-ray path is the method surface of
+`network.renderer.NeuralRayBaseRenderer` (render_by_depth / fine_render_impl / render_impl, network/renderer.py:168-226),
+reached from render.py:90-95,143-144 (`name2network[cfg['network']](cfg)`, `.load_state_dict`, `.cuda()`, `.eval()`,
+`renderer(data)`) and train/trainer.py:50,123 (`self.train_network(train_data)`).  `patch_reference()` grafts the methods
+of neuray_amd/network/hip_path.py onto that class, so every subclass the reference registers in `name2network`
+(NeuralRayGenRenderer, NeuralRayFtRenderer) - with its own constructor, checkpoint format, dataset layer, init nets and
+encoders - renders and back-propagates through libneuray_hip.so.  Nothing of the reference is edited or copied.
+
+    import neuray_amd.integrate as nri
+    nri.patch_reference()                     # after the reference tree is importable (it is sys.path[0] for render.py)
+    from network.renderer import name2network
+
+or, with the reference's scripts untouched:
+
+    python -m neuray_amd.launch render.py --cfg configs/gen/neuray_gen_depth.yaml --database ... --pose_type eval
+    python -m neuray_amd.launch run_training.py --cfg configs/train/ft/...yaml
+
+Options swap the neighbouring per-image pieces too (each is the same arithmetic on a HIP kernel / channels-last conv):
+  render_ops=True   network.render_ops' 12 free functions -> stand-alone kernels (neuray_amd/network/render_ops.py)
+  init_nets=True    DepthInitNet.get_diff_feats -> neuray_diff_feats
+"""
+import importlib
+import sys
+
+from .network.hip_path import HOT_PATH_METHODS, HipRenderPath
+
+_PATCHED = {}
+
+
+def patch_renderer_class(cls):
+    """Graft the HIP hot path onto `cls` (the reference's NeuralRayBaseRenderer or anything shaped like it: instances carry
+    cfg / dist_decoder / agg_net [/ fine_dist_decoder / fine_agg_net]).  Idempotent; returns the saved originals."""
+    if cls in _PATCHED:
+        return _PATCHED[cls]
+    saved = {}
+    for name in HOT_PATH_METHODS:
+        if name in cls.__dict__:
+            saved[name] = cls.__dict__[name]
+        setattr(cls, name, HipRenderPath.__dict__[name])
+    _PATCHED[cls] = saved
+    return saved
+
+
+def unpatch_renderer_class(cls):
+    saved = _PATCHED.pop(cls, None)
+    if saved is None:
+        return
+    for name in HOT_PATH_METHODS:
+        if name in saved:
+            setattr(cls, name, saved[name])
+        elif name in cls.__dict__:
+            delattr(cls, name)
+
+
+def patch_reference(renderer_module=None, render_ops=False, init_nets=False):
+    """Patch the reference's `network.renderer` (imported here if it is not yet; the reference tree must be importable).
+    -> the patched module."""
+    mod = renderer_module if renderer_module is not None else (
+        sys.modules.get('network.renderer') or importlib.import_module('network.renderer'))
+    patch_renderer_class(mod.NeuralRayBaseRenderer)
+    if render_ops:
+        from .network import render_ops as hip_ops
+        ref_ops = importlib.import_module('network.render_ops')
+        for name in hip_ops.__all__:
+            if hasattr(ref_ops, name):
+                _PATCHED.setdefault(ref_ops, {})[name] = getattr(ref_ops, name)
+                setattr(ref_ops, name, getattr(hip_ops, name))
+                if hasattr(mod, name):           # `from network.render_ops import *` in network/renderer.py:17
+                    setattr(mod, name, getattr(hip_ops, name))
+    if init_nets:
+        from .network import init_net as hip_init
+        ref_init = importlib.import_module('network.init_net')
+        _PATCHED.setdefault(ref_init, {})['get_diff_feats'] = ref_init.get_diff_feats
+        ref_init.get_diff_feats = hip_init.get_diff_feats
+    return mod
+
+
+def unpatch_reference(renderer_module=None):
+    mod = renderer_module if renderer_module is not None else sys.modules.get('network.renderer')
+    if mod is not None:
+        unpatch_renderer_class(mod.NeuralRayBaseRenderer)
+    for target in [t for t in _PATCHED if not isinstance(t, type)]:
+        for name, fn in _PATCHED.pop(target).items():
+            setattr(target, name, fn)
+            if mod is not None and hasattr(mod, name) and target.__name__ == 'network.render_ops':
+                setattr(mod, name, fn)

@@ -10,6 +10,10 @@ import torch
 
 from ..engine import RenderEngine
 
+__all__ = ['coords2rays', 'depth2points', 'depth2dists', 'depth2inv_dists', 'interpolate_feature_map', 'alpha_values2hit_prob',
+           'project_points_coords', 'project_points_directions', 'project_points_ref_views', 'project_points_dict',
+           'sample_depth', 'sample_fine_depth']
+
 _ENGINES = {}
 _TEST_LIB = None      # CPU test-suite hook: emulator build of the kernels
 

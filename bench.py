@@ -5,16 +5,29 @@
 A "step" is one pass of the hot path (coarse + fine render_impl over every ray batch) over one synthetic
 "lego-800" image: 800x800 = 640,000 rays, 8 reference views, 64 coarse + 32 fine samples (the configuration
 BASELINE.json's metric is quoted on), seeded random weights and feature maps; inputs are
-resident in HBM before the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL),
-images sharded across ranks (no data-path collective; rays and images are independent), weak scaling; the timed
-region is bracketed by barrier + synchronize and the max over ranks is taken.
+resident in HBM before the timed region.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started without a launcher (`WORLD_SIZE` unset),
+`python bench.py --gpus N` re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` and refuses to run if fewer than N GPUs are visible; started under a launcher it insists that
+WORLD_SIZE == N.  Images are sharded across ranks (no data-path collective; rays and images are independent), weak
+scaling; the timed region is bracketed by barrier + synchronize and the max over ranks is taken.  After the timed
+region an N > 1 run adds two side legs to the line: `split_image` (ONE image split over the ranks + one fused all-gather
+of the tiles) and `train_ddp` (forward + backward + ONE flattened gradient all-reduce per step).
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the MFMA point kernel):
 achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream).
-`cpu_baseline` times the numpy oracle (a port of the reference algorithm) on a bounded sample of the same
-workload on the host cores.  At N = 1 two side measurements ride along (reported baselines, not the metric):
-`eager_torch_baseline` (the eager-PyTorch port of the reference op sequence on the same GPU) and `training_step`
-(forward + backward kernels vs autograd of that port).  These legs are the only places this file touches oracle/.
+`cpu_baseline` times the golden-checked eager-PyTorch port of the reference's op sequence (oracle/torch_eager_port.py;
+the reference tree itself does not exist on the GPU box) on the host with torch.set_num_threads(physical cores) on a
+bounded sample of the same workload.  At N = 1 side measurements ride along (reported baselines, not the metric):
+`eager_torch_baseline` (the same port on the same GPU - the stand-in for "the reference on stock PyTorch-ROCm"),
+`numpy_oracle` (parity of the rendered image against the numpy oracle + its speed), `extra` (64+64 samples, the
+reference CLI's 4096-ray batches), `training_step`, `init_net`, `bf16_variant`.  These legs are the only places this
+file touches oracle/.
+
+`--emulator-lib PATH` is a TEST HOOK (tests/test_bench_launcher.py): the same code path - launcher, process group,
+sharding, collectives, JSON line - on CPU tensors with the `gloo` backend and the CPU emulator build of the kernels, on a
+tiny image; its numbers are not measurements and the line says so.
 """
 import argparse
 import json
@@ -35,6 +48,7 @@ from neuray_amd.network.renderer import NeuralRayBaseRenderer  # noqa: E402
 H = W = 800
 RFN = 8
 DN_COARSE = 64
+RAY_BATCH = 32768
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA dense peak
 
 
@@ -48,18 +62,19 @@ def algorithmic_macs_per_point(rfn, vis_head_used):
     return rfn * per_view + per_point
 
 
-def build_case(device, fdn, seed):
+def build_case(device, fdn, seed, test_lib=None):
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False},
            'depth_sample_num': DN_COARSE, 'fine_depth_sample_num': fdn,
            'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
-           'ray_batch_num': 32768}
+           'ray_batch_num': RAY_BATCH}
     torch.manual_seed(0)
     renderer = NeuralRayBaseRenderer(cfg).eval()
     weights = {k: v.detach().numpy().copy() for k, v in renderer.state_dict().items()}
     renderer = renderer.to(device)
+    renderer._engine_test_lib = test_lib
     que, ref = synthetic.make_scene(H, W, RFN, seed=seed)
     que['coords'] = synthetic.meshgrid_coords(H, W)
-    que['Ks_inv'] = torch.inverse(torch.from_numpy(que['Ks'])).numpy()
+    # no `Ks_inv` key: the query constants take the drop-in route (K^-1 = torch.inverse on the host, engine.prepare_query)
     tq = {k: torch.from_numpy(v).to(device) for k, v in que.items()}
     tr = {k: torch.from_numpy(v).to(device) for k, v in ref.items()}
     return cfg, renderer, weights, que, ref, tq, tr
@@ -75,13 +90,76 @@ def render_image(renderer, tq, tr, split=False):
         return renderer.render(q, r, False)
 
 
-def cpu_baseline(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
-    """Oracle (numpy port of the reference algorithm) on `sample_rays` rays of the same workload."""
+def host_cpu():
+    """-> (physical cores, model name) of the box this runs on"""
+    model, pairs, phys, core = 'unknown', set(), None, None
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+            elif line.startswith('physical id'):
+                phys = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':', 1)[1].strip()
+                pairs.add((phys, core))
+    except OSError:
+        pass
+    n = len(pairs)
+    if n == 0:
+        try:
+            import psutil
+            n = psutil.cpu_count(logical=False) or 0
+        except Exception:                       # noqa: BLE001
+            n = 0
+    return (n or os.cpu_count() or 1), model
+
+
+def cpu_baseline(cfg, weights, que, ref, budget_s=20.0, rays_per_batch=4096, max_batches=8):
+    """The reference's CPU path as it can be timed on this box: the eager-PyTorch port of the reference's op sequence
+    (oracle/torch_eager_port.py, checked against reference-generated goldens by tests/test_oracle_golden.py), fp32,
+    torch.no_grad(), torch.set_num_threads(physical cores), the reference CLI's 4096-ray batches (render.py:205), one
+    warm-up batch, then batches of the same 800x800 image until ~budget_s of CPU work."""
+    from oracle import torch_eager_port as tep
+    cores, model = host_cpu()
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        w = {k: torch.from_numpy(v) for k, v in weights.items()}
+        tq = {k: torch.from_numpy(v) for k, v in que.items()}
+        tr = {k: torch.from_numpy(v) for k, v in ref.items()}
+        ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+        n = tq['coords'].shape[1]
+        rays_per_batch = min(rays_per_batch, n)
+        starts = np.linspace(0, n - rays_per_batch, max_batches + 1).astype(np.int64)
+
+        def run(st):
+            q = dict(tq)
+            q['coords'] = tq['coords'][:, st:st + rays_per_batch]
+            with torch.no_grad():
+                return tep.render_impl(w, ocfg, q, tr)
+        run(int(starts[0]))
+        done, t0 = 0, time.perf_counter()
+        for st in starts[1:]:
+            run(int(st))
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old)
+    return {'value': done * rays_per_batch / dt, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port', 'cpu_model': model,
+            'sample': '%d batches of %d rays of the same 800x800 image (64+%d samples, 8 views), eager-PyTorch port of the '
+                      'reference op sequence, fp32, torch.set_num_threads(%d), %.1f s after one warm-up batch'
+                      % (done, rays_per_batch, cfg['fine_depth_sample_num'], cores, dt)}
+
+
+def numpy_oracle_leg(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
+    """Parity of the rendered image against the numpy oracle on `sample_rays` strided rays (+ the oracle's own speed)."""
     from oracle import neuray_oracle as orc
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    except Exception:
+    except Exception:                       # noqa: BLE001
         cores = os.cpu_count() or 1
     ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
     n = que['coords'].shape[1]
@@ -96,21 +174,17 @@ def cpu_baseline(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
     want = np.concatenate(outs, 1)
     got = got_pixels[:, idx]
     err = np.abs(got - want).max(-1)
-    return {
-        'value': sample_rays / dt, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port',
-        'sample': '%d rays of the same 800x800 image (every %d-th ray), coarse+fine, numpy oracle, %.1f s'
-                  % (sample_rays, max(1, n // sample_rays), dt),
-    }, {
-        'psnr_vs_oracle_db': synthetic.psnr_uint8(got, want),
-        'max_abs_err_vs_oracle': float(err.max()),
-        'frac_rays_within_2e-4': float(np.mean(err <= 2e-4)),
-    }
+    return {'value': sample_rays / dt, 'unit': 'rays/s', 'blas_threads': int(cores), 'kind': 'port (numpy oracle, the parity checker)',
+            'sample': '%d strided rays of the same image, %.1f s' % (sample_rays, dt)}, \
+           {'psnr_vs_oracle_db': synthetic.psnr_uint8(got, want), 'max_abs_err_vs_oracle': float(err.max()),
+            'frac_rays_within_2e-4': float(np.mean(err <= 2e-4))}
 
 
 def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch=4096):
-    """'Stock PyTorch-ROCm' baseline (the denominator of the north star's >= 10x): the eager-PyTorch
-    port of the reference's op sequence (oracle/torch_eager_port.py; the reference tree itself does not exist on
-    the GPU box) on the same device, same workload, the reference's default 4096-ray batches (render.py:205)."""
+    """Stand-in for BASELINE.md B2 ("the reference on stock PyTorch-ROCm", the denominator of the north star's >= 10x):
+    the reference tree does not exist on the GPU box, so this is the golden-checked eager-PyTorch PORT of the reference's
+    op sequence (oracle/torch_eager_port.py: the same ~700 small kernels per ray batch through PyTorch-ROCm) on the same
+    device, same workload, the reference's default 4096-ray batches (render.py:205)."""
     from oracle import torch_eager_port as tep
     w = {k: torch.from_numpy(v).to(device) for k, v in weights.items()}
     ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
@@ -131,6 +205,7 @@ def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     return {'value': batches * rays_per_batch / dt, 'unit': 'rays/s',
+            'kind': 'port of the reference (not the reference tree itself)',
             'what': 'eager-PyTorch port of the reference op sequence on the same MI355X, %d batches of %d rays'
                     % (batches, rays_per_batch)}
 
@@ -194,7 +269,7 @@ def bf16_variant_timing(device, fdn, tq, tr, fp32_pixels, steps=2):
     K-steps of every layer), fp32 accumulation, everything else fp32 - with its distance from the fp32 render."""
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': DN_COARSE,
            'fine_depth_sample_num': fdn, 'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
-           'ray_batch_num': 32768, 'hip_variant': 'bf16'}
+           'ray_batch_num': RAY_BATCH, 'hip_variant': 'bf16'}
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).eval().to(device)
     eng = r.engine(device)
@@ -275,32 +350,170 @@ def side(fn, *a, **k):
         return {'error': '%s: %s' % (type(e).__name__, e)}
 
 
-def main():
+def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
+    """The same image at another sampling / batching configuration (reported next to the headline, never instead of it)."""
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': DN_COARSE,
+           'fine_depth_sample_num': fdn, 'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
+           'ray_batch_num': ray_batch}
+    torch.manual_seed(0)
+    r = NeuralRayBaseRenderer(cfg).eval().to(device)
+    eng = r.engine(device)
+    render_image(r, tq, tr)
+    eng.timing = []
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        render_image(r, tq, tr)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in eng.timing if name == 'points']
+    eng.timing = None
+    achieved = 2.0 * algorithmic_macs_per_point(RFN, False) * sum(n for _, n in pts) / sum(t for t, _ in pts) / 1e12
+    return {'samples': '64+%d' % fdn, 'ray_batch': ray_batch, 'value': steps * H * W / dt, 'unit': 'rays/s',
+            'point_kernel_ms_per_launch': 1e3 * sum(t for t, _ in pts) / len(pts), 'point_kernel_frac_of_fp32_mfma_peak': achieved / MFMA_F32_PEAK_TFLOPS}
+
+
+def train_ddp_leg(device, world, test_lib, steps, rays=512):
+    """N > 1 side leg: data-parallel training (the reference has none, train/trainer.py:65-70).  Every rank runs
+    render_impl(is_train=True) + backward on its OWN `rays` rays through the HIP kernels, then neuray_amd.parallel
+    sums the gradients of the shared networks with ONE flattened all-reduce (RCCL over xGMI) and Adam steps."""
+    import torch.distributed as dist
+    from neuray_amd import parallel
+    small = test_lib is not None
+    dn = 8 if small else 64
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': dn,
+           'fine_depth_sample_num': dn, 'agg_net_cfg': {'sample_num': dn}, 'fine_agg_net_cfg': {'sample_num': dn}}
+    torch.manual_seed(0)
+    r = NeuralRayBaseRenderer(cfg).train().to(device)
+    r._engine_test_lib = test_lib
+    h, w = (32, 48) if small else (400, 600)
+    rays = 6 if small else rays
+    rank = dist.get_rank()
+    que, ref = synthetic.make_scene(h, w, 3 if small else 8, seed=rank)
+    rng = np.random.RandomState(rank)
+    que['coords'] = (rng.rand(1, rays, 2) * np.array([w - 1, h - 1])).astype(np.float32)
+    tq = {k: torch.from_numpy(v).to(device) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v).to(device) for k, v in ref.items()}
+    tgt = torch.rand(1, rays, 3, device=device)
+    opt = torch.optim.Adam(r.parameters(), lr=1e-4)
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == 'cuda' else (lambda: None)
+
+    def step():
+        return parallel.train_step(r, None, lambda out: ((out['pixel_colors_nr'] - tgt) ** 2).mean() +
+                                   ((out['pixel_colors_nr_fine'] - tgt) ** 2).mean(), opt)
+    r.forward = lambda _data: r.render_impl(tq, tr, True)
+    step()
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync(); dist.barrier(); sync()
+    dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    first = torch.stack([p.detach().double().sum() for p in r.parameters()]).sum().reshape(1)      # checksum of every parameter
+    lo, hi = first.clone(), first.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    nparam = sum(p.numel() for p in r.parameters() if p.requires_grad)
+    return {'what': 'forward + backward + ONE flattened gradient all-reduce + Adam per step, %d rays per rank, %d+%d samples' % (rays, dn, dn),
+            'world_size': world, 'ms_per_step': 1e3 * float(dt.item()) / steps, 'value': world * rays * steps / float(dt.item()),
+            'unit': 'rays/s (training)', 'allreduce_bytes_per_step': 4 * nparam, 'replicas_identical_after_steps': bool(lo.item() == hi.item())}
+
+
+def split_image_leg(renderer, tq, tr, device, world, steps):
+    """N > 1 side leg: ONE image split over the ranks (contiguous ray ranges) + one fused all-gather of the tiles."""
+    import torch.distributed as dist
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == 'cuda' else (lambda: None)
+    render_image(renderer, tq, tr, True)
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = render_image(renderer, tq, tr, True)
+    sync(); dist.barrier(); sync()
+    dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    return {'what': 'one %dx%d image split over %d ranks, one fused all-gather of the rendered tiles per image' % (H, W, world),
+            'scaling': 'strong', 'value': steps * H * W / float(dt.item()), 'unit': 'rays/s', 'ms_per_image': 1e3 * float(dt.item()) / steps,
+            'gathered_rays': int(out['pixel_colors_nr_fine'].shape[1])}
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file under torch.distributed.run."""
+    import subprocess
+    if not args.emulator_lib:
+        seen = torch.cuda.device_count()
+        if seen < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) visible - refusing to report a line with the wrong n_gpus" % (args.gpus, seen))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % args.gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd))
+
+
+def main(argv=None):
+    global H, W, RFN, DN_COARSE, RAY_BATCH
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--fine-samples', type=int, default=32, help='32 = BASELINE.json wording, 64 = reference default')
-    ap.add_argument('--cpu-sample-rays', type=int, default=8192)
+    ap.add_argument('--cpu-sample-rays', type=int, default=8192, help='rays of the numpy-oracle parity leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-eager-baseline', action='store_true')
+    ap.add_argument('--no-eager-baseline', action='store_true', help='skip every side leg (baselines, extras)')
     ap.add_argument('--split-image', action='store_true',
-                    help='N > 1: split ONE image over the ranks (contiguous ray ranges) and all-gather the rendered tiles '
-                         '(strong scaling, RCCL all-gather) instead of one image per rank (weak scaling, no collective)')
-    args = ap.parse_args()
+                    help='N > 1: make the TIMED region the split of ONE image over the ranks + all-gather of the tiles '
+                         '(strong scaling) instead of one image per rank (weak scaling, no collective)')
+    ap.add_argument('--no-side-legs', action='store_true', help='N > 1: skip the split_image / train_ddp side legs')
+    ap.add_argument('--emulator-lib', default=None, help='TEST HOOK: CPU emulator build of the kernels, gloo, tiny image')
+    ap.add_argument('--size', type=int, nargs=2, default=None, metavar=('H', 'W'), help='test hook: image size (default 800 800)')
+    args = ap.parse_args(argv)
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args, argv)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or with no "
+                 "launcher at all)" % (args.gpus, world, args.gpus))
+    emu = None
+    if args.emulator_lib:
+        from neuray_amd import _lib
+        emu = _lib.bind(args.emulator_lib)
+        assert emu.neuray_is_device_build() == 0
+        H, W = args.size or (16, 24)
+        RFN, DN_COARSE, RAY_BATCH, args.fine_samples = 3, 8, 64, 8
+        device = torch.device('cpu')
+    else:
+        if args.size:
+            H, W = args.size
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
+        device = torch.device('cuda', local_rank)
+        torch.cuda.set_device(device)
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == 'cuda' else (lambda: None)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if emu is not None:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
+        seen = torch.tensor([1.0], device=device)
+        dist.all_reduce(seen)                      # every rank that joined the group counts itself: the world size RCCL saw
+        world_seen = int(seen.item())
+        assert world_seen == world == dist.get_world_size()
+    else:
+        world_seen = 1
 
     split = args.split_image and world > 1
-    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=0 if split else rank)
+    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=0 if split else rank, test_lib=emu)
     eng = renderer.engine(device)
     nrays = H * W
 
@@ -308,10 +521,10 @@ def main():
         out = render_image(renderer, tq, tr, split)
 
     def fence():
-        torch.cuda.synchronize(device)
+        sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(device)
+            sync()
 
     eng.timing = []
     fence()
@@ -326,56 +539,81 @@ def main():
         dt = float(t.item())
     timing, eng.timing = eng.timing, None
 
+    legs = {}
+    if world > 1 and not args.no_side_legs:        # collectives: every rank takes part
+        if not split:
+            c2, r2, _, _, _, tq2, tr2 = build_case(device, args.fine_samples, seed=0, test_lib=emu)
+            legs['split_image'] = side(split_image_leg, r2, tq2, tr2, device, world, max(1, min(args.steps, 3)))
+        legs['train_ddp'] = side(train_ddp_leg, device, world, emu, 2 if emu is not None else 5)
+
     if rank == 0:
         value = (1 if split else world) * args.steps * nrays / dt
-        # dominant kernel: the point kernel.  Duration from HIP events on the launch stream.
-        pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in timing if name == 'points']
-        rays_k = [e0.elapsed_time(e1) * 1e-3 for name, e0, e1, n in timing if name == 'rays']
-        t_pts = sum(t for t, _ in pts)
-        n_pts = sum(n for _, n in pts)
-        flops_pt = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False)
-        # HBM/fabric traffic of the point kernel per launch: PMC passes are run separately (rocprofv3 --pmc cannot run
-        # inside this process); the committed summary of the same command is reported here (profiles/README.md)
-        traffic, tsrc = None, None
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')),
-                        key=lambda f: (len(os.path.basename(f)), os.path.basename(f)))   # r01_traffic < r01_e_traffic < r02_...
-        if args.fine_samples == 32 and tfiles:
-            traffic = json.load(open(tfiles[-1])).get('bytes_per_launch')
-            tsrc = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)' % os.path.basename(tfiles[-1])
-        achieved = flops_pt * n_pts / t_pts / 1e12
+        standard = (H, W, RFN, DN_COARSE) == (800, 800, 8, 64) and emu is None
         line = {
             'metric': 'rays/sec (64 coarse+%d fine samples), lego 800x800 synthetic' % args.fine_samples,
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if split else 'weak',
             'vs_baseline': None,
-            'dtype': 'fp32', 'data': 'synthetic',
-            'config': {'workload': 'lego-800 synthetic (nerf_synthetic/lego/black_800 shape): 800x800 = 640000 rays/image, '
-                                   '8 ref views, 64 coarse + %d fine samples, maps 200x200x32, 1 image per step per GPU'
-                                   % args.fine_samples,
+            'dtype': 'fp32', 'data': 'synthetic' if emu is None else 'synthetic (CPU EMULATOR smoke of the launcher path - NOT a measurement)',
+            'world_size_seen_by_process_group': world_seen,
+            'config': {'workload': 'lego-800 synthetic (nerf_synthetic/lego/black_800 shape): %dx%d = %d rays/image, '
+                                   '%d ref views, %d coarse + %d fine samples, maps %dx%dx32, 1 image per step per GPU'
+                                   % (H, W, nrays, RFN, DN_COARSE, args.fine_samples, H // 4, W // 4) +
+                                   ('' if standard else ' [NON-STANDARD SIZE: test hook]'),
                        'ray_batch': cfg['ray_batch_num'], 'parallelism': ('one image split over %d GPUs, all-gather of tiles' % world) if split else
                                       ('images sharded over %d GPU(s), no collective' % world)},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic,
-                         'traffic_source': tsrc,
-                         'kernel': 'nr::points_kernel', 'launches': len(pts),
-                         'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
-                         'algorithmic_flops_per_point': flops_pt,
-                         'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt},
         }
-        if world == 1 and not args.no_cpu_baseline and args.cpu_sample_rays > 0:   # baselines: rank 0 at N = 1 only
-            base, parity = cpu_baseline(cfg, weights, que, ref, out['pixel_colors_nr_fine'].cpu().numpy(),
-                                        args.cpu_sample_rays, 1024)
-            line['cpu_baseline'] = base
-            line['parity'] = parity
-        if world == 1 and not args.no_eager_baseline and not args.no_cpu_baseline:
-            eb = eager_torch_baseline(cfg, weights, tq, tr, device)
-            eb['speedup_vs_eager'] = value / (1 if split else world) / eb['value']
+        if device.type == 'cuda':
+            # dominant kernel: the point kernel.  Duration from HIP events on the launch stream.
+            pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in timing if name == 'points']
+            rays_k = [e0.elapsed_time(e1) * 1e-3 for name, e0, e1, n in timing if name == 'rays']
+            t_pts = sum(t for t, _ in pts)
+            n_pts = sum(n for _, n in pts)
+            flops_pt = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False)
+            # HBM/fabric traffic of the point kernel per launch: PMC passes are run separately (rocprofv3 --pmc cannot run
+            # inside this process); the committed summary of the same command is reported here (profiles/README.md)
+            traffic, tsrc = None, None
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')),
+                            key=lambda f: (len(os.path.basename(f)), os.path.basename(f)))   # r01_traffic < r01_e_traffic < r02_...
+            if args.fine_samples == 32 and standard and tfiles:
+                tj = json.load(open(tfiles[-1]))
+                traffic = tj.get('bytes_per_launch')
+                tsrc = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; collected on tree %s)' % (
+                    os.path.basename(tfiles[-1]), tj.get('commit', 'of that profile run'))
+            achieved = flops_pt * n_pts / t_pts / 1e12
+            line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
+                                'kernel': 'nr::points_kernel', 'launches': len(pts),
+                                'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
+                                'algorithmic_flops_per_point': flops_pt,
+                                'gather_demand_tb_per_s': 1088.0 * RFN * n_pts / t_pts / 1e12,
+                                'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt}
+        else:
+            line['roofline'] = None
+        line.update(legs)
+        if world == 1 and emu is None and not args.no_cpu_baseline:   # baselines: rank 0 at N = 1 only
+            line['cpu_baseline'] = side(cpu_baseline, cfg, weights, que, ref)
+            if args.cpu_sample_rays > 0:
+                res = side(numpy_oracle_leg, cfg, weights, que, ref, out['pixel_colors_nr_fine'].cpu().numpy(), args.cpu_sample_rays, 1024)
+                if isinstance(res, tuple):
+                    line['numpy_oracle'], line['parity'] = res
+                else:
+                    line['numpy_oracle'] = res
+        if world == 1 and emu is None and not args.no_eager_baseline and not args.no_cpu_baseline:
+            eb = side(eager_torch_baseline, cfg, weights, tq, tr, device)
+            if 'value' in eb:
+                eb['speedup_vs_eager'] = value / eb['value']
             line['eager_torch_baseline'] = eb
+            line['extra'] = {
+                'reference_default_64+64': side(extra_config_timing, device, 64, RAY_BATCH, tq, tr),
+                'reference_cli_ray_batch_4096': side(extra_config_timing, device, args.fine_samples, 4096, tq, tr),
+            }
             line['training_step'] = side(training_step_timing, device)
             line['init_net'] = side(init_net_timing, device)
             line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

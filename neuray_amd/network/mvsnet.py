@@ -109,7 +109,9 @@ class MVSNet(nn.Module):
 
 def extract_model_state_dict(ckpt_path, prefixes_to_ignore=()):
     """mvsnet.py:205-229: a pytorch-lightning checkpoint ('state_dict' with a 'model.' prefix) or bare model weights"""
-    ckpt = torch.load(ckpt_path, map_location='cpu')
+    # the reference's mvsnet_pl.ckpt is a pytorch-lightning checkpoint (hyper-parameters, callbacks, ... next to the
+    # tensors): a trusted file that torch >= 2.6's default weights_only=True refuses to unpickle
+    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
     if 'state_dict' in ckpt:
         items = ((k[6:], v) for k, v in ckpt['state_dict'].items() if k.startswith('model.'))
     else:

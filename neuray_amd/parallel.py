@@ -31,18 +31,32 @@ def render_ray_shard(renderer, que_imgs_info, ref_imgs_info, rank, world, is_tra
 
 
 def gather_tiles(local, n_total, rank, world, group=None):
-    """All-gather per-ray tensors [1, n_local, ...] of the ranks' contiguous shards into [1, n_total, ...]."""
+    """All-gather per-ray tensors [1, n_local, ...] of the ranks' contiguous shards into [1, n_total, ...] with ONE
+    collective: every output key is flattened to columns of one fp32 buffer [pad, C] (bools as 0/1 - exact), the buffer
+    is all-gathered once, and the columns are cut back (launch latency dominates the 7.7 MB of an
+    800 x 800 image, so one fused all-gather per image).  Keys are walked in sorted order, which every rank agrees on."""
+    if n_total < world:
+        raise ValueError("neuray_amd.parallel: %d rays cannot be split over %d ranks (every rank needs at least one ray)" % (n_total, world))
     sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
-    pad = max(sizes)
-    out = {}
-    for k, v in local.items():
-        t = v.to(torch.float32) if v.dtype == torch.bool else v
-        buf = torch.zeros((v.shape[0], pad) + tuple(v.shape[2:]), dtype=t.dtype, device=t.device)
-        buf[:, :v.shape[1]] = t
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        full = torch.cat([p[:, :s] for p, s in zip(parts, sizes)], 1)
-        out[k] = full.bool() if v.dtype == torch.bool else full
+    pad, keys = max(sizes), sorted(local)
+    cols, spec = [], []
+    for k in keys:
+        v = local[k]
+        assert v.shape[0] == 1 and v.shape[1] == sizes[rank], (k, tuple(v.shape))
+        flat = v[0].reshape(v.shape[1], -1).to(torch.float32)
+        spec.append((k, v.dtype, tuple(v.shape[2:]), flat.shape[1]))
+        cols.append(flat)
+    packed = torch.cat(cols, 1)
+    buf = torch.zeros(pad, packed.shape[1], dtype=torch.float32, device=packed.device)
+    buf[:packed.shape[0]] = packed
+    parts = torch.empty(world, pad, packed.shape[1], dtype=torch.float32, device=packed.device)
+    dist.all_gather_into_tensor(parts.view(world * pad, -1), buf, group=group)
+    full = torch.cat([parts[r, :s] for r, s in enumerate(sizes)], 0)           # [n_total, C]
+    out, c0 = {}, 0
+    for k, dtype, tail, c in spec:
+        t = full[:, c0:c0 + c].reshape((1, n_total) + tail)
+        out[k] = t > 0.5 if dtype == torch.bool else t.to(dtype)
+        c0 += c
     return out
 
 
@@ -50,32 +64,67 @@ def render_image_sharded(renderer, que_imgs_info, ref_imgs_info, group=None):
     """One image split over all ranks of the default (or given) process group; every rank gets the full image."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = que_imgs_info['coords'].shape[1]
+    if n < world:
+        raise ValueError("neuray_amd.parallel: %d rays cannot be split over %d ranks" % (n, world))
     local, _ = render_ray_shard(renderer, que_imgs_info, ref_imgs_info, rank, world)
     return gather_tiles(local, n, rank, world, group)
 
 
-def allreduce_gradients(parameters, average=True, group=None):
+def allreduce_gradients(parameters, average=True, group=None, skip=()):
     """Data-parallel training step: sum (or average) the gradients of `parameters` over the ranks with
     ONE flattened all-reduce (the shared nets are ~2.2 M parameters = 8.7 MB: a single bucket; on the MI355X node
-    this is RCCL over xGMI via backend 'nccl').  Parameters without a gradient on this rank contribute zeros, so every
-    rank ends up with the same gradient for every parameter that received one anywhere."""
-    import torch.distributed as dist
-    params = [p for p in parameters if p.requires_grad]
+    this is RCCL over xGMI via backend 'nccl').  A parameter that received a gradient on SOME rank ends up with the same
+    gradient on every rank; a parameter that received none anywhere keeps `grad = None` everywhere (one flag per
+    parameter rides in the same buffer), so torch.optim skips it on every replica exactly as the reference's
+    single-process training does.  `skip`: parameters to leave alone - in fine-tuning mode the per-view
+    `NeuralRayFtRenderer.ray_feats` (512 MB on lego-800), which go through allreduce_scene_feature_gradients instead."""
+    skip_ids = {id(p) for p in skip}
+    params = [p for p in parameters if p.requires_grad and id(p) not in skip_ids]
     if not params:
         return
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dev = params[0].device
+    flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=dev)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params] + [flags])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    got = flat[-len(params):].tolist()
     if average:
         flat /= dist.get_world_size(group)
     off = 0
-    for p in params:
+    for p, any_grad in zip(params, got):
         n = p.numel()
-        g = flat[off:off + n].view_as(p).to(p.dtype)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        if any_grad > 0:
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
         off += n
+
+
+def shared_parameters(model):
+    """every parameter of a renderer except the per-view `ray_feats` maps of NeuralRayFtRenderer"""
+    own = {id(p) for p in getattr(model, 'ray_feats', [])}
+    return [p for p in model.parameters() if id(p) not in own]
+
+
+def train_step(model, data, loss_fn, optimizer, group=None):
+    """One data-parallel training step around the reference's `train_network(train_data)` call (train/trainer.py:123;
+    the reference itself refuses multi-GPU training, trainer.py:65-70): every rank runs forward + backward on its own
+    sample through the HIP kernels, the shared networks' gradients are summed with one all-reduce, a fine-tuning
+    renderer's per-view maps with the sparse exchange, then every replica takes the same optimiser step.
+    -> (outputs, loss)"""
+    optimizer.zero_grad(set_to_none=True)
+    outputs = model(data)
+    loss = loss_fn(outputs)
+    loss.backward()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        ray_feats = getattr(model, 'ray_feats', None)
+        allreduce_gradients(model.parameters(), group=group, skip=list(ray_feats) if ray_feats is not None else ())
+        if ray_feats is not None:
+            allreduce_scene_feature_gradients(ray_feats, getattr(model, 'touched_views', range(len(ray_feats))),
+                                              model.cfg['neighbor_view_num'] + 1, group=group)
+    optimizer.step()
+    return outputs, loss
 
 
 def allreduce_scene_feature_gradients(ray_feats, touched, max_touched, average=True, group=None):

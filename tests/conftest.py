@@ -1,3 +1,4 @@
+import ast
 import os
 import sys
 
@@ -18,7 +19,7 @@ def pytest_configure(config):
 def load_case(name):
     """-> (cfg, que, ref, out, mid, extra) from tests/golden/case_<name>.npz"""
     z = np.load(os.path.join(GOLDEN_DIR, 'case_%s.npz' % name), allow_pickle=False)
-    cfg = eval(str(z['cfg_json']))  # repr() of a plain dict written by make_golden.py
+    cfg = ast.literal_eval(str(z['cfg_json']))  # repr() of a plain dict written by make_golden.py
     que = {k[4:]: z[k] for k in z.files if k.startswith('que.')}
     ref = {k[4:]: z[k] for k in z.files if k.startswith('ref.')}
     out = {k[4:]: z[k] for k in z.files if k.startswith('out.')}

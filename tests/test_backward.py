@@ -164,7 +164,7 @@ def test_training_gradients_match_reference_autograd(backend):
     from conftest import GOLDEN_DIR
     from neuray_amd.network.renderer import NeuralRayBaseRenderer
     z = np.load(os.path.join(GOLDEN_DIR, 'case_g_grads.npz'))
-    cfg = eval(str(z['cfg_json']))
+    cfg = __import__('ast').literal_eval(str(z['cfg_json']))
     dev = 'cpu' if backend == 'emu' else 'cuda:0'
     r = NeuralRayBaseRenderer(cfg)
     sd = {k: torch.from_numpy(v) for k, v in load_weights(False).items()}

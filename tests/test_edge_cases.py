@@ -170,7 +170,7 @@ def test_two_query_views_in_one_call(backend):
     sampling normalised with view 0's range for both (render_ops.py:183,225)."""
     from conftest import GOLDEN_DIR
     z = np.load(os.path.join(GOLDEN_DIR, 'case_h_two_queries.npz'))
-    cfg = eval(str(z['cfg_json']))
+    cfg = __import__('ast').literal_eval(str(z['cfg_json']))
     r = NeuralRayBaseRenderer(cfg).eval()
     r.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w.')}, strict=True)
     if backend == 'emu':

@@ -131,7 +131,7 @@ def test_training_step_backpropagates_through_the_patched_class(patched):
     (tests/golden/case_g_grads.npz)"""
     mod, dev = patched
     z = np.load(os.path.join(GOLDEN_DIR, 'case_g_grads.npz'))
-    cfg = eval(str(z['cfg_json']))      # noqa: S307  repr() of a plain dict written by make_golden.py
+    cfg = __import__('ast').literal_eval(str(z['cfg_json']))      # noqa: S307  repr() of a plain dict written by make_golden.py
     r = mod.NeuralRayBaseRenderer(cfg)
     r.load_state_dict({k: torch.from_numpy(v) for k, v in load_weights().items()}, strict=False)
     r = place(r.train(), dev)

@@ -115,7 +115,7 @@ def test_torch_eager_port_gradients_match_reference():
     from conftest import GOLDEN_DIR
     from oracle import torch_eager_port as tep
     z = np.load(os.path.join(GOLDEN_DIR, 'case_g_grads.npz'))
-    cfg = eval(str(z['cfg_json']))
+    cfg = __import__('ast').literal_eval(str(z['cfg_json']))
     que = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('que.')}
     ref = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('ref.')}
     w = {k: torch.from_numpy(v).requires_grad_(True) for k, v in load_weights(False).items()}

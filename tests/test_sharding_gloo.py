@@ -67,7 +67,7 @@ def _train_worker(rank, world, port, out_dir):
     from conftest import GOLDEN_DIR
     from neuray_amd.network.renderer import NeuralRayBaseRenderer
     z = np.load(os.path.join(GOLDEN_DIR, 'case_g_grads.npz'))
-    cfg = eval(str(z['cfg_json']))
+    cfg = __import__('ast').literal_eval(str(z['cfg_json']))
     r = NeuralRayBaseRenderer(cfg)
     r.load_state_dict({k: torch.from_numpy(v) for k, v in load_weights(False).items()}, strict=True)
     r.train()

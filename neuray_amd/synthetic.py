@@ -21,10 +21,27 @@ def sphere_pos(radius, azim_deg, elev_deg):
     return np.array([radius * np.cos(e) * np.cos(a), radius * np.cos(e) * np.sin(a), radius * np.sin(e)])
 
 
+def smooth_field(rng, n, c, h, w, waves=6, max_cycles=5.0):
+    """[n,c,h,w] band-limited random fields (sums of `waves` plane waves of at most `max_cycles` periods across the map),
+    zero mean and about unit variance per channel: the smooth counterpart of the white-noise maps - neighbouring texels
+    and neighbouring views' values are correlated, as encoder outputs of real images are."""
+    ys = np.linspace(0.0, 1.0, h)[None, None, :, None]
+    xs = np.linspace(0.0, 1.0, w)[None, None, None, :]
+    out = np.zeros((n, c, h, w), np.float64)
+    for _ in range(waves):
+        fx = rng.uniform(-max_cycles, max_cycles, size=(n, c, 1, 1))
+        fy = rng.uniform(-max_cycles, max_cycles, size=(n, c, 1, 1))
+        ph = rng.uniform(0.0, 2.0 * np.pi, size=(n, c, 1, 1))
+        amp = rng.uniform(0.5, 1.0, size=(n, c, 1, 1))
+        out += amp * np.sin(2.0 * np.pi * (fx * xs + fy * ys) + ph)
+    return out * np.sqrt(2.0 / (waves * 0.583))          # E[amp^2] = 0.583, E[sin^2] = 1/2
+
+
 def make_scene(h=800, w=800, rfn=8, seed=0, depth_range=(2.0, 6.0), radius=4.03, feat_dim=32,
-               que_imgs=False, fov_x=0.6911112070083618):
+               que_imgs=False, fov_x=0.6911112070083618, smooth=False):
     """Seeded synthetic 'lego-like' scene: cameras on a sphere looking at the origin,
-    random images and feature maps (the per-image encoders are bypassed)."""
+    random images and feature maps (the per-image encoders are bypassed).  `smooth`: band-limited images and maps
+    (smooth_field) instead of white noise."""
     rng = np.random.RandomState(seed)
     f = 0.5 * w / np.tan(0.5 * fov_x)
     K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
@@ -34,6 +51,15 @@ def make_scene(h=800, w=800, rfn=8, seed=0, depth_range=(2.0, 6.0), radius=4.03,
     que_pose = look_at_pose(sphere_pos(radius, 30.0, 25.0))
     ref_poses = np.stack([look_at_pose(sphere_pos(radius, 30.0 + a, 25.0 + e)) for a, e in offs[:rfn]])
     fh, fw = h // 4, w // 4
+    if smooth:
+        img = lambda n: np.clip(0.5 + 0.22 * smooth_field(rng, n, 3, h, w), 0.0, 1.0).astype(np.float32)      # noqa: E731
+        feat = lambda n: smooth_field(rng, n, feat_dim, fh, fw).astype(np.float32)                            # noqa: E731
+        ref = {'imgs': img(rfn), 'poses': ref_poses.astype(np.float32), 'Ks': np.repeat(K[None], rfn, 0),
+               'depth_range': np.repeat(np.asarray(depth_range, np.float32)[None], rfn, 0), 'ray_feats': feat(rfn), 'img_feats': feat(rfn)}
+        que = {'poses': que_pose[None], 'Ks': K[None].copy(), 'depth_range': np.asarray(depth_range, np.float32)[None]}
+        if que_imgs:
+            que['imgs'], que['ray_feats'] = img(1), feat(1)
+        return que, ref
     ref = {
         'imgs': rng.rand(rfn, 3, h, w).astype(np.float32),
         'poses': ref_poses.astype(np.float32),

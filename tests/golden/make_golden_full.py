@@ -1,0 +1,163 @@
+"""Golden tiles at BASELINE.json's shapes, produced by running the REFERENCE itself (CPU, read-only /root/reference).
+
+    python tests/golden/make_golden_full.py            (build container only; ~2 min)
+
+The scenes are the seeded generators of neuray_amd/synthetic.py (pure numpy: regenerated at test time, not stored - the
+maps of one 800x800 scene are 143 MB), the weights are the reference constructors under torch.manual_seed(0) (=
+tests/golden/weights_seed0.npz, asserted).  Stored per case: cfg, the scene's arguments, the strided ray coordinates, every
+output of `NeuralRayBaseRenderer.render_impl`, plus the coarse depths, the reference's coarse `hit_prob` and its sorted
+fine depths, so that every stage can be compared on IDENTICAL inputs (the chained coarse -> fine comparison is bounded by
+the reference's own `denom < 1e-5` discontinuity).
+
+  c2_tile_32 / c2_tile_64   BASELINE config 2: 800x800, 8 views, 64 coarse + 32 (BASELINE wording) / 64 (reference default) fine
+  c2_smooth                 the same shape on band-limited (non white-noise) images and maps
+  c1_tile                   config 1: 400x400, 3 views, 32 + 32
+  c3_tile                   config 3: LLFF 756x1008 query, references padded to 768x1024, depth range [1.2, 12]
+  c4_train                  configs 4/5 shape: DTU 600x800, 512 random rays, is_train (CPU-drawn uniforms captured), self hit
+                            prob, loss.backward(): gradients of every hot-path parameter and of the feature maps
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness  # noqa: E402
+from neuray_amd import synthetic  # noqa: E402
+
+HOT = ('dist_decoder.', 'agg_net.', 'fine_dist_decoder.', 'fine_agg_net.')
+
+
+def scene_from_args(a):
+    """the scene of a case from its stored arguments (used by the tests as well)"""
+    que, ref = synthetic.make_scene(int(a['h']), int(a['w']), int(a['rfn']), seed=int(a['seed']),
+                                    depth_range=tuple(float(x) for x in a['depth_range']), que_imgs=bool(a['que_imgs']),
+                                    smooth=bool(a['smooth']))
+    if int(a['qh']) != int(a['h']) or int(a['qw']) != int(a['w']):      # query smaller than the padded references (LLFF)
+        que['Ks'] = que['Ks'].copy()
+        que['Ks'][0, 0, 2], que['Ks'][0, 1, 2] = int(a['qw']) / 2, int(a['qh']) / 2
+    return que, ref
+
+
+def build(ns, cfg, train=False):
+    torch.manual_seed(0)
+    r = ns.renderer.NeuralRayBaseRenderer(cfg)
+    r.train() if train else r.eval()
+    ws = np.load(os.path.join(HERE, 'weights_seed0.npz'))
+    sd = r.state_dict()
+    for k in ws.files:
+        assert np.array_equal(sd[k].numpy(), ws[k]), k            # the committed weights ARE the seed-0 constructors
+    return r
+
+
+def record_passes(renderer):
+    """wrap render_by_depth to keep the sample depths of both passes"""
+    seen = {}
+    inner = renderer.render_by_depth
+
+    def wrapped(que_depth, que_imgs_info, ref_imgs_info, is_train, is_fine):
+        seen['fine_depth' if is_fine else 'coarse_depth'] = que_depth.detach().numpy().copy()
+        return inner(que_depth, que_imgs_info, ref_imgs_info, is_train, is_fine)
+    renderer.render_by_depth = wrapped
+    return seen
+
+
+def tile_case(ns, name, cfg, args, rn):
+    que, ref = scene_from_args(args)
+    n = int(args['qh']) * int(args['qw'])
+    idx = np.linspace(0, n - 1, rn).astype(np.int64)
+    coords = synthetic.meshgrid_coords(int(args['qh']), int(args['qw']))[:, idx]
+    que['coords'] = coords
+    r = build(ns, cfg)
+    seen = record_passes(r)
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v) for k, v in ref.items()}
+    with torch.no_grad():
+        out = r.render_impl(tq, tr, False)
+    save = {'cfg_json': np.array(repr(cfg)), 'coords': coords, 'ray_index': idx}
+    save.update({'arg.' + k: np.asarray(v) for k, v in args.items()})
+    save.update({'out.' + k: v.numpy() for k, v in out.items()})
+    save.update({'mid.' + k: v for k, v in seen.items()})
+    np.savez_compressed(os.path.join(HERE, 'case_%s.npz' % name), **save)
+    print('wrote case_%s.npz' % name, {k: tuple(v.shape) for k, v in out.items()})
+
+
+def train_case(ns, name, cfg, args, rn):
+    que, ref = scene_from_args(args)
+    rng = np.random.RandomState(404)
+    que['coords'] = (rng.rand(1, rn, 2) * np.array([int(args['qw']) - 1, int(args['qh']) - 1])).astype(np.float32)
+    r = build(ns, cfg, train=True)
+    seen = record_passes(r)
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v) for k, v in ref.items()}
+    for t in (tr['ray_feats'], tr['img_feats'], tq['ray_feats']):
+        t.requires_grad_(True)
+    captured, real_rand = {}, torch.rand
+
+    def rand_capture(*a, **k):
+        o = real_rand(*a, **k)
+        captured.setdefault('u', o.clone())
+        return o
+    torch.rand = rand_capture
+    try:
+        torch.manual_seed(2468)
+        out = r.render_impl(tq, tr, True)
+    finally:
+        torch.rand = real_rand
+    gt = out['pixel_colors_gt'].detach()
+    # the losses of the fine-tuning configs: render loss on both passes + consistency between hit_prob_nr and hit_prob_self
+    loss = ((out['pixel_colors_nr'] - gt) ** 2).mean() + ((out['pixel_colors_nr_fine'] - gt) ** 2).mean()
+    for sfx in ('', '_fine'):
+        p, q = out['hit_prob_nr' + sfx].detach(), out['hit_prob_self' + sfx]
+        loss = loss + 0.1 * torch.nn.functional.binary_cross_entropy(q.clamp(1e-4, 1 - 1e-4), p.clamp(0, 1))
+    loss.backward()
+    save = {'cfg_json': np.array(repr(cfg)), 'coords': que['coords'], 'u': captured['u'].numpy(), 'loss': loss.detach().numpy()}
+    save.update({'arg.' + k: np.asarray(v) for k, v in args.items()})
+    save.update({'out.' + k: v.detach().numpy() for k, v in out.items()})
+    save.update({'mid.' + k: v for k, v in seen.items()})
+    for k, p in r.named_parameters():
+        if k.startswith(HOT):
+            save['grad.' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    # the maps' gradients are 7.7 MB each: keep the per-(view, channel) sums, the per-view |g| totals and a strided sample
+    for tag, t in (('ref.ray_feats', tr['ray_feats']), ('ref.img_feats', tr['img_feats']), ('que.ray_feats', tq['ray_feats'])):
+        g = t.grad.numpy()
+        save['gsum.' + tag] = g.sum((2, 3))
+        save['gabs.' + tag] = np.abs(g).sum((1, 2, 3))
+        flat = g.reshape(g.shape[0], g.shape[1], -1)
+        nz = np.argsort(-np.abs(flat).sum((0, 1)))[:512]             # the 512 texels with the largest gradient
+        save['gidx.' + tag] = nz
+        save['gval.' + tag] = flat[:, :, nz]
+    np.savez_compressed(os.path.join(HERE, 'case_%s.npz' % name), **save)
+    print('wrote case_%s.npz' % name, 'loss', float(loss), {k: tuple(v.shape) for k, v in out.items()})
+
+
+def main(only=()):
+    ns = ref_harness.import_reference()
+    torch.set_num_threads(8)
+    base = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}}
+    lego = {'h': 800, 'w': 800, 'qh': 800, 'qw': 800, 'rfn': 8, 'seed': 0, 'depth_range': (2.0, 6.0), 'que_imgs': False, 'smooth': False}
+    c2_32 = {**base, 'depth_sample_num': 64, 'fine_depth_sample_num': 32, 'agg_net_cfg': {'sample_num': 64}, 'fine_agg_net_cfg': {'sample_num': 32}}
+    want = lambda name: not only or name in only      # noqa: E731
+    if want('c2_tile_32'):
+        tile_case(ns, 'c2_tile_32', c2_32, lego, 1280)
+    if want('c2_tile_64'):
+        tile_case(ns, 'c2_tile_64', {**base}, lego, 1024)
+    if want('c2_smooth'):
+        tile_case(ns, 'c2_smooth', c2_32, {**lego, 'seed': 7, 'smooth': True}, 1280)
+    c1 = {**base, 'depth_sample_num': 32, 'fine_depth_sample_num': 32, 'agg_net_cfg': {'sample_num': 32}, 'fine_agg_net_cfg': {'sample_num': 32}}
+    if want('c1_tile'):
+        tile_case(ns, 'c1_tile', c1, {**lego, 'h': 400, 'w': 400, 'qh': 400, 'qw': 400, 'rfn': 3, 'seed': 1}, 1024)
+    if want('c3_tile'):
+        tile_case(ns, 'c3_tile', {**base}, {**lego, 'h': 768, 'w': 1024, 'qh': 756, 'qw': 1008, 'seed': 3, 'depth_range': (1.2, 12.0)}, 1024)
+    c4 = {**base, 'use_self_hit_prob': True, 'render_depth': True}
+    if want('c4_train'):
+        train_case(ns, 'c4_train', c4, {**lego, 'h': 600, 'w': 800, 'qh': 600, 'qw': 800, 'seed': 4, 'que_imgs': True, 'smooth': True}, 512)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

@@ -224,6 +224,8 @@ def render_impl(w, cfg, que, ref, is_train=False, u=None):
             out[k + '_fine'] = v
         if self_hp:
             out['hit_prob_self_fine'] = self_hit_prob(w, cfg, fd, que, True)
+        out['_fine_depth'] = fd.detach()
+    out['_coarse_depth'] = depth.detach()
     return out
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 1
+#define NEURAY_ABI_VERSION 2
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -161,8 +161,15 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* args, void* stream);
  * Weights and their gradients use the FLAT NATURAL layout: the NEURAY_PASS_TENSORS tensors, row-major as in the
  * state_dict, concatenated in the order of neuray_pack_pass_weights (vis-decoder slots always present; zeros without a
  * vis head); neuray_flat_pass_floats() floats, neuray_flat_tensor_offset(i) = start of tensor i.
- * d_flat, d_ray_feats_nhwc and d_img_feats_nhwc are ACCUMULATED into (zero them first).  workspace:
- * neuray_points_backward_workspace_floats(rn * dn, rfn) floats of scratch.  First, correctness-oriented version (no MFMA). */
+ * d_flat, d_ray_feats_nhwc and d_img_feats_nhwc are ACCUMULATED into (zero them first).
+ * Two kernels sit behind this entry point:
+ *   - the register / LDS resident one (csrc/nr_kernels_bwd2.h; rfn <= 8, any dn): 8 waves per 16-point tile, wave = reference
+ *     view, activations and gradients chained in registers on the fp32 MFMA, weight gradients accumulated in registers
+ *     over the whole launch.  It is taken when packed_weights_dev (the forward's packed weights, neuray_pack_pass_weights
+ *     layout) and packed_t_weights_dev (the transposed layers: packed_t[i] = flat[index[i]] with the index map of
+ *     neuray_pack_pass_t_index_map, neuray_packed_t_floats() floats) are given; workspace_dev may then be NULL;
+ *   - the first version (one wave per workgroup, activation arena in global memory) for rfn > 8 or when the packed buffers
+ *     are NULL; workspace: neuray_points_backward_workspace_floats(rn * dn, rfn) floats of scratch. */
 size_t neuray_flat_pass_floats(void);
 size_t neuray_flat_tensor_offset(int tensor);
 size_t neuray_points_backward_workspace_floats(int npoints, int rfn);
@@ -182,7 +189,12 @@ typedef struct NeurayPointsBwdArgs {
     float* workspace_dev;
     int rfn, rn, dn, h, w, fh, fw, has_vis_head, use_vis;
     float var_bias;
+    const float* packed_weights_dev;   /* [neuray_packed_pass_floats()] or NULL */
+    const float* packed_t_weights_dev; /* [neuray_packed_t_floats()] or NULL */
 } NeurayPointsBwdArgs;
+size_t neuray_packed_t_floats(void);
+/* index[neuray_packed_t_floats()] (host, int32): packed_t[i] = index[i] >= 0 ? flat[index[i]] : 0 */
+int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
 
 /* ---- backward of the a19 path (renderer.py:137-155): hit_prob_self [rn][dn] as a function of the gathered query-view

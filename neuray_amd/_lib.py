@@ -63,7 +63,7 @@ class NeurayPointsBwdArgs(C.Structure):
         'rgba_dev', 'flat_weights_dev', 'd_point_rec_dev', 'd_flat_weights_dev', 'd_ray_feats_nhwc_dev',
         'd_img_feats_nhwc_dev', 'workspace_dev')] + \
         [(n, C.c_int) for n in ('rfn', 'rn', 'dn', 'h', 'w', 'fh', 'fw', 'has_vis_head', 'use_vis')] + \
-        [('var_bias', C.c_float)]
+        [('var_bias', C.c_float), ('packed_weights_dev', C.c_void_p), ('packed_t_weights_dev', C.c_void_p)]
 
 
 PACKED_RAY_FLOATS = 1348
@@ -112,6 +112,8 @@ SYMBOLS = {
     'neuray_flat_pass_floats': (C.c_size_t, []),
     'neuray_flat_tensor_offset': (C.c_size_t, [C.c_int]),
     'neuray_points_backward_workspace_floats': (C.c_size_t, [C.c_int, C.c_int]),
+    'neuray_packed_t_floats': (C.c_size_t, []),
+    'neuray_pack_pass_t_index_map': (C.c_int, [C.c_int, C.c_void_p]),
     'neuray_render_points_backward': (C.c_int, [C.POINTER(NeurayPointsBwdArgs), C.c_void_p]),
     'neuray_self_hit_backward_workspace_floats': (C.c_size_t, [C.c_int]),
     'neuray_self_hit_prob_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,

@@ -3,6 +3,9 @@
 // CPU test emulator, g++ -DNEURAY_EMU (tests/emu/build_emu.py).
 #include "nr_kernels.h"
 #include "nr_kernels_bwd.h"
+#ifndef NR_BF16_QUADS
+#include "nr_kernels_bwd2.h"
+#endif
 #include "nr_pack.h"
 #include "../../include/neuray_hip.h"
 
@@ -314,6 +317,16 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* a, void* stream) {
 }
 
 size_t neuray_flat_pass_floats(void) { return (size_t)nr::kFlatPassFloats; }
+size_t neuray_packed_t_floats(void) { return (size_t)nr::kPackedTFloats; }
+int neuray_pack_pass_t_index_map(int has_vis_head, int* index) {
+    if (!index) return fail("neuray_pack_pass_t_index_map: null argument");
+#ifdef NR_BF16_QUADS
+    return fail("neuray_pack_pass_t_index_map: the bf16-operand library is inference only");
+#else
+    const int rc = nr::pack_pass_t_index_map(has_vis_head != 0, index);
+    return rc ? fail("neuray_pack_pass_t_index_map: tensor %d missing", rc - 1) : 0;
+#endif
+}
 size_t neuray_flat_tensor_offset(int t) { return (t < 0 || t > nr::T_COUNT) ? (size_t)0 : (size_t)nr::tensor_offset(t); }
 
 namespace {
@@ -334,10 +347,41 @@ size_t neuray_points_backward_workspace_floats(int npoints, int rfn) {
 int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
     if (!a || !a->query_const_dev || !a->view_const_dev || !a->coords_dev || !a->depth_dev || !a->ray_feats_nhwc_dev ||
         !a->img_feats_nhwc_dev || !a->rgba_dev || !a->flat_weights_dev || !a->d_point_rec_dev || !a->d_flat_weights_dev ||
-        !a->d_ray_feats_nhwc_dev || !a->d_img_feats_nhwc_dev || !a->workspace_dev)
+        !a->d_ray_feats_nhwc_dev || !a->d_img_feats_nhwc_dev)
         return fail("neuray_render_points_backward: null argument");
     if (a->rfn < 1 || a->rfn > NEURAY_MAX_VIEWS) return fail("neuray_render_points_backward: rfn=%d outside [1,%d]", a->rfn, NEURAY_MAX_VIEWS);
     if (a->rn < 1 || a->dn < 3 || a->dn > NEURAY_MAX_SAMPLES) return fail("neuray_render_points_backward: rn=%d dn=%d", a->rn, a->dn);
+#ifdef NR_BF16_QUADS
+    if (a->packed_weights_dev || a->packed_t_weights_dev) return fail("neuray_render_points_backward: the bf16-operand library is inference only");
+#else
+    if (a->packed_weights_dev && a->packed_t_weights_dev && a->rfn <= nr::kB2Waves) {      // register / LDS resident kernel
+        nr::PointBwd2Params q;
+        q.que_const = a->query_const_dev; q.view_const = a->view_const_dev; q.coords = a->coords_dev; q.depth = a->depth_dev;
+        q.ray_feats = a->ray_feats_nhwc_dev; q.img_feats = a->img_feats_nhwc_dev; q.rgba = a->rgba_dev;
+        q.weights = a->packed_weights_dev; q.weights_t = a->packed_t_weights_dev;
+        q.d_point_rec = a->d_point_rec_dev; q.d_flat = a->d_flat_weights_dev; q.d_ray_feats = a->d_ray_feats_nhwc_dev;
+        q.d_img_feats = a->d_img_feats_nhwc_dev;
+        q.rfn = a->rfn; q.rn = a->rn; q.dn = a->dn; q.h = a->h; q.w = a->w; q.fh = a->fh; q.fw = a->fw;
+        q.use_vis = a->use_vis; q.var_bias = a->var_bias;
+        const size_t smem = nr::point_bwd2_smem_bytes();
+        const int grid2 = grid_for((long long)a->rn * a->dn, 16, 256);            // persistent: one workgroup per CU
+        if (a->has_vis_head) {
+            auto k = nr::points_backward2_kernel<true>;
+#ifndef NEURAY_EMU
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+            NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
+        } else {
+            auto k = nr::points_backward2_kernel<false>;
+#ifndef NEURAY_EMU
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+            NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
+        }
+        return check_launch("neuray_render_points_backward (resident)");
+    }
+#endif
+    if (!a->workspace_dev) return fail("neuray_render_points_backward: workspace_dev is NULL (needed by the first-version kernel)");
     nr::PointBwdParams p;
     p.que_const = a->query_const_dev; p.view_const = a->view_const_dev; p.coords = a->coords_dev; p.depth = a->depth_dev;
     p.ray_feats = a->ray_feats_nhwc_dev; p.img_feats = a->img_feats_nhwc_dev; p.rgba = a->rgba_dev; p.flat = a->flat_weights_dev;

@@ -43,6 +43,24 @@ enum LayerId {
     L_RF1, L_RF2, L_RF3,     // rgb_fc 37 -> 16 -> 8 -> 1 (vector row)              ibrnet.py:281-285
     L_BG,                    // base_fc.0 columns [mean0 var0 mean1 var1] (per point; read from global by the owner waves)
     L_GF1, L_GF2,            // geometry_fc 65 -> 64 -> 16 (per point)              ibrnet.py:271-274
+    L_FWD_COUNT,
+    // ---- transposed layers of the backward pass (points_backward2_kernel): dX = W^T dY as one more layer in the same
+    // fragment format, in a SECOND packed buffer (offsets restart at 0).  Input = the gradient w.r.t. the forward layer's
+    // output rows in the D layout, output = the gradient w.r.t. its input columns in the register order the forward
+    // pass holds them (natural D layout, or the gathered order "lane group g holds channels 8g..8g+7").  Unscaled (true
+    // weights); extra scalar inputs / outputs of the forward layer appear as single K-steps / vector rows.
+    LT_DM1 = L_FWD_COUNT, LT_DM2, LT_DV1, LT_DV2, LT_DA1, LT_DA2, LT_DS1, LT_DS2,   // dist heads: 32 -> 32 (x2)
+    LT_PE1, LT_PE2,          // prob_embed: d h -> d [f_ray | hit, vis (vector rows)], d e -> d h
+    LT_RD2,                  // ray_dir_fc.2: d [img rows (gathered) | rgb rows (single K-step)] -> d h16
+    LT_NF1,                  // neuray_fc.0: d h8 -> d e
+    LT_BV,                   // base_fc.0 per-view columns: d h64 -> d [gi (gathered) | e] (+ d rgb: vector rows)
+    LT_B2,                   // base_fc.2: d x -> d h64
+    LT_BG,                   // base_fc.0 per-point columns: sum_v d h64 -> d [mean0 var0 mean1 var1] image part (8 tiles)
+    LT_BG_R0, LT_BG_R1, LT_BG_R2, LT_BG_R3,   // ... rgb part of statistic j (vector rows only)
+    LT_VF1, LT_VF2,          // vis_fc (row 32 of vis_fc.2 enters as a single K-step)
+    LT_V21,                  // vis_fc2.0
+    LT_RF1, LT_RF2,          // rgb_fc.0: d h16 -> d x2 (+ d vis: vector row), rgb_fc.2: d h8 -> d h16
+    LT_GF1, LT_GF2,          // geometry_fc.0: d h64 -> d [mean var] (+ d mean weight: vector row), geometry_fc.2: d G -> d h64
     L_COUNT
 };
 
@@ -55,9 +73,20 @@ enum LayerId {
 // (ray_dir_fc.2, base_fc.2, vis_fc.2, geometry_fc.2) keep the plain form.
 constexpr double kLog2e = 1.4426950408889634074;
 //                                     DM1 DM2 FM  DV1 DV2 FV  DA1 DA2 FA  DS1 DS2 FS  PE1 PE2 RD1 RD2 NF1 NF2 BV0 BV1 B2  VF1 VF2 V21 V22 RF1 RF2 RF3 BG  GF1 GF2
-constexpr bool kOutScaled[31] = {       1,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  1,  0};
-constexpr bool kInScaled[31] = {        0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  0,  1};
-static_assert(L_COUNT == 31, "kOutScaled / kInScaled follow the LayerId order");
+constexpr bool kOutScaledFwd[31] = {    1,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  1,  1,  0,  1,  0,  1,  0,  1,  1,  0,  1,  1,  0};
+constexpr bool kInScaledFwd[31] = {     0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  1,  1,  0,  0,  0,  1,  0,  1,  0,  0,  1,  0,  1,  0,  1,  0,  1,  1,  0,  0,  1};
+static_assert(L_FWD_COUNT == 31, "kOutScaledFwd / kInScaledFwd follow the LayerId order");
+// (the transposed layers carry true weights: never scaled)
+struct ScaledFlags {
+    bool v[L_COUNT];
+    constexpr bool operator[](int l) const { return v[l]; }
+};
+constexpr ScaledFlags make_scaled(const bool (&f)[31]) {
+    ScaledFlags s{};
+    for (int i = 0; i < L_COUNT; ++i) s.v[i] = i < L_FWD_COUNT ? f[i] : false;
+    return s;
+}
+constexpr ScaledFlags kOutScaled = make_scaled(kOutScaledFwd), kInScaled = make_scaled(kInScaledFwd);
 
 struct LayerShape { int mt_out, kq, k1; };
 
@@ -75,6 +104,19 @@ constexpr LayerShape kShape[L_COUNT] = {
     {1, 2, 2}, {1, 1, 0}, {0, 0, 0},
     {4, 8, 4},
     {4, 4, 1}, {1, 4, 0},
+    // transposed layers
+    {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0}, {2, 2, 0},
+    {2, 2, 0}, {2, 2, 0},
+    {1, 2, 1},
+    {2, 1, 0},
+    {4, 4, 0},
+    {4, 2, 0},
+    {8, 4, 0},
+    {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},
+    {2, 2, 0}, {2, 2, 1},
+    {2, 2, 0},
+    {2, 1, 0}, {1, 1, 0},
+    {4, 4, 0}, {4, 1, 0},
 };
 
 // ---- vector rows ---------------------------------------------------------------------------------
@@ -99,6 +141,19 @@ constexpr VecShape kVec[L_COUNT] = {
     {0, 0}, {0, 0}, {1, 1},
     {0, 0},
     {0, 0}, {0, 0},
+    // transposed layers
+    {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0},
+    {2, 2}, {0, 0},          // LT_PE1: d hit, d vis
+    {0, 0},
+    {0, 0},
+    {3, 4},                  // LT_BV: d rgb_feat[0..2]
+    {0, 0},
+    {0, 0},
+    {3, 4}, {3, 4}, {3, 4}, {3, 4},     // LT_BG_Rj: d (rgb part of statistic j)
+    {0, 0}, {0, 0},
+    {0, 0},
+    {1, 1}, {0, 0},          // LT_RF1: d vis
+    {1, 4}, {0, 0},          // LT_GF1: d mean weight
 };
 
 // sizes in floats
@@ -108,9 +163,11 @@ constexpr int bias_floats(int l) { return kShape[l].mt_out * 16; }
 constexpr int vec_floats(int l) { return kVec[l].n > 0 ? kVec[l].n * kVec[l].tiles * 16 + 16 : 0; }
 constexpr int layer_floats(int l) { return quads_floats(l) + single_floats(l) + bias_floats(l) + vec_floats(l); }
 
-constexpr int layer_offset(int l) {   // float offset of layer l inside the packed pass buffer
+// float offset of layer l inside its packed buffer: the forward layers in the pass buffer, the transposed layers in
+// the second ("T") buffer, where the offsets restart at 0
+constexpr int layer_offset(int l) {
     int off = 0;
-    for (int i = 0; i < l; ++i) off += layer_floats(i);
+    for (int i = (l >= L_FWD_COUNT ? (int)L_FWD_COUNT : 0); i < l; ++i) off += layer_floats(i);
     return off;
 }
 constexpr int quads_offset(int l) { return layer_offset(l); }
@@ -119,7 +176,13 @@ constexpr int bias_offset(int l) { return layer_offset(l) + quads_floats(l) + si
 constexpr int vec_offset(int l) { return bias_offset(l) + bias_floats(l); }               // [n][tiles][16]
 constexpr int vec_bias_offset(int l) { return vec_offset(l) + kVec[l].n * kVec[l].tiles * 16; }
 
-constexpr int kPackedPointFloats = layer_offset(L_COUNT);
+constexpr int packed_range_floats(int first, int last) {
+    int off = 0;
+    for (int i = first; i < last; ++i) off += layer_floats(i);
+    return off;
+}
+constexpr int kPackedPointFloats = packed_range_floats(0, L_FWD_COUNT);
+constexpr int kPackedTFloats = packed_range_floats(L_FWD_COUNT, L_COUNT);      // the transposed layers (backward pass)
 
 // ---- LDS staging phases of the point kernel ------------------------------------------------------------
 // Contiguous layer ranges [first, last] that are copied into LDS before they are used (the per-point layers L_BG,

@@ -215,6 +215,138 @@ int pack_pass_weights(const float* const* t, float* dst) {
     return 0;
 }
 
+// ---- transposed layers (nr_layout.h LT_*): dX = W^T dY for the backward pass, second packed buffer --------------------
+namespace {
+
+// Wt[c * rows + r] = W[r * ldw + c]
+std::vector<float> transposed(const float* W, int rows, int ldw, int cols) {
+    std::vector<float> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = W[(size_t)r * ldw + c];
+    return t;
+}
+// output rows in the gathered register order: tile mo, lane group g, register r <-> channel 8g + 4mo + r (+ col0)
+std::vector<int> out_gathered32(int col0) {
+    std::vector<int> m(32);
+    for (int mo = 0; mo < 2; ++mo)
+        for (int g = 0; g < 4; ++g)
+            for (int r = 0; r < 4; ++r) m[mo * 16 + 4 * g + r] = col0 + 8 * g + 4 * mo + r;
+    return m;
+}
+std::vector<int> out_natural_at(int col0, int n, int tiles) {
+    std::vector<int> m(tiles * 16);
+    for (int i = 0; i < tiles * 16; ++i) m[i] = i < n ? col0 + i : -1;
+    return m;
+}
+void append(std::vector<int>& a, const std::vector<int>& b) { a.insert(a.end(), b.begin(), b.end()); }
+
+// 32 -> 32 head layers: first (input = gathered f_ray) and second (input = D layout)
+void pack_mlp32_t(float* dst, int lt1, int lt2, const float* w0, const float* w2) {
+    const std::vector<float> t0 = transposed(w0, 32, 32, 32), t2 = transposed(w2, 32, 32, 32);
+    LayerMaps m1; m1.out_map = out_gathered32(0); in_dlayout(m1.in_map, 0, 32, 2);
+    pack_layer(dst, lt1, t0.data(), 32, nullptr, m1);
+    LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
+    pack_layer(dst, lt2, t2.data(), 32, nullptr, m2);
+}
+
+}  // namespace
+
+int pack_pass_t_weights(const float* const* t, float* dst) {
+    for (int i = 0; i < T_COUNT; ++i) {
+        const bool optional = (i >= T_VIS0_W && i <= T_VIS4_B);
+        if (!t[i] && !optional) return 1 + i;
+    }
+    const bool has_vis = t[T_VIS0_W] != nullptr;
+    std::memset(dst, 0, sizeof(float) * kPackedTFloats);
+    pack_mlp32_t(dst, LT_DM1, LT_DM2, t[T_MEAN0_W], t[T_MEAN2_W]);
+    pack_mlp32_t(dst, LT_DV1, LT_DV2, t[T_VAR0_W], t[T_VAR2_W]);
+    pack_mlp32_t(dst, LT_DA1, LT_DA2, t[T_AW0_W], t[T_AW2_W]);
+    if (has_vis) pack_mlp32_t(dst, LT_DS1, LT_DS2, t[T_VIS0_W], t[T_VIS2_W]);
+    {   // prob_embed.0 (32 x 34): d h -> d f_ray (gathered) + vector rows d hit, d vis;  prob_embed.2 (32 x 32)
+        const std::vector<float> w = transposed(t[T_PE0_W], 32, 34, 34);
+        LayerMaps m; m.out_map = out_gathered32(0); in_dlayout(m.in_map, 0, 32, 2);
+        pack_layer(dst, LT_PE1, w.data(), 32, nullptr, m);
+        const int rows[2] = {32, 33};
+        pack_vec(dst, LT_PE1, w.data(), 32, nullptr, rows, 0, 32);
+        const std::vector<float> w2 = transposed(t[T_PE2_W], 32, 32, 32);
+        LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
+        pack_layer(dst, LT_PE2, w2.data(), 32, nullptr, m2);
+    }
+    {   // ray_dir_fc.2 (35 x 16): input rows [3 + gathered img channel | rgb rows 0..2 as one single K-step] -> d h16
+        const std::vector<float> w = transposed(t[T_RD2_W], 35, 16, 16);
+        LayerMaps m; m.out_map = out_natural(1, 16); in_gathered32(m.in_map, 3);
+        for (int g = 0; g < 4; ++g) m.in1_map.push_back(g < 3 ? g : -1);
+        pack_layer(dst, LT_RD2, w.data(), 35, nullptr, m);
+    }
+    {   // neuray_fc.0 (8 x 32): d h8 -> d e
+        const std::vector<float> w = transposed(t[T_NF0_W], 8, 32, 32);
+        LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 8, 1);
+        pack_layer(dst, LT_NF1, w.data(), 8, nullptr, m);
+    }
+    {   // base_fc.0 (64 x 207): per-view columns [140..142 rgb | 143..174 img (gathered) | 175..206 e], per-point 0..139
+        const std::vector<float> w = transposed(t[T_BASE0_W], 64, 207, 207);
+        LayerMaps m; m.out_map = out_gathered32(143); append(m.out_map, out_natural_at(175, 32, 2)); in_dlayout(m.in_map, 0, 64, 4);
+        pack_layer(dst, LT_BV, w.data(), 64, nullptr, m);
+        const int rgb[3] = {140, 141, 142};
+        pack_vec(dst, LT_BV, w.data(), 64, nullptr, rgb, 0, 64);
+        LayerMaps g; in_dlayout(g.in_map, 0, 64, 4);
+        for (int j = 0; j < 4; ++j) append(g.out_map, out_gathered32(35 * j + 3));
+        pack_layer(dst, LT_BG, w.data(), 64, nullptr, g);
+        for (int j = 0; j < 4; ++j) {
+            const int rows[3] = {35 * j, 35 * j + 1, 35 * j + 2};
+            pack_vec(dst, LT_BG_R0 + j, w.data(), 64, nullptr, rows, 0, 64);
+        }
+        const std::vector<float> w2 = transposed(t[T_BASE2_W], 32, 64, 64);
+        LayerMaps m2; m2.out_map = out_natural(4, 64); in_dlayout(m2.in_map, 0, 32, 2);
+        pack_layer(dst, LT_B2, w2.data(), 32, nullptr, m2);
+    }
+    {   // vis_fc (32 x 32, 33 x 32: row 32 as a single K-step), vis_fc2.0 (32 x 32)
+        const std::vector<float> w0 = transposed(t[T_VF0_W], 32, 32, 32), w2 = transposed(t[T_VF2_W], 33, 32, 32),
+                                 v0 = transposed(t[T_V20_W], 32, 32, 32);
+        LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 32, 2);
+        pack_layer(dst, LT_VF1, w0.data(), 32, nullptr, m);
+        LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
+        for (int g = 0; g < 4; ++g) m2.in1_map.push_back(g == 0 ? 32 : -1);
+        pack_layer(dst, LT_VF2, w2.data(), 33, nullptr, m2);
+        LayerMaps m3; m3.out_map = out_natural(2, 32); in_dlayout(m3.in_map, 0, 32, 2);
+        pack_layer(dst, LT_V21, v0.data(), 32, nullptr, m3);
+    }
+    {   // rgb_fc.0 (16 x 37): d h16 -> d x2 (32) + vector row d vis (column 32);  rgb_fc.2 (8 x 16): d h8 -> d h16
+        const std::vector<float> w = transposed(t[T_RF0_W], 16, 37, 37), w2 = transposed(t[T_RF2_W], 8, 16, 16);
+        LayerMaps m; m.out_map = out_natural(2, 32); in_dlayout(m.in_map, 0, 16, 1);
+        pack_layer(dst, LT_RF1, w.data(), 16, nullptr, m);
+        const int row[1] = {32};
+        pack_vec(dst, LT_RF1, w.data(), 16, nullptr, row, 0, 16);
+        LayerMaps m2; m2.out_map = out_natural(1, 16); in_dlayout(m2.in_map, 0, 8, 1);
+        pack_layer(dst, LT_RF2, w2.data(), 8, nullptr, m2);
+    }
+    {   // geometry_fc.0 (64 x 65): d h64 -> d [mean 32 | var 32] + vector row d mean weight;  geometry_fc.2 (16 x 64)
+        const std::vector<float> w = transposed(t[T_GF0_W], 64, 65, 65), w2 = transposed(t[T_GF2_W], 16, 64, 64);
+        LayerMaps m; m.out_map = out_natural(4, 64); in_dlayout(m.in_map, 0, 64, 4);
+        pack_layer(dst, LT_GF1, w.data(), 64, nullptr, m);
+        const int row[1] = {64};
+        pack_vec(dst, LT_GF1, w.data(), 64, nullptr, row, 0, 64);
+        LayerMaps m2; m2.out_map = out_natural(4, 64); in_dlayout(m2.in_map, 0, 16, 1);
+        pack_layer(dst, LT_GF2, w2.data(), 16, nullptr, m2);
+    }
+    return 0;
+}
+
+// packed_t[i] = flat[index[i]] (index -1: padding, 0): the transposed layers carry the true weights, no factors
+int pack_pass_t_index_map(bool has_vis, int* index) {
+    std::vector<float> pos(kFlatPassFloats), tmp(kPackedTFloats);
+    for (int i = 0; i < kFlatPassFloats; ++i) pos[i] = (float)(i + 1);        // < 2^24: exact
+    const float* tp[T_COUNT];
+    for (int t = 0; t < T_COUNT; ++t) {
+        const bool vis_slot = t >= T_VIS0_W && t <= T_VIS4_B;
+        tp[t] = (vis_slot && !has_vis) ? nullptr : pos.data() + tensor_offset(t);
+    }
+    const int rc = pack_pass_t_weights(tp, tmp.data());
+    if (rc) return rc;
+    for (int i = 0; i < kPackedTFloats; ++i) index[i] = (int)tmp[i] - 1;
+    return 0;
+}
+
 // The packing is a gather with a per-element factor: packed[i] = flat[index[i]] * scale[i] (index -1: padding, 0).
 // Obtained from the packer itself: once on tensors whose elements are their own flat position + 1 (scaling off), once
 // on all-ones tensors (scaling on).

@@ -25,4 +25,9 @@ int pack_pass_weights(const float* const* tensors, float* dst);
 // packed[i] = flat[index[i]] * scale[i] (flat natural layout, nr_layout.h); index -1 = padding.  kPackedPassFloats entries each.
 int pack_pass_index_map(bool has_vis, int* index, float* scale);
 
+// The transposed layers of the backward pass (nr_layout.h LT_*) -> dst (kPackedTFloats floats); true weights.
+int pack_pass_t_weights(const float* const* tensors, float* dst);
+// packed_t[i] = flat[index[i]]; index -1 = padding.  kPackedTFloats entries.
+int pack_pass_t_index_map(bool has_vis, int* index);
+
 }  // namespace nr

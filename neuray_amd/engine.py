@@ -93,6 +93,7 @@ class RenderEngine:
         # (name, start_event, end_event, n_points) recorded on the launch stream (HIP events)
         self.timing = None
         self.max_backward_samples = _lib.MAX_BACKWARD_SAMPLES
+        self.points_backward_kernel = 'auto'       # 'v1': force the first-version point backward (A/B timing, tests)
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -379,19 +380,41 @@ class RenderEngine:
                 out[k] = d_flat[off[i]:off[i + 1]].view(v.shape)
         return out
 
-    def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05):
-        """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC)."""
+    def pack_pass_t_device(self, flat, has_vis):
+        """The transposed layers of the backward pass (nr_layout.h LT_*) from the flat natural layout, on the device:
+        packed_t = flat[index] (neuray_pack_pass_t_index_map); true weights, no factors."""
+        cache = self.__dict__.setdefault('_pack_t_maps', {})
+        if has_vis not in cache:
+            n = int(self.lib.neuray_packed_t_floats())
+            idx = torch.empty(n, dtype=torch.int32)
+            self._check(self.lib.neuray_pack_pass_t_index_map(int(has_vis), C.c_void_p(idx.data_ptr())))
+            cache[has_vis] = ((idx >= 0).to(self.device), idx.clamp(min=0).long().to(self.device))
+        ok, idx = cache[has_vis]
+        return flat[idx] * ok
+
+    def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05,
+                               packed=None, kernel='auto'):
+        """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC).
+        packed: the forward's PackedPass of the same weights (built from `flat` here if absent).  kernel: 'auto' = the
+        register / LDS resident kernel when it applies (rfn <= 8), 'v1' = force the first-version kernel (tests)."""
         coords, depth, d_point_rec = self._f32(coords), self._f32(depth), self._f32(d_point_rec)
         rn, dn = depth.shape
         d_flat = torch.zeros_like(flat)
         d_rf = torch.zeros_like(views.ray_feats)
         d_if = torch.zeros_like(views.img_feats)
-        ws = self.empty(int(self.lib.neuray_points_backward_workspace_floats(rn * dn, views.rfn)))
+        resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
+        ws = pk = pt = None
+        if resident:
+            pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
+            pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+        else:
+            ws = self.empty(int(self.lib.neuray_points_backward_workspace_floats(rn * dn, views.rfn)))
         a = _lib.NeurayPointsBwdArgs(
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
             views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_point_rec.data_ptr(), d_flat.data_ptr(),
-            d_rf.data_ptr(), d_if.data_ptr(), ws.data_ptr(), views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
-            int(has_vis_head), int(bool(use_vis)), float(var_bias))
+            d_rf.data_ptr(), d_if.data_ptr(), ws.data_ptr() if ws is not None else None, views.rfn, rn, dn, views.h, views.w,
+            views.fh, views.fw, int(has_vis_head), int(bool(use_vis)), float(var_bias),
+            pk.data_ptr() if pk is not None else None, pt.data_ptr() if pt is not None else None)
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         return d_flat, d_rf, d_if
 

@@ -65,7 +65,7 @@ class RenderPassFn(torch.autograd.Function):
                                                 d_depth.contiguous() if d_depth is not None else None)
         sd = run.state()
         d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
-                                                        run.use_vis, d_rec, var_bias=run.var_bias)
+                                                        run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g

@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--ft', action='store_true', help='a NeuralRayFtRenderer.train_step on a 24-view 800 x 800 in-memory scene '
                                                       '(per-view learnable ray_feats, encoders trained) instead of the bare render_impl step')
+    ap.add_argument('--kernel', default='auto', help="'v1': the first-version point backward (A/B)")
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     if args.ft:
@@ -58,6 +59,7 @@ def main():
            'use_self_hit_prob': True}
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).train().to(dev)
+    r.engine(dev).points_backward_kernel = args.kernel
     que, ref = synthetic.make_scene(400, 600, 8, seed=0, que_imgs=True)
     rng = np.random.RandomState(0)
     que['coords'] = (rng.rand(1, args.rays, 2) * np.array([599, 399])).astype(np.float32)
@@ -82,7 +84,7 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps
 
-    res = {'rays': args.rays, 'views': 8, 'samples': '64+64', 'hip_ms_per_step': 1e3 * timeit(step_ours)}
+    res = {'rays': args.rays, 'views': 8, 'samples': '64+64', 'point_backward_kernel': args.kernel, 'hip_ms_per_step': 1e3 * timeit(step_ours)}
     print(json.dumps(res))
 
 

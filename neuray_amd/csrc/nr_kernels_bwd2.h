@@ -103,6 +103,9 @@ constexpr int kDwBias = dw_bias0(DW_COUNT), kDwBiasAcc = (kDwBias + kB2Waves - 1
 // NCQ: column groups of 16 (8 = all views, 1 = per-point operands with stride kB2PStride)
 template <int ID>
 __device__ __forceinline__ void dw_jobs(v4f (&acc)[kDwAcc], float (&bacc)[kDwBiasAcc], const float* S, int rowA, int rowB, int wave, int lane) {
+#ifdef NR_B2_SKIP_DW
+    return;
+#endif
     constexpr int OT = dw_ot(ID), KT = dw_kt(ID), J0 = dw_job0(ID), B0 = dw_bias0(ID);
     constexpr bool PP = kDw[ID].per_point;
     constexpr int STR = PP ? kB2PStride : kB2Stride, NCQ = PP ? 1 : 8;
@@ -174,6 +177,9 @@ __device__ __forceinline__ void dw_flush(const v4f (&acc)[kDwAcc], const float (
 // D-layout registers x[4t + r] = feature 16t + 4g + r of point c -> rows row0 + feature
 template <int NREG>
 __device__ __forceinline__ void st_nat(float* S, int stride, int row0, const float (&x)[NREG], int col, int g) {
+#ifdef NR_B2_SKIP_STAGE
+    return;
+#endif
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NREG / 4; ++t)
         NR_PRAGMA_UNROLL
@@ -181,6 +187,9 @@ __device__ __forceinline__ void st_nat(float* S, int stride, int row0, const flo
 }
 // gathered-order registers x[k] = channel 8g + k
 __device__ __forceinline__ void st_gat(float* S, int stride, int row0, const float (&x)[8], int col, int g) {
+#ifdef NR_B2_SKIP_STAGE
+    return;
+#endif
     NR_PRAGMA_UNROLL
     for (int k = 0; k < 8; ++k) S[(row0 + 8 * g + k) * stride + col] = x[k];
 }

@@ -53,7 +53,7 @@ constexpr int kB2Rmax = 12;              // rows of the widest all-reduce
 // backward) | stash (the four cross-view statistics, lane layout: 44 values per lane) | hx (hand-off of per-point
 // gradients from their owner waves to every wave: <= 44 values per lane) | staging (also: per-point staging, geometry
 // exchange, scatter slabs)
-constexpr int kB2Red = (kB2Waves + 1) * kB2Rmax * 64;
+constexpr int kB2Red = (kB2Waves + 1) * kB2Rmax * 64 + (kB2Waves + 1) * 64;      // all-reduce scratch + the scratch of the one max-reduce      // three rotating sum banks + the scratch of the one max-reduce
 constexpr int kB2Xch = 16 * 64;
 constexpr int kB2Stash = 44 * 64;
 constexpr int kB2Hx = 44 * 64;
@@ -103,9 +103,6 @@ constexpr int kDwBias = dw_bias0(DW_COUNT), kDwBiasAcc = (kDwBias + kB2Waves - 1
 // NCQ: column groups of 16 (8 = all views, 1 = per-point operands with stride kB2PStride)
 template <int ID>
 __device__ __forceinline__ void dw_jobs(v4f (&acc)[kDwAcc], float (&bacc)[kDwBiasAcc], const float* S, int rowA, int rowB, int wave, int lane) {
-#ifdef NR_B2_SKIP_DW
-    return;
-#endif
     constexpr int OT = dw_ot(ID), KT = dw_kt(ID), J0 = dw_job0(ID), B0 = dw_bias0(ID);
     constexpr bool PP = kDw[ID].per_point;
     constexpr int STR = PP ? kB2PStride : kB2Stride, NCQ = PP ? 1 : 8;
@@ -118,12 +115,17 @@ __device__ __forceinline__ void dw_jobs(v4f (&acc)[kDwAcc], float (&bacc)[kDwBia
             if (job % kB2Waves == wave) {
                 const float* pa = S + (rowA + 16 * a + m) * STR + 4 * kk;
                 const float* pb = S + (rowB + 16 * b + m) * STR + 4 * kk;
+                // (software pipeline: the operands of column group j + 1 are read while group j is on the matrix pipe)
                 v4f d = acc[job / kB2Waves];
+                float4 av = ld4(pa), bv = ld4(pb);
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < NCQ; ++j) {
-                    const float4 av = ld4(pa + 16 * j), bv = ld4(pb + 16 * j);
+                    float4 an = av, bn = bv;
+                    if (j + 1 < NCQ) { an = ld4(pa + 16 * (j + 1)); bn = ld4(pb + 16 * (j + 1)); }
+                    NR_PIN();
                     d = nr_mfma16(av.x, bv.x, d); d = nr_mfma16(av.y, bv.y, d);
                     d = nr_mfma16(av.z, bv.z, d); d = nr_mfma16(av.w, bv.w, d);
+                    av = an; bv = bn;
                 }
                 acc[job / kB2Waves] = d;
             }
@@ -177,9 +179,6 @@ __device__ __forceinline__ void dw_flush(const v4f (&acc)[kDwAcc], const float (
 // D-layout registers x[4t + r] = feature 16t + 4g + r of point c -> rows row0 + feature
 template <int NREG>
 __device__ __forceinline__ void st_nat(float* S, int stride, int row0, const float (&x)[NREG], int col, int g) {
-#ifdef NR_B2_SKIP_STAGE
-    return;
-#endif
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NREG / 4; ++t)
         NR_PRAGMA_UNROLL
@@ -187,9 +186,6 @@ __device__ __forceinline__ void st_nat(float* S, int stride, int row0, const flo
 }
 // gathered-order registers x[k] = channel 8g + k
 __device__ __forceinline__ void st_gat(float* S, int stride, int row0, const float (&x)[8], int col, int g) {
-#ifdef NR_B2_SKIP_STAGE
-    return;
-#endif
     NR_PRAGMA_UNROLL
     for (int k = 0; k < 8; ++k) S[(row0 + 8 * g + k) * stride + col] = x[k];
 }
@@ -221,10 +217,33 @@ __device__ __forceinline__ void vec_bwd(const VecPre<L>& p, const float (&dy)[kV
     }
 }
 
-// one all-reduce (sum) over the 8 view waves of R per-lane values
+// bwd_prob (nr_kernels_bwd.h) on the hardware transcendentals (tanh_ of nr_device.h: ~1e-7 absolute, as the forward kernel)
+__device__ __forceinline__ void b2_prob_bwd(float nearv, float farv, float mu0, float mu1, float sd0, float sd1, float aw, float nuu,
+                                            bool use_vis, float dv, float dh, float& dmu0, float& dmu1, float& dsd0, float& dsd1,
+                                            float& daw, float& dnu) {
+    const float t00 = tanh_((nearv - mu0) * sd0), t01 = tanh_((nearv - mu1) * sd1);
+    const float t10 = tanh_((farv - mu0) * sd0), t11 = tanh_((farv - mu1) * sd1);
+    const float g00 = 0.5f + 0.5f * t00, g01 = 0.5f + 0.5f * t01, g10 = 0.5f + 0.5f * t10, g11 = 0.5f + 0.5f * t11;
+    const float c00 = g00 * nuu, c01 = g01 * nuu, c10 = g10 * nuu, c11 = g11 * nuu;
+    const float mix0 = aw, mix1 = 1.0f - aw;
+    const float dmix0 = dv * (1.0f - c00) + dh * (c10 - c00), dmix1 = dv * (1.0f - c01) + dh * (c11 - c01);
+    const float dc00 = -mix0 * (dv + dh), dc01 = -mix1 * (dv + dh), dc10 = mix0 * dh, dc11 = mix1 * dh;
+    if (use_vis) dnu += dc00 * g00 + dc01 * g01 + dc10 * g10 + dc11 * g11;
+    const float da00 = dc00 * nuu * 0.5f * (1.0f - t00 * t00), da01 = dc01 * nuu * 0.5f * (1.0f - t01 * t01);
+    const float da10 = dc10 * nuu * 0.5f * (1.0f - t10 * t10), da11 = dc11 * nuu * 0.5f * (1.0f - t11 * t11);
+    dmu0 += -sd0 * (da00 + da10); dmu1 += -sd1 * (da01 + da11);
+    dsd0 += (nearv - mu0) * da00 + (farv - mu0) * da10;
+    dsd1 += (nearv - mu1) * da01 + (farv - mu1) * da11;
+    daw += dmix0 - dmix1;
+}
+
+// One all-reduce (sum) over the 8 view waves of R per-lane values: the forward kernel's deterministic reduce-scatter +
+// all-gather through LDS (two barriers).  (Tried: every wave adds into one bank with LDS float atomics and a single
+// barrier - ds_add_f32 from eight waves onto the same 64 words made the kernel 0.4 ms slower, 1.09 -> 1.49 ms.)
+struct B2Red { float* base; };
 template <int R>
-__device__ __forceinline__ void b2_allsum(float (&v)[R], float* red, int wave, int lane) {
-    block_allreduce<R, kB2Rmax, RED_SUM>(v, red, wave, kB2Waves, lane);
+__device__ __forceinline__ void b2_allsum(float (&v)[R], B2Red& rd, int wave, int lane) {
+    block_allreduce<R, kB2Rmax, RED_SUM>(v, rd.base, wave, kB2Waves, lane);
 }
 
 // the three (four) 32 -> 32 -> 32 -> out heads of the dist decoder: forward on f_ray, outputs only
@@ -296,8 +315,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
     const int g = lane >> 4, c = lane & 15;
-    float* red = smem;
-    float* xch = red + kB2Red;
+    float* redm = smem + (kB2Waves + 1) * kB2Rmax * 64;     // scratch of the max-reduce (block_allreduce with RMAX = 1)
+    B2Red red{smem};
+    float* xch = smem + kB2Red;
     float* stash = xch + kB2Xch;
     float* hx = stash + kB2Stash;
     float* S = hx + kB2Hx;
@@ -525,7 +545,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         float beta, svis, wh, swh, gmean[8], gvar[8];
         {
             float zm[1] = {z};
-            block_allreduce<1, kB2Rmax, RED_MAX>(zm, red, wave, kB2Waves, lane);
+            block_allreduce<1, 1, RED_MAX>(zm, redm, wave, kB2Waves, lane);
             const float ez = vok ? nr_fast_exp(z - zm[0]) : 0.0f;     // (padding waves take no part in the softmax)
             float s3[3] = {ez, vis2, 0.0f};
             b2_allsum<3>(s3, red, wave, lane);
@@ -877,10 +897,10 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         // ---- probabilities backward (dist_decoder.py:109-140) and the dist decoder heads
         {
             float dmu0 = 0.0f, dmu1 = 0.0f, dsd0 = 0.0f, dsd1 = 0.0f, daw = 0.0f, dnu = 0.0f;
-            bwd_prob(tref - lo, tref + hi, mu0, mu1, s0, s1, aw, nuu, use_vis, dvis * mask, dhit * mask, dmu0, dmu1, dsd0, dsd1, daw, dnu);
+            b2_prob_bwd(tref - lo, tref + hi, mu0, mu1, s0, s1, aw, nuu, use_vis, dvis * mask, dhit * mask, dmu0, dmu1, dsd0, dsd1, daw, dnu);
             // through the output non-linearities: softplus' = 1 - exp(-softplus), sigmoid' = s (1 - s)
-            const float dm[2] = {dmu0 * (1.0f - expf(-mu0)), dmu1 * (1.0f - expf(-mu1))};
-            const float dv[2] = {dsd0 * (1.0f - expf(-(s0 - p.var_bias))), dsd1 * (1.0f - expf(-(s1 - p.var_bias)))};
+            const float dm[2] = {dmu0 * (1.0f - nr_fast_exp(-mu0)), dmu1 * (1.0f - nr_fast_exp(-mu1))};
+            const float dv[2] = {dsd0 * (1.0f - nr_fast_exp(-(s0 - p.var_bias))), dsd1 * (1.0f - nr_fast_exp(-(s1 - p.var_bias)))};
             const float da[1] = {daw * aw * (1.0f - aw)};
             b2_dist_head_bwd<L_DM1, L_DM2, L_DFIN_M, LT_DM1, LT_DM2, DW_M4, DW_M2, DW_M0, 2>(W, WT, glane, lane, wave, col, g, fray, dm, dfr, S, acc, bacc);
             b2_dist_head_bwd<L_DV1, L_DV2, L_DFIN_V, LT_DV1, LT_DV2, DW_V4, DW_V2, DW_V0, 2>(W, WT, glane, lane, wave, col, g, fray, dv, dfr, S, acc, bacc);

@@ -129,7 +129,7 @@ int neuray_render_rays(const NeurayRaysArgs* args, void* stream);
  * d_ray_weights [NEURAY_PACKED_RAY_FLOATS] is ACCUMULATED into (zero it first); layout = the ray part of the packed
  * pass, row-major copies at the NEURAY_RW_* offsets: ray_attention.w_qs / w_ks / w_vs / fc .weight (16x16 each),
  * layer_norm.weight / .bias (16), out_geometry_fc.0.weight (16x16) / .bias (16), out_geometry_fc.2.weight (16) / .bias.
- * dn <= 64. */
+ * dn <= NEURAY_MAX_SAMPLES: one wave per ray, one sample per lane up to 64 samples, two per lane above. */
 #define NEURAY_PACKED_RAY_FLOATS 1348
 #define NEURAY_RW_WQ 0
 #define NEURAY_RW_WK 256

@@ -22,7 +22,7 @@ QUERY_CONST = 28
 DBG_FIELDS = 16
 MAX_VIEWS = 16
 MAX_SAMPLES = 128
-MAX_BACKWARD_SAMPLES = 64      # samples per ray and pass the backward kernels take (include/neuray_hip.h)
+MAX_BACKWARD_SAMPLES = 128     # samples per ray and pass the backward kernels take (include/neuray_hip.h): = MAX_SAMPLES
 
 c_float_p = C.POINTER(C.c_float)
 

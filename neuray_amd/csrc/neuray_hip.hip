@@ -301,18 +301,27 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* a, void* stream) {
         !a->d_point_rec_dev || !a->d_ray_weights_dev)
         return fail("neuray_render_rays_backward: null argument");
     if (a->rn < 1) return fail("neuray_render_rays_backward: rn=%d", a->rn);
-    if (a->dn < 3 || a->dn > 64) return fail("neuray_render_rays_backward: dn=%d outside [3,64]", a->dn);
+    if (a->dn < 3 || a->dn > NEURAY_MAX_SAMPLES) return fail("neuray_render_rays_backward: dn=%d outside [3,%d]", a->dn, NEURAY_MAX_SAMPLES);
     nr::RayBwdParams p;
     p.point_rec = a->point_rec_dev; p.depth = a->depth_dev; p.pos_enc = a->pos_enc_dev; p.weights = a->packed_weights_dev;
     p.d_pixel = a->d_pixel_dev; p.d_hit_prob = a->d_hit_prob_dev; p.d_depth = a->d_render_depth_dev;
     p.d_point_rec = a->d_point_rec_dev; p.d_weights = a->d_ray_weights_dev; p.rn = a->rn; p.dn = a->dn;
     const size_t smem = nr::ray_bwd_smem_bytes(a->dn);
-    const int grid = grid_for(a->rn, nr::kRayWaves, 256 * 4);
-    auto k = nr::rays_backward_kernel;
+    const int waves = nr::ray_bwd_waves(a->dn);            // rays per workgroup
+    const int grid = grid_for(a->rn, waves, 256 * 4);
+    if (a->dn <= 64) {
+        auto k = nr::rays_backward_kernel<1>;
 #ifndef NEURAY_EMU
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-    NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+        NR_LAUNCH(k, dim3(grid), dim3(64 * waves), smem, stream, p);
+    } else {                                               // two samples per lane
+        auto k = nr::rays_backward_kernel<2>;
+#ifndef NEURAY_EMU
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+        NR_LAUNCH(k, dim3(grid), dim3(64 * waves), smem, stream, p);
+    }
     return check_launch("neuray_render_rays_backward");
 }
 

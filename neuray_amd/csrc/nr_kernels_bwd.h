@@ -31,8 +31,10 @@ struct RayBwdParams {
 
 constexpr int kRayBwdPerSample = 16 * 4 + 12 + 3;     // K, V, q~, do | shift, den, D | t, alpha, u
 constexpr int kRayBwdTranspose = 2 * 64 * 17;         // per wave: two [64][17] buffers of wave_outer_add
+// rays per workgroup: 4 (one sample per lane, dn <= 64) or 2 (two samples per lane, dn <= 128: the per-sample LDS state doubles)
+inline int ray_bwd_waves(int dn) { return dn <= 64 ? kRayWaves : 2; }
 inline size_t ray_bwd_smem_bytes(int dn) {
-    return sizeof(float) * (2 * (kPackedRayFloats + 12) + kRayWaves * ((size_t)dn * kRayBwdPerSample + kRayBwdTranspose));
+    return sizeof(float) * (2 * (kPackedRayFloats + 12) + ray_bwd_waves(dn) * ((size_t)dn * kRayBwdPerSample + kRayBwdTranspose));
 }
 
 // acc[o * 16 + k] += sum over the wave of a[o] * b[k]   (acc in LDS, shared by the waves of the workgroup).
@@ -71,11 +73,22 @@ __device__ __forceinline__ void matvec16_t(const float* __restrict__ M, const fl
         }
 }
 
+// per-sample state that lives from the forward to the backward stages of a ray (one instance per sample a lane owns)
+struct RayBwdSample {
+    float G[16], kk[16], vv[16], q[16], o[16], mx[4], den[4], yh[16], z[16], pre1[16], h1[16];
+    float c[3], nvalid, rstd, alpha, ti, em, hit, T, dhit;
+    bool inr, act, qmask, sig_on;
+    int i;
+};
+
+// NCH samples per lane: NCH = 1 for dn <= 64 (4 rays per workgroup), NCH = 2 for dn <= 128 (2 rays per workgroup)
+template <int NCH>
 __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
-    const int dn = p.dn;                               // <= 64: one sample per lane
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int dn = p.dn;
     float* RW = smem + nr_opaque_zero();
     float* WA = smem + kPackedRayFloats + 12;          // weight-gradient accumulators of the workgroup
     float* base = smem + 2 * (kPackedRayFloats + 12) + (size_t)wave * (dn * kRayBwdPerSample + kRayBwdTranspose);
@@ -85,189 +98,212 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
     float* tA = us + dn; float* tB = tA + 64 * 17;
     for (int i = threadIdx.x; i < kPackedRayFloats; i += blockDim.x) { RW[i] = p.weights[kPackedPointFloats + i]; WA[i] = 0.0f; }
     __syncthreads();
-    const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
-    const int iraw = lane;
-    const bool inr = iraw < dn;
-    const int i = inr ? iraw : dn - 1;                 // lanes past the last sample redo sample dn-1 and contribute nothing
+    const int nray_iter = (p.rn + nwaves - 1) / nwaves;
 
     for (int it = blockIdx.x; it < nray_iter; it += gridDim.x) {
-        int ray = it * kRayWaves + wave;
+        int ray = it * nwaves + wave;
         const bool rvalid = ray < p.rn;
         ray = rvalid ? ray : p.rn - 1;
-        const bool act = inr && rvalid;
-        const float* rec = p.point_rec + ((size_t)ray * dn + i) * kPointRec;
+        RayBwdSample sm[NCH];
         asm volatile("" ::: "memory");
         // ---- forward, part 1: G, K, V
-        float G[16], kk[16], vv[16];
         NR_PRAGMA_UNROLL
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const float4 a = ld4(rec + 4 * k4), b = ld4(p.pos_enc + i * 16 + 4 * k4);
-            G[4 * k4] = a.x + b.x; G[4 * k4 + 1] = a.y + b.y; G[4 * k4 + 2] = a.z + b.z; G[4 * k4 + 3] = a.w + b.w;
-        }
-        const float4 c4 = ld4(rec + 16);               // colour (3), number of valid views
-        const float nvalid = c4.w;
-        matvec16(RW + RW_WK, G, kk);
-        matvec16(RW + RW_WV, G, vv);
-        if (inr) {
+        for (int ch = 0; ch < NCH; ++ch) {
+            RayBwdSample& s = sm[ch];
+            const int iraw = ch * 64 + lane;
+            s.inr = iraw < dn;
+            s.i = s.inr ? iraw : dn - 1;               // lanes past the last sample redo sample dn-1 and contribute nothing
+            s.act = s.inr && rvalid;
+            const float* rec = p.point_rec + ((size_t)ray * dn + s.i) * kPointRec;
             NR_PRAGMA_UNROLL
-            for (int k = 0; k < 16; ++k) { ks[i * 16 + k] = kk[k]; vs[i * 16 + k] = vv[k]; }
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float4 a = ld4(rec + 4 * k4), b = ld4(p.pos_enc + s.i * 16 + 4 * k4);
+                s.G[4 * k4] = a.x + b.x; s.G[4 * k4 + 1] = a.y + b.y; s.G[4 * k4 + 2] = a.z + b.z; s.G[4 * k4 + 3] = a.w + b.w;
+            }
+            const float4 c4 = ld4(rec + 16);           // colour (3), number of valid views
+            s.c[0] = c4.x; s.c[1] = c4.y; s.c[2] = c4.z; s.nvalid = c4.w;
+            matvec16(RW + RW_WK, s.G, s.kk);
+            matvec16(RW + RW_WV, s.G, s.vv);
+            if (s.inr) {
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) { ks[s.i * 16 + k] = s.kk[k]; vs[s.i * 16 + k] = s.vv[k]; }
+            }
         }
         __syncthreads();
         // ---- forward, part 2: attention, LayerNorm, sigma head
-        float q[16], o[16], mx[4], den[4];
-        matvec16(RW + RW_WQ, G, q);
-        const bool qmask = !(nvalid > 1.0f);           // quirk A.9.3: the row's scores are all -1e9 <=> q~ = 0
         NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) q[k] = qmask ? 0.0f : q[k] / 2.0f;
-        NR_PRAGMA_UNROLL
-        for (int hh = 0; hh < 4; ++hh) {
-            float m_ = -INFINITY;
-            for (int j = 0; j < dn; ++j) {
-                const float4 kj = ld4(ks + j * 16 + hh * 4);
-                m_ = fmaxf(m_, fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x))));
+        for (int ch = 0; ch < NCH; ++ch) {
+            RayBwdSample& s = sm[ch];
+            matvec16(RW + RW_WQ, s.G, s.q);
+            s.qmask = !(s.nvalid > 1.0f);              // quirk A.9.3: the row's scores are all -1e9 <=> q~ = 0
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 16; ++k) s.q[k] = s.qmask ? 0.0f : s.q[k] / 2.0f;
+            NR_PRAGMA_UNROLL
+            for (int hh = 0; hh < 4; ++hh) {
+                float m_ = -INFINITY;
+                for (int j = 0; j < dn; ++j) {
+                    const float4 kj = ld4(ks + j * 16 + hh * 4);
+                    m_ = fmaxf(m_, fmaf(s.q[hh * 4 + 3], kj.w, fmaf(s.q[hh * 4 + 2], kj.z, fmaf(s.q[hh * 4 + 1], kj.y, s.q[hh * 4] * kj.x))));
+                }
+                float d_ = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                for (int j = 0; j < dn; ++j) {
+                    const float4 kj = ld4(ks + j * 16 + hh * 4);
+                    const float sc = fmaf(s.q[hh * 4 + 3], kj.w, fmaf(s.q[hh * 4 + 2], kj.z, fmaf(s.q[hh * 4 + 1], kj.y, s.q[hh * 4] * kj.x)));
+                    const float e_ = expf(sc - m_);
+                    const float4 vj = ld4(vs + j * 16 + hh * 4);
+                    d_ += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
+                }
+                s.mx[hh] = m_; s.den[hh] = d_;
+                s.o[hh * 4] = a0 / d_; s.o[hh * 4 + 1] = a1 / d_; s.o[hh * 4 + 2] = a2 / d_; s.o[hh * 4 + 3] = a3 / d_;
             }
-            float d_ = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            for (int j = 0; j < dn; ++j) {
-                const float4 kj = ld4(ks + j * 16 + hh * 4);
-                const float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
-                const float e_ = expf(s - m_);
-                const float4 vj = ld4(vs + j * 16 + hh * 4);
-                d_ += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
+            float y[16], mean = 0.0f, var = 0.0f;
+            matvec16(RW + RW_FC, s.o, y);
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 16; ++k) { y[k] += s.G[k]; mean += y[k]; }
+            mean /= 16.0f;
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 16; ++k) { const float d_ = y[k] - mean; var = fmaf(d_, d_, var); }
+            var /= 16.0f;
+            s.rstd = 1.0f / sqrtf(var + 1e-6f);
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 16; ++k) { s.yh[k] = (y[k] - mean) * s.rstd; s.z[k] = fmaf(s.yh[k], RW[RW_LNW + k], RW[RW_LNB + k]); }
+            matvec16(RW + RW_OG0W, s.z, s.pre1);
+            float spre = RW[RW_OG2B];
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 16; ++k) {
+                s.pre1[k] += RW[RW_OG0B + k];
+                s.h1[k] = s.pre1[k] > 0.0f ? s.pre1[k] : expf(s.pre1[k]) - 1.0f;
+                spre = fmaf(RW[RW_OG2W + k], s.h1[k], spre);
             }
-            mx[hh] = m_; den[hh] = d_;
-            o[hh * 4] = a0 / d_; o[hh * 4 + 1] = a1 / d_; o[hh * 4 + 2] = a2 / d_; o[hh * 4 + 3] = a3 / d_;
+            s.sig_on = (spre > 0.0f) && !(s.nvalid < 1.0f);
+            const float sg = s.sig_on ? spre : 0.0f;
+            s.em = expf(-sg);                          // 1 - alpha
+            s.alpha = 1.0f - s.em;
+            s.ti = (1.0f - s.alpha) + 1e-10f;
+            if (s.inr) { tr[s.i] = s.ti; al[s.i] = s.alpha; }
         }
-        float y[16], yh[16], z[16], pre1[16], h1[16], mean = 0.0f, var = 0.0f;
-        matvec16(RW + RW_FC, o, y);
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) { y[k] += G[k]; mean += y[k]; }
-        mean /= 16.0f;
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) { const float d_ = y[k] - mean; var = fmaf(d_, d_, var); }
-        var /= 16.0f;
-        const float rstd = 1.0f / sqrtf(var + 1e-6f);
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) { yh[k] = (y[k] - mean) * rstd; z[k] = fmaf(yh[k], RW[RW_LNW + k], RW[RW_LNB + k]); }
-        matvec16(RW + RW_OG0W, z, pre1);
-        float spre = RW[RW_OG2B];
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) {
-            pre1[k] += RW[RW_OG0B + k];
-            h1[k] = pre1[k] > 0.0f ? pre1[k] : expf(pre1[k]) - 1.0f;
-            spre = fmaf(RW[RW_OG2W + k], h1[k], spre);
-        }
-        const bool sig_on = (spre > 0.0f) && !(nvalid < 1.0f);
-        const float sg = sig_on ? spre : 0.0f;
-        const float em = expf(-sg);                    // 1 - alpha
-        const float alpha = 1.0f - em;
-        const float ti = (1.0f - alpha) + 1e-10f;
-        if (inr) { tr[i] = ti; al[i] = alpha; }
         __syncthreads();
         // ---- compositing forward + its backward
-        float T = 1.0f;
-        for (int j = 0; j < dn; ++j) { const float tj = tr[j]; T = (j < i) ? T * tj : T; }
-        const float hit = alpha * T;
         const float gp0 = p.d_pixel[(size_t)ray * 3], gp1 = p.d_pixel[(size_t)ray * 3 + 1], gp2 = p.d_pixel[(size_t)ray * 3 + 2];
-        float dhit = gp0 * c4.x + gp1 * c4.y + gp2 * c4.z;
-        if (p.d_depth) dhit = fmaf(p.d_depth[ray], p.depth[(size_t)ray * dn + i], dhit);
-        if (p.d_hit_prob) dhit += p.d_hit_prob[(size_t)ray * dn + i];
-        if (inr) us[i] = dhit * hit;
+        NR_PRAGMA_UNROLL
+        for (int ch = 0; ch < NCH; ++ch) {
+            RayBwdSample& s = sm[ch];
+            float T = 1.0f;
+            for (int j = 0; j < dn; ++j) { const float tj = tr[j]; T = (j < s.i) ? T * tj : T; }
+            s.T = T;
+            s.hit = s.alpha * T;
+            float dhit = gp0 * s.c[0] + gp1 * s.c[1] + gp2 * s.c[2];
+            if (p.d_depth) dhit = fmaf(p.d_depth[ray], p.depth[(size_t)ray * dn + s.i], dhit);
+            if (p.d_hit_prob) dhit += p.d_hit_prob[(size_t)ray * dn + s.i];
+            s.dhit = dhit;
+            if (s.inr) us[s.i] = dhit * s.hit;
+        }
         __syncthreads();
-        float S = 0.0f;
-        for (int j = 0; j < dn; ++j) { const float uj = us[j]; S = (j > i) ? S + uj : S; }
-        const float dalpha = dhit * T - S / ti;
-        const float dsg = sig_on ? dalpha * em : 0.0f;
-        // ---- sigma head backward
-        float dpre1[16], dz[16], dyh[16], dy[16], dO[16];
+        float dq[NCH][16];
+        float dyk[NCH][16];
         NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) dpre1[k] = dsg * RW[RW_OG2W + k] * (pre1[k] > 0.0f ? 1.0f : h1[k] + 1.0f);
-        {
-            float t16[16];
+        for (int ch = 0; ch < NCH; ++ch) {
+            RayBwdSample& s = sm[ch];
+            float S = 0.0f;
+            for (int j = 0; j < dn; ++j) { const float uj = us[j]; S = (j > s.i) ? S + uj : S; }
+            const float dalpha = s.dhit * s.T - S / s.ti;
+            const float dsg = s.sig_on ? dalpha * s.em : 0.0f;
+            // ---- sigma head backward
+            float dpre1[16], dz[16], dyh[16], dO[16];
             NR_PRAGMA_UNROLL
-            for (int k = 0; k < 16; ++k) t16[k] = dsg * h1[k];
-            wave_vec_add(WA + RW_OG2W, t16, act, lane);
-            const float sb = wave_sum(act ? dsg : 0.0f);
-            if (lane == 0) atomicAdd(WA + RW_OG2B, sb);
-            wave_vec_add(WA + RW_OG0B, dpre1, act, lane);
-            wave_outer_add(WA + RW_OG0W, dpre1, z, act, lane, tA, tB);
-        }
-        matvec16_t(RW + RW_OG0W, dpre1, dz);
-        // ---- LayerNorm backward
-        float m1 = 0.0f, m2 = 0.0f;
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) { dyh[k] = dz[k] * RW[RW_LNW + k]; m1 += dyh[k]; m2 = fmaf(dyh[k], yh[k], m2); }
-        m1 /= 16.0f; m2 /= 16.0f;
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) dy[k] = rstd * (dyh[k] - m1 - yh[k] * m2);
-        {
-            float t16[16];
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 16; ++k) t16[k] = dz[k] * yh[k];
-            wave_vec_add(WA + RW_LNW, t16, act, lane);
-            wave_vec_add(WA + RW_LNB, dz, act, lane);
-            wave_outer_add(WA + RW_FC, dy, o, act, lane, tA, tB);
-        }
-        matvec16_t(RW + RW_FC, dy, dO);
-        // ---- attention backward, query side (this lane = query i)
-        float dq[16], Dh[4];
-        NR_PRAGMA_UNROLL
-        for (int hh = 0; hh < 4; ++hh) {
-            Dh[hh] = dO[hh * 4] * o[hh * 4] + dO[hh * 4 + 1] * o[hh * 4 + 1] + dO[hh * 4 + 2] * o[hh * 4 + 2] + dO[hh * 4 + 3] * o[hh * 4 + 3];
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            for (int j = 0; j < dn; ++j) {
-                const float4 kj = ld4(ks + j * 16 + hh * 4);
-                const float4 vj = ld4(vs + j * 16 + hh * 4);
-                const float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
-                const float P = expf(s - mx[hh]) / den[hh];
-                const float dP = dO[hh * 4] * vj.x + dO[hh * 4 + 1] * vj.y + dO[hh * 4 + 2] * vj.z + dO[hh * 4 + 3] * vj.w;
-                const float dS = P * (dP - Dh[hh]);
-                a0 = fmaf(dS, kj.x, a0); a1 = fmaf(dS, kj.y, a1); a2 = fmaf(dS, kj.z, a2); a3 = fmaf(dS, kj.w, a3);
+            for (int k = 0; k < 16; ++k) dpre1[k] = dsg * RW[RW_OG2W + k] * (s.pre1[k] > 0.0f ? 1.0f : s.h1[k] + 1.0f);
+            {
+                float t16[16];
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) t16[k] = dsg * s.h1[k];
+                wave_vec_add(WA + RW_OG2W, t16, s.act, lane);
+                const float sb = wave_sum(s.act ? dsg : 0.0f);
+                if (lane == 0) atomicAdd(WA + RW_OG2B, sb);
+                wave_vec_add(WA + RW_OG0B, dpre1, s.act, lane);
+                wave_outer_add(WA + RW_OG0W, dpre1, s.z, s.act, lane, tA, tB);
             }
-            // q~ = q / 2 (and q~ = 0, without gradient, on masked rows)
-            dq[hh * 4] = qmask ? 0.0f : a0 * 0.5f; dq[hh * 4 + 1] = qmask ? 0.0f : a1 * 0.5f;
-            dq[hh * 4 + 2] = qmask ? 0.0f : a2 * 0.5f; dq[hh * 4 + 3] = qmask ? 0.0f : a3 * 0.5f;
-        }
-        if (inr) {
+            matvec16_t(RW + RW_OG0W, dpre1, dz);
+            // ---- LayerNorm backward
+            float m1 = 0.0f, m2 = 0.0f;
             NR_PRAGMA_UNROLL
-            for (int k = 0; k < 16; ++k) { qs[i * 16 + k] = q[k]; dos[i * 16 + k] = act ? dO[k] : 0.0f; }
+            for (int k = 0; k < 16; ++k) { dyh[k] = dz[k] * RW[RW_LNW + k]; m1 += dyh[k]; m2 = fmaf(dyh[k], s.yh[k], m2); }
+            m1 /= 16.0f; m2 /= 16.0f;
             NR_PRAGMA_UNROLL
-            for (int hh = 0; hh < 4; ++hh) { st[i * 12 + hh] = mx[hh]; st[i * 12 + 4 + hh] = den[hh]; st[i * 12 + 8 + hh] = Dh[hh]; }
+            for (int k = 0; k < 16; ++k) dyk[ch][k] = s.rstd * (dyh[k] - m1 - s.yh[k] * m2);
+            {
+                float t16[16];
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) t16[k] = dz[k] * s.yh[k];
+                wave_vec_add(WA + RW_LNW, t16, s.act, lane);
+                wave_vec_add(WA + RW_LNB, dz, s.act, lane);
+                wave_outer_add(WA + RW_FC, dyk[ch], s.o, s.act, lane, tA, tB);
+            }
+            matvec16_t(RW + RW_FC, dyk[ch], dO);
+            // ---- attention backward, query side (this lane = query i)
+            float Dh[4];
+            NR_PRAGMA_UNROLL
+            for (int hh = 0; hh < 4; ++hh) {
+                Dh[hh] = dO[hh * 4] * s.o[hh * 4] + dO[hh * 4 + 1] * s.o[hh * 4 + 1] + dO[hh * 4 + 2] * s.o[hh * 4 + 2] + dO[hh * 4 + 3] * s.o[hh * 4 + 3];
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                for (int j = 0; j < dn; ++j) {
+                    const float4 kj = ld4(ks + j * 16 + hh * 4);
+                    const float4 vj = ld4(vs + j * 16 + hh * 4);
+                    const float sc = fmaf(s.q[hh * 4 + 3], kj.w, fmaf(s.q[hh * 4 + 2], kj.z, fmaf(s.q[hh * 4 + 1], kj.y, s.q[hh * 4] * kj.x)));
+                    const float P = expf(sc - s.mx[hh]) / s.den[hh];
+                    const float dP = dO[hh * 4] * vj.x + dO[hh * 4 + 1] * vj.y + dO[hh * 4 + 2] * vj.z + dO[hh * 4 + 3] * vj.w;
+                    const float dS = P * (dP - Dh[hh]);
+                    a0 = fmaf(dS, kj.x, a0); a1 = fmaf(dS, kj.y, a1); a2 = fmaf(dS, kj.z, a2); a3 = fmaf(dS, kj.w, a3);
+                }
+                // q~ = q / 2 (and q~ = 0, without gradient, on masked rows)
+                dq[ch][hh * 4] = s.qmask ? 0.0f : a0 * 0.5f; dq[ch][hh * 4 + 1] = s.qmask ? 0.0f : a1 * 0.5f;
+                dq[ch][hh * 4 + 2] = s.qmask ? 0.0f : a2 * 0.5f; dq[ch][hh * 4 + 3] = s.qmask ? 0.0f : a3 * 0.5f;
+            }
+            if (s.inr) {
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 16; ++k) { qs[s.i * 16 + k] = s.q[k]; dos[s.i * 16 + k] = s.act ? dO[k] : 0.0f; }
+                NR_PRAGMA_UNROLL
+                for (int hh = 0; hh < 4; ++hh) { st[s.i * 12 + hh] = s.mx[hh]; st[s.i * 12 + 4 + hh] = s.den[hh]; st[s.i * 12 + 8 + hh] = Dh[hh]; }
+            }
         }
         __syncthreads();
         // ---- attention backward, key side (this lane = key i): dk_i, dv_i
-        float dk[16], dv[16];
         NR_PRAGMA_UNROLL
-        for (int hh = 0; hh < 4; ++hh) {
-            float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, k3 = 0.0f, v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-            for (int j = 0; j < dn; ++j) {               // j = query
-                const float4 qj = ld4(qs + j * 16 + hh * 4);
-                const float4 dj = ld4(dos + j * 16 + hh * 4);
-                const float s = fmaf(qj.w, kk[hh * 4 + 3], fmaf(qj.z, kk[hh * 4 + 2], fmaf(qj.y, kk[hh * 4 + 1], qj.x * kk[hh * 4])));
-                const float P = expf(s - st[j * 12 + hh]) / st[j * 12 + 4 + hh];
-                const float dP = dj.x * vv[hh * 4] + dj.y * vv[hh * 4 + 1] + dj.z * vv[hh * 4 + 2] + dj.w * vv[hh * 4 + 3];
-                const float dS = P * (dP - st[j * 12 + 8 + hh]);
-                // rows whose ray is invalid carry do = 0 and D = 0: dS = 0, no contribution
-                k0 = fmaf(dS, qj.x, k0); k1 = fmaf(dS, qj.y, k1); k2 = fmaf(dS, qj.z, k2); k3 = fmaf(dS, qj.w, k3);
-                v0 = fmaf(P, dj.x, v0); v1 = fmaf(P, dj.y, v1); v2 = fmaf(P, dj.z, v2); v3 = fmaf(P, dj.w, v3);
-            }
-            dk[hh * 4] = k0; dk[hh * 4 + 1] = k1; dk[hh * 4 + 2] = k2; dk[hh * 4 + 3] = k3;
-            dv[hh * 4] = v0; dv[hh * 4 + 1] = v1; dv[hh * 4 + 2] = v2; dv[hh * 4 + 3] = v3;
-        }
-        wave_outer_add(WA + RW_WQ, dq, G, act, lane, tA, tB);
-        wave_outer_add(WA + RW_WK, dk, G, act, lane, tA, tB);
-        wave_outer_add(WA + RW_WV, dv, G, act, lane, tA, tB);
-        float gq[16], gk[16], gv[16];
-        matvec16_t(RW + RW_WQ, dq, gq);
-        matvec16_t(RW + RW_WK, dk, gk);
-        matvec16_t(RW + RW_WV, dv, gv);
-        if (act) {
-            float* out = p.d_point_rec + ((size_t)ray * dn + i) * kPointRec;
+        for (int ch = 0; ch < NCH; ++ch) {
+            RayBwdSample& s = sm[ch];
+            float dk[16], dv[16];
             NR_PRAGMA_UNROLL
-            for (int k4 = 0; k4 < 4; ++k4)
-                *reinterpret_cast<float4*>(out + 4 * k4) =
-                    make_float4(dy[4 * k4] + gq[4 * k4] + gk[4 * k4] + gv[4 * k4], dy[4 * k4 + 1] + gq[4 * k4 + 1] + gk[4 * k4 + 1] + gv[4 * k4 + 1],
-                                dy[4 * k4 + 2] + gq[4 * k4 + 2] + gk[4 * k4 + 2] + gv[4 * k4 + 2], dy[4 * k4 + 3] + gq[4 * k4 + 3] + gk[4 * k4 + 3] + gv[4 * k4 + 3]);
-            *reinterpret_cast<float4*>(out + 16) = make_float4(hit * gp0, hit * gp1, hit * gp2, 0.0f);
+            for (int hh = 0; hh < 4; ++hh) {
+                float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f, k3 = 0.0f, v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+                for (int j = 0; j < dn; ++j) {               // j = query
+                    const float4 qj = ld4(qs + j * 16 + hh * 4);
+                    const float4 dj = ld4(dos + j * 16 + hh * 4);
+                    const float sc = fmaf(qj.w, s.kk[hh * 4 + 3], fmaf(qj.z, s.kk[hh * 4 + 2], fmaf(qj.y, s.kk[hh * 4 + 1], qj.x * s.kk[hh * 4])));
+                    const float P = expf(sc - st[j * 12 + hh]) / st[j * 12 + 4 + hh];
+                    const float dP = dj.x * s.vv[hh * 4] + dj.y * s.vv[hh * 4 + 1] + dj.z * s.vv[hh * 4 + 2] + dj.w * s.vv[hh * 4 + 3];
+                    const float dS = P * (dP - st[j * 12 + 8 + hh]);
+                    // rows whose ray is invalid carry do = 0 and D = 0: dS = 0, no contribution
+                    k0 = fmaf(dS, qj.x, k0); k1 = fmaf(dS, qj.y, k1); k2 = fmaf(dS, qj.z, k2); k3 = fmaf(dS, qj.w, k3);
+                    v0 = fmaf(P, dj.x, v0); v1 = fmaf(P, dj.y, v1); v2 = fmaf(P, dj.z, v2); v3 = fmaf(P, dj.w, v3);
+                }
+                dk[hh * 4] = k0; dk[hh * 4 + 1] = k1; dk[hh * 4 + 2] = k2; dk[hh * 4 + 3] = k3;
+                dv[hh * 4] = v0; dv[hh * 4 + 1] = v1; dv[hh * 4 + 2] = v2; dv[hh * 4 + 3] = v3;
+            }
+            wave_outer_add(WA + RW_WQ, dq[ch], s.G, s.act, lane, tA, tB);
+            wave_outer_add(WA + RW_WK, dk, s.G, s.act, lane, tA, tB);
+            wave_outer_add(WA + RW_WV, dv, s.G, s.act, lane, tA, tB);
+            float gq[16], gk[16], gv[16];
+            matvec16_t(RW + RW_WQ, dq[ch], gq);
+            matvec16_t(RW + RW_WK, dk, gk);
+            matvec16_t(RW + RW_WV, dv, gv);
+            if (s.act) {
+                float* out = p.d_point_rec + ((size_t)ray * dn + s.i) * kPointRec;
+                NR_PRAGMA_UNROLL
+                for (int k4 = 0; k4 < 4; ++k4)
+                    *reinterpret_cast<float4*>(out + 4 * k4) =
+                        make_float4(dyk[ch][4 * k4] + gq[4 * k4] + gk[4 * k4] + gv[4 * k4], dyk[ch][4 * k4 + 1] + gq[4 * k4 + 1] + gk[4 * k4 + 1] + gv[4 * k4 + 1],
+                                    dyk[ch][4 * k4 + 2] + gq[4 * k4 + 2] + gk[4 * k4 + 2] + gv[4 * k4 + 2], dyk[ch][4 * k4 + 3] + gq[4 * k4 + 3] + gk[4 * k4 + 3] + gv[4 * k4 + 3]);
+                *reinterpret_cast<float4*>(out + 16) = make_float4(s.hit * gp0, s.hit * gp1, s.hit * gp2, 0.0f);
+            }
         }
         __syncthreads();
     }

@@ -38,7 +38,7 @@ def ray_part_torch(w, g, colors, nvalid, depth):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('rn,dn,with_aux', [(5, 16, True), (9, 64, False), (3, 7, True)])
+@pytest.mark.parametrize('rn,dn,with_aux', [(5, 16, True), (9, 64, False), (3, 7, True), (3, 128, True), (5, 96, False), (2, 65, True)])
 def test_rays_backward_matches_autograd(rn, dn, with_aux, backend):
     from neuray_amd.engine import RenderEngine
     dev = 'cpu' if backend == 'emu' else 'cuda:0'
@@ -85,9 +85,9 @@ def test_rays_backward_rejects_long_rays(backend):
     dev = 'cpu' if backend == 'emu' else 'cuda:0'
     eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
     packed = eng.pack_pass(load_weights(False), 'dist_decoder.', 'agg_net.')
-    z = torch.zeros(1, 65, 20, device=dev)
-    with pytest.raises(RuntimeError, match='dn=65'):
-        eng.render_rays_backward(z, torch.ones(1, 65, device=dev), packed, torch.zeros(1, 3, device=dev))
+    z = torch.zeros(1, 129, 20, device=dev)
+    with pytest.raises(RuntimeError, match='dn=129'):
+        eng.render_rays_backward(z, torch.ones(1, 129, device=dev), packed, torch.zeros(1, 3, device=dev))
 
 
 # ---- whole pass: ray backward chained into the point backward, against autograd of the eager port -----------------
@@ -282,3 +282,49 @@ def test_adam_steps_reduce_the_render_loss(backend):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.9 * losses[0], losses
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_training_with_fine_depth_use_all(backend):
+    """fine_depth_use_all (renderer.py:210-213): the fine pass renders the 64 coarse + 64 fine depths merged = 128 samples per
+    ray; forward and backward kernels (two samples per lane in the ray kernels) against autograd of the eager port with the
+    same uniforms."""
+    from neuray_amd.network.renderer import NeuralRayBaseRenderer
+    from neuray_amd import synthetic
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'fine_depth_use_all': True,
+           'fine_agg_net_cfg': {'sample_num': 128}}
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    r = NeuralRayBaseRenderer(cfg)
+    weights = load_weights(False)
+    r.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    r.train()
+    if backend == 'emu':
+        r._engine_test_lib = emu_lib()
+    r = r.to(dev)
+    que, ref = synthetic.make_scene(48, 64, 2, seed=8)
+    rng = np.random.RandomState(9)
+    que['coords'] = (rng.rand(1, 5, 2) * np.array([63, 47])).astype(np.float32)
+    tq = {k: torch.from_numpy(v).to(dev) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v).to(dev) for k, v in ref.items()}
+    tr['ray_feats'].requires_grad_(True)
+    lw = torch.from_numpy(rng.randn(1, 5, 3).astype(np.float32))
+    torch.manual_seed(77)
+    u = torch.rand(1, 5, 64)
+    torch.manual_seed(77)
+    out = r.render_impl(tq, tr, True)
+    assert out['hit_prob_nr_fine'].shape == (1, 5, 128)
+    (out['pixel_colors_nr_fine'] * lw.to(dev)).sum().backward()
+    w = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in weights.items()}
+    cq = {k: torch.from_numpy(v) for k, v in que.items()}
+    cr = {k: torch.from_numpy(v.copy()) for k, v in ref.items()}
+    cr['ray_feats'].requires_grad_(True)
+    ocfg = {'depth_sample_num': 64, 'fine_depth_sample_num': 64, **cfg, 'coarse_use_vis': False, 'fine_use_vis': True}
+    want = tep.render_impl(w, ocfg, cq, cr, is_train=True, u=u)
+    assert np.abs(out['pixel_colors_nr_fine'].detach().cpu().numpy() - want['pixel_colors_nr_fine'].detach().numpy()).max() <= 5e-4
+    (want['pixel_colors_nr_fine'] * lw).sum().backward()
+    for k, p_ in r.named_parameters():
+        if k.startswith('fine_'):
+            g = w[k].grad.numpy() if w[k].grad is not None else np.zeros(tuple(p_.shape), np.float32)
+            assert np.abs(p_.grad.cpu().numpy() - g).max() <= 1e-2 * max(1e-3, float(np.abs(g).max())), k
+    g = cr['ray_feats'].grad.numpy()
+    assert np.abs(tr['ray_feats'].grad.cpu().numpy() - g).max() <= 1e-2 * float(np.abs(g).max())

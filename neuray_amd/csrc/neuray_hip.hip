@@ -54,7 +54,6 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
     // persistent-style grid: enough workgroups to fill 256 CUs several times over, grid-stride beyond
     int grid = grid_for(npts, 16 * NT, 256 * 16);
-    if (const char* e = getenv("NEURAY_MAX_GRID")) grid = grid < atoi(e) ? grid : atoi(e);   // test knob: force grid-stride
     grid = (grid + 7) / 8 * 8;                         // the XCD-aware tile map needs a multiple of 8
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")
@@ -165,11 +164,8 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev;
     p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
     p.use_vis = a->use_vis; p.var_bias = a->var_bias;
-    p.stagger_groups = getenv("NEURAY_STAGGER") ? atoi(getenv("NEURAY_STAGGER")) : 0;      // tuning knobs
-    p.stagger_units = getenv("NEURAY_STAGGER_UNITS") ? atoi(getenv("NEURAY_STAGGER_UNITS")) : 6;
     // work decomposition: reference views processed per wave (0 = default)
     int vpw = a->views_per_wave ? a->views_per_wave : (a->rfn >= 2 ? 2 : 1);
-    if (const char* e = getenv("NEURAY_VPW")) vpw = atoi(e);     // tuning / test knob
     // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
     // reference-view path when the coarse decoder has use_vis = False: quirk A.9.2)
     const bool vis = a->has_vis_head && a->use_vis;
@@ -342,7 +338,6 @@ namespace {
 int points_bwd_grid(int npoints, int vp) {
     const int ppw = 64 / vp;
     int cap = 4096;                               // 4096 x 230 KB of arena; four waves per SIMD
-    if (const char* e = getenv("NEURAY_BWD_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;     // tuning knob
     return grid_for(npoints, ppw, cap);
 }
 int pow2_at_least(int n) { int v = 1; while (v < n) v <<= 1; return v; }

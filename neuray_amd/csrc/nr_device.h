@@ -19,21 +19,8 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
 // activations (PyTorch semantics: ELU alpha=1 via exp(x)-1, Softplus beta=1 threshold=20)
 // ---------------------------------------------------------------------------------------------
 // Built on the hardware exp2/log2/rcp (about 1 ulp each): absolute error ~1e-7 per activation, two orders of
-// magnitude inside the fp32 parity tolerance (tests/test_render_parity.py), at 5 VALU instructions per ELU instead
+// magnitude inside the fp32 parity tolerance (tests/test_render_parity.py), at 3-4 VALU instructions per ELU instead
 // of ~18 for the libm-exact expf (the precise forms made the point kernel VALU-bound: 10.8 VALU per MFMA).
-#ifdef NR_PRECISE_MATH
-__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
-__device__ __forceinline__ float elu_s(float x) { return x > 0.0f ? x : (float)kLog2e * expm1f(x * 0.693147180559945309f); }
-__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
-#elif defined(NR_ABLATE) && (NR_ABLATE & 2)
-__device__ __forceinline__ float elu(float x) { return x; }
-__device__ __forceinline__ float elu_s(float x) { return x; }
-__device__ __forceinline__ float softplus(float x) { return x; }
-__device__ __forceinline__ float sigmoidf(float x) { return x; }
-__device__ __forceinline__ float tanh_(float x) { return x; }
-#else
 // ELU(x) = median(x, exp(x) - 1, 0): for x > 0 the order is 0 < x <= exp(x)-1, for x < 0 it is x < exp(x)-1 < 0, so one
 // v_med3_f32 replaces the compare + select (4 instead of 5 VALU per activation; +inf from exp overflow is harmless)
 __device__ __forceinline__ float elu(float x) { return nr_med3(x, nr_fast_exp(x) - 1.0f, 0.0f); }
@@ -47,7 +34,6 @@ __device__ __forceinline__ float sigmoidf(float x) { return nr_fast_rcp(1.0f + n
 __device__ __forceinline__ float tanh_(float x) {   // 1 - 2/(exp(2x)+1); saturates cleanly to +-1
     return 1.0f - 2.0f * nr_fast_rcp(nr_fast_exp(2.0f * x) + 1.0f);
 }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // a1  coarse depth sample i of dn, uniform in inverse depth       network/render_ops.py:146-170
@@ -187,27 +173,12 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_fu
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// weight-fragment / map loads (separate entry points so that timing ablations can stub one class)
-__device__ __forceinline__ float4 wld4(nr_wbuf W, int voff, int soff) {
-#if defined(NR_ABLATE) && (NR_ABLATE & 4)
-    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
-#else
-    return nr_buf_ld4(W, voff, soff);
-#endif
-}
-__device__ __forceinline__ float wld1(nr_wbuf W, int voff, int soff) {
-#if defined(NR_ABLATE) && (NR_ABLATE & 4)
-    return 1e-3f * voff;
-#else
-    return nr_buf_ld1(W, voff, soff);
-#endif
-}
+// weight-fragment / map loads
+__device__ __forceinline__ float4 wld4(nr_wbuf W, int voff, int soff) { return nr_buf_ld4(W, voff, soff); }
+__device__ __forceinline__ float wld1(nr_wbuf W, int voff, int soff) { return nr_buf_ld1(W, voff, soff); }
 // a staged phase of the packed weights in LDS: same byte offsets as the global buffer, rebased to the phase start
 struct LdsW { const float* base; int begin_bytes; };
 __device__ __forceinline__ float4 wld4(LdsW w, int voff, int soff) {
-#if defined(NR_ABLATE) && (NR_ABLATE & 32)
-    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
-#endif
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
 }
 __device__ __forceinline__ float2 wld2(nr_wbuf W, int voff, int soff) { return nr_buf_ld2(W, voff, soff); }
@@ -226,13 +197,7 @@ template <class WS> __device__ __forceinline__ float4 wldq(WS W, int voff, int s
     return wld4(W, voff, soff);
 #endif
 }
-__device__ __forceinline__ float4 mld4(nr_mbuf M, int voff, int soff) {
-#if defined(NR_ABLATE) && (NR_ABLATE & 16)
-    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
-#else
-    return nr_buf_ld4(M, voff, soff);
-#endif
-}
+__device__ __forceinline__ float4 mld4(nr_mbuf M, int voff, int soff) { return nr_buf_ld4(M, voff, soff); }
 
 __device__ __forceinline__ float blend4(float a, float b, float c, float d, const Taps& t) {
     return fmaf(d, t.w11, fmaf(c, t.w01, fmaf(b, t.w10, a * t.w00)));
@@ -354,11 +319,6 @@ __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (
     for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.z, xq[t][4 * kq + 2], acc[t]);
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
-#if defined(NR_EXTRA_MFMA) && !defined(NEURAY_EMU)          // marginal-cost probe: NR_EXTRA_MFMA dummy MFMAs per quad
-    v4f dacc = {0.f, 0.f, 0.f, 0.f};
-    for (int e_ = 0; e_ < NR_EXTRA_MFMA; ++e_)
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(dacc) : "v"(a.x), "v"(xq[0][4 * kq]));
-#endif
 }
 
 // accumulate a K-slice (quads [KQ0, KQ0+KQN), singles [K10, K10+K1N)) of output tile `mo` (may be a runtime value)
@@ -513,7 +473,6 @@ template <int A, int L> __device__ __forceinline__ float apply_act(float x) {
 // two activations at a time: the multiply-add around the exponentials is one packed instruction for the pair (bitwise the
 // scalar result); exp2 and med3 have no packed form
 template <int A, int L> __device__ __forceinline__ void apply_act2(float x0, float x1, float& y0, float& y1) {
-#if !defined(NR_PRECISE_MATH) && !(defined(NR_ABLATE) && (NR_ABLATE & 2))
     if (A == ACT_ELU) {
         if (kOutScaled[L]) {       // L(2^x - 1)
             const nr_v2 f = nr_v2_fma(nr_v2_make(nr_fast_exp2(x0), nr_fast_exp2(x1)), nr_v2_make((float)kLog2e, (float)kLog2e),
@@ -522,7 +481,6 @@ template <int A, int L> __device__ __forceinline__ void apply_act2(float x0, flo
             return;
         }
     }
-#endif
     y0 = apply_act<A, L>(x0); y1 = apply_act<A, L>(x1);
 }
 
@@ -533,7 +491,6 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre<L>& pre
                                           const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4], PN& next) {
     constexpr int MT = kShape[L].mt_out;
     v4f acc[NT][MT];
-    NR_SCHED_FENCE();
     NR_PRAGMA_UNROLL
     for (int mo = 0; mo < MT; ++mo)
         NR_PRAGMA_UNROLL
@@ -541,7 +498,6 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre<L>& pre
             acc[t][mo][0] = pre.b[mo].x; acc[t][mo][1] = pre.b[mo].y; acc[t][mo][2] = pre.b[mo].z; acc[t][mo][3] = pre.b[mo].w;
         }
     layer_acc<L, NT>(W, lane, pre, xq, x1, acc, next);
-    NR_SCHED_FENCE();
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t)
         NR_PRAGMA_UNROLL
@@ -549,10 +505,6 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre<L>& pre
             NR_PRAGMA_UNROLL
             for (int r = 0; r < 4; r += 2) {
                 apply_act2<A, L>(acc[t][mo][r], acc[t][mo][r + 1], y[t][4 * mo + r], y[t][4 * mo + r + 1]);
-#if defined(NR_EXTRA_VALU) && !defined(NEURAY_EMU)      // marginal-cost probe: NR_EXTRA_VALU dummy VALU ops per output register
-                float dummy = y[t][4 * mo + r];
-                for (int e_ = 0; e_ < 2 * NR_EXTRA_VALU; ++e_) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(dummy));
-#endif
             }
 }
 
@@ -606,9 +558,6 @@ template <int OP, int MAXSTRIDE> __device__ __forceinline__ float red_combine(fl
 template <int R, int RMAX, int OP, int MAXSTRIDE = 1>
 __device__ __forceinline__ void block_allreduce(float (&v)[R], float* red, int wave, int nw, int lane) {
     static_assert(R <= RMAX, "allreduce scratch too small");
-#if defined(NR_ABLATE) && (NR_ABLATE & 1)
-    return;
-#endif
     NR_PRIO_HI();
     NR_PRAGMA_UNROLL
     for (int r = 0; r < R; ++r) red[(wave * RMAX + r) * 64 + lane] = v[r];

@@ -95,8 +95,6 @@ struct PointParams {
     int rfn, rn, dn, h, w, fh, fw;
     int use_vis;               // the COARSE decoder's use_vis governs compute_prob in both passes (renderer.py:75)
     float var_bias;            // AddBias value of var_decoder (dist_decoder.py:81)
-    int stagger_groups;        // >1: delay workgroup start by (blockIdx/256 % groups) * stagger_units sleeps
-    int stagger_units;
 };
 
 constexpr int kDbgFields = 16;
@@ -179,15 +177,6 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     const int dn = p.dn;
     const bool use_vis = p.use_vis != 0;
     const bool dbg_lane = (p.dbg != nullptr) && (g == 0);
-#ifndef NEURAY_EMU
-    // de-phase the workgroups that share a CU: identical work + simultaneous start would keep their memory phases
-    // and MFMA phases aligned for the whole launch, so the matrix pipe idles while everybody loads
-    if (p.stagger_groups > 1) {
-        const int d = (int)((blockIdx.x / 256) % p.stagger_groups) * p.stagger_units;
-        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-
     // XCD-aware tile map: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Giving every
     // XCD a contiguous run of tiles keeps the texels that neighbouring samples / rays share inside one private L2
     // instead of fetching them into all eight (the grid is a multiple of 8).

@@ -97,12 +97,6 @@ static inline void nr_dma16(nr_buf b, float* lds_wave_base, int lane, int voff, 
     memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, b.p + voff + soff, 16);
 }
 #else
-// pointer-based variant (debug A/B): same interface, plain global loads
-struct nr_pbuf { const char* p; };
-__device__ __forceinline__ nr_pbuf nr_make_pbuf(const float* p, size_t) { return nr_pbuf{(const char*)p}; }
-__device__ __forceinline__ float4 nr_buf_ld4(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
-__device__ __forceinline__ float nr_buf_ld1(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
-__device__ __forceinline__ float2 nr_buf_ld2(nr_pbuf b, int voff, int soff) { return *reinterpret_cast<const float2*>(b.p + voff + soff); }
 struct nr_buf { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ nr_buf nr_make_buf(const float* p, size_t bytes) {
     nr_buf b;
@@ -110,9 +104,6 @@ __device__ __forceinline__ nr_buf nr_make_buf(const float* p, size_t bytes) {
     return b;
 }
 __device__ __forceinline__ float4 nr_buf_ld4(nr_buf b, int voff, int soff) {
-#if defined(NR_ABLATE) && (NR_ABLATE & 8)
-    return make_float4(1e-3f * voff, 2e-3f, 3e-3f, 4e-3f);
-#endif
     // NOTE: cast the WHOLE vector.  Element-wise `__builtin_bit_cast(float, u.x)` on the builtin's result makes
     // hipcc (ROCm 7.2) narrow the load to buffer_load_dword and replicate .x into y/z/w (tests/hw/bufprobe.hip).
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -136,31 +127,12 @@ __device__ __forceinline__ float2 nr_buf_ld2(nr_buf b, int voff, int soff) {    
 __device__ __forceinline__ void nr_dma16(nr_buf b, float* lds_wave_base, int /*lane*/, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
-__device__ __forceinline__ void nr_dma16(nr_pbuf b, float* lds_wave_base, int lane, int voff, int soff) {   // debug A/B
-    *reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_wave_base) + lane * 16) = *reinterpret_cast<const float4*>(b.p + voff + soff);
-}
 #endif
 
-#if defined(NEURAY_EMU)
-typedef nr_buf nr_wbuf; typedef nr_buf nr_mbuf;
+typedef nr_buf nr_wbuf;      // packed weights
+typedef nr_buf nr_mbuf;      // feature / colour maps
 #define nr_make_wbuf nr_make_buf
 #define nr_make_mbuf nr_make_buf
-#else
-#ifdef NR_PTR_WEIGHTS
-typedef nr_pbuf nr_wbuf;
-#define nr_make_wbuf nr_make_pbuf
-#else
-typedef nr_buf nr_wbuf;
-#define nr_make_wbuf nr_make_buf
-#endif
-#ifdef NR_PTR_MAPS
-typedef nr_pbuf nr_mbuf;
-#define nr_make_mbuf nr_make_pbuf
-#else
-typedef nr_buf nr_mbuf;
-#define nr_make_mbuf nr_make_buf
-#endif
-#endif
 
 // a zero the compiler cannot see through, in a VGPR: `base + nr_opaque_zero()` keeps LDS reads of workgroup-uniform data
 // on one address register + immediate offsets (otherwise hipcc materialises every uniform address in an SGPR, copies
@@ -179,8 +151,8 @@ __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32
 #define NR_KEEP(x) asm volatile("" : "+v"(x))
 #endif
 
-// wave priority around the short, latency-critical all-reduce sections (+0.2 %; -DNR_NO_PRIO turns it off)
-#if !defined(NR_NO_PRIO) && !defined(NEURAY_EMU)
+// wave priority around the short, latency-critical all-reduce sections (+0.2 %)
+#if !defined(NEURAY_EMU)
 #define NR_PRIO_HI() __builtin_amdgcn_s_setprio(3)
 #define NR_PRIO_LO() __builtin_amdgcn_s_setprio(0)
 #else
@@ -195,24 +167,8 @@ __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32
 #define NR_PIN() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-// scheduling fence: keeps hipcc from hoisting the next layers' weight-fragment loads across layer boundaries (it
-// otherwise clusters loads until it overshoots the VGPR budget and spills)
-#ifdef NEURAY_EMU
-#define NR_SCHED_FENCE() do {} while (0)
-#else
-#ifdef NR_LAYER_FENCE
-#define NR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define NR_SCHED_FENCE() do {} while (0)
-#endif
-#endif
-
-// workgroup barrier of the point kernel (timing probe NR_ABLATE & 128: compiler fence only, results are garbage)
-#if defined(NR_ABLATE) && (NR_ABLATE & 128)
-#define NR_BLOCK_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
-#else
+// workgroup barrier of the point kernel
 #define NR_BLOCK_SYNC() __syncthreads()
-#endif
 
 // fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32: ~1 ulp each)
 #ifdef NEURAY_EMU

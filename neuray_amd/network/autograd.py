@@ -21,6 +21,10 @@ class PassRun:
             self.dist._neuray_named = hit
         return hit[1]
 
+    def dist_params(self):
+        """the dist decoder's parameters only (the self-hit path of renderer.py:137-155 does not touch the aggregation net)"""
+        return [(k, v) for k, v in self.named_params() if k.startswith('d.')]
+
     def state(self):
         return dict(self.named_params())       # only keys and shapes are used (unflatten_pass_grads)
 
@@ -69,12 +73,14 @@ class RenderPassFn(torch.autograd.Function):
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g
-        return (None, d_rf.permute(0, 3, 1, 2).contiguous(), d_if.permute(0, 3, 1, 2).contiguous()) + \
+        # (the NHWC gradient buffers viewed as NCHW = channels-last tensors: what the channels-last encoders' backward wants,
+        # and no relayout pass here)
+        return (None, d_rf.permute(0, 3, 1, 2), d_if.permute(0, 3, 1, 2)) + \
             tuple(grads[k] for k, _ in run.named_params())      # views of one buffer: no per-parameter copies
 
 
 class SelfHitFn(torch.autograd.Function):
-    """(que ray_feats NCHW [1,32,fh,fw], *dist params) -> hit_prob_self [rn,dn]   (renderer.py:137-155)"""
+    """(que ray_feats NCHW [1,32,fh,fw], *run.dist_params()) -> hit_prob_self [rn,dn]   (renderer.py:137-155)"""
 
     @staticmethod
     def forward(ctx, run, h, w, que_ray_feats, *params):
@@ -98,4 +104,4 @@ class SelfHitFn(torch.autograd.Function):
                                                      d_hit.contiguous(), var_bias=run.var_bias)
         d_map = eng.interpolate_feats_backward(d_feats[None], ctx.shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
-        return (None, None, None, d_map) + tuple(grads[k] for k, _ in run.named_params())
+        return (None, None, None, d_map) + tuple(grads[k] for k, _ in run.dist_params())

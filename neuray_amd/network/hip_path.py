@@ -124,7 +124,7 @@ class HipRenderPath:
         if torch.is_grad_enabled() and (que_imgs_info['ray_feats'].requires_grad or any(p.requires_grad for p in dec.parameters())):
             srun = PassRun(eng, qconst, None, coords[0].contiguous(), que_depth[0].detach().contiguous(), dec, agg,
                            dec.cfg['use_vis'], dec.cfg['bias_val'], 0, 0, False)
-            return SelfHitFn.apply(srun, h, w, que_imgs_info['ray_feats'], *[p for _, p in srun.named_params()])[None]
+            return SelfHitFn.apply(srun, h, w, que_imgs_info['ray_feats'], *[p for _, p in srun.dist_params()])[None]
         feats = eng.interpolate_feats(que_imgs_info['ray_feats'], coords, h, w, align_corners=False)      # [1,rn,32]
         mean, var, vis, aw = eng.dist_decoder_rows(feats[0], packed if packed is not None else self._packed_pass(eng, is_fine),
                                                    dec.cfg['bias_val'])

@@ -22,7 +22,8 @@ the reference tree itself does not exist on the GPU box) on the host with torch.
 bounded sample of the same workload.  At N = 1 side measurements ride along (reported baselines, not the metric):
 `eager_torch_baseline` (the same port on the same GPU - the stand-in for "the reference on stock PyTorch-ROCm"),
 `numpy_oracle` (parity of the rendered image against the numpy oracle + its speed), `extra` (64+64 samples, the
-reference CLI's 4096-ray batches), `training_step`, `init_net`, `bf16_variant`.  These legs are the only places this
+reference CLI's 4096-ray batches), `training_step`, `init_net`, `pipeline_pcie_inclusive` (host buffers in, uint8 image
+out), `bf16_variant`.  These legs are the only places this
 file touches oracle/.
 
 `--emulator-lib PATH` is a TEST HOOK (tests/test_bench_launcher.py): the same code path - launcher, process group,
@@ -342,6 +343,38 @@ def init_net_timing(device, reps=10):
     return res
 
 
+def pipeline_timing(device, fdn, poses=3, views=16):
+    """Side measurement: host buffers in -> uint8 image out.  An in-memory scene with the reference's
+    database accessors (uint8 images, masks, depth maps on the HOST), render.py's loop through neuray_amd.pipeline: working
+    views by camera distance, uint8 upload of each view once (DeviceViewCache), depth init net + encoders + the 64+fdn render
+    path, quantisation on the GPU, uint8 copy back.  PCIe-inclusive rays/s: first pass (every working view uploaded) and
+    resident pass."""
+    from neuray_amd import pipeline
+    from neuray_amd.network import renderer as R
+    db = synthetic.MemoryDatabase(views, H, W, seed=0)
+    gen = R.NeuralRayGenRenderer({'use_hierarchical_sampling': True, 'fine_depth_sample_num': fdn, 'fine_agg_net_cfg': {'sample_num': fdn},
+                                  'ray_batch_num': RAY_BATCH, 'init_net_type': 'depth', 'dist_decoder_cfg': {'use_vis': False}}).eval().to(device)
+    qposes = np.stack([synthetic.look_at_pose(synthetic.sphere_pos(4.03, 360.0 * (i + 0.37) / views, 27.0)) for i in range(poses)]).astype(np.float32)
+    ref_ids = pipeline.select_working_views_db(db, None, qposes, RFN, False)
+    K, shape, dr = [db.get_K(0)] * poses, [(H, W)] * poses, [(2.0, 6.0)] * poses
+    cache = pipeline.DeviceViewCache(db, device, pad_interval=16)
+    pipeline.render_poses(gen, db, qposes[:1], K[:1], shape[:1], dr[:1], ref_ids[:1], save_fn=lambda qi, im: None)     # warm-up (MIOpen search)
+
+    def timed():
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        pipeline.render_poses(gen, db, qposes, K, shape, dr, ref_ids, cache=cache, save_fn=lambda qi, im: None)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    t_first = timed()
+    up = cache.uploaded_bytes
+    t_warm = timed()
+    return {'what': 'host uint8 views in -> uint8 image out: depth init net + encoders + 64+%d render, %d working views of a %d-view %dx%d scene, %d poses'
+                    % (fdn, RFN, views, H, W, poses),
+            'first_pass_rays_per_s': poses * H * W / t_first, 'h2d_MB_per_image_first_pass': up / poses / 1e6,
+            'resident_rays_per_s': poses * H * W / t_warm, 'd2h_MB_per_image': H * W * 3 / 1e6}
+
+
 def side(fn, *a, **k):
     """a side measurement must never cost the headline line: report its failure instead"""
     try:
@@ -611,6 +644,7 @@ def main(argv=None):
             }
             line['training_step'] = side(training_step_timing, device)
             line['init_net'] = side(init_net_timing, device)
+            line['pipeline_pcie_inclusive'] = side(pipeline_timing, device, args.fine_samples)
             line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
         print(json.dumps(line))
         sys.stdout.flush()

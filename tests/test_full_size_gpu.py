@@ -74,10 +74,16 @@ def test_sample_against_oracle(full_render):
     assert np.abs(got['pixel_colors_nr'].cpu().numpy() - want['pixel_colors_nr_fine']).max() <= 2e-4
     assert np.abs(got['hit_prob_nr'].cpu().numpy() - want['hit_prob_nr_fine']).max() <= 1e-4
     assert np.array_equal(got['ray_mask'].cpu().numpy(), want['ray_mask_fine'])
-    # (4) chained end to end: statistical
+    # (4) chained end to end: statistical.  The few displaced fine samples of DESIGN.md 2.4 dominate the PSNR of a small sample
+    # (white-noise images / features are the pathological input for them), so the gate is taken on 8192 strided rays, where
+    # bench.py measures 99.7 % within 2e-4 and 75.5 dB: BASELINE.md B4's 60 dB with margin.
     err = np.abs(out['pixel_colors_nr_fine'][:, idx] - want['pixel_colors_nr_fine']).max(-1)
     assert np.mean(err <= 2e-4) >= 0.97, np.mean(err <= 2e-4)
-    # white-noise images/features make this scene maximally sensitive to those few displaced samples: the oracle
-    # against itself with 4e-6 noise on the coarse hit_prob scores 58.6 dB here, so the chained bound is 50 dB
-    # (stage (3) above is the tight check; smooth real images are far less sensitive)
-    assert orc.psnr_uint8(out['pixel_colors_nr_fine'][:, idx], want['pixel_colors_nr_fine']) >= 50.0
+    idx8 = np.linspace(0, 800 * 800 - 1, 8192).astype(np.int64)
+    q8 = dict(que)
+    q8['coords'] = que['coords'][:, idx8]
+    want8 = np.concatenate([orc.render_impl(weights, ocfg, dict(q8, coords=q8['coords'][:, i:i + 1024]), ref)['pixel_colors_nr_fine']
+                            for i in range(0, 8192, 1024)], 1)
+    err8 = np.abs(out['pixel_colors_nr_fine'][:, idx8] - want8).max(-1)
+    psnr = orc.psnr_uint8(out['pixel_colors_nr_fine'][:, idx8], want8)
+    assert np.mean(err8 <= 2e-4) >= 0.99 and psnr >= 60.0, (float(np.mean(err8 <= 2e-4)), psnr)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 2
+#define NEURAY_ABI_VERSION 3
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -206,6 +206,13 @@ int neuray_self_hit_prob_backward(const float* query_const_dev, const float* dep
                                   const float* flat_weights_dev, int has_vis_head, int use_vis, float var_bias,
                                   const float* d_hit_dev, int rn, int dn, float* d_feats_dev, float* d_flat_weights_dev,
                                   float* workspace_dev, void* stream);
+/* The same on the resident scheme of neuray_render_points_backward (one wave per 16 rays, decoder in registers on the packed and
+ * transposed packs, no workspace): packed_weights_dev [neuray_packed_pass_floats()], packed_t_weights_dev
+ * [neuray_packed_t_floats()].  Not in the bf16-operand build. */
+int neuray_self_hit_prob_backward_resident(const float* query_const_dev, const float* depth_dev, const float* feats_dev,
+                                           const float* packed_weights_dev, const float* packed_t_weights_dev, int has_vis_head,
+                                           int use_vis, float var_bias, const float* d_hit_dev, int rn, int dn, float* d_feats_dev,
+                                           float* d_flat_weights_dev, void* stream);
 /* ---- backward of neuray_dist_decoder_rows: gradients w.r.t. the decoder outputs (any of d_mean [n][2], d_var [n][2],
  * d_aw [n], d_vis [n] may be NULL) -> d_feats [n][32]; d_flat (flat natural layout) ACCUMULATED.  workspace:
  * neuray_self_hit_backward_workspace_floats(n) floats. */

@@ -205,7 +205,7 @@ int neuray_sample_fine_depth(const float* query_const, const float* depth, const
 int neuray_interpolate_feats(const float* feats, const float* points, const float* mask, int b, int n, int c, int fh, int fw,
                              int h_full, int w_full, int align_corners, float* out, void* stream) {
     if (b < 1 || n < 1 || c < 1) return fail("neuray_interpolate_feats: bad shape b=%d n=%d c=%d", b, n, c);
-    const int grid = grid_for((long long)b * n, 256, 256 * 8);
+    const int grid = grid_for((long long)b * n * c, 256, 256 * 8);
     NR_LAUNCH(nr::interpolate_kernel, dim3(grid), dim3(256), 0, stream, feats, points, mask, b, n, c, fh, fw, h_full, w_full,
               align_corners, out);
     return check_launch("neuray_interpolate_feats");
@@ -416,6 +416,25 @@ int neuray_self_hit_prob_backward(const float* qc, const float* depth, const flo
     return check_launch("neuray_self_hit_prob_backward");
 }
 
+int neuray_self_hit_prob_backward_resident(const float* qc, const float* depth, const float* feats, const float* packed, const float* packed_t,
+                                           int has_vis_head, int use_vis, float var_bias, const float* d_hit, int rn, int dn,
+                                           float* d_feats, float* d_flat, void* stream) {
+#ifdef NR_BF16_QUADS
+    return fail("neuray_self_hit_prob_backward_resident: the bf16-operand variant is inference only");
+#else
+    if (!qc || !depth || !feats || !packed || !packed_t || !d_hit || !d_feats || !d_flat)
+        return fail("neuray_self_hit_prob_backward_resident: null argument");
+    if (rn < 1 || dn < 3 || dn > NEURAY_MAX_SAMPLES) return fail("neuray_self_hit_prob_backward_resident: rn=%d dn=%d", rn, dn);
+    nr::SelfHitBwd2Params p;
+    p.que_const = qc; p.depth = depth; p.feats = feats; p.weights = packed; p.weights_t = packed_t; p.d_hit = d_hit;
+    p.d_feats = d_feats; p.d_flat = d_flat; p.rn = rn; p.dn = dn; p.use_vis = use_vis; p.var_bias = var_bias;
+    const dim3 grid(grid_for(rn, 16, 2048));
+    if (has_vis_head) NR_LAUNCH(nr::self_hit_backward2_kernel<true>, grid, dim3(64), 0, stream, p);
+    else NR_LAUNCH(nr::self_hit_backward2_kernel<false>, grid, dim3(64), 0, stream, p);
+    return check_launch("neuray_self_hit_prob_backward_resident");
+#endif
+}
+
 int neuray_dist_decoder_rows_backward(const float* feats, const float* flat, int n, int has_vis_head, float var_bias,
                                       const float* d_mean, const float* d_var, const float* d_aw, const float* d_vis,
                                       float* d_feats, float* d_flat, float* workspace, void* stream) {
@@ -432,7 +451,7 @@ int neuray_interpolate_feats_backward(const float* d_out, const float* points, c
                                       int fw, int h_full, int w_full, int align_corners, float* d_feats, void* stream) {
     if (!d_out || !points || !d_feats) return fail("neuray_interpolate_feats_backward: null argument");
     if (b < 1 || n < 1 || c < 1 || fh < 1 || fw < 1) return fail("neuray_interpolate_feats_backward: bad shape");
-    NR_LAUNCH(nr::interpolate_backward_kernel, dim3(grid_for((long long)b * n, 256, 4096)), dim3(256), 0, stream, d_out, points,
+    NR_LAUNCH(nr::interpolate_backward_kernel, dim3(grid_for((long long)b * n * c, 256, 4096)), dim3(256), 0, stream, d_out, points,
               mask, b, n, c, fh, fw, h_full, w_full, align_corners, d_feats);
     return check_launch("neuray_interpolate_feats_backward");
 }
@@ -441,5 +460,17 @@ int neuray_group_sum_selftest(const float* x, float* y, void* stream) {
     NR_LAUNCH(nr::group_sum_selftest_kernel, dim3(1), dim3(64), 0, stream, x, y);
     return check_launch("neuray_group_sum_selftest");
 }
+
+#ifdef NR_B2_PROFILE
+// profile build only (tools/profile_bwd2.py): read (and optionally clear) the per-mark cycle sums of points_backward2_kernel
+int neuray_debug_b2_profile(unsigned long long* out, int clear) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(nr::nr_b2_prof), sizeof(unsigned long long) * nr::kB2Marks * 8) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zeros[nr::kB2Marks * 8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nr::nr_b2_prof), zeros, sizeof(zeros)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 }  // extern "C"

@@ -1138,8 +1138,11 @@ __global__ void __launch_bounds__(256) diff_feats_kernel(DiffFeatsParams p) {
 __global__ void interpolate_kernel(const float* __restrict__ feats, const float* __restrict__ points,
                                    const float* __restrict__ mask, int b, int n, int c, int fh, int fw,
                                    int h_full, int w_full, int align, float* __restrict__ out) {
-    const long long total = (long long)b * n;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // one thread per (point, channel): the training batches are a few hundred points, one thread per point left the GPU idle
+    const long long total = (long long)b * n * c;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / c;
+        const int ch = (int)(e - i * c);
         const int bi = (int)(i / n);
         const float u = points[2 * i], v = points[2 * i + 1];
         const float ix = texel_coord(u, (float)w_full, (float)fw, align != 0);
@@ -1155,11 +1158,8 @@ __global__ void interpolate_kernel(const float* __restrict__ feats, const float*
         if (x0 + 1 > fw - 1) { t.w10 = 0.0f; t.w11 = 0.0f; }
         if (y0 + 1 > fh - 1) { t.w01 = 0.0f; t.w11 = 0.0f; }
         const float m = mask ? mask[i] : 1.0f;
-        const float* f = feats + (size_t)bi * c * fh * fw;
-        for (int ch = 0; ch < c; ++ch) {
-            const float* pl = f + (size_t)ch * fh * fw;
-            out[i * c + ch] = blend4(pl[t.o00], pl[t.o10], pl[t.o01], pl[t.o11], t) * m;
-        }
+        const float* pl = feats + ((size_t)bi * c + ch) * fh * fw;
+        out[e] = blend4(pl[t.o00], pl[t.o10], pl[t.o01], pl[t.o11], t) * m;
     }
 }
 

@@ -1118,8 +1118,10 @@ __global__ void __launch_bounds__(64, 4) decoder_rows_backward_kernel(RowsBwdPar
 __global__ void interpolate_backward_kernel(const float* __restrict__ d_out, const float* __restrict__ points, const float* __restrict__ mask,
                                             int b, int n, int c, int fh, int fw, int h_full, int w_full, int align,
                                             float* __restrict__ d_feats) {
-    const long long total = (long long)b * n;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long total = (long long)b * n * c;          // one thread per (point, channel)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / c;
+        const int ch = (int)(e - i * c);
         const int bi = (int)(i / n);
         const float mk = mask ? mask[i] : 1.0f;
         if (mk == 0.0f) continue;
@@ -1128,12 +1130,10 @@ __global__ void interpolate_backward_kernel(const float* __restrict__ d_out, con
         const Taps t = taps_from(ix, iy, fw, fh);
         const int offs[4] = {t.o00, t.o10, t.o01, t.o11};
         const float wts[4] = {t.w00, t.w10, t.w01, t.w11};
-        float* dst = d_feats + (size_t)bi * c * fh * fw;
-        for (int ch = 0; ch < c; ++ch) {
-            const float g = d_out[i * c + ch] * mk;
-            for (int a = 0; a < 4; ++a)
-                if (wts[a] != 0.0f) atomicAdd(dst + (size_t)ch * fh * fw + offs[a], wts[a] * g);
-        }
+        float* dst = d_feats + ((size_t)bi * c + ch) * fh * fw;
+        const float g = d_out[e] * mk;
+        for (int a = 0; a < 4; ++a)
+            if (wts[a] != 0.0f) atomicAdd(dst + offs[a], wts[a] * g);
     }
 }
 

@@ -60,6 +60,20 @@ constexpr int kB2Hx = 44 * 64;
 constexpr int kB2Stage = kB2StageRows * kB2Stride;
 inline size_t point_bwd2_smem_bytes() { return sizeof(float) * (size_t)(kB2Red + kB2Xch + kB2Stash + kB2Hx + kB2Stage); }
 
+// ---- profile build (-DNR_B2_PROFILE, tools/profile_bwd2.py): cycles between consecutive marks, summed over the tiles of
+// workgroup 0, per wave.  Not compiled into the product library.
+#ifdef NR_B2_PROFILE
+constexpr int kB2Marks = 64;
+__device__ unsigned long long nr_b2_prof[kB2Marks * 8];
+#define B2_MARK(i) do { if (blockIdx.x == 0 && lane == 0) { const unsigned long long t_ = clock64(); nr_b2_prof[(i) * 8 + wave] += t_ - tprev_; tprev_ = t_; } } while (0)
+#define B2_MARK_ARGS , unsigned long long& tprev_
+#define B2_MARK_PASS , tprev_
+#else
+#define B2_MARK(i) do {} while (0)
+#define B2_MARK_ARGS
+#define B2_MARK_PASS
+#endif
+
 // ---- weight-gradient jobs -----------------------------------------------------------------------------------------
 // One entry per weight tensor (or column range of one): dW[O x K] = sum_columns dY X^T, as OT x KT tiles of 16 x 16.
 struct DwSpec { int tw, tb, ldw, col0, O, K; bool xscaled; bool per_point; };
@@ -273,10 +287,12 @@ __device__ __forceinline__ void b2_dist_fwd(nr_wbuf W, int lane, const float (&f
 template <int L1, int L2, int LF, int T1, int T2, int D4, int D2, int D0, int NOUT>
 __device__ __forceinline__ void b2_dist_head_bwd(nr_wbuf W, nr_wbuf WT, int wlane, int lane, int wave, int col, int g, const float (&fray)[1][8],
                                                  const float (&dout)[NOUT], float (&dfr)[8], float* S,
-                                                 v4f (&acc)[kDwAcc], float (&bacc)[kDwBiasAcc]) {
+                                                 v4f (&acc)[kDwAcc], float (&bacc)[kDwBiasAcc] B2_MARK_ARGS) {
     float none[1][1] = {{0.0f}}, h1[1][8], h2[1][8], dh2[1][8], dh1[1][8], dx[1][8];
+    B2_MARK(34);
     layer_fwd<L1, 1, ACT_ELU>(W, wlane, fray, none, h1);
     layer_fwd<L2, 1, ACT_ELU>(W, wlane, h1, none, h2);
+    B2_MARK(35);
     VecPre<LF> pf;
     layer_prefetch<LF>(W, wlane, pf);
     float dy[kVec[LF].n];
@@ -292,16 +308,21 @@ __device__ __forceinline__ void b2_dist_head_bwd(nr_wbuf W, nr_wbuf WT, int wlan
     NR_PRAGMA_UNROLL
     for (int k = 0; k < 8; ++k) dfr[k] += dx[0][k];
     // rows: 0 d out (16), 16 h2 (32), 48 d h2 (32), 80 h1 (32), 112 d h1 (32), 144 f_ray (32)
+    B2_MARK(36);
     __syncthreads();
+    B2_MARK(37);
     NR_PRAGMA_UNROLL
     for (int j = 0; j < NOUT; ++j) st_one(S, kB2Stride, j, dout[j], col, g);
     st_nat<8>(S, kB2Stride, 16, h2[0], col, g); st_nat<8>(S, kB2Stride, 48, dh2[0], col, g);
     st_nat<8>(S, kB2Stride, 80, h1[0], col, g); st_nat<8>(S, kB2Stride, 112, dh1[0], col, g);
     st_gat(S, kB2Stride, 144, fray[0], col, g);
+    B2_MARK(38);
     __syncthreads();
+    B2_MARK(39);
     dw_jobs<D4>(acc, bacc, S, 0, 16, wave, lane);
     dw_jobs<D2>(acc, bacc, S, 48, 80, wave, lane);
     dw_jobs<D0>(acc, bacc, S, 112, 144, wave, lane);
+    B2_MARK(40);
 }
 
 template <int... IDS>
@@ -351,6 +372,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
     for (int base = (int)blockIdx.x * 16; base < npts; base += (int)gridDim.x * 16) {
         const int glane = lane + nr_opaque_zero();
         const int gg = glane >> 4;
+#ifdef NR_B2_PROFILE
+        unsigned long long tprev_ = clock64();
+#endif
         // ================= geometry + gathers (as points_kernel) =================
         int pi = base + c;
         const bool pvalid = pi < npts;
@@ -384,9 +408,11 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             blend8(qi, tfs, mask, fimg);
             blend_rgb(qcl, tcs, mask, rgb);
         }
+        B2_MARK(0);
         // ================= forward (recomputed; checkpoints stay in registers) =================
         float mu0, mu1, s0, s1, aw, nu;
         b2_dist_fwd<HAS_VIS>(W, glane, fray, p.var_bias, mu0, mu1, s0, s1, aw, nu);
+        B2_MARK(1);
         const float nuu = use_vis ? nu : 1.0f;
         float vis, hit;
         {
@@ -423,6 +449,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             layer_vec<L_NF2, 1>(W, glane, h, o);
             sn = sigmoidf(o[0][0]);
         }
+        B2_MARK(2);
         // cross-view statistics (ibrnet.py:334-340), exactly as the first version computes them:
         //   weight = mask / (sum mask + 1e-8), weight0 = sn * weight; mean_k = sum_v w_k x, var_k = sum_v w_k (x - mean_k)^2
         float wv, w0, sa0, sa1;
@@ -463,6 +490,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             var0[11] = 0.0f; var1[11] = 0.0f;
             b2_allsum<kB2Rmax>(var0, red, wave, lane);
             b2_allsum<kB2Rmax>(var1, red, wave, lane);
+            B2_MARK(3);
             // base_fc.0 per-point part by the owner waves (output tile = wave, waves 0..3), statistics order [mean0 var0 mean1 var1]
             if (wave < 4) {
                 v4f accg[1];
@@ -489,6 +517,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             }
             __syncthreads();
         }
+        B2_MARK(4);
         // base_fc -> x;  h64 is recomputed in the backward from xch
         float x[1][8];
         auto base_hidden = [&](float (&h64)[1][16]) {
@@ -541,6 +570,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             layer_vec<L_RF3, 1>(W, glane, h8, o);
             z = mask > 0.0f ? o[0][0] : -1e9f;
         }
+        B2_MARK(5);
         // softmax blend weights, visibility-weighted statistics (ibrnet.py:350-354,366-367)
         float beta, svis, wh, swh, gmean[8], gvar[8];
         {
@@ -564,6 +594,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         }
         const float meanw = swh * inv_rfn;
 
+        B2_MARK(6);
         // ================= backward =================
         const float* up = p.d_point_rec + (size_t)pi * kPointRec;
         const float gsc = pvalid ? 1.0f : 0.0f;
@@ -585,23 +616,29 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
                 NR_PRAGMA_UNROLL
                 for (int r_ = 0; r_ < 4; ++r_) xg[(wave * 4 + r_) * 64 + lane] = elu_s(accf[0][r_]);
             }
+            B2_MARK(7);
             __syncthreads();
+            B2_MARK(8);
             // per-point staging (stride kB2PStride): rows 0 d Gpre (16), 16 h64 (64), 80 d h64 (64), 144 input (65 -> 80)
             float* SP = S;
             if (wave == 0) {
                 float h[1][16], G[1][4], dG[1][4], dh[1][16], din[1][16];
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) h[0][k] = xg[k * 64 + lane];
+                B2_MARK(9);
                 layer_fwd<L_GF2, 1, ACT_ELU>(W, glane, h, none, G);
+                B2_MARK(10);
                 const float4 u4 = ld4(up + 4 * g);
                 dG[0][0] = u4.x * gsc * delu(G[0][0]); dG[0][1] = u4.y * gsc * delu(G[0][1]);
                 dG[0][2] = u4.z * gsc * delu(G[0][2]); dG[0][3] = u4.w * gsc * delu(G[0][3]);
                 layer_fwd<LT_GF2, 1, ACT_NONE>(WT, glane, dG, none, dh);
+                B2_MARK(11);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) dh[0][k] *= delu_s(h[0][k]);
                 layer_fwd<LT_GF1, 1, ACT_NONE>(WT, glane, dh, none, din);
                 float dmw[1][1];
                 layer_vec<LT_GF1, 1>(WT, glane, dh, dmw);
+                B2_MARK(12);
                 // hand d mean / d var / d mean weight to every wave
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) hx[k * 64 + lane] = din[0][k];
@@ -612,13 +649,16 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
                 st_nat<8>(SP, kB2PStride, 144, gmean, c, g);
                 st_nat<8>(SP, kB2PStride, 176, gvar, c, g);
                 st_one(SP, kB2PStride, 208, meanw, c, g);
+                B2_MARK(13);
             }
             __syncthreads();
+            B2_MARK(14);
             NR_PRAGMA_UNROLL
             for (int k = 0; k < 8; ++k) { dgm[k] = hx[k * 64 + lane]; dgv[k] = hx[(8 + k) * 64 + lane]; }
             dmeanw = hx[16 * 64 + lane];
             dw_jobs<DW_GF2>(acc, bacc, SP, 0, 16, wave, lane);
             dw_jobs<DW_GF0>(acc, bacc, SP, 80, 144, wave, lane);
+            B2_MARK(15);
         }
         // ---- visibility-weighted mean / variance + softmax blend -> d x2, d vis2, d z
         float dx2[1][8], dvis2, dz;
@@ -639,6 +679,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             dz = beta * (dbeta - s2[1]);
             if (!(mask > 0.0f)) dz = 0.0f;
         }
+        B2_MARK(16);
         // ---- rgb_fc backward (ibrnet.py:363-365)
         {
             float x1[1][2], h16[1][4], h8[1][4], d8[1][4], d16[1][4], dxa[1][8], o1[1][1];
@@ -661,7 +702,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             for (int k = 0; k < 8; ++k) dx2[0][k] += dxa[0][k];
             dvis2 += o1[0][0];
             // rows: 0 dz (16), 16 h8 (16), 32 d8 (16), 48 h16 (16), 64 d16 (16), 80 [x2 32, vis2, dl 4] (48)
+            B2_MARK(17);
             __syncthreads();
+            B2_MARK(18);
             st_one(S, kB2Stride, 0, dz, col, g);
             st_nat<4>(S, kB2Stride, 16, h8[0], col, g); st_nat<4>(S, kB2Stride, 32, d8[0], col, g);
             st_nat<4>(S, kB2Stride, 48, h16[0], col, g); st_nat<4>(S, kB2Stride, 64, d16[0], col, g);
@@ -669,10 +712,13 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             st_one(S, kB2Stride, 112, vis2, col, g);
             NR_PRAGMA_UNROLL
             for (int j = 0; j < 4; ++j) st_one(S, kB2Stride, 113 + j, dlt[j], col, g);
+            B2_MARK(19);
             __syncthreads();
+            B2_MARK(20);
             dw_jobs<DW_RF4>(acc, bacc, S, 0, 16, wave, lane);
             dw_jobs<DW_RF2>(acc, bacc, S, 32, 48, wave, lane);
             dw_jobs<DW_RF0>(acc, bacc, S, 64, 80, wave, lane);
+            B2_MARK(21);
         }
         // ---- vis_fc2 backward (ibrnet.py:347-348): vis2 = sigmoid(a) * mask
         float dvisp;
@@ -701,6 +747,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             dw_jobs<DW_V22>(acc, bacc, S, 0, 16, wave, lane);
             dw_jobs<DW_V20>(acc, bacc, S, 48, 80, wave, lane);
         }
+        B2_MARK(22);
         // ---- vis_fc backward (ibrnet.py:343-346): x2 = x + y, visp = sigmoid(ELU(y32)) * mask; dx2 becomes d x
         float dx[1][8];
         {
@@ -728,6 +775,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             dw_jobs<DW_VF2>(acc, bacc, S, 0, 48, wave, lane);
             dw_jobs<DW_VF0>(acc, bacc, S, 80, 112, wave, lane);
         }
+        B2_MARK(23);
         // ---- base_fc backward (ibrnet.py:342) -> d gi, d gr, d e, d (statistics)
         float dgi[8], dgr[3], de[1][8];
         {
@@ -745,10 +793,13 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             NR_PRAGMA_UNROLL
             for (int j = 0; j < 3; ++j) dgr[j] = drgb[0][j];
             // round 1 rows: 0 dxp (32), 32 h64 (64)
+            B2_MARK(24);
             __syncthreads();
+            B2_MARK(25);
             st_nat<8>(S, kB2Stride, 0, dxp[0], col, g); st_nat<16>(S, kB2Stride, 32, h64[0], col, g);
             __syncthreads();
             dw_jobs<DW_B2>(acc, bacc, S, 0, 32, wave, lane);
+            B2_MARK(26);
             // round 2 rows: 0 dh64 (64), 64 [rgb 3 | img 32 | e 32] (67 -> 80): the natural column order 140..206 of base_fc.0
             __syncthreads();
             st_nat<16>(S, kB2Stride, 0, dh64[0], col, g);
@@ -758,6 +809,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             st_nat<8>(S, kB2Stride, 99, e[0], col, g);
             __syncthreads();
             dw_jobs<DW_BV>(acc, bacc, S, 0, 64, wave, lane);
+            B2_MARK(27);
             // per-point part: sum over the views of d h64, then d statistics = W_gl^T (sum d h64) by owner waves
             float sd16[1][16];
             {
@@ -771,6 +823,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
                 b2_allsum<4>(p4, red, wave, lane);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 4; ++k) sd16[0][12 + k] = p4[k];
+                B2_MARK(28);
             }
             // d statistic tile `wave` of LT_BG (8 tiles: statistic wave / 2, half wave % 2 of its 32 gathered channels):
             //   register r of lane group g of tile 2j + mo = channel 8g + 4mo + r of statistic j
@@ -807,7 +860,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
                     }
                 }
                 __syncthreads();
+                B2_MARK(29);
                 dw_jobs<DW_BG>(acc, bacc, SP, 0, 64, wave, lane);
+                B2_MARK(30);
             }
         }
         // ---- cross-view statistics backward: d statistics (per point, in hx rows 0..43) -> d gi / d gr +=, d sn
@@ -828,6 +883,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             }
             dsn = (nr_group_sum(dw0) + dw0r) * wv;              // img channels: 8 registers x 4 lane groups; rgb replicated
         }
+        B2_MARK(31);
         // ---- neuray_fc backward -> d e +=            (rows: 0 do (16), 16 h8 (16), 32 dh8 (16), 48 e (32))
         // ---- ray_dir_fc backward (weights only)      (rows: 80 dy35 (48), 128 h16 (16), 144 dh16 (16), 160 dl (16))
         {
@@ -871,6 +927,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             dw_jobs<DW_RD2>(acc, bacc, S, 80, 128, wave, lane);
             dw_jobs<DW_RD0>(acc, bacc, S, 144, 160, wave, lane);
         }
+        B2_MARK(32);
         // ---- prob_embed backward -> d f_ray, d hit, d vis     (rows: 0 de (32), 32 h (32), 64 dh (32), 96 [f_ray 32, hit', vis'] (48))
         float dfr[8], dhit, dvis;
         {
@@ -894,6 +951,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             dw_jobs<DW_PE2>(acc, bacc, S, 0, 32, wave, lane);
             dw_jobs<DW_PE0>(acc, bacc, S, 64, 96, wave, lane);
         }
+        B2_MARK(33);
         // ---- probabilities backward (dist_decoder.py:109-140) and the dist decoder heads
         {
             float dmu0 = 0.0f, dmu1 = 0.0f, dsd0 = 0.0f, dsd1 = 0.0f, daw = 0.0f, dnu = 0.0f;
@@ -902,14 +960,15 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             const float dm[2] = {dmu0 * (1.0f - nr_fast_exp(-mu0)), dmu1 * (1.0f - nr_fast_exp(-mu1))};
             const float dv[2] = {dsd0 * (1.0f - nr_fast_exp(-(s0 - p.var_bias))), dsd1 * (1.0f - nr_fast_exp(-(s1 - p.var_bias)))};
             const float da[1] = {daw * aw * (1.0f - aw)};
-            b2_dist_head_bwd<L_DM1, L_DM2, L_DFIN_M, LT_DM1, LT_DM2, DW_M4, DW_M2, DW_M0, 2>(W, WT, glane, lane, wave, col, g, fray, dm, dfr, S, acc, bacc);
-            b2_dist_head_bwd<L_DV1, L_DV2, L_DFIN_V, LT_DV1, LT_DV2, DW_V4, DW_V2, DW_V0, 2>(W, WT, glane, lane, wave, col, g, fray, dv, dfr, S, acc, bacc);
-            b2_dist_head_bwd<L_DA1, L_DA2, L_DFIN_A, LT_DA1, LT_DA2, DW_A4, DW_A2, DW_A0, 1>(W, WT, glane, lane, wave, col, g, fray, da, dfr, S, acc, bacc);
+            b2_dist_head_bwd<L_DM1, L_DM2, L_DFIN_M, LT_DM1, LT_DM2, DW_M4, DW_M2, DW_M0, 2>(W, WT, glane, lane, wave, col, g, fray, dm, dfr, S, acc, bacc B2_MARK_PASS);
+            b2_dist_head_bwd<L_DV1, L_DV2, L_DFIN_V, LT_DV1, LT_DV2, DW_V4, DW_V2, DW_V0, 2>(W, WT, glane, lane, wave, col, g, fray, dv, dfr, S, acc, bacc B2_MARK_PASS);
+            b2_dist_head_bwd<L_DA1, L_DA2, L_DFIN_A, LT_DA1, LT_DA2, DW_A4, DW_A2, DW_A0, 1>(W, WT, glane, lane, wave, col, g, fray, da, dfr, S, acc, bacc B2_MARK_PASS);
             if constexpr (HAS_VIS) {
                 const float ds[1] = {dnu * nu * (1.0f - nu)};
-                b2_dist_head_bwd<L_DS1, L_DS2, L_DFIN_S, LT_DS1, LT_DS2, DW_S4, DW_S2, DW_S0, 1>(W, WT, glane, lane, wave, col, g, fray, ds, dfr, S, acc, bacc);
+                b2_dist_head_bwd<L_DS1, L_DS2, L_DFIN_S, LT_DS1, LT_DS2, DW_S4, DW_S2, DW_S0, 1>(W, WT, glane, lane, wave, col, g, fray, ds, dfr, S, acc, bacc B2_MARK_PASS);
             }
         }
+        B2_MARK(41);
         // ---- gathers backward: f_ray = mask * bilinear(ray_feats), f_img = mask * bilinear(img_feats) (render_ops.py:54-70).
         // The wave's 16 columns go through a private LDS slab [16 points][64 channels: 32 ray | 32 img] so that 32 lanes add the
         // 32 contiguous channels of one texel with one instruction; the two halves of the wave take two taps at a time.
@@ -941,12 +1000,199 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
                 }
             }
             __syncthreads();
+            B2_MARK(42);
         }
     }
     // ================= end of the launch: accumulated weight gradients -> global =================
     dw_flush_all<DW_RF4, DW_RF2, DW_RF0, DW_V22, DW_V20, DW_VF2, DW_VF0, DW_B2, DW_BV, DW_NF2, DW_NF0, DW_RD2, DW_RD0, DW_PE2, DW_PE0,
                  DW_M4, DW_M2, DW_M0, DW_V4, DW_V2, DW_V0, DW_A4, DW_A2, DW_A0, DW_GF2, DW_GF0, DW_BG>(acc, bacc, p.d_flat, wave, lane);
     if constexpr (HAS_VIS) dw_flush_all<DW_S4, DW_S2, DW_S0>(acc, bacc, p.d_flat, wave, lane);
+}
+
+// =====================================================================================================================
+// self_hit_backward2_kernel: backward of the a19 path (renderer.py:137-155; dist_decoder.py:99-107,109-140,146-151) on the
+// resident scheme: hit_prob_self [rn][dn] as a function of the gathered query-view feature [rn][32] and the dist decoder.
+// One wave per tile of 16 rays (lane = (ray c, lane group g)); the decoder runs in registers on the packed / transposed
+// packs exactly as in points_backward2_kernel; the probability backward of a ray's dn samples is split over its four lane
+// groups; the weight gradients contract the 16 rays of the tile (4 MFMA per 16 x 16 tile, operands staged in LDS) into
+// register accumulators that go to global memory once per wave.  (The first version, self_hit_backward_kernel: lane = ray,
+// activations in a global arena, 8 waves for 512 rays - 0.26 ms per pass, 11 % of a training step.)
+// =====================================================================================================================
+struct SelfHitBwd2Params {
+    const float* que_const;
+    const float* depth;        // [rn][dn]
+    const float* feats;        // [rn][32] gathered query-view ray feature
+    const float* weights;      // packed pass weights
+    const float* weights_t;    // packed transposed layers
+    const float* d_hit;        // [rn][dn]
+    float* d_feats;            // [rn][32]
+    float* d_flat;             // accumulated (dist decoder tensors only)
+    int rn, dn, use_vis;
+    float var_bias;
+};
+
+constexpr int kShIds[12] = {DW_M4, DW_M2, DW_M0, DW_V4, DW_V2, DW_V0, DW_A4, DW_A2, DW_A0, DW_S4, DW_S2, DW_S0};
+constexpr int sh_job0(int id) {          // first accumulator of weight tensor id (DW_COUNT: the total)
+    int j = 0;
+    for (int i = 0; i < 12 && kShIds[i] != id; ++i) j += dw_ot(kShIds[i]) * dw_kt(kShIds[i]);
+    return j;
+}
+constexpr int sh_bias0(int id) {
+    int j = 0;
+    for (int i = 0; i < 12 && kShIds[i] != id; ++i) j += dw_ot(kShIds[i]);
+    return j;
+}
+constexpr int kShAcc = sh_job0(DW_COUNT), kShBias = sh_bias0(DW_COUNT);
+constexpr int kShStageRows = 176;
+
+// all 16 x 16 tiles of weight tensor ID: acc += dY[rows rowA..] X[rows rowB..]^T over the tile's 16 columns
+template <int ID>
+__device__ __forceinline__ void sh_tiles(v4f (&acc)[kShAcc], float (&bacc)[kShBias], const float* S, int rowA, int rowB, int lane) {
+    constexpr int OT = dw_ot(ID), KT = dw_kt(ID), J0 = sh_job0(ID), B0 = sh_bias0(ID);
+    const int m = lane & 15, kk = lane >> 4;
+    NR_PRAGMA_UNROLL
+    for (int a = 0; a < OT; ++a) {
+        const float4 av = ld4(S + (rowA + 16 * a + m) * kB2PStride + 4 * kk);
+        NR_PRAGMA_UNROLL
+        for (int b = 0; b < KT; ++b) {
+            const float4 bv = ld4(S + (rowB + 16 * b + m) * kB2PStride + 4 * kk);
+            v4f d = acc[J0 + a * KT + b];
+            d = nr_mfma16(av.x, bv.x, d); d = nr_mfma16(av.y, bv.y, d);
+            d = nr_mfma16(av.z, bv.z, d); d = nr_mfma16(av.w, bv.w, d);
+            acc[J0 + a * KT + b] = d;
+        }
+        bacc[B0 + a] += (av.x + av.y) + (av.z + av.w);
+    }
+}
+template <int ID>
+__device__ __forceinline__ void sh_flush(const v4f (&acc)[kShAcc], const float (&bacc)[kShBias], float* d_flat, int lane) {
+    constexpr int OT = dw_ot(ID), KT = dw_kt(ID), J0 = sh_job0(ID), B0 = sh_bias0(ID);
+    constexpr DwSpec sp = kDw[ID];
+    const float xs = sp.xscaled ? (float)(1.0 / kLog2e) : 1.0f;
+    const int m = lane & 15, kk = lane >> 4;
+    NR_PRAGMA_UNROLL
+    for (int a = 0; a < OT; ++a) {
+        NR_PRAGMA_UNROLL
+        for (int b = 0; b < KT; ++b) {
+            const v4f d = acc[J0 + a * KT + b];
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * a + 4 * kk + r, k = 16 * b + m;
+                if (o < sp.O && k < sp.K) atomicAdd(d_flat + tensor_offset(sp.tw) + o * sp.ldw + sp.col0 + k, d[r] * xs);
+            }
+        }
+        const float sb = nr_group_sum(bacc[B0 + a]);
+        const int o = 16 * a + m;
+        if (kk == 0 && o < sp.O) atomicAdd(d_flat + tensor_offset(sp.tb) + o, sb);
+    }
+}
+
+template <int L1, int L2, int LF, int T1, int T2, int D4, int D2, int D0, int NOUT>
+__device__ __forceinline__ void sh_head_bwd(nr_wbuf W, nr_wbuf WT, int wlane, int lane, const float (&fray)[1][8], const float (&dout)[NOUT],
+                                            float (&dfr)[8], float* S, v4f (&acc)[kShAcc], float (&bacc)[kShBias]) {
+    const int g = lane >> 4, c = lane & 15;
+    float none[1][1] = {{0.0f}}, h1[1][8], h2[1][8], dh2[1][8], dh1[1][8], dx[1][8];
+    layer_fwd<L1, 1, ACT_ELU>(W, wlane, fray, none, h1);
+    layer_fwd<L2, 1, ACT_ELU>(W, wlane, h1, none, h2);
+    VecPre<LF> pf;
+    layer_prefetch<LF>(W, wlane, pf);
+    float dy[kVec[LF].n];
+    NR_PRAGMA_UNROLL
+    for (int j = 0; j < NOUT; ++j) dy[j] = dout[j];
+    vec_bwd<LF>(pf, dy, dh2[0]);
+    NR_PRAGMA_UNROLL
+    for (int k = 0; k < 8; ++k) dh2[0][k] *= delu_s(h2[0][k]);
+    layer_fwd<T2, 1, ACT_NONE>(WT, wlane, dh2, none, dh1);
+    NR_PRAGMA_UNROLL
+    for (int k = 0; k < 8; ++k) dh1[0][k] *= delu_s(h1[0][k]);
+    layer_fwd<T1, 1, ACT_NONE>(WT, wlane, dh1, none, dx);
+    NR_PRAGMA_UNROLL
+    for (int k = 0; k < 8; ++k) dfr[k] += dx[0][k];
+    // rows: 0 d out (16), 16 h2 (32), 48 d h2 (32), 80 h1 (32), 112 d h1 (32), 144 f_ray (32)
+    __syncthreads();
+    NR_PRAGMA_UNROLL
+    for (int j = 0; j < NOUT; ++j) st_one(S, kB2PStride, j, dout[j], c, g);
+    st_nat<8>(S, kB2PStride, 16, h2[0], c, g); st_nat<8>(S, kB2PStride, 48, dh2[0], c, g);
+    st_nat<8>(S, kB2PStride, 80, h1[0], c, g); st_nat<8>(S, kB2PStride, 112, dh1[0], c, g);
+    st_gat(S, kB2PStride, 144, fray[0], c, g);
+    __syncthreads();
+    sh_tiles<D4>(acc, bacc, S, 0, 16, lane);
+    sh_tiles<D2>(acc, bacc, S, 48, 80, lane);
+    sh_tiles<D0>(acc, bacc, S, 112, 144, lane);
+}
+
+template <bool HAS_VIS>
+__global__ void __launch_bounds__(64) self_hit_backward2_kernel(SelfHitBwd2Params p) {
+    __shared__ __attribute__((aligned(16))) float S[kShStageRows * kB2PStride];
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
+    const nr_wbuf WT = nr_make_wbuf(p.weights_t, sizeof(float) * kPackedTFloats);
+    const float nearp = p.que_const[24], farp = p.que_const[25];
+    const bool use_vis = HAS_VIS && p.use_vis != 0;
+    const int dn = p.dn;
+    v4f acc[kShAcc];
+    float bacc[kShBias];
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < kShAcc; ++i) { acc[i][0] = 0.0f; acc[i][1] = 0.0f; acc[i][2] = 0.0f; acc[i][3] = 0.0f; }
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < kShBias; ++i) bacc[i] = 0.0f;
+    const int ntiles = (p.rn + 15) / 16;
+    for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+        const int glane = lane + nr_opaque_zero();
+        int ray = tile * 16 + c;
+        const bool valid = ray < p.rn;
+        ray = valid ? ray : p.rn - 1;
+        float fray[1][8];
+        {
+            const float4 f0 = ld4(p.feats + (size_t)ray * 32 + 8 * g), f1 = ld4(p.feats + (size_t)ray * 32 + 8 * g + 4);
+            fray[0][0] = f0.x; fray[0][1] = f0.y; fray[0][2] = f0.z; fray[0][3] = f0.w;
+            fray[0][4] = f1.x; fray[0][5] = f1.y; fray[0][6] = f1.z; fray[0][7] = f1.w;
+        }
+        float mu0, mu1, s0, s1, aw, nu;
+        b2_dist_fwd<HAS_VIS>(W, glane, fray, p.var_bias, mu0, mu1, s0, s1, aw, nu);
+        const float nuu = use_vis ? nu : 1.0f;
+        // probability backward (is_ref = False interval rule, dist_decoder.py:109-127): lane group g takes samples g, g + 4, ...
+        float dmu0 = 0.0f, dmu1 = 0.0f, dsd0 = 0.0f, dsd1 = 0.0f, daw = 0.0f, dnu = 0.0f;
+        const float* drow = p.depth + (size_t)ray * dn;
+        for (int smp = g; smp < dn; smp += 4) {
+            const float t_c = norm_inv_depth(fmaxf(drow[smp], 1e-5f), nearp, farp);
+            float lo, hi;
+            if (smp == 0) lo = t_c - (norm_inv_depth(drow[1], nearp, farp) - norm_inv_depth(drow[0], nearp, farp)) / 2.0f;
+            else lo = (norm_inv_depth(fmaxf(drow[smp - 1], 1e-5f), nearp, farp) + t_c) / 2.0f;
+            if (smp == dn - 1) hi = t_c + 500000.0f;
+            else hi = (t_c + norm_inv_depth(fmaxf(drow[smp + 1], 1e-5f), nearp, farp)) / 2.0f;
+            const float dh = valid ? p.d_hit[(size_t)ray * dn + smp] : 0.0f;
+            b2_prob_bwd(lo, hi, mu0, mu1, s0, s1, aw, nuu, use_vis, 0.0f, dh, dmu0, dmu1, dsd0, dsd1, daw, dnu);
+        }
+        dmu0 = nr_group_sum(dmu0); dmu1 = nr_group_sum(dmu1); dsd0 = nr_group_sum(dsd0); dsd1 = nr_group_sum(dsd1);
+        daw = nr_group_sum(daw); dnu = nr_group_sum(dnu);
+        // through the output non-linearities: softplus' = 1 - exp(-softplus), sigmoid' = s (1 - s)
+        const float dm[2] = {dmu0 * (1.0f - nr_fast_exp(-mu0)), dmu1 * (1.0f - nr_fast_exp(-mu1))};
+        const float dv[2] = {dsd0 * (1.0f - nr_fast_exp(-(s0 - p.var_bias))), dsd1 * (1.0f - nr_fast_exp(-(s1 - p.var_bias)))};
+        const float da[1] = {daw * aw * (1.0f - aw)};
+        float dfr[8];
+        NR_PRAGMA_UNROLL
+        for (int k = 0; k < 8; ++k) dfr[k] = 0.0f;
+        sh_head_bwd<L_DM1, L_DM2, L_DFIN_M, LT_DM1, LT_DM2, DW_M4, DW_M2, DW_M0, 2>(W, WT, glane, lane, fray, dm, dfr, S, acc, bacc);
+        sh_head_bwd<L_DV1, L_DV2, L_DFIN_V, LT_DV1, LT_DV2, DW_V4, DW_V2, DW_V0, 2>(W, WT, glane, lane, fray, dv, dfr, S, acc, bacc);
+        sh_head_bwd<L_DA1, L_DA2, L_DFIN_A, LT_DA1, LT_DA2, DW_A4, DW_A2, DW_A0, 1>(W, WT, glane, lane, fray, da, dfr, S, acc, bacc);
+        if constexpr (HAS_VIS) {
+            const float ds[1] = {dnu * nu * (1.0f - nu)};
+            sh_head_bwd<L_DS1, L_DS2, L_DFIN_S, LT_DS1, LT_DS2, DW_S4, DW_S2, DW_S0, 1>(W, WT, glane, lane, fray, ds, dfr, S, acc, bacc);
+        }
+        if (valid) {
+            float* o = p.d_feats + (size_t)ray * 32 + 8 * g;
+            *reinterpret_cast<float4*>(o) = make_float4(dfr[0], dfr[1], dfr[2], dfr[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(dfr[4], dfr[5], dfr[6], dfr[7]);
+        }
+    }
+    sh_flush<DW_M4>(acc, bacc, p.d_flat, lane); sh_flush<DW_M2>(acc, bacc, p.d_flat, lane); sh_flush<DW_M0>(acc, bacc, p.d_flat, lane);
+    sh_flush<DW_V4>(acc, bacc, p.d_flat, lane); sh_flush<DW_V2>(acc, bacc, p.d_flat, lane); sh_flush<DW_V0>(acc, bacc, p.d_flat, lane);
+    sh_flush<DW_A4>(acc, bacc, p.d_flat, lane); sh_flush<DW_A2>(acc, bacc, p.d_flat, lane); sh_flush<DW_A0>(acc, bacc, p.d_flat, lane);
+    if constexpr (HAS_VIS) {
+        sh_flush<DW_S4>(acc, bacc, p.d_flat, lane); sh_flush<DW_S2>(acc, bacc, p.d_flat, lane); sh_flush<DW_S0>(acc, bacc, p.d_flat, lane);
+    }
 }
 
 }  // namespace nr

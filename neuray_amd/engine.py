@@ -88,6 +88,7 @@ class RenderEngine:
         else:
             self.lib = _test_lib
         self.views_per_wave = views_per_wave
+        self.variant = variant
         self._posenc = {}
         # optional kernel timing: set to a list and every point/ray launch appends
         # (name, start_event, end_event, n_points) recorded on the launch stream (HIP events)
@@ -418,12 +419,20 @@ class RenderEngine:
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         return d_flat, d_rf, d_if
 
-    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05):
-        """Backward of dist_decoder_rows + self_hit_prob: -> (d_feats [rn,32], d_flat)"""
+    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05, packed=None, kernel='auto'):
+        """Backward of dist_decoder_rows + self_hit_prob: -> (d_feats [rn,32], d_flat).  The resident kernel (one wave per 16 rays, decoder
+        in registers on the packed / transposed packs) unless kernel == 'v1' (first version: lane = ray, global arena)."""
         depth, feats, d_hit = self._f32(depth), self._f32(feats), self._f32(d_hit)
         rn, dn = depth.shape
         d_feats = self.empty(rn, 32)
         d_flat = torch.zeros_like(flat)
+        if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant == 'fp32':
+            pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
+            pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+            self._check(self.lib.neuray_self_hit_prob_backward_resident(
+                qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), pk.data_ptr(), pt.data_ptr(), int(has_vis_head), int(bool(use_vis)),
+                float(var_bias), d_hit.data_ptr(), rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), self._stream()))
+            return d_feats, d_flat
         ws = self.empty(int(self.lib.neuray_self_hit_backward_workspace_floats(rn)))
         self._check(self.lib.neuray_self_hit_prob_backward(qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), flat.data_ptr(),
                                                            int(has_vis_head), int(bool(use_vis)), float(var_bias), d_hit.data_ptr(),

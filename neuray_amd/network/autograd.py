@@ -86,7 +86,7 @@ class SelfHitFn(torch.autograd.Function):
     def forward(ctx, run, h, w, que_ray_feats, *params):
         eng = run.eng
         flat, packed, has_vis = run.device_weights()
-        ctx.flat, ctx.has_vis = flat, has_vis
+        ctx.flat, ctx.has_vis, ctx.packed = flat, has_vis, packed
         feats = eng.interpolate_feats(que_ray_feats, run.coords[None], h, w, align_corners=False)      # [1,rn,32]
         mean, var, vis, aw = eng.dist_decoder_rows(feats[0], packed, run.var_bias)
         vis = vis if run.use_vis else None
@@ -101,7 +101,7 @@ class SelfHitFn(torch.autograd.Function):
         feats, = ctx.saved_tensors
         sd = run.state()
         d_feats, d_flat = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], ctx.flat, ctx.has_vis, run.use_vis,
-                                                     d_hit.contiguous(), var_bias=run.var_bias)
+                                                     d_hit.contiguous(), var_bias=run.var_bias, packed=ctx.packed)
         d_map = eng.interpolate_feats_backward(d_feats[None], ctx.shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         return (None, None, None, d_map) + tuple(grads[k] for k, _ in run.dist_params())

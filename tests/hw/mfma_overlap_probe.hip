@@ -90,6 +90,41 @@ __global__ void __launch_bounds__(512) mixed(const float* in, float* out, int it
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// cost of one VALU instruction of a given kind issued between the MFMAs of the same wave (OP: 0 v_fma_f32, 1 v_exp_f32,
+// 2 v_pk_fma_f32 (two results), 3 v_med3_f32, 4 v_rcp_f32), NV of them per MFMA, independent chains
+template <int OP, int NV>
+__global__ void __launch_bounds__(512) opcost(const float* in, float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    v4f acc[4];
+    for (int k = 0; k < 4; ++k) acc[k] = (v4f){in[lane], 0.f, 0.f, 0.f};
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    float f[8]; v2f p[8];
+    for (int k = 0; k < 8; ++k) { f[k] = in[lane + k]; p[k] = (v2f){in[lane + k], in[lane + k + 8]}; }
+    const float a = in[lane], b = in[lane + 64];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m] = mfma<false>(a, b, acc[m]);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int j = (4 * q + m * NV + k) & 7;
+                    if (OP == 0) f[j] = __builtin_fmaf(f[j], 1.0001f, 0.5f);
+                    if (OP == 1) f[j] = __builtin_amdgcn_exp2f(f[j]);
+                    if (OP == 2) p[j] = __builtin_elementwise_fma(p[j], (v2f){1.0001f, 1.0001f}, (v2f){0.5f, 0.5f});
+                    if (OP == 3) f[j] = __builtin_amdgcn_fmed3f(f[j], 0.25f, 0.0f);
+                    if (OP == 4) f[j] = __builtin_amdgcn_rcpf(f[j]);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+    for (int k = 0; k < 8; ++k) s += f[k] + p[k].x + p[k].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <class F>
 float time_ms(F launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -124,6 +159,18 @@ int main() {
     const float b32 = time_ms([&](int it) { mixed<false, 0><<<256, 512>>>(in, out, it); });
     printf("fp32 MFMA only, 2 waves/SIMD: %.2f ms (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n", b32, b32 * 1e-3 * 2.4e9 / (4000.0 * 32 * 2));
     mix<false, 1>(in, out, b32); mix<false, 2>(in, out, b32); mix<false, 4>(in, out, b32); mix<false, 8>(in, out, b32);
+    {
+        const float base = time_ms([&](int it) { opcost<0, 0><<<256, 512>>>(in, out, it); });
+        const double mf = 4000.0 * 32 * 2;                       // MFMAs per SIMD (2 waves)
+        auto cost = [&](const char* name, float t, int nv) {
+            printf("%-14s %d per MFMA: %6.2f ms -> %.1f SIMD cycles per instruction\n", name, nv, t, (t - base) * 1e-3 * 2.4e9 / (mf * nv));
+        };
+        cost("v_fma_f32", time_ms([&](int it) { opcost<0, 4><<<256, 512>>>(in, out, it); }), 4);
+        cost("v_exp_f32", time_ms([&](int it) { opcost<1, 4><<<256, 512>>>(in, out, it); }), 4);
+        cost("v_pk_fma_f32", time_ms([&](int it) { opcost<2, 4><<<256, 512>>>(in, out, it); }), 4);
+        cost("v_med3_f32", time_ms([&](int it) { opcost<3, 4><<<256, 512>>>(in, out, it); }), 4);
+        cost("v_rcp_f32", time_ms([&](int it) { opcost<4, 4><<<256, 512>>>(in, out, it); }), 4);
+    }
     const float b16 = time_ms([&](int it) { mixed<true, 0><<<256, 512>>>(in, out, it); });
     printf("bf16 MFMA only, 2 waves/SIMD: %.2f ms (%.1f cycles per MFMA per SIMD)\n", b16, b16 * 1e-3 * 2.4e9 / (4000.0 * 32 * 2));
     mix<true, 1>(in, out, b16); mix<true, 2>(in, out, b16); mix<true, 4>(in, out, b16);

@@ -328,3 +328,56 @@ def test_training_with_fine_depth_use_all(backend):
             assert np.abs(p_.grad.cpu().numpy() - g).max() <= 1e-2 * max(1e-3, float(np.abs(g).max())), k
     g = cr['ray_feats'].grad.numpy()
     assert np.abs(tr['ray_feats'].grad.cpu().numpy() - g).max() <= 1e-2 * float(np.abs(g).max())
+
+
+# ---- a19: the query view's own hit probabilities (renderer.py:137-155), backward on the resident scheme -------------------------
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('rn,dn,vis_head', [(5, 8, False), (37, 16, True), (16, 5, True), (70, 64, False)])
+def test_self_hit_backward_matches_autograd_and_the_first_version(rn, dn, vis_head, backend):
+    from neuray_amd import synthetic
+    from neuray_amd.engine import RenderEngine
+    from oracle import neuray_oracle as orc
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
+    que, _ = synthetic.make_scene(48, 64, 2, seed=70 + rn)
+    rng = np.random.RandomState(71 + rn)
+    que['coords'] = (rng.rand(1, rn, 2) * np.array([63, 47])).astype(np.float32)
+    que['ray_feats'] = (0.5 * rng.randn(1, 32, 24, 32)).astype(np.float32)          # the query view's own vis-encoder output
+    que.setdefault('imgs', np.zeros((1, 3, 48, 64), np.float32))
+    weights = load_weights(vis_head)
+    depth = orc.sample_depth(que['depth_range'], rn, dn)
+    depth = (depth * (1.0 + 0.02 * rng.rand(1, rn, dn))).astype(np.float32); depth.sort(-1)
+    lw = rng.randn(rn, dn).astype(np.float32)
+
+    # ---- autograd of the eager port
+    w = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in weights.items() if k.startswith('dist_decoder.')}
+    tq = {k: torch.from_numpy(v.copy()) for k, v in que.items()}
+    tq['ray_feats'].requires_grad_(True)
+    hp = tep.self_hit_prob(w, {'coarse_use_vis': vis_head, 'fine_use_vis': True}, torch.from_numpy(depth), tq, False)
+    (hp[0] * torch.from_numpy(lw)).sum().backward()
+
+    # ---- ours: gathered feature -> both backward kernels
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    qc = eng.prepare_query({k: t(v) for k, v in que.items()})
+    feats = eng.interpolate_feats(t(que['ray_feats']), t(que['coords']), 48, 64, align_corners=False)[0]      # [rn,32]
+    flat, has_vis = eng.flat_pass(weights, 'dist_decoder.', 'agg_net.')
+    got = {}
+    for kernel in ('auto', 'v1'):
+        d_feats, d_flat = eng.self_hit_prob_backward(qc, t(depth[0]), feats, flat, has_vis, vis_head, t(lw), kernel=kernel)
+        d_map = eng.interpolate_feats_backward(d_feats[None], tuple(tq['ray_feats'].shape), t(que['coords']), 48, 64, align_corners=False)
+        got[kernel] = (eng.unflatten_pass_grads(d_flat, weights, 'dist_decoder.', 'agg_net.'), d_map, d_feats)
+
+    def close(a, b, name, rel):
+        a, b = a.detach().cpu().numpy(), (b.detach().cpu().numpy() if torch.is_tensor(b) else b)
+        tol = rel * max(1e-3, float(np.abs(b).max()))
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol, (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+    for k, p_ in w.items():
+        want = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        close(got['auto'][0][k], want, k, 2e-3)
+        close(got['auto'][0][k], got['v1'][0][k], k + ' (v1)', 1e-4)
+    close(got['auto'][1], tq['ray_feats'].grad, 'que ray_feats', 2e-3)
+    close(got['auto'][2], got['v1'][2], 'd_feats (v1)', 1e-4)
+    for k, g in got['auto'][0].items():                      # nothing but the dist decoder is touched
+        if not k.startswith('dist_decoder.'):
+            assert float(g.abs().max()) == 0.0, k

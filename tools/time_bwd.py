@@ -20,15 +20,16 @@ def main():
     ap.add_argument('--kernel', default='auto')
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--rays', type=int, default=512)
+    ap.add_argument('--hw', type=int, nargs=2, default=[400, 600], help='image size (the feature maps are 8 x h x w x 32 floats each)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer({'use_hierarchical_sampling': False, 'dist_decoder_cfg': {'use_vis': False}})
     sd = {k: v for k, v in r.state_dict().items()}
     eng = RenderEngine(dev)
-    que, ref = synthetic.make_scene(400, 600, 8, seed=0)
+    que, ref = synthetic.make_scene(args.hw[0], args.hw[1], 8, seed=0)
     rng = np.random.RandomState(0)
-    coords = torch.from_numpy((rng.rand(args.rays, 2) * np.array([599, 399])).astype(np.float32)).to(dev)
+    coords = torch.from_numpy((rng.rand(args.rays, 2) * np.array([args.hw[1] - 1, args.hw[0] - 1])).astype(np.float32)).to(dev)
     t = lambda a: torch.from_numpy(a).to(dev)                      # noqa: E731
     views = eng.prepare_views({k: t(v) for k, v in ref.items()})
     qc = eng.prepare_query({k: t(v) for k, v in que.items()})

@@ -250,16 +250,18 @@ def training_step_timing(device, steps=3):
             p_.grad = None
         loss_of(tep.render_impl(w, ocfg, que_t, ref_t, is_train=True)).backward()
 
-    def timeit(fn):
-        fn()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+    def timeit(fn, warm, n):
+        # (the first ~100 ms after the CPU legs' torch.set_num_threads() calls run several times slower on the host side: warm up past it)
+        for _ in range(warm):
             fn()
         torch.cuda.synchronize(device)
-        return 1e3 * (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(device)
+        return 1e3 * (time.perf_counter() - t0) / n
 
-    a, b = timeit(ours), timeit(eager)
+    a, b = timeit(ours, 40, 10 * steps), timeit(eager, 1, steps)
     return {'what': 'forward + backward, 512 rays x 8 views x 64+64 samples, HIP kernels vs autograd of the eager-PyTorch port',
             'hip_ms_per_step': a, 'eager_torch_ms_per_step': b, 'speedup_vs_eager': b / a}
 

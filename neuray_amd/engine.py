@@ -52,9 +52,21 @@ def posenc_table(d_hid, n_samples):
     return torch.from_numpy(t.astype(np.float32))
 
 
+_K_INV_CACHE = {}
+
+
 def host_inverse(Ks):
-    """torch.inverse of [n,3,3] intrinsics on the host in fp32 (see RenderEngine.prepare_query)"""
-    return torch.inverse(torch.as_tensor(Ks).detach().to('cpu', torch.float32))
+    """torch.inverse of [n,3,3] intrinsics on the host in fp32 (see RenderEngine.prepare_query).  Memoised on the matrix bytes: a
+    training run or a render loop sees a handful of distinct cameras, and the LAPACK call is the one host-side op of a step whose cost
+    depends on the process's thread settings (25 ms per call after torch.set_num_threads(128): MKL then threads even a 3 x 3 getrf)."""
+    k = torch.as_tensor(Ks).detach().to('cpu', torch.float32).contiguous()
+    key = (tuple(k.shape), k.numpy().tobytes())
+    inv = _K_INV_CACHE.get(key)
+    if inv is None:
+        if len(_K_INV_CACHE) >= 4096:
+            _K_INV_CACHE.clear()
+        inv = _K_INV_CACHE[key] = torch.inverse(k)
+    return inv.clone()
 
 
 class PackedPass:

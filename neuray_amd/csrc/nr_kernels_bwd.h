@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
     float* WA = smem + kPackedRayFloats + 12;          // weight-gradient accumulators of the workgroup
     float* base = smem + 2 * (kPackedRayFloats + 12) + (size_t)wave * (dn * kRayBwdPerSample + kRayBwdTranspose);
     float* ks = base; float* vs = ks + dn * 16; float* qs = vs + dn * 16; float* dos = qs + dn * 16;
-    float* st = dos + dn * 16;                         // [dn][12]: softmax shift (4), denominator (4), D (4)
+    float* st = dos + dn * 16;                         // [dn][12]: softmax shift (4), 1 / denominator (4), D (4)
     float* tr = st + dn * 12; float* al = tr + dn; float* us = al + dn;
     float* tA = us + dn; float* tB = tA + 64 * 17;
     for (int i = threadIdx.x; i < kPackedRayFloats; i += blockDim.x) { RW[i] = p.weights[kPackedPointFloats + i]; WA[i] = 0.0f; }
@@ -149,12 +149,13 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
                 for (int j = 0; j < dn; ++j) {
                     const float4 kj = ld4(ks + j * 16 + hh * 4);
                     const float sc = fmaf(s.q[hh * 4 + 3], kj.w, fmaf(s.q[hh * 4 + 2], kj.z, fmaf(s.q[hh * 4 + 1], kj.y, s.q[hh * 4] * kj.x)));
-                    const float e_ = expf(sc - m_);
+                    const float e_ = nr_fast_exp(sc - m_);
                     const float4 vj = ld4(vs + j * 16 + hh * 4);
                     d_ += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
                 }
-                s.mx[hh] = m_; s.den[hh] = d_;
-                s.o[hh * 4] = a0 / d_; s.o[hh * 4 + 1] = a1 / d_; s.o[hh * 4 + 2] = a2 / d_; s.o[hh * 4 + 3] = a3 / d_;
+                const float rd_ = 1.0f / d_;        // (the key loops below multiply by it: one division per head instead of one per key)
+                s.mx[hh] = m_; s.den[hh] = rd_;
+                s.o[hh * 4] = a0 * rd_; s.o[hh * 4 + 1] = a1 * rd_; s.o[hh * 4 + 2] = a2 * rd_; s.o[hh * 4 + 3] = a3 * rd_;
             }
             float y[16], mean = 0.0f, var = 0.0f;
             matvec16(RW + RW_FC, s.o, y);
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
                     const float4 kj = ld4(ks + j * 16 + hh * 4);
                     const float4 vj = ld4(vs + j * 16 + hh * 4);
                     const float sc = fmaf(s.q[hh * 4 + 3], kj.w, fmaf(s.q[hh * 4 + 2], kj.z, fmaf(s.q[hh * 4 + 1], kj.y, s.q[hh * 4] * kj.x)));
-                    const float P = expf(sc - s.mx[hh]) / s.den[hh];
+                    const float P = nr_fast_exp(sc - s.mx[hh]) * s.den[hh];
                     const float dP = dO[hh * 4] * vj.x + dO[hh * 4 + 1] * vj.y + dO[hh * 4 + 2] * vj.z + dO[hh * 4 + 3] * vj.w;
                     const float dS = P * (dP - Dh[hh]);
                     a0 = fmaf(dS, kj.x, a0); a1 = fmaf(dS, kj.y, a1); a2 = fmaf(dS, kj.z, a2); a3 = fmaf(dS, kj.w, a3);
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
                     const float4 qj = ld4(qs + j * 16 + hh * 4);
                     const float4 dj = ld4(dos + j * 16 + hh * 4);
                     const float sc = fmaf(qj.w, s.kk[hh * 4 + 3], fmaf(qj.z, s.kk[hh * 4 + 2], fmaf(qj.y, s.kk[hh * 4 + 1], qj.x * s.kk[hh * 4])));
-                    const float P = expf(sc - st[j * 12 + hh]) / st[j * 12 + 4 + hh];
+                    const float P = nr_fast_exp(sc - st[j * 12 + hh]) * st[j * 12 + 4 + hh];
                     const float dP = dj.x * s.vv[hh * 4] + dj.y * s.vv[hh * 4 + 1] + dj.z * s.vv[hh * 4 + 2] + dj.w * s.vv[hh * 4 + 3];
                     const float dS = P * (dP - st[j * 12 + 8 + hh]);
                     // rows whose ray is invalid carry do = 0 and D = 0: dS = 0, no contribution

@@ -428,7 +428,7 @@ int neuray_self_hit_prob_backward_resident(const float* qc, const float* depth, 
     nr::SelfHitBwd2Params p;
     p.que_const = qc; p.depth = depth; p.feats = feats; p.weights = packed; p.weights_t = packed_t; p.d_hit = d_hit;
     p.d_feats = d_feats; p.d_flat = d_flat; p.rn = rn; p.dn = dn; p.use_vis = use_vis; p.var_bias = var_bias;
-    const dim3 grid(grid_for(rn, 16, 2048));
+    const dim3 grid(grid_for(rn, 16, 512));
     if (has_vis_head) NR_LAUNCH(nr::self_hit_backward2_kernel<true>, grid, dim3(64), 0, stream, p);
     else NR_LAUNCH(nr::self_hit_backward2_kernel<false>, grid, dim3(64), 0, stream, p);
     return check_launch("neuray_self_hit_prob_backward_resident");

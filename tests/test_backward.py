@@ -332,7 +332,8 @@ def test_training_with_fine_depth_use_all(backend):
 
 # ---- a19: the query view's own hit probabilities (renderer.py:137-155), backward on the resident scheme -------------------------
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('rn,dn,vis_head', [(5, 8, False), (37, 16, True), (16, 5, True), (70, 64, False)])
+@pytest.mark.parametrize('rn,dn,vis_head', [(5, 8, False), (37, 16, True), (16, 5, True), (70, 64, False),
+                                            (8300, 3, False)])      # (more tiles than workgroups: the persistent loop)
 def test_self_hit_backward_matches_autograd_and_the_first_version(rn, dn, vis_head, backend):
     from neuray_amd import synthetic
     from neuray_amd.engine import RenderEngine

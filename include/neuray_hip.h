@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 3
+#define NEURAY_ABI_VERSION 4
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -101,7 +101,12 @@ typedef struct NeurayPointsArgs {
     int use_vis;         /* the COARSE decoder's cfg['use_vis'] (renderer.py:75 uses it for both passes) */
     float var_bias;      /* dist_decoder cfg['bias_val'] (0.05) */
     int views_per_wave;  /* reference views processed by one wavefront: 0 = default (2), 1 or 2 */
+    float* saved_dev;    /* NULL, or (training forward, rfn <= 8) [neuray_points_saved_floats(rn * dn)]: the cross-view quantities of
+                          * every 16-point tile - base_fc.0's per-point part, the four weighted statistics, the mask sum, the dist
+                          * decoder outputs (csrc/nr_kernels.h kSaved*) - which neuray_render_points_backward reads instead of
+                          * recomputing them */
 } NeurayPointsArgs;
+size_t neuray_points_saved_floats(int npts);
 int neuray_render_points(const NeurayPointsArgs* args, void* stream);
 
 /* ---- a14-a16: per-ray attention + sigma head + compositing ---------------------------------------------------
@@ -191,6 +196,7 @@ typedef struct NeurayPointsBwdArgs {
     float var_bias;
     const float* packed_weights_dev;   /* [neuray_packed_pass_floats()] or NULL */
     const float* packed_t_weights_dev; /* [neuray_packed_t_floats()] or NULL */
+    const float* saved_dev;            /* resident kernel: what neuray_render_points left in NeurayPointsArgs.saved_dev for the same inputs */
 } NeurayPointsBwdArgs;
 size_t neuray_packed_t_floats(void);
 /* index[neuray_packed_t_floats()] (host, int32): packed_t[i] = index[i] >= 0 ? flat[index[i]] : 0 */

@@ -35,7 +35,7 @@ class NeurayPointsArgs(C.Structure):
         ('dbg_dev', C.c_void_p),
         ('rfn', C.c_int), ('rn', C.c_int), ('dn', C.c_int), ('h', C.c_int), ('w', C.c_int), ('fh', C.c_int),
         ('fw', C.c_int), ('has_vis_head', C.c_int), ('use_vis', C.c_int), ('var_bias', C.c_float),
-        ('views_per_wave', C.c_int),
+        ('views_per_wave', C.c_int), ('saved_dev', C.c_void_p),
     ]
 
 
@@ -63,7 +63,7 @@ class NeurayPointsBwdArgs(C.Structure):
         'rgba_dev', 'flat_weights_dev', 'd_point_rec_dev', 'd_flat_weights_dev', 'd_ray_feats_nhwc_dev',
         'd_img_feats_nhwc_dev', 'workspace_dev')] + \
         [(n, C.c_int) for n in ('rfn', 'rn', 'dn', 'h', 'w', 'fh', 'fw', 'has_vis_head', 'use_vis')] + \
-        [('var_bias', C.c_float), ('packed_weights_dev', C.c_void_p), ('packed_t_weights_dev', C.c_void_p)]
+        [('var_bias', C.c_float), ('packed_weights_dev', C.c_void_p), ('packed_t_weights_dev', C.c_void_p), ('saved_dev', C.c_void_p)]
 
 
 PACKED_RAY_FLOATS = 1348
@@ -84,6 +84,7 @@ SYMBOLS = {
     'neuray_is_device_build': (C.c_int, []),
     'neuray_operand_precision': (C.c_int, []),
     'neuray_packed_pass_floats': (C.c_size_t, []),
+    'neuray_points_saved_floats': (C.c_size_t, [C.c_int]),
     'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_index_map': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_setup_views': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

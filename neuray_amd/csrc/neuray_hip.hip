@@ -46,7 +46,7 @@ static_assert(NEURAY_PASS_TENSORS == nr::T_COUNT, "abi");
 static_assert(NEURAY_DBG_FIELDS == nr::kDbgFields, "abi");
 static_assert(NEURAY_MAX_SAMPLES == nr::kMaxSamples, "abi");
 
-template <int NT, int VPW, bool HAS_VIS, int OWN, int MINW>
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MINW, bool SAVE = false>
 int launch_points_own(const nr::PointParams& p, void* stream) {
     const int npts = p.rn * p.dn;
     const int nwaves = (p.rfn + VPW - 1) / VPW;
@@ -57,7 +57,7 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     grid = (grid + 7) / 8 * 8;                         // the XCD-aware tile map needs a multiple of 8
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")
-    auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW>;
+    auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, SAVE>;
 #ifndef NEURAY_EMU
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
@@ -71,6 +71,22 @@ int launch_points(const nr::PointParams& p, void* stream) {
     if (nwaves >= 4) return launch_points_own<NT, VPW, HAS_VIS, 1, MINW>(p, stream);
     if (nwaves >= 2) return launch_points_own<NT, VPW, HAS_VIS, 2, MINW>(p, stream);
     return launch_points_own<NT, VPW, HAS_VIS, 4, MINW>(p, stream);
+}
+
+// training forward: the same kernels with the cross-view quantities written out for the resident backward (rfn <= 8; two views per
+// wave, one for a single view)
+template <bool HAS_VIS>
+int launch_points_save(const nr::PointParams& p, void* stream) {
+#ifdef NR_BF16_QUADS
+    return fail("neuray_render_points: saved_dev is a training feature; the bf16-operand variant is inference only");
+#else
+    if (p.rfn > 8) return fail("neuray_render_points: saved_dev needs rfn <= 8 (rfn=%d)", p.rfn);
+    if (p.rfn == 1) return launch_points_own<1, 1, HAS_VIS, 4, 4, true>(p, stream);
+    const int nwaves = (p.rfn + 1) / 2;
+    if (nwaves >= 4) return launch_points_own<1, 2, HAS_VIS, 1, 3, true>(p, stream);
+    if (nwaves >= 2) return launch_points_own<1, 2, HAS_VIS, 2, 3, true>(p, stream);
+    return launch_points_own<1, 2, HAS_VIS, 4, 3, true>(p, stream);
+#endif
 }
 
 // Built decompositions (measured on MI355X, DESIGN.md "point kernel tuning"):
@@ -161,7 +177,7 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     nr::PointParams p;
     p.que_const = a->query_const_dev; p.view_const = a->view_const_dev; p.coords = a->coords_dev; p.depth = a->depth_dev;
     p.ray_feats = a->ray_feats_nhwc_dev; p.img_feats = a->img_feats_nhwc_dev; p.rgba = a->rgba_dev;
-    p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev;
+    p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev; p.saved = a->saved_dev;
     p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
     p.use_vis = a->use_vis; p.var_bias = a->var_bias;
     // work decomposition: reference views processed per wave (0 = default)
@@ -169,6 +185,7 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
     // reference-view path when the coarse decoder has use_vis = False: quirk A.9.2)
     const bool vis = a->has_vis_head && a->use_vis;
+    if (a->saved_dev) return vis ? launch_points_save<true>(p, stream) : launch_points_save<false>(p, stream);
     return vis ? launch_points_cfg<true>(p, vpw, stream) : launch_points_cfg<false>(p, vpw, stream);
 }
 
@@ -323,6 +340,7 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* a, void* stream) {
 
 size_t neuray_flat_pass_floats(void) { return (size_t)nr::kFlatPassFloats; }
 size_t neuray_packed_t_floats(void) { return (size_t)nr::kPackedTFloats; }
+size_t neuray_points_saved_floats(int npts) { return npts < 1 ? 0 : (size_t)((npts + 15) / 16) * nr::kSavedTileFloats; }
 int neuray_pack_pass_t_index_map(int has_vis_head, int* index) {
     if (!index) return fail("neuray_pack_pass_t_index_map: null argument");
 #ifdef NR_BF16_QUADS
@@ -359,12 +377,13 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
     if (a->packed_weights_dev || a->packed_t_weights_dev) return fail("neuray_render_points_backward: the bf16-operand library is inference only");
 #else
     if (a->packed_weights_dev && a->packed_t_weights_dev && a->rfn <= nr::kB2Waves) {      // register / LDS resident kernel
+        if (!a->saved_dev) return fail("neuray_render_points_backward: the resident kernel needs saved_dev (run neuray_render_points with saved_dev on the same inputs first)");
         nr::PointBwd2Params q;
         q.que_const = a->query_const_dev; q.view_const = a->view_const_dev; q.coords = a->coords_dev; q.depth = a->depth_dev;
         q.ray_feats = a->ray_feats_nhwc_dev; q.img_feats = a->img_feats_nhwc_dev; q.rgba = a->rgba_dev;
         q.weights = a->packed_weights_dev; q.weights_t = a->packed_t_weights_dev;
         q.d_point_rec = a->d_point_rec_dev; q.d_flat = a->d_flat_weights_dev; q.d_ray_feats = a->d_ray_feats_nhwc_dev;
-        q.d_img_feats = a->d_img_feats_nhwc_dev;
+        q.d_img_feats = a->d_img_feats_nhwc_dev; q.saved = a->saved_dev;
         q.rfn = a->rfn; q.rn = a->rn; q.dn = a->dn; q.h = a->h; q.w = a->w; q.fh = a->fh; q.fw = a->fw;
         q.use_vis = a->use_vis; q.var_bias = a->var_bias;
         const size_t smem = nr::point_bwd2_smem_bytes();

@@ -92,12 +92,21 @@ struct PointParams {
     const float* weights;      // packed pass weights
     float* point_out;          // [rn*dn][kPointRec]
     float* dbg;                // optional [rn*dn][rfn][16]
+    float* saved;              // training (SAVE kernels): [ceil(rn*dn / 16)][kSavedTileFloats] cross-view quantities for the backward
     int rfn, rn, dn, h, w, fh, fw;
     int use_vis;               // the COARSE decoder's use_vis governs compute_prob in both passes (renderer.py:75)
     float var_bias;            // AddBias value of var_decoder (dist_decoder.py:81)
 };
 
 constexpr int kDbgFields = 16;
+
+// What the training forward leaves for points_backward2_kernel, per tile of 16 consecutive sample points ([rows][64 lanes],
+// lane = 16 g + point): rows 0..15 base_fc.0's per-point part (output tile mo, register r -> row 4 mo + r; the LDS exchange
+// layout of both kernels), rows 16..59 the four cross-view statistics mean0 | var0 | mean1 | var1 (11 rows each: 8 image
+// channels 8 g + k, 3 rgb), row 60 sum of the view masks, then [8 views][8][16 points]: mu0, mu1, s0, s1, aw, nu of the dist
+// decoder.  The backward reads them instead of redoing the decoder forward, six all-reduces and the per-point layer slices.
+constexpr int kSavedBgRow = 0, kSavedStatRow = 16, kSavedMsumRow = 60, kSavedDist = 61 * 64;
+constexpr int kSavedTileFloats = kSavedDist + 8 * 8 * 16;
 
 __device__ __forceinline__ float sel4(int g, float a, float b, float c, float d) {
     return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
@@ -152,7 +161,7 @@ __device__ __forceinline__ void view_allreduce(const float (&v)[NT * VPW][R], fl
 // fragment and give the MFMA pipe NS independent accumulator chains.
 //   OWN = number of 16-feature output tiles of the per-point layers (base_fc.0 global part, geometry_fc.0) a wave
 //         owns: ceil(4 / nwaves).
-template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW>
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW, bool SAVE = false>
 __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     constexpr int RMAX = point_rmax<NT>();
@@ -316,6 +325,12 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 logistic_prob(tref[s], lo[t], hi[t], mu0[s], mu1[s], s0[s], s1[s], aw[s], nu[s], use_vis && HAS_VIS, v_, h_);
                 vis[s] = v_ * mask[s]; hit[s] = h_ * mask[s];
                 const int vraw = wave * VPW + s / NT;
+                if constexpr (SAVE) {
+                    if (g == 0 && vraw < p.rfn && vraw < 8) {
+                        float* d_ = p.saved + (size_t)(base / 16 + t) * kSavedTileFloats + kSavedDist + vraw * 128 + c;
+                        d_[0] = mu0[s]; d_[16] = mu1[s]; d_[32] = s0[s]; d_[48] = s1[s]; d_[64] = aw[s]; d_[80] = nu[s];
+                    }
+                }
                 if (dbg_lane && pvalid[t] && vraw < p.rfn) {
                     float* d_ = p.dbg + ((size_t)pidx[t] * p.rfn + vraw) * kDbgFields;
                     d_[4] = hit[s]; d_[5] = vis[s]; d_[6] = mu0[s]; d_[7] = mu1[s]; d_[8] = s0[s]; d_[9] = s1[s];
@@ -407,6 +422,12 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 }
                 NR_PRAGMA_UNROLL
                 for (int s = 0; s < NS; ++s) wv[s] = mask[s] * nr_fast_rcp(msum[s % NT] + 1e-8f);
+                if constexpr (SAVE) {
+                    if (wave == 0) {
+                        NR_PRAGMA_UNROLL
+                        for (int t = 0; t < NT; ++t) p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + kSavedMsumRow * 64 + lane] = msum[t];
+                    }
+                }
             }
             // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0 ;  k = 1: weight -> mean1, var1
             NR_PRAGMA_UNROLL
@@ -436,6 +457,20 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, sv, red, wave, nw, lane);
                 if (k == 0) bg_accumulate<NT, OWN, 1>(W, glane, g, wave, nw, sv, accg);
                 else bg_accumulate<NT, OWN, 3>(W, glane, g, wave, nw, sv, accg);
+                if constexpr (SAVE) {                          // every wave holds the statistics: wave 2k % nw writes the mean, (2k + 1) % nw the variance
+                    NR_PRAGMA_UNROLL
+                    for (int t = 0; t < NT; ++t) {
+                        float* d_ = p.saved + (size_t)(base / 16 + t) * kSavedTileFloats + (kSavedStatRow + 22 * k) * 64 + lane;
+                        if (wave == (2 * k) % nw) {
+                            NR_PRAGMA_UNROLL
+                            for (int q = 0; q < 11; ++q) d_[q * 64] = st[t * 11 + q];
+                        }
+                        if (wave == (2 * k + 1) % nw) {
+                            NR_PRAGMA_UNROLL
+                            for (int q = 0; q < 11; ++q) d_[(11 + q) * 64] = sv[t * 11 + q];
+                        }
+                    }
+                }
             }
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
@@ -445,6 +480,13 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     for (int t = 0; t < NT; ++t)
                         NR_PRAGMA_UNROLL
                         for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = accg[j][t][r];
+                    if constexpr (SAVE) {
+                        NR_PRAGMA_UNROLL
+                        for (int t = 0; t < NT; ++t)
+                            NR_PRAGMA_UNROLL
+                            for (int r = 0; r < 4; ++r)
+                                p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedBgRow + mo * 4 + r) * 64 + lane] = accg[j][t][r];
+                    }
                 }
             }
             NR_BLOCK_SYNC();

@@ -36,6 +36,7 @@ struct PointBwd2Params {
     const float* weights;      // packed pass weights (forward layers)
     const float* weights_t;    // packed transposed layers (kPackedTFloats)
     const float* d_point_rec;  // [rn*dn][kPointRec]: [0..15] d geometry feature, [16..18] d colour
+    const float* saved;        // [ceil(rn*dn / 16)][kSavedTileFloats]: what the training forward (points_kernel<SAVE>) left (nr_kernels.h)
     float* d_flat;             // [kFlatPassFloats], accumulated
     float* d_ray_feats;        // [rfn][fh][fw][32], accumulated
     float* d_img_feats;        // [rfn][fh][fw][32], accumulated
@@ -375,6 +376,13 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
 #ifdef NR_B2_PROFILE
         unsigned long long tprev_ = clock64();
 #endif
+        // base_fc.0's per-point part and the four statistics of this tile, as the forward kernel left them: global -> xch | stash by
+        // LDS-DMA (15 KB, two 1 KB pieces per wave); visible after the barriers of the first all-reduce below
+        const float* svt = p.saved + (size_t)(base / 16) * kSavedTileFloats;
+        {
+            const nr_wbuf SV = nr_make_wbuf(svt, sizeof(float) * kSavedTileFloats);
+            for (int i = wave; i < (kB2Xch + kB2Stash) / 256; i += kB2Waves) nr_dma16(SV, xch + i * 256, lane, lane * 16, i * 1024);
+        }
         // ================= geometry + gathers (as points_kernel) =================
         int pi = base + c;
         const bool pvalid = pi < npts;
@@ -410,8 +418,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         }
         B2_MARK(0);
         // ================= forward (recomputed; checkpoints stay in registers) =================
-        float mu0, mu1, s0, s1, aw, nu;
-        b2_dist_fwd<HAS_VIS>(W, glane, fray, p.var_bias, mu0, mu1, s0, s1, aw, nu);
+        // the dist decoder's outputs come from the forward (its layers are recomputed head by head in the backward part only)
+        const float* sd = svt + kSavedDist + view * 128 + c;
+        const float mu0 = sd[0], mu1 = sd[16], s0 = sd[32], s1 = sd[48], aw = sd[64], nu = sd[80];
         B2_MARK(1);
         const float nuu = use_vis ? nu : 1.0f;
         float vis, hit;
@@ -450,73 +459,17 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             sn = sigmoidf(o[0][0]);
         }
         B2_MARK(2);
-        // cross-view statistics (ibrnet.py:334-340), exactly as the first version computes them:
-        //   weight = mask / (sum mask + 1e-8), weight0 = sn * weight; mean_k = sum_v w_k x, var_k = sum_v w_k (x - mean_k)^2
+        // cross-view weights (ibrnet.py:334-340): weight = mask / (sum mask + 1e-8), weight0 = sn * weight.  The statistics themselves
+        // (mean_k = sum_v w_k x, var_k = sum_v w_k (x - mean_k)^2) and base_fc.0's per-point part are the forward's (stash, xch).
         float wv, w0, sa0, sa1;
         {
-            float ms[1] = {mask};
-            b2_allsum<1>(ms, red, wave, lane);
-            wv = mask / (ms[0] + 1e-8f);
+            wv = mask / (svt[kSavedMsumRow * 64 + lane] + 1e-8f);
             w0 = sn * wv;
             float sa[2] = {w0, wv};
             b2_allsum<2>(sa, red, wave, lane);
             sa0 = sa[0]; sa1 = sa[1];
         }
-        float mean0[11], mean1[11];                         // lane layout: 8 img channels (8g + k) + 3 rgb
-        {
-            float v22[kB2Rmax];
-            // means of both weightings in two all-reduces of 11, then the variances likewise
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) v22[k] = w0 * gi[k];
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < 3; ++j) v22[8 + j] = w0 * gr[j];
-            v22[11] = 0.0f;
-            b2_allsum<kB2Rmax>(v22, red, wave, lane);
-            NR_PRAGMA_UNROLL
-            for (int q = 0; q < 11; ++q) mean0[q] = v22[q];
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) v22[k] = wv * gi[k];
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < 3; ++j) v22[8 + j] = wv * gr[j];
-            v22[11] = 0.0f;
-            b2_allsum<kB2Rmax>(v22, red, wave, lane);
-            NR_PRAGMA_UNROLL
-            for (int q = 0; q < 11; ++q) mean1[q] = v22[q];
-            float var0[kB2Rmax], var1[kB2Rmax];
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) { const float a = gi[k] - mean0[k], b = gi[k] - mean1[k]; var0[k] = w0 * (a * a); var1[k] = wv * (b * b); }
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < 3; ++j) { const float a = gr[j] - mean0[8 + j], b = gr[j] - mean1[8 + j]; var0[8 + j] = w0 * (a * a); var1[8 + j] = wv * (b * b); }
-            var0[11] = 0.0f; var1[11] = 0.0f;
-            b2_allsum<kB2Rmax>(var0, red, wave, lane);
-            b2_allsum<kB2Rmax>(var1, red, wave, lane);
-            B2_MARK(3);
-            // base_fc.0 per-point part by the owner waves (output tile = wave, waves 0..3), statistics order [mean0 var0 mean1 var1]
-            if (wave < 4) {
-                v4f accg[1];
-                const float4 b = wld4(W, gg * 16, (bias_offset(L_BG) + wave * 16) * 4);
-                accg[0][0] = b.x; accg[0][1] = b.y; accg[0][2] = b.z; accg[0][3] = b.w;
-                float xq[1][8], x1[1][1];
-                auto feed = [&](const float* st, auto STAT) {
-                    NR_PRAGMA_UNROLL
-                    for (int k = 0; k < 8; ++k) xq[0][k] = st[k];
-                    x1[0][0] = sel4(g, st[8], st[9], st[10], 0.0f);
-                    layer_tile_slice<L_BG, 1, 2 * decltype(STAT)::value, 2, decltype(STAT)::value, 1>(W, glane, wave, xq, x1, accg);
-                };
-                feed(mean0, std::integral_constant<int, 0>{}); feed(var0, std::integral_constant<int, 1>{});
-                feed(mean1, std::integral_constant<int, 2>{}); feed(var1, std::integral_constant<int, 3>{});
-                NR_PRAGMA_UNROLL
-                for (int r_ = 0; r_ < 4; ++r_) xch[(wave * 4 + r_) * 64 + lane] = accg[0][r_];
-            }
-            if (wave == 4) {          // the statistics themselves: kept for the backward (stats backward, dW of base_fc.0)
-                NR_PRAGMA_UNROLL
-                for (int q = 0; q < 11; ++q) {
-                    stash[q * 64 + lane] = mean0[q]; stash[(11 + q) * 64 + lane] = var0[q];
-                    stash[(22 + q) * 64 + lane] = mean1[q]; stash[(33 + q) * 64 + lane] = var1[q];
-                }
-            }
-            __syncthreads();
-        }
+        B2_MARK(3);
         B2_MARK(4);
         // base_fc -> x;  h64 is recomputed in the backward from xch
         float x[1][8];

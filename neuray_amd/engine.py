@@ -406,10 +406,11 @@ class RenderEngine:
         return flat[idx] * ok
 
     def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05,
-                               packed=None, kernel='auto'):
+                               packed=None, kernel='auto', saved=None):
         """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC).
         packed: the forward's PackedPass of the same weights (built from `flat` here if absent).  kernel: 'auto' = the
-        register / LDS resident kernel when it applies (rfn <= 8), 'v1' = force the first-version kernel (tests)."""
+        register / LDS resident kernel when it applies (rfn <= 8), 'v1' = force the first-version kernel (tests).
+        saved: render_pass(save=True)['saved'] of the same inputs (resident kernel; produced here by one more forward if absent)."""
         coords, depth, d_point_rec = self._f32(coords), self._f32(depth), self._f32(d_point_rec)
         rn, dn = depth.shape
         d_flat = torch.zeros_like(flat)
@@ -418,8 +419,11 @@ class RenderEngine:
         resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
         ws = pk = pt = None
         if resident:
-            pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
+            packed = packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))
+            pk = packed.dev
             pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+            if saved is None:
+                saved = self.render_points_saved(qconst, views, coords, depth, packed, use_vis, var_bias)
         else:
             ws = self.empty(int(self.lib.neuray_points_backward_workspace_floats(rn * dn, views.rfn)))
         a = _lib.NeurayPointsBwdArgs(
@@ -427,7 +431,8 @@ class RenderEngine:
             views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_point_rec.data_ptr(), d_flat.data_ptr(),
             d_rf.data_ptr(), d_if.data_ptr(), ws.data_ptr() if ws is not None else None, views.rfn, rn, dn, views.h, views.w,
             views.fh, views.fw, int(has_vis_head), int(bool(use_vis)), float(var_bias),
-            pk.data_ptr() if pk is not None else None, pt.data_ptr() if pt is not None else None)
+            pk.data_ptr() if pk is not None else None, pt.data_ptr() if pt is not None else None,
+            saved.data_ptr() if (resident and saved is not None) else None)
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         return d_flat, d_rf, d_if
 
@@ -521,21 +526,25 @@ class RenderEngine:
         return out
 
     def render_pass(self, qconst, views, coords, depth, packed, use_vis, var_bias=0.05, ray_mask_view_num=2,
-                    ray_mask_point_num=8, want_depth=False, want_density=False, want_dbg=False):
+                    ray_mask_point_num=8, want_depth=False, want_density=False, want_dbg=False, save=False):
         """One pass (coarse or fine) over rays `coords` [rn,2] at sample depths `depth` [rn,dn].
-        -> dict(hit_prob [rn,dn], pixel [rn,3], ray_mask [rn] bool, render_depth?, density?, dbg?)"""
+        -> dict(hit_prob [rn,dn], pixel [rn,3], ray_mask [rn] bool, render_depth?, density?, dbg?, saved?)
+        save (training forward, rfn <= 8): also return 'saved', the cross-view quantities render_points_backward reads instead of
+        recomputing them (include/neuray_hip.h NeurayPointsArgs.saved_dev)."""
         coords, depth = self._f32(coords), self._f32(depth)
         rn, dn = depth.shape
         assert coords.shape == (rn, 2)
         s = self._stream()
         rec = self.empty(rn * dn, _lib.POINT_REC)
         dbg = self.empty(rn * dn, views.rfn, _lib.DBG_FIELDS) if want_dbg else None
+        saved = self.points_saved_buffer(rn * dn) if save and views.rfn <= 8 else None
         a = _lib.NeurayPointsArgs(
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(),
             views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
             rec.data_ptr(), dbg.data_ptr() if want_dbg else None,
             views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
-            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.views_per_wave))
+            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.views_per_wave),
+            saved.data_ptr() if saved is not None else None)
         ev = self._event_pair()
         self._check(self.lib.neuray_render_points(C.byref(a), s))
         self._event_done(ev, 'points', rn * dn)
@@ -558,4 +567,24 @@ class RenderEngine:
         out['point_rec'] = rec.view(rn, dn, _lib.POINT_REC)
         if want_dbg:
             out['dbg'] = dbg.view(rn, dn, views.rfn, _lib.DBG_FIELDS)
+        if saved is not None:
+            out['saved'] = saved
         return out
+
+    def points_saved_buffer(self, npts):
+        return self.empty(int(self.lib.neuray_points_saved_floats(int(npts))))
+
+    def render_points_saved(self, qconst, views, coords, depth, packed, use_vis, var_bias=0.05):
+        """The point kernel alone in its training form: -> the saved buffer of render_pass(save=True) (for callers of
+        render_points_backward that did not keep the forward's)."""
+        coords, depth = self._f32(coords), self._f32(depth)
+        rn, dn = depth.shape
+        rec = self.empty(rn * dn, _lib.POINT_REC)
+        saved = self.points_saved_buffer(rn * dn)
+        a = _lib.NeurayPointsArgs(
+            qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(),
+            views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
+            rec.data_ptr(), None, views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
+            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), 0, saved.data_ptr())
+        self._check(self.lib.neuray_render_points(C.byref(a), self._stream()))
+        return saved

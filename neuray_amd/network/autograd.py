@@ -51,8 +51,9 @@ class RenderPassFn(torch.autograd.Function):
         ctx.flat, ctx.has_vis = flat, has_vis
         res = run.eng.render_pass(run.qconst, run.views, run.coords, run.depth, packed, use_vis=run.use_vis,
                                   var_bias=run.var_bias, ray_mask_view_num=run.mask_view_num,
-                                  ray_mask_point_num=run.mask_point_num, want_depth=True)
+                                  ray_mask_point_num=run.mask_point_num, want_depth=True, save=True)
         ctx.run, ctx.packed = run, packed
+        ctx.point_saved = res.get('saved')                # cross-view quantities of the point kernel, read by its backward
         ctx.save_for_backward(res['point_rec'])
         ctx.mark_non_differentiable(res['ray_mask'])
         return res['pixel'], res['hit_prob'], res['ray_mask'], res['render_depth']
@@ -69,7 +70,8 @@ class RenderPassFn(torch.autograd.Function):
                                                 d_depth.contiguous() if d_depth is not None else None)
         sd = run.state()
         d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
-                                                        run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed)
+                                                        run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed,
+                                                        saved=ctx.point_saved)
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g

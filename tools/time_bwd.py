@@ -37,7 +37,8 @@ def main():
     flat, has_vis = eng.flat_pass(sd, 'dist_decoder.', 'agg_net.')
     packed = eng.pack_pass_device(flat, has_vis)
     d_rec = torch.randn(args.rays, 64, 20, device=dev) * 1e-2
-    run = lambda: eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec, packed=packed, kernel=args.kernel)   # noqa: E731
+    saved = eng.render_points_saved(qc, views, coords, depth, packed, False)       # what the training forward leaves for the backward
+    run = lambda: eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec, packed=packed, kernel=args.kernel, saved=saved)   # noqa: E731
     run(); run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()

@@ -103,9 +103,13 @@ constexpr int kDbgFields = 16;
 // What the training forward leaves for points_backward2_kernel, per tile of 16 consecutive sample points ([rows][64 lanes],
 // lane = 16 g + point): rows 0..15 base_fc.0's per-point part (output tile mo, register r -> row 4 mo + r; the LDS exchange
 // layout of both kernels), rows 16..59 the four cross-view statistics mean0 | var0 | mean1 | var1 (11 rows each: 8 image
-// channels 8 g + k, 3 rgb), row 60 sum of the view masks, then [8 views][8][16 points]: mu0, mu1, s0, s1, aw, nu of the dist
-// decoder.  The backward reads them instead of redoing the decoder forward, six all-reduces and the per-point layer slices.
-constexpr int kSavedBgRow = 0, kSavedStatRow = 16, kSavedMsumRow = 60, kSavedDist = 61 * 64;
+// channels 8 g + k, 3 rgb), row 60 sum of the view masks, row 61 sum of weight0, rows 62..77 geometry_fc.0's (scaled-ELU) hidden
+// layer (tile mo, register r -> row 62 + 4 mo + r), 78..85 / 86..93 visibility-weighted mean / variance (channel 16 (k / 4) + 4 g +
+// k % 4 in row k: the D layout), 94..97 geometry_fc's output, 98 max z, 99 sum exp(z - max z), 100 sum vis'', then
+// [8 views][8][16 points]: mu0, mu1, s0, s1, aw, nu of the dist decoder.  The backward reads them instead of redoing the decoder
+// forward, every cross-view all-reduce and the per-point layers' forward.
+constexpr int kSavedBgRow = 0, kSavedStatRow = 16, kSavedMsumRow = 60, kSavedSw0Row = 61, kSavedGeoRow = 62, kSavedGmeanRow = 78,
+              kSavedGvarRow = 86, kSavedGRow = 94, kSavedZmaxRow = 98, kSavedSezRow = 99, kSavedSvisRow = 100, kSavedDist = 101 * 64;
 constexpr int kSavedTileFloats = kSavedDist + 8 * 8 * 16;
 
 __device__ __forceinline__ float sel4(int g, float a, float b, float c, float d) {
@@ -586,18 +590,22 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // Two all-reduces: {max z, sum vis''} and {sum wh x (8), sum e (1), sum e rgb (3)} with e = exp(z - max z); the
         // softmax blend sum(rgb * e / sum e) is evaluated as sum(rgb * e) / sum(e), the mean weight sum(wh) / rfn from
         // sum(vis'') directly.
-        float zv[NT * 2], big[NT * 12], wh[NS], meanw[NT];
+        constexpr int ZR = SAVE ? 3 : 2;                       // (training: sum of weight0 = sn * weight rides along for the backward)
+        float zv[NT * ZR], big[NT * 12], wh[NS], meanw[NT];
         {
-            float z2[NS][2];
+            float z2[NS][ZR];
             NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) { z2[s][0] = z[s]; z2[s][1] = vis2[s]; }
-            view_allreduce<NT, VPW, 2, RMAX, RED_MAX0>(z2, zv, red, wave, nw, lane);
+            for (int s = 0; s < NS; ++s) {
+                z2[s][0] = z[s]; z2[s][1] = vis2[s];
+                if constexpr (SAVE) z2[s][2] = sn[s] * wv[s];
+            }
+            view_allreduce<NT, VPW, ZR, RMAX, RED_MAX0>(z2, zv, red, wave, nw, lane);
             float b12[NS][12];
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NS; ++s) {
                 const int t = s % NT;
-                const float ev = nr_fast_exp(z[s] - zv[2 * t]);
-                wh[s] = vis2[s] * nr_fast_rcp(zv[2 * t + 1] + 1e-8f);
+                const float ev = nr_fast_exp(z[s] - zv[ZR * t]);
+                wh[s] = vis2[s] * nr_fast_rcp(zv[ZR * t + 1] + 1e-8f);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) b12[s][k] = x[s][k] * wh[s];
                 b12[s][8] = ev;
@@ -609,7 +617,21 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             for (int t = 0; t < NT; ++t) {
                 const float ie = nr_fast_rcp(big[t * 12 + 8]);
                 big[t * 12 + 9] *= ie; big[t * 12 + 10] *= ie; big[t * 12 + 11] *= ie;
-                meanw[t] = zv[2 * t + 1] * nr_fast_rcp(zv[2 * t + 1] + 1e-8f);
+                meanw[t] = zv[ZR * t + 1] * nr_fast_rcp(zv[ZR * t + 1] + 1e-8f);
+            }
+            if constexpr (SAVE) {
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t) {
+                    float* d_ = p.saved + (size_t)(base / 16 + t) * kSavedTileFloats + lane;
+                    if (wave == 0) {
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) d_[(kSavedGmeanRow + k) * 64] = big[t * 12 + k];
+                    }
+                    if (wave == 2 % nw) {
+                        d_[kSavedZmaxRow * 64] = zv[ZR * t]; d_[kSavedSezRow * 64] = big[t * 12 + 8];
+                        d_[kSavedSvisRow * 64] = zv[ZR * t + 1]; d_[kSavedSw0Row * 64] = zv[ZR * t + 2];
+                    }
+                }
             }
         }
         // geometry_fc.0 (a14): owner waves stream the mean part, then the variance part   ibrnet.py:353-354
@@ -640,6 +662,14 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
             }
             view_allreduce<NT, VPW, 8, RMAX, RED_SUM>(v8, var, red, wave, nw, lane);
+            if constexpr (SAVE) {
+                if (wave == 1 % nw) {
+                    NR_PRAGMA_UNROLL
+                    for (int t = 0; t < NT; ++t)
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedGvarRow + k) * 64 + lane] = var[t * 8 + k];
+                }
+            }
         }
         {
             float xq[NT][8], nonet[NT][1];
@@ -658,6 +688,13 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     for (int t = 0; t < NT; ++t)
                         NR_PRAGMA_UNROLL
                         for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu_s(accf[j][t][r]);   // kOutScaled[L_GF1]
+                    if constexpr (SAVE) {
+                        NR_PRAGMA_UNROLL
+                        for (int t = 0; t < NT; ++t)
+                            NR_PRAGMA_UNROLL
+                            for (int r = 0; r < 4; ++r)
+                                p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedGeoRow + mo * 4 + r) * 64 + lane] = elu_s(accf[j][t][r]);
+                    }
                 }
             }
         }
@@ -675,6 +712,12 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             for (int t = 0; t < NT; ++t)
                 if (pvalid[t])
                     *reinterpret_cast<float4*>(p.point_out + (size_t)pidx[t] * kPointRec + 4 * g) = make_float4(G[t][0], G[t][1], G[t][2], G[t][3]);
+            if constexpr (SAVE) {
+                NR_PRAGMA_UNROLL
+                for (int t = 0; t < NT; ++t)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedGRow + r) * 64 + lane] = G[t][r];
+            }
         }
         if (wave == (nw > 1 ? 1 : 0) && g == 0) {
             NR_PRAGMA_UNROLL

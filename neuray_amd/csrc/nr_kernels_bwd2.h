@@ -382,6 +382,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         {
             const nr_wbuf SV = nr_make_wbuf(svt, sizeof(float) * kSavedTileFloats);
             for (int i = wave; i < (kB2Xch + kB2Stash) / 256; i += kB2Waves) nr_dma16(SV, xch + i * 256, lane, lane * 16, i * 1024);
+            // rows kSavedGeoRow .. kSavedSvisRow (39 rows; 40 copied) -> the geometry exchange area xg: hidden layer of geometry_fc (16
+            // rows), weighted mean (8) / variance (8), geometry_fc's output (4), max z, sum exp, sum vis''
+            for (int i = wave; i < 10; i += kB2Waves) nr_dma16(SV, xg + i * 256, lane, lane * 16, (kSavedGeoRow * 64 + i * 256) * 4);
         }
         // ================= geometry + gathers (as points_kernel) =================
         int pi = base + c;
@@ -463,11 +466,12 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         // (mean_k = sum_v w_k x, var_k = sum_v w_k (x - mean_k)^2) and base_fc.0's per-point part are the forward's (stash, xch).
         float wv, w0, sa0, sa1;
         {
-            wv = mask / (svt[kSavedMsumRow * 64 + lane] + 1e-8f);
+            const float msum = svt[kSavedMsumRow * 64 + lane];
+            wv = mask / (msum + 1e-8f);
             w0 = sn * wv;
-            float sa[2] = {w0, wv};
-            b2_allsum<2>(sa, red, wave, lane);
-            sa0 = sa[0]; sa1 = sa[1];
+            sa0 = svt[kSavedSw0Row * 64 + lane];
+            sa1 = msum / (msum + 1e-8f);
+            __syncthreads();                                   // every wave's DMA pieces have landed (the fence waits for them)
         }
         B2_MARK(3);
         B2_MARK(4);
@@ -524,26 +528,16 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             z = mask > 0.0f ? o[0][0] : -1e9f;
         }
         B2_MARK(5);
-        // softmax blend weights, visibility-weighted statistics (ibrnet.py:350-354,366-367)
-        float beta, svis, wh, swh, gmean[8], gvar[8];
+        // softmax blend weights (ibrnet.py:350-354,366-367) from the forward's max z / sum exp / sum vis''; the visibility-weighted mean
+        // and variance stay in xg (rows 16..31) until the blend backward
+        float beta, svis, wh, swh;
+        const float* gm_l = xg + 16 * 64 + lane;              // weighted mean row k: gm_l[k * 64], variance: gm_l[(8 + k) * 64]
         {
-            float zm[1] = {z};
-            block_allreduce<1, 1, RED_MAX>(zm, redm, wave, kB2Waves, lane);
-            const float ez = vok ? nr_fast_exp(z - zm[0]) : 0.0f;     // (padding waves take no part in the softmax)
-            float s3[3] = {ez, vis2, 0.0f};
-            b2_allsum<3>(s3, red, wave, lane);
-            beta = ez / s3[0];
-            svis = s3[1];
+            const float ez = vok ? nr_fast_exp(z - xg[36 * 64 + lane]) : 0.0f;     // (padding waves take no part in the softmax)
+            beta = ez / xg[37 * 64 + lane];
+            svis = xg[38 * 64 + lane];
             wh = vis2 / (svis + 1e-8f);
-            float m9[9];
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) m9[k] = wh * x2[0][k];
-            m9[8] = wh;
-            b2_allsum<9>(m9, red, wave, lane);
-            swh = m9[8];
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) { gmean[k] = m9[k]; const float a = x2[0][k] - gmean[k]; gvar[k] = wh * (a * a); }
-            b2_allsum<8>(gvar, red, wave, lane);
+            swh = svis / (svis + 1e-8f);
         }
         const float meanw = swh * inv_rfn;
 
@@ -551,57 +545,47 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         // ================= backward =================
         const float* up = p.d_point_rec + (size_t)pi * kPointRec;
         const float gsc = pvalid ? 1.0f : 0.0f;
-        // ---- geometry_fc (per point; ibrnet.py:353-354): hidden tiles by waves 0..3, the rest by wave 0
+        // ---- geometry_fc (per point; ibrnet.py:353-354).  Hidden layer h and output G are the forward's (xg rows 0..15, 32..35).
+        // Waves 0..3 each redo the small transposed geometry_fc.2 and take output tile `wave` of geometry_fc.0^T.
         float dgm[8], dgv[8], dmeanw;                          // d mean, d var (natural D layout), d mean weight
         {
-            if (wave < 4) {
-                v4f accf[1];
-                const float4 b = wld4(W, gg * 16, (bias_offset(L_GF1) + wave * 16) * 4);
-                accf[0][0] = b.x; accf[0][1] = b.y; accf[0][2] = b.z; accf[0][3] = b.w;
-                float xq[1][8], x1[1][1], n1[1][1] = {{0.0f}};
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) xq[0][k] = gmean[k];
-                x1[0][0] = sel4(g, meanw, 0.0f, 0.0f, 0.0f);
-                layer_tile_slice<L_GF1, 1, 0, 2, 0, 1>(W, glane, wave, xq, x1, accf);
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) xq[0][k] = gvar[k];
-                layer_tile_slice<L_GF1, 1, 2, 2, 0, 0>(W, glane, wave, xq, n1, accf);
-                NR_PRAGMA_UNROLL
-                for (int r_ = 0; r_ < 4; ++r_) xg[(wave * 4 + r_) * 64 + lane] = elu_s(accf[0][r_]);
-            }
-            B2_MARK(7);
-            __syncthreads();
-            B2_MARK(8);
             // per-point staging (stride kB2PStride): rows 0 d Gpre (16), 16 h64 (64), 80 d h64 (64), 144 input (65 -> 80)
             float* SP = S;
-            if (wave == 0) {
-                float h[1][16], G[1][4], dG[1][4], dh[1][16], din[1][16];
+            B2_MARK(7);
+            if (wave < 4) {
+                float h[1][16], dG[1][4], dh[1][16];
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) h[0][k] = xg[k * 64 + lane];
-                B2_MARK(9);
-                layer_fwd<L_GF2, 1, ACT_ELU>(W, glane, h, none, G);
-                B2_MARK(10);
                 const float4 u4 = ld4(up + 4 * g);
-                dG[0][0] = u4.x * gsc * delu(G[0][0]); dG[0][1] = u4.y * gsc * delu(G[0][1]);
-                dG[0][2] = u4.z * gsc * delu(G[0][2]); dG[0][3] = u4.w * gsc * delu(G[0][3]);
+                dG[0][0] = u4.x * gsc * delu(xg[32 * 64 + lane]); dG[0][1] = u4.y * gsc * delu(xg[33 * 64 + lane]);
+                dG[0][2] = u4.z * gsc * delu(xg[34 * 64 + lane]); dG[0][3] = u4.w * gsc * delu(xg[35 * 64 + lane]);
+                B2_MARK(9);
                 layer_fwd<LT_GF2, 1, ACT_NONE>(WT, glane, dG, none, dh);
                 B2_MARK(11);
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) dh[0][k] *= delu_s(h[0][k]);
-                layer_fwd<LT_GF1, 1, ACT_NONE>(WT, glane, dh, none, din);
-                float dmw[1][1];
-                layer_vec<LT_GF1, 1>(WT, glane, dh, dmw);
-                B2_MARK(12);
-                // hand d mean / d var / d mean weight to every wave
+                v4f a4[1];
+                a4[0][0] = 0.0f; a4[0][1] = 0.0f; a4[0][2] = 0.0f; a4[0][3] = 0.0f;
+                layer_tile<LT_GF1, 1>(WT, glane, wave, dh, none, a4);
+                // hand d mean / d var / d mean weight to every wave (hx row 4 tile + r: d mean rows 0..7, d var rows 8..15)
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) hx[k * 64 + lane] = din[0][k];
-                hx[16 * 64 + lane] = dmw[0][0];
-                st_nat<4>(SP, kB2PStride, 0, dG[0], c, g);
-                st_nat<16>(SP, kB2PStride, 16, h[0], c, g);
-                st_nat<16>(SP, kB2PStride, 80, dh[0], c, g);
-                st_nat<8>(SP, kB2PStride, 144, gmean, c, g);
-                st_nat<8>(SP, kB2PStride, 176, gvar, c, g);
-                st_one(SP, kB2PStride, 208, meanw, c, g);
+                for (int r_ = 0; r_ < 4; ++r_) hx[(wave * 4 + r_) * 64 + lane] = a4[0][r_];
+                if (wave == 0) {
+                    float dmw[1][1];
+                    layer_vec<LT_GF1, 1>(WT, glane, dh, dmw);
+                    hx[16 * 64 + lane] = dmw[0][0];
+                    st_nat<4>(SP, kB2PStride, 0, dG[0], c, g);
+                    st_nat<16>(SP, kB2PStride, 16, h[0], c, g);
+                }
+                B2_MARK(12);
+                if (wave == 1) st_nat<16>(SP, kB2PStride, 80, dh[0], c, g);
+                if (wave == 2) {
+                    float gmv[16];
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 16; ++k) gmv[k] = gm_l[k * 64];
+                    st_nat<16>(SP, kB2PStride, 144, gmv, c, g);           // rows 144..175 mean, 176..207 variance
+                    st_one(SP, kB2PStride, 208, meanw, c, g);
+                }
                 B2_MARK(13);
             }
             __syncthreads();
@@ -619,7 +603,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             float part = 0.0f;
             NR_PRAGMA_UNROLL
             for (int k = 0; k < 8; ++k) {
-                const float xv = x2[0][k], mean = gmean[k];
+                const float xv = x2[0][k], mean = gm_l[k * 64];
                 const float dmt = dgm[k] - 2.0f * dgv[k] * mean * (1.0f - swh);
                 dx2[0][k] = wh * (dmt + 2.0f * (xv - mean) * dgv[k]);
                 part += dmt * xv + dgv[k] * (xv - mean) * (xv - mean);

@@ -11,16 +11,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, '_ab', 'lib_b2prof.so')
-NAMES = {0: 'projection + gathers', 1: 'dist decoder fwd', 2: 'prob, prob_embed, ray_dir_fc, neuray_fc fwd', 3: 'statistics all-reduces (6)',
-         4: 'base_fc.0 per-point part + barrier', 5: 'base_fc .. rgb_fc fwd', 6: 'softmax + weighted statistics (4 all-reduces)',
-         7: 'geometry: hidden tiles (waves 0-3)', 8: '  barrier', 9: '  wave 0: read hidden', 10: '  wave 0: geometry_fc.2 fwd',
-         11: '  wave 0: geometry_fc.2^T', 12: '  wave 0: geometry_fc.0^T', 13: '  wave 0: hand-off + staging', 14: '  barrier',
-         15: '  read hand-off + jobs', 16: 'blend bwd (1 all-reduce)', 17: 'rgb_fc chain', 18: '  barrier', 19: '  staging writes', 20: '  barrier',
-         21: '  jobs', 22: 'vis_fc2 bwd (whole round)', 23: 'vis_fc bwd (whole round)', 24: 'base_fc chain', 25: '  barrier', 26: '  staging + barrier + jobs B2',
-         27: '  staging + 2 barriers + jobs BV', 28: '  two all-reduces of d h64', 29: '  statistics^T tiles, hand-off, staging, 2 barriers',
-         30: '  jobs BG (per point)', 31: 'statistics bwd', 32: 'neuray_fc + ray_dir_fc bwd (whole round)', 33: 'prob_embed bwd (whole round)',
-         34: 'prob bwd / between heads', 35: 'head: fwd 2 layers', 36: 'head: vec^T, 2 transposed layers', 37: 'head: barrier', 38: 'head: staging writes',
-         39: 'head: barrier', 40: 'head: jobs', 41: '(after last head)', 42: 'scatter'}
+NAMES = {0: 'DMA of the saved tile + projection + gathers', 1: 'dist decoder outputs (saved)', 2: 'prob, prob_embed, ray_dir_fc, neuray_fc fwd',
+         3: 'weights + barrier (DMA visible)', 4: '-', 5: 'base_fc .. rgb_fc fwd', 6: 'softmax weights (saved sums)',
+         7: '-', 9: 'geometry: waves 0-3 read hidden, G', 11: '  geometry_fc.2^T', 12: '  geometry_fc.0^T tile + hand-off (+ vec, staging on wave 0)',
+         13: '  staging (waves 1, 2)', 14: '  barrier', 15: '  read hand-off + jobs', 16: 'blend bwd (1 all-reduce)', 17: 'rgb_fc chain', 18: '  barrier',
+         19: '  staging writes', 20: '  barrier', 21: '  jobs', 22: 'vis_fc2 bwd (whole round)', 23: 'vis_fc bwd (whole round)', 24: 'base_fc chain',
+         25: '  barrier', 26: '  staging + barrier + jobs B2', 27: '  staging + 2 barriers + jobs BV', 28: '  two all-reduces of d h64',
+         29: '  statistics^T tiles, hand-off, staging, 2 barriers', 30: '  jobs BG (per point)', 31: 'statistics bwd',
+         32: 'neuray_fc + ray_dir_fc bwd (whole round)', 33: 'prob_embed bwd (whole round)', 34: 'prob bwd / between heads', 35: 'head: fwd 2 layers',
+         36: 'head: vec^T, 2 transposed layers', 37: 'head: barrier', 38: 'head: staging writes', 39: 'head: barrier', 40: 'head: jobs',
+         41: '(after last head)', 42: 'scatter'}
 
 
 def build():

@@ -436,13 +436,15 @@ class RenderEngine:
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         return d_flat, d_rf, d_if
 
-    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05, packed=None, kernel='auto'):
+    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05, packed=None, kernel='auto',
+                               d_flat=None):
         """Backward of dist_decoder_rows + self_hit_prob: -> (d_feats [rn,32], d_flat).  The resident kernel (one wave per 16 rays, decoder
-        in registers on the packed / transposed packs) unless kernel == 'v1' (first version: lane = ray, global arena)."""
+        in registers on the packed / transposed packs) unless kernel == 'v1' (first version: lane = ray, global arena).
+        d_flat: an existing flat gradient buffer to accumulate into (the kernels add atomically) instead of a fresh zeroed one."""
         depth, feats, d_hit = self._f32(depth), self._f32(feats), self._f32(d_hit)
         rn, dn = depth.shape
         d_feats = self.empty(rn, 32)
-        d_flat = torch.zeros_like(flat)
+        d_flat = torch.zeros_like(flat) if d_flat is None else d_flat
         if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant == 'fp32':
             pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
             pt = self.pack_pass_t_device(flat, bool(has_vis_head))

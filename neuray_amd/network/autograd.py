@@ -81,6 +81,55 @@ class RenderPassFn(torch.autograd.Function):
             tuple(grads[k] for k, _ in run.named_params())      # views of one buffer: no per-parameter copies
 
 
+class RenderPassSelfFn(torch.autograd.Function):
+    """RenderPassFn and SelfHitFn of the same pass as ONE node: (ray_feats, img_feats, que ray_feats, *params) -> pixel, hit_prob,
+    ray_mask, render_depth, hit_prob_self.  Both backward kernels accumulate into one flat gradient buffer, so every parameter receives a
+    single gradient (as two nodes the dist decoder's 18 tensors arrive twice per pass and autograd adds them: 36 small kernels a step)."""
+
+    @staticmethod
+    def forward(ctx, run, hw, ray_feats, img_feats, que_ray_feats, *params):
+        eng = run.eng
+        flat, packed, has_vis = run.device_weights()
+        ctx.flat, ctx.has_vis = flat, has_vis
+        res = eng.render_pass(run.qconst, run.views, run.coords, run.depth, packed, use_vis=run.use_vis,
+                              var_bias=run.var_bias, ray_mask_view_num=run.mask_view_num,
+                              ray_mask_point_num=run.mask_point_num, want_depth=True, save=True)
+        feats = eng.interpolate_feats(que_ray_feats, run.coords[None], hw[0], hw[1], align_corners=False)      # [1,rn,32]
+        mean, var, vis, aw = eng.dist_decoder_rows(feats[0], packed, run.var_bias)
+        self_use_vis = run.dist.cfg['use_vis']
+        hit_self = eng.self_hit_prob(run.qconst, run.depth, mean, var, aw, vis if self_use_vis else None)
+        ctx.run, ctx.packed, ctx.hw, ctx.que_shape, ctx.self_use_vis = run, packed, hw, tuple(que_ray_feats.shape), self_use_vis
+        ctx.point_saved = res.get('saved')
+        ctx.save_for_backward(res['point_rec'], feats)
+        ctx.mark_non_differentiable(res['ray_mask'])
+        return res['pixel'], res['hit_prob'], res['ray_mask'], res['render_depth'], hit_self
+
+    @staticmethod
+    def backward(ctx, d_pixel, d_hit, _d_mask, d_depth, d_hit_self):
+        run, eng = ctx.run, ctx.run.eng
+        point_rec, feats = ctx.saved_tensors
+        rn, dn = run.depth.shape
+        if d_pixel is None:
+            d_pixel = torch.zeros(rn, 3, device=point_rec.device)
+        d_rec, g_ray = eng.render_rays_backward(point_rec, run.depth, ctx.packed, d_pixel.contiguous(),
+                                                d_hit.contiguous() if d_hit is not None else None,
+                                                d_depth.contiguous() if d_depth is not None else None)
+        d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
+                                                        run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed,
+                                                        saved=ctx.point_saved)
+        d_map = None
+        if d_hit_self is not None:
+            d_feats, _ = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], ctx.flat, ctx.has_vis, ctx.self_use_vis,
+                                                    d_hit_self.contiguous(), var_bias=run.var_bias, packed=ctx.packed, d_flat=d_flat)
+            if ctx.needs_input_grad[4]:
+                d_map = eng.interpolate_feats_backward(d_feats[None], ctx.que_shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
+        grads = eng.unflatten_pass_grads(d_flat, run.state(), 'd.', 'a.')
+        for name, g in g_ray.items():
+            grads['a.agg_impl.' + name] = g
+        return (None, None, d_rf.permute(0, 3, 1, 2), d_if.permute(0, 3, 1, 2), d_map) + \
+            tuple(grads[k] for k, _ in run.named_params())
+
+
 class SelfHitFn(torch.autograd.Function):
     """(que ray_feats NCHW [1,32,fh,fw], *run.dist_params()) -> hit_prob_self [rn,dn]   (renderer.py:137-155)"""
 

@@ -13,7 +13,7 @@ never silently switches to an eager implementation.
 import torch
 
 from ..engine import RenderEngine
-from .autograd import PassRun, RenderPassFn, SelfHitFn
+from .autograd import PassRun, RenderPassFn, RenderPassSelfFn, SelfHitFn
 
 HOT_PATH_METHODS = ('engine', '_packed_pass', '_same_tensors', '_views', '_query', '_self_hit_prob',
                     'render_by_depth', 'predict_self_hit_prob', 'fine_render_impl', 'render_impl')
@@ -89,9 +89,17 @@ class HipRenderPath:
             if que_depth.shape[-1] > eng.max_backward_samples:
                 raise NotImplementedError("neuray_amd: the backward kernels take at most %d samples per ray and pass"
                                           % eng.max_backward_samples)
-            pix, hitp, rmask, rdepth = RenderPassFn.apply(run, ref_imgs_info['ray_feats'], ref_imgs_info['img_feats'],
-                                                          *[p for _, p in run.named_params()])
-            res = {'pixel': pix, 'hit_prob': hitp, 'ray_mask': rmask, 'render_depth': rdepth}
+            if is_train and cfg['use_self_hit_prob'] and 'ray_feats' in que_imgs_info and 'imgs' in que_imgs_info:
+                # the pass and the query view's own hit probabilities (renderer.py:137-155) as one autograd node: one gradient per parameter
+                _, _, qh, qw = que_imgs_info['imgs'].shape
+                pix, hitp, rmask, rdepth, hit_self = RenderPassSelfFn.apply(
+                    run, (qh, qw), ref_imgs_info['ray_feats'], ref_imgs_info['img_feats'], que_imgs_info['ray_feats'],
+                    *[p for _, p in run.named_params()])
+            else:
+                hit_self = None
+                pix, hitp, rmask, rdepth = RenderPassFn.apply(run, ref_imgs_info['ray_feats'], ref_imgs_info['img_feats'],
+                                                              *[p for _, p in run.named_params()])
+            res = {'pixel': pix, 'hit_prob': hitp, 'ray_mask': rmask, 'render_depth': rdepth, 'hit_self': hit_self}
         else:
             packed = self._packed_pass(eng, is_fine)
             res = eng.render_pass(qconst, views, run.coords, run.depth, packed, use_vis=use_vis, var_bias=run.var_bias,
@@ -99,7 +107,8 @@ class HipRenderPath:
                                   want_depth=cfg['render_depth'])
         outputs = {'pixel_colors_nr': res['pixel'][None], 'hit_prob_nr': res['hit_prob'][None]}
         if is_train and cfg['use_self_hit_prob']:
-            outputs['hit_prob_self'] = self._self_hit_prob(que_imgs_info, que_depth, is_fine, run, packed)
+            outputs['hit_prob_self'] = res['hit_self'][None] if res.get('hit_self') is not None else \
+                self._self_hit_prob(que_imgs_info, que_depth, is_fine, run, packed)
         if 'imgs' in que_imgs_info:
             outputs['pixel_colors_gt'] = eng.interpolate_feats(que_imgs_info['imgs'], coords, align_corners=True)
         if cfg['use_ray_mask']:

@@ -433,7 +433,9 @@ class RenderEngine:
             views.fh, views.fw, int(has_vis_head), int(bool(use_vis)), float(var_bias),
             pk.data_ptr() if pk is not None else None, pt.data_ptr() if pt is not None else None,
             saved.data_ptr() if (resident and saved is not None) else None)
+        ev = self._event_pair()
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
+        self._event_done(ev, 'points_backward', rn * dn)
         return d_flat, d_rf, d_if
 
     def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05, packed=None, kernel='auto',

@@ -52,8 +52,11 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     const int nwaves = (p.rfn + VPW - 1) / VPW;
     const size_t smem = nr::point_smem_bytes<NT>(nwaves);
     if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
-    // persistent-style grid: enough workgroups to fill 256 CUs several times over, grid-stride beyond
-    int grid = grid_for(npts, 16 * NT, 256 * 16);
+    // persistent-style grid: enough workgroups to fill the 768 resident slots (3 per CU) ten times over, grid-stride beyond.  Measured on
+    // the 800 x 800 workload (131 072 tiles per coarse launch), same box: 768 workgroups 2.30 M rays/s, 1536 2.35, 3072 / 3840 2.38,
+    // 4096 2.42, 6144 2.37, 8192 ... 32768 2.44 - finer-grained balancing wins over fewer prologues, and counts that divide the tiles
+    // evenly beat those that do not
+    int grid = grid_for(npts, 16 * NT, 256 * 32);
     grid = (grid + 7) / 8 * 8;                         // the XCD-aware tile map needs a multiple of 8
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")

@@ -382,3 +382,40 @@ def test_self_hit_backward_matches_autograd_and_the_first_version(rn, dn, vis_he
     for k, g in got['auto'][0].items():                      # nothing but the dist decoder is touched
         if not k.startswith('dist_decoder.'):
             assert float(g.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_resident_point_backward_uses_the_forwards_saved_quantities(backend):
+    """the C ABI refuses the resident kernel without NeurayPointsBwdArgs.saved_dev; the engine produces the buffer itself when the
+    caller did not keep the forward's, and both routes give the same gradients"""
+    import ctypes as C
+    from neuray_amd import _lib
+    from neuray_amd.engine import RenderEngine
+    from oracle import neuray_oracle as orc
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
+    que, ref, weights, rng = _pass_case(4, 6, 7, False, seed=91)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    views = eng.prepare_views({k: t(v) for k, v in ref.items()})
+    qc = eng.prepare_query({k: t(v) for k, v in que.items()})
+    depth = t(orc.sample_depth(que['depth_range'], 6, 7)[0])
+    coords = t(que['coords'][0])
+    packed = eng.pack_pass(weights, 'dist_decoder.', 'agg_net.')
+    flat, has_vis = eng.flat_pass(weights, 'dist_decoder.', 'agg_net.')
+    fwd = eng.render_pass(qc, views, coords, depth, packed, use_vis=False, save=True)
+    assert fwd['saved'].numel() == int(eng.lib.neuray_points_saved_floats(6 * 7)) > 0
+    d_rec = t(rng.randn(6, 7, 20).astype(np.float32))
+    a = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec, packed=packed, saved=fwd['saved'])
+    b = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec, packed=packed)      # engine reruns the forward
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+    # straight through the C ABI with saved_dev = NULL
+    pt = eng.pack_pass_t_device(flat, has_vis)
+    d_flat, d_rf, d_if = torch.zeros_like(flat), torch.zeros_like(views.ray_feats), torch.zeros_like(views.img_feats)
+    args = _lib.NeurayPointsBwdArgs(
+        qc.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
+        views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_rec.data_ptr(), d_flat.data_ptr(), d_rf.data_ptr(),
+        d_if.data_ptr(), None, views.rfn, 6, 7, views.h, views.w, views.fh, views.fw, int(has_vis), 0, 0.05,
+        packed.dev.data_ptr(), pt.data_ptr(), None)
+    assert eng.lib.neuray_render_points_backward(C.byref(args), eng._stream()) != 0
+    assert b'saved_dev' in eng.lib.neuray_last_error()

@@ -391,7 +391,9 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
         q.use_vis = a->use_vis; q.var_bias = a->var_bias;
         const size_t smem = nr::point_bwd2_smem_bytes();
         const int grid2 = grid_for((long long)a->rn * a->dn, 16, 256);            // persistent: one workgroup per CU
-        if (a->has_vis_head) {
+        // (a vis head that compute_prob does not consume - the fine decoder's when the coarse decoder has use_vis = False, quirk A.9.2 -
+        // has an identically zero gradient on this path: the kernel without the head is the same computation)
+        if (a->has_vis_head && a->use_vis) {
             auto k = nr::points_backward2_kernel<true>;
 #ifndef NEURAY_EMU
             (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -451,7 +453,7 @@ int neuray_self_hit_prob_backward_resident(const float* qc, const float* depth, 
     p.que_const = qc; p.depth = depth; p.feats = feats; p.weights = packed; p.weights_t = packed_t; p.d_hit = d_hit;
     p.d_feats = d_feats; p.d_flat = d_flat; p.rn = rn; p.dn = dn; p.use_vis = use_vis; p.var_bias = var_bias;
     const dim3 grid(grid_for(rn, 16, 512));
-    if (has_vis_head) NR_LAUNCH(nr::self_hit_backward2_kernel<true>, grid, dim3(64), 0, stream, p);
+    if (has_vis_head && use_vis) NR_LAUNCH(nr::self_hit_backward2_kernel<true>, grid, dim3(64), 0, stream, p);   // (an unused vis head: zero gradient)
     else NR_LAUNCH(nr::self_hit_backward2_kernel<false>, grid, dim3(64), 0, stream, p);
     return check_launch("neuray_self_hit_prob_backward_resident");
 #endif

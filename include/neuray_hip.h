@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 4
+#define NEURAY_ABI_VERSION 5
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -124,6 +124,8 @@ typedef struct NeurayRaysArgs {
     unsigned char* ray_mask_dev;    /* [rn] or NULL */
     float* density_dev;             /* [rn][dn] or NULL */
     int rn, dn, ray_mask_view_num, ray_mask_point_num;
+    float* att_save_dev;            /* NULL, or (training forward) [rn][dn][NEURAY_RAY_ATT_SAVE]: softmax shift (4 heads), 1 / denominator
+                                     * (4), attention output (16) of every sample, for neuray_render_rays_backward */
 } NeurayRaysArgs;
 int neuray_render_rays(const NeurayRaysArgs* args, void* stream);
 
@@ -136,6 +138,7 @@ int neuray_render_rays(const NeurayRaysArgs* args, void* stream);
  * layer_norm.weight / .bias (16), out_geometry_fc.0.weight (16x16) / .bias (16), out_geometry_fc.2.weight (16) / .bias.
  * dn <= NEURAY_MAX_SAMPLES: one wave per ray, one sample per lane up to 64 samples, two per lane above. */
 #define NEURAY_PACKED_RAY_FLOATS 1348
+#define NEURAY_RAY_ATT_SAVE 24
 #define NEURAY_RW_WQ 0
 #define NEURAY_RW_WK 256
 #define NEURAY_RW_WV 512
@@ -157,6 +160,7 @@ typedef struct NeurayRaysBwdArgs {
     float* d_point_rec_dev;           /* [rn][dn][NEURAY_POINT_REC] */
     float* d_ray_weights_dev;         /* [NEURAY_PACKED_RAY_FLOATS], accumulated */
     int rn, dn;
+    const float* att_saved_dev;       /* NULL (the attention forward is recomputed), or NeurayRaysArgs.att_save_dev of the same inputs */
 } NeurayRaysBwdArgs;
 int neuray_render_rays_backward(const NeurayRaysBwdArgs* args, void* stream);
 

@@ -45,6 +45,7 @@ class NeurayRaysArgs(C.Structure):
         ('packed_weights_dev', C.c_void_p), ('hit_prob_dev', C.c_void_p), ('pixel_dev', C.c_void_p),
         ('render_depth_dev', C.c_void_p), ('ray_mask_dev', C.c_void_p), ('density_dev', C.c_void_p),
         ('rn', C.c_int), ('dn', C.c_int), ('ray_mask_view_num', C.c_int), ('ray_mask_point_num', C.c_int),
+        ('att_save_dev', C.c_void_p),
     ]
 
 
@@ -53,7 +54,7 @@ class NeurayRaysBwdArgs(C.Structure):
         ('point_rec_dev', C.c_void_p), ('depth_dev', C.c_void_p), ('pos_enc_dev', C.c_void_p),
         ('packed_weights_dev', C.c_void_p), ('d_pixel_dev', C.c_void_p), ('d_hit_prob_dev', C.c_void_p),
         ('d_render_depth_dev', C.c_void_p), ('d_point_rec_dev', C.c_void_p), ('d_ray_weights_dev', C.c_void_p),
-        ('rn', C.c_int), ('dn', C.c_int),
+        ('rn', C.c_int), ('dn', C.c_int), ('att_saved_dev', C.c_void_p),
     ]
 
 
@@ -67,6 +68,7 @@ class NeurayPointsBwdArgs(C.Structure):
 
 
 PACKED_RAY_FLOATS = 1348
+RAY_ATT_SAVE = 24            # NEURAY_RAY_ATT_SAVE
 # (state_dict suffix under agg_net.agg_impl., offset, shape) of the ray-part weights inside d_ray_weights (include/neuray_hip.h)
 RAY_WEIGHT_SLOTS = (
     ('ray_attention.w_qs.weight', 0, (16, 16)), ('ray_attention.w_ks.weight', 256, (16, 16)),

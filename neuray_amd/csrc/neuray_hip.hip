@@ -44,6 +44,7 @@ static_assert(NEURAY_VIEW_CONST == nr::kViewConst, "abi");
 static_assert(NEURAY_QUERY_CONST == nr::kQueryConst, "abi");
 static_assert(NEURAY_PASS_TENSORS == nr::T_COUNT, "abi");
 static_assert(NEURAY_DBG_FIELDS == nr::kDbgFields, "abi");
+static_assert(NEURAY_RAY_ATT_SAVE == nr::kRayAttSave, "abi");
 static_assert(NEURAY_MAX_SAMPLES == nr::kMaxSamples, "abi");
 
 template <int NT, int VPW, bool HAS_VIS, int OWN, int MINW, bool SAVE = false>
@@ -198,15 +199,24 @@ int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {
     nr::RayParams p;
     p.point_rec = a->point_rec_dev; p.depth = a->depth_dev; p.pos_enc = a->pos_enc_dev; p.weights = a->packed_weights_dev;
     p.hit_prob = a->hit_prob_dev; p.pixel = a->pixel_dev; p.render_depth = a->render_depth_dev; p.ray_mask = a->ray_mask_dev;
-    p.density = a->density_dev; p.rn = a->rn; p.dn = a->dn;
+    p.density = a->density_dev; p.att_save = a->att_save_dev; p.rn = a->rn; p.dn = a->dn;
     p.mask_view_num = a->ray_mask_view_num; p.mask_point_num = a->ray_mask_point_num;
     const size_t smem = nr::ray_smem_bytes(a->dn);
     if (smem > 160 * 1024) return fail("neuray_render_rays: dn=%d needs %zu bytes of LDS", a->dn, smem);
     const int grid = grid_for(a->rn, nr::kRayWaves, 256 * 16);
+    if (a->att_save_dev) {                                 // training forward: the attention's softmax statistics are kept for the backward
+        auto k = nr::rays_kernel<true>;
 #ifndef NEURAY_EMU
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)nr::rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-    NR_LAUNCH(nr::rays_kernel, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+        NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+    } else {
+        auto k = nr::rays_kernel<false>;
+#ifndef NEURAY_EMU
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+        NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+    }
     return check_launch("neuray_render_rays");
 }
 
@@ -321,7 +331,7 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* a, void* stream) {
     nr::RayBwdParams p;
     p.point_rec = a->point_rec_dev; p.depth = a->depth_dev; p.pos_enc = a->pos_enc_dev; p.weights = a->packed_weights_dev;
     p.d_pixel = a->d_pixel_dev; p.d_hit_prob = a->d_hit_prob_dev; p.d_depth = a->d_render_depth_dev;
-    p.d_point_rec = a->d_point_rec_dev; p.d_weights = a->d_ray_weights_dev; p.rn = a->rn; p.dn = a->dn;
+    p.d_point_rec = a->d_point_rec_dev; p.d_weights = a->d_ray_weights_dev; p.att_saved = a->att_saved_dev; p.rn = a->rn; p.dn = a->dn;
     const size_t smem = nr::ray_bwd_smem_bytes(a->dn);
     const int waves = nr::ray_bwd_waves(a->dn);            // rays per workgroup
     const int grid = grid_for(a->rn, waves, 256 * 4);

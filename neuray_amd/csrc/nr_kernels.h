@@ -744,8 +744,10 @@ struct RayParams {
     float* render_depth;      // [rn] or null
     unsigned char* ray_mask;  // [rn] or null
     float* density;           // [rn][dn] or null (debug / tests)
+    float* att_save;          // training (SAVE kernel): [rn][dn][kRayAttSave] softmax shift (4), 1 / denominator (4), attention output (16)
     int rn, dn, mask_view_num, mask_point_num;
 };
+constexpr int kRayAttSave = 24;
 
 constexpr int kRayWaves = 4;
 // LDS: attention / sigma-head weights (shared by the workgroup) + per wave K, V, transmittance factors, alpha
@@ -779,6 +781,7 @@ __device__ __forceinline__ void matvec16(const float* __restrict__ M, const floa
     }
 }
 
+template <bool SAVE>
 __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     const int lane = threadIdx.x & 63;
@@ -855,7 +858,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                 // needs no pass over the keys.  exp(s - c) cannot overflow; it could underflow for every key only if
                 // c - max_j s_ij > 87, so rows with c > 40 (never seen with trained or kaiming weights, exercised by
                 // tests/test_edge_cases.py) take the exact two-pass form.
-                float cb[4];
+                float cb[4], a_sh[4], a_rd[4];                 // (a_sh / a_rd: the shift and 1 / denominator actually used, for the backward)
                 bool fast = true;
                 NR_PRAGMA_UNROLL
                 for (int hh = 0; hh < 4; ++hh) {
@@ -876,6 +879,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                             den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
                         }
                         o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
+                        if constexpr (SAVE) { a_sh[hh] = cb[hh]; a_rd[hh] = 1.0f / den; }
                     }
                 } else {
                     NR_PRAGMA_UNROLL
@@ -895,6 +899,17 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                             den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
                         }
                         o[hh * 4] = a0 / den; o[hh * 4 + 1] = a1 / den; o[hh * 4 + 2] = a2 / den; o[hh * 4 + 3] = a3 / den;
+                        if constexpr (SAVE) { a_sh[hh] = mx; a_rd[hh] = 1.0f / den; }
+                    }
+                }
+                if constexpr (SAVE) {
+                    if (act && rvalid) {
+                        float* d_ = p.att_save + ((size_t)ray * dn + i) * kRayAttSave;
+                        *reinterpret_cast<float4*>(d_) = make_float4(a_sh[0], a_sh[1], a_sh[2], a_sh[3]);
+                        *reinterpret_cast<float4*>(d_ + 4) = make_float4(a_rd[0], a_rd[1], a_rd[2], a_rd[3]);
+                        NR_PRAGMA_UNROLL
+                        for (int k4 = 0; k4 < 4; ++k4)
+                            *reinterpret_cast<float4*>(d_ + 8 + 4 * k4) = make_float4(o[4 * k4], o[4 * k4 + 1], o[4 * k4 + 2], o[4 * k4 + 3]);
                     }
                 }
                 float y[16], mean = 0.0f;

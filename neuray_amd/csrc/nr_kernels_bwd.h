@@ -26,6 +26,7 @@ struct RayBwdParams {
     const float* d_depth;     // [rn] (gradient of render_depth) or null
     float* d_point_rec;       // [rn][dn][kPointRec]: [0..15] d geometry feature, [16..18] d colour, [19] 0
     float* d_weights;         // [kPackedRayFloats], accumulated (+=)
+    const float* att_saved;   // null, or what rays_kernel<SAVE> left: [rn][dn][kRayAttSave] softmax shift, 1 / denominator, attention output
     int rn, dn;
 };
 
@@ -138,6 +139,17 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
             s.qmask = !(s.nvalid > 1.0f);              // quirk A.9.3: the row's scores are all -1e9 <=> q~ = 0
             NR_PRAGMA_UNROLL
             for (int k = 0; k < 16; ++k) s.q[k] = s.qmask ? 0.0f : s.q[k] / 2.0f;
+            if (p.att_saved) {                         // the forward's softmax shift, 1 / denominator and attention output
+                const float* sv = p.att_saved + ((size_t)ray * dn + s.i) * kRayAttSave;
+                const float4 sh = ld4(sv), rd = ld4(sv + 4);
+                s.mx[0] = sh.x; s.mx[1] = sh.y; s.mx[2] = sh.z; s.mx[3] = sh.w;
+                s.den[0] = rd.x; s.den[1] = rd.y; s.den[2] = rd.z; s.den[3] = rd.w;
+                NR_PRAGMA_UNROLL
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 o4 = ld4(sv + 8 + 4 * k4);
+                    s.o[4 * k4] = o4.x; s.o[4 * k4 + 1] = o4.y; s.o[4 * k4 + 2] = o4.z; s.o[4 * k4 + 3] = o4.w;
+                }
+            } else {
             NR_PRAGMA_UNROLL
             for (int hh = 0; hh < 4; ++hh) {
                 float m_ = -INFINITY;
@@ -156,6 +168,7 @@ __global__ void __launch_bounds__(256) rays_backward_kernel(RayBwdParams p) {
                 const float rd_ = 1.0f / d_;        // (the key loops below multiply by it: one division per head instead of one per key)
                 s.mx[hh] = m_; s.den[hh] = rd_;
                 s.o[hh * 4] = a0 * rd_; s.o[hh * 4 + 1] = a1 * rd_; s.o[hh * 4 + 2] = a2 * rd_; s.o[hh * 4 + 3] = a3 * rd_;
+            }
             }
             float y[16], mean = 0.0f, var = 0.0f;
             matvec16(RW + RW_FC, s.o, y);

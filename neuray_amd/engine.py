@@ -488,9 +488,10 @@ class RenderEngine:
                                                                d_feats.data_ptr(), self._stream()))
         return d_feats
 
-    def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None):
+    def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None, att_saved=None):
         """Backward of the ray kernel (attention, sigma head, compositing): gradients of a scalar loss w.r.t. the
         per-point records [rn,dn,POINT_REC] (geometry feature 0..15, colour 16..18) and the ray-part weights.
+        att_saved: render_pass(save=True)['att_saved'] (the forward's softmax statistics; recomputed if absent).
         -> (d_point_rec [rn,dn,POINT_REC], {state_dict suffix: grad})   (suffixes under `agg_net.agg_impl.`)"""
         point_rec, depth, d_pixel = self._f32(point_rec), self._f32(depth), self._f32(d_pixel)
         rn, dn = depth.shape
@@ -502,7 +503,7 @@ class RenderEngine:
         a = _lib.NeurayRaysBwdArgs(
             point_rec.data_ptr(), depth.data_ptr(), self.posenc(dn).data_ptr(), packed.dev.data_ptr(), d_pixel.data_ptr(),
             dh.data_ptr() if dh is not None else None, dd.data_ptr() if dd is not None else None,
-            d_rec.data_ptr(), d_w.data_ptr(), rn, dn)
+            d_rec.data_ptr(), d_w.data_ptr(), rn, dn, att_saved.data_ptr() if att_saved is not None else None)
         self._check(self.lib.neuray_render_rays_backward(C.byref(a), self._stream()))
         grads = {name: d_w[off:off + int(np.prod(shape))].view(*shape) for name, off, shape in _lib.RAY_WEIGHT_SLOTS}
         return d_rec, grads
@@ -558,12 +559,13 @@ class RenderEngine:
             out['render_depth'] = self.empty(rn)
         if want_density:
             out['density'] = self.empty(rn, dn)
+        att = self.empty(rn, dn, _lib.RAY_ATT_SAVE) if save else None
         r = _lib.NeurayRaysArgs(
             rec.data_ptr(), depth.data_ptr(), self.posenc(dn).data_ptr(), packed.dev.data_ptr(),
             out['hit_prob'].data_ptr(), out['pixel'].data_ptr(),
             out['render_depth'].data_ptr() if want_depth else None, out['ray_mask'].data_ptr(),
             out['density'].data_ptr() if want_density else None,
-            rn, dn, int(ray_mask_view_num), int(ray_mask_point_num))
+            rn, dn, int(ray_mask_view_num), int(ray_mask_point_num), att.data_ptr() if att is not None else None)
         ev = self._event_pair()
         self._check(self.lib.neuray_render_rays(C.byref(r), s))
         self._event_done(ev, 'rays', rn * dn)
@@ -573,6 +575,22 @@ class RenderEngine:
             out['dbg'] = dbg.view(rn, dn, views.rfn, _lib.DBG_FIELDS)
         if saved is not None:
             out['saved'] = saved
+        if att is not None:
+            out['att_saved'] = att
+        return out
+
+    def render_rays(self, point_rec, depth, packed, save=False, ray_mask_view_num=2, ray_mask_point_num=8):
+        """The ray kernel alone on per-point records [rn,dn,POINT_REC]: -> dict(hit_prob, pixel, att_saved?)"""
+        point_rec, depth = self._f32(point_rec), self._f32(depth)
+        rn, dn = depth.shape
+        out = {'hit_prob': self.empty(rn, dn), 'pixel': self.empty(rn, 3)}
+        att = self.empty(rn, dn, _lib.RAY_ATT_SAVE) if save else None
+        r = _lib.NeurayRaysArgs(point_rec.data_ptr(), depth.data_ptr(), self.posenc(dn).data_ptr(), packed.dev.data_ptr(),
+                                out['hit_prob'].data_ptr(), out['pixel'].data_ptr(), None, None, None,
+                                rn, dn, int(ray_mask_view_num), int(ray_mask_point_num), att.data_ptr() if att is not None else None)
+        self._check(self.lib.neuray_render_rays(C.byref(r), self._stream()))
+        if att is not None:
+            out['att_saved'] = att
         return out
 
     def points_saved_buffer(self, npts):

@@ -53,7 +53,7 @@ class RenderPassFn(torch.autograd.Function):
                                   var_bias=run.var_bias, ray_mask_view_num=run.mask_view_num,
                                   ray_mask_point_num=run.mask_point_num, want_depth=True, save=True)
         ctx.run, ctx.packed = run, packed
-        ctx.point_saved = res.get('saved')                # cross-view quantities of the point kernel, read by its backward
+        ctx.point_saved, ctx.att_saved = res.get('saved'), res.get('att_saved')                # cross-view quantities of the point kernel, read by its backward
         ctx.save_for_backward(res['point_rec'])
         ctx.mark_non_differentiable(res['ray_mask'])
         return res['pixel'], res['hit_prob'], res['ray_mask'], res['render_depth']
@@ -67,7 +67,7 @@ class RenderPassFn(torch.autograd.Function):
             d_pixel = torch.zeros(rn, 3, device=point_rec.device)
         d_rec, g_ray = eng.render_rays_backward(point_rec, run.depth, ctx.packed, d_pixel.contiguous(),
                                                 d_hit.contiguous() if d_hit is not None else None,
-                                                d_depth.contiguous() if d_depth is not None else None)
+                                                d_depth.contiguous() if d_depth is not None else None, att_saved=ctx.att_saved)
         sd = run.state()
         d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
                                                         run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed,
@@ -99,7 +99,7 @@ class RenderPassSelfFn(torch.autograd.Function):
         self_use_vis = run.dist.cfg['use_vis']
         hit_self = eng.self_hit_prob(run.qconst, run.depth, mean, var, aw, vis if self_use_vis else None)
         ctx.run, ctx.packed, ctx.hw, ctx.que_shape, ctx.self_use_vis = run, packed, hw, tuple(que_ray_feats.shape), self_use_vis
-        ctx.point_saved = res.get('saved')
+        ctx.point_saved, ctx.att_saved = res.get('saved'), res.get('att_saved')
         ctx.save_for_backward(res['point_rec'], feats)
         ctx.mark_non_differentiable(res['ray_mask'])
         return res['pixel'], res['hit_prob'], res['ray_mask'], res['render_depth'], hit_self
@@ -113,7 +113,7 @@ class RenderPassSelfFn(torch.autograd.Function):
             d_pixel = torch.zeros(rn, 3, device=point_rec.device)
         d_rec, g_ray = eng.render_rays_backward(point_rec, run.depth, ctx.packed, d_pixel.contiguous(),
                                                 d_hit.contiguous() if d_hit is not None else None,
-                                                d_depth.contiguous() if d_depth is not None else None)
+                                                d_depth.contiguous() if d_depth is not None else None, att_saved=ctx.att_saved)
         d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
                                                         run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed,
                                                         saved=ctx.point_saved)

@@ -77,6 +77,14 @@ def test_rays_backward_matches_autograd(rn, dn, with_aux, backend):
         want = w[IP + name].grad.numpy()
         assert grad.shape == want.shape, name
         assert np.abs(grad.cpu().numpy() - want).max() <= 3e-4 * scale(want), name
+    # the same with the attention statistics the training forward leaves behind instead of recomputing them
+    if dn <= 128:
+        fwd = eng.render_rays(t(rec), t(depth), packed, save=True)
+        assert np.abs(fwd['pixel'].cpu().numpy() - pix.detach().numpy()).max() <= 2e-5 * scale(pix.detach().numpy())
+        d_rec2, gw2 = eng.render_rays_backward(t(rec), t(depth), packed, t(d_pixel), t(d_hit), t(d_dep), att_saved=fwd['att_saved'])
+        assert np.abs(d_rec2.cpu().numpy() - d_rec).max() <= 1e-5 * scale(d_rec)
+        for name, grad in gw2.items():
+            assert np.abs((grad - gw[name]).cpu().numpy()).max() <= 1e-5 * scale(gw[name].cpu().numpy()), name
 
 
 @pytest.mark.parametrize('backend', BACKENDS)

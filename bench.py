@@ -123,35 +123,47 @@ def cpu_baseline(cfg, weights, que, ref, budget_s=20.0, rays_per_batch=4096, max
     from oracle import torch_eager_port as tep
     cores, model = host_cpu()
     old = torch.get_num_threads()
-    torch.set_num_threads(cores)
-    try:
-        w = {k: torch.from_numpy(v) for k, v in weights.items()}
-        tq = {k: torch.from_numpy(v) for k, v in que.items()}
-        tr = {k: torch.from_numpy(v) for k, v in ref.items()}
-        ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
-        n = tq['coords'].shape[1]
-        rays_per_batch = min(rays_per_batch, n)
-        starts = np.linspace(0, n - rays_per_batch, max_batches + 1).astype(np.int64)
+    w = {k: torch.from_numpy(v) for k, v in weights.items()}
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v) for k, v in ref.items()}
+    ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+    n = tq['coords'].shape[1]
+    rays_per_batch = min(rays_per_batch, n)
+    starts = np.linspace(0, n - rays_per_batch, max_batches + 1).astype(np.int64)
 
-        def run(st):
-            q = dict(tq)
-            q['coords'] = tq['coords'][:, st:st + rays_per_batch]
-            with torch.no_grad():
-                return tep.render_impl(w, ocfg, q, tr)
+    def run(st):
+        q = dict(tq)
+        q['coords'] = tq['coords'][:, st:st + rays_per_batch]
+        with torch.no_grad():
+            return tep.render_impl(w, ocfg, q, tr)
+
+    def timed(threads, budget):
+        torch.set_num_threads(threads)
         run(int(starts[0]))
         done, t0 = 0, time.perf_counter()
         for st in starts[1:]:
             run(int(st))
             done += 1
-            if time.perf_counter() - t0 > budget_s:
+            if time.perf_counter() - t0 > budget:
                 break
         dt = time.perf_counter() - t0
+        return done * rays_per_batch / dt, done, dt
+
+    # all physical cores (what BASELINE.md asks for) and, on a many-core host, 16 threads: an op-by-op eager graph on 4096-ray
+    # batches does not scale to 128 threads, and the baseline should be the faster of the two
+    tried = {}
+    try:
+        for threads in ([cores, 16] if cores > 16 else [cores]):
+            tried[threads] = timed(threads, budget_s / (2 if cores > 16 else 1))
     finally:
         torch.set_num_threads(old)
-    return {'value': done * rays_per_batch / dt, 'unit': 'rays/s', 'cores': int(cores), 'kind': 'port', 'cpu_model': model,
+    best = max(tried, key=lambda t: tried[t][0])
+    v, done, dt = tried[best]
+    return {'value': v, 'unit': 'rays/s', 'cores': int(best), 'kind': 'port', 'cpu_model': model, 'physical_cores': int(cores),
+            'rays_per_s_by_threads': {str(t): tried[t][0] for t in tried},
             'sample': '%d batches of %d rays of the same 800x800 image (64+%d samples, 8 views), eager-PyTorch port of the '
-                      'reference op sequence, fp32, torch.set_num_threads(%d), %.1f s after one warm-up batch'
-                      % (done, rays_per_batch, cfg['fine_depth_sample_num'], cores, dt)}
+                      'reference op sequence, fp32, torch.set_num_threads(%d) (the faster of %s threads), %.1f s after one warm-up batch'
+                      % (done, rays_per_batch, cfg['fine_depth_sample_num'], best, ' / '.join(str(t) for t in tried), dt)}
 
 
 def numpy_oracle_leg(cfg, weights, que, ref, got_pixels, sample_rays, chunk):

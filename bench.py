@@ -18,8 +18,8 @@ of the tiles) and `train_ddp` (forward + backward + ONE flattened gradient all-r
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the MFMA point kernel):
 achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream).
 `cpu_baseline` times the golden-checked eager-PyTorch port of the reference's op sequence (oracle/torch_eager_port.py;
-the reference tree itself does not exist on the GPU box) on the host with torch.set_num_threads(physical cores) on a
-bounded sample of the same workload.  At N = 1 side measurements ride along (reported baselines, not the metric):
+the reference tree itself does not exist on the GPU box) on the host - with torch.set_num_threads(physical cores) and,
+on a many-core host, with 16 threads; the faster one is `value` - on a bounded sample of the same workload.  At N = 1 side measurements ride along (reported baselines, not the metric):
 `eager_torch_baseline` (the same port on the same GPU - the stand-in for "the reference on stock PyTorch-ROCm"),
 `numpy_oracle` (parity of the rendered image against the numpy oracle + its speed), `extra` (64+64 samples, the
 reference CLI's 4096-ray batches), `training_step`, `init_net`, `pipeline_pcie_inclusive` (host buffers in, uint8 image
@@ -118,8 +118,8 @@ def host_cpu():
 def cpu_baseline(cfg, weights, que, ref, budget_s=20.0, rays_per_batch=4096, max_batches=8):
     """The reference's CPU path as it can be timed on this box: the eager-PyTorch port of the reference's op sequence
     (oracle/torch_eager_port.py, checked against reference-generated goldens by tests/test_oracle_golden.py), fp32,
-    torch.no_grad(), torch.set_num_threads(physical cores), the reference CLI's 4096-ray batches (render.py:205), one
-    warm-up batch, then batches of the same 800x800 image until ~budget_s of CPU work."""
+    torch.no_grad(), the reference CLI's 4096-ray batches (render.py:205), one warm-up batch, then batches of the same 800x800
+    image until ~budget_s of CPU work, split between torch.set_num_threads(physical cores) and 16 threads."""
     from oracle import torch_eager_port as tep
     cores, model = host_cpu()
     old = torch.get_num_threads()

@@ -16,8 +16,11 @@
 //     the [O x 128] x [128 x K] products run as 16 x 16 tiles ("jobs") on the fp32 MFMA, dealt round-robin to the 8
 //     waves; every wave keeps the accumulators of its jobs in registers across ALL tiles of the launch (persistent grid)
 //     and adds them to global memory once, at the end: one atomicAdd per weight and workgroup.
-//   * per-point layers (base_fc.0's statistics columns, geometry_fc) are handled by owner waves as in the forward kernel;
-//     cross-view reductions are the forward kernel's deterministic LDS all-reduce.
+//   * what needs the OTHER views in the forward direction is not recomputed: the training forward (points_kernel<.., SAVE>)
+//     leaves per tile base_fc.0's per-point part, the four weighted statistics, the softmax / visibility sums, geometry_fc's
+//     hidden layer and output and every view's dist decoder outputs (nr_kernels.h kSaved*); they arrive here by LDS-DMA /
+//     plain loads.  The per-view layers are recomputed.  The backward direction's own cross-view sums (blend, d h64) are the
+//     forward kernel's deterministic LDS all-reduce; the transposed per-point layers run on owner waves.
 // Formulas: the first version (nr_kernels_bwd.h, kept as the rfn > 8 fallback and as an on-device cross-check).
 #pragma once
 #include <type_traits>

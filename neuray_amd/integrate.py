@@ -65,14 +65,15 @@ def patch_reference(renderer_module=None, render_ops=False, init_nets=False):
         ref_ops = importlib.import_module('network.render_ops')
         for name in hip_ops.__all__:
             if hasattr(ref_ops, name):
-                _PATCHED.setdefault(ref_ops, {})[name] = getattr(ref_ops, name)
+                # (setdefault: a second patch_reference() call must not record the installed HIP function as the original)
+                _PATCHED.setdefault(ref_ops, {}).setdefault(name, getattr(ref_ops, name))
                 setattr(ref_ops, name, getattr(hip_ops, name))
                 if hasattr(mod, name):           # `from network.render_ops import *` in network/renderer.py:17
                     setattr(mod, name, getattr(hip_ops, name))
     if init_nets:
         from .network import init_net as hip_init
         ref_init = importlib.import_module('network.init_net')
-        _PATCHED.setdefault(ref_init, {})['get_diff_feats'] = ref_init.get_diff_feats
+        _PATCHED.setdefault(ref_init, {}).setdefault('get_diff_feats', ref_init.get_diff_feats)
         ref_init.get_diff_feats = hip_init.get_diff_feats
     return mod
 

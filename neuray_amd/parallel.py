@@ -43,6 +43,8 @@ def gather_tiles(local, n_total, rank, world, group=None):
     for k in keys:
         v = local[k]
         assert v.shape[0] == 1 and v.shape[1] == sizes[rank], (k, tuple(v.shape))
+        if v.dtype not in (torch.float32, torch.bool):       # the fp32 round trip is exact for these only
+            raise TypeError("neuray_amd.parallel.gather_tiles: output %r is %s; only float32 and bool tiles are gathered" % (k, v.dtype))
         flat = v[0].reshape(v.shape[1], -1).to(torch.float32)
         spec.append((k, v.dtype, tuple(v.shape[2:]), flat.shape[1]))
         cols.append(flat)
@@ -121,26 +123,38 @@ def train_step(model, data, loss_fn, optimizer, group=None):
         ray_feats = getattr(model, 'ray_feats', None)
         allreduce_gradients(model.parameters(), group=group, skip=list(ray_feats) if ray_feats is not None else ())
         if ray_feats is not None:
-            allreduce_scene_feature_gradients(ray_feats, getattr(model, 'touched_views', range(len(ray_feats))),
-                                              model.cfg['neighbor_view_num'] + 1, group=group)
+            # the views this rank's step gave a gradient to.  The mirror class records them (`touched_views`); the
+            # reference's own NeuralRayFtRenderer (renderer.py:437, what integrate.patch_reference() runs) has only the
+            # ParameterList, so there the set is read off the gradients themselves
+            touched = getattr(model, 'touched_views', None)
+            if touched is None:
+                touched = [i for i, p in enumerate(ray_feats) if p.grad is not None]
+            allreduce_scene_feature_gradients(ray_feats, touched, group=group)
     optimizer.step()
     return outputs, loss
 
 
-def allreduce_scene_feature_gradients(ray_feats, touched, max_touched, average=True, group=None):
+def allreduce_scene_feature_gradients(ray_feats, touched, max_touched=None, average=True, group=None):
     """Fine-tuning mode (SURVEY.md 8(e) caveat): `ray_feats` is the per-view nn.ParameterList of NeuralRayFtRenderer
     (100 views x 5 MB on lego-800) and a step gives gradients to the <= neighbor_view_num + 1 views this rank rendered
     from (`touched`: their indices, e.g. renderer.touched_views).  Instead of reducing all 512 MB (or marking unused
     parameters), the ranks all-gather their touched ids (fixed length `max_touched`, padded with -1) and all-reduce only
     the union's maps in one flattened buffer (<= world * 9 x 5 MB).  Afterwards every rank holds the same gradient for
     every view of the union and `grad is None` for all others, so per-parameter Adam state advances identically on all
-    ranks (torch.optim skips parameters without a gradient, as the reference's single-GPU training does).
+    ranks (torch.optim skips parameters without a gradient, as the reference's single-GPU training does).  `max_touched=None`: the ranks agree on
+    the padded length first (one scalar MAX all-reduce), so a caller need not know how many views a step can touch.
     -> sorted list of the union's view indices"""
     world = dist.get_world_size(group)
     dev = ray_feats[0].device
+    touched = sorted(set(int(i) for i in touched))
+    if max_touched is None:
+        n = torch.tensor([len(touched)], dtype=torch.int64, device=dev)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+        max_touched = max(1, int(n.item()))
+    if len(touched) > max_touched:
+        raise ValueError("neuray_amd.parallel: this rank touched %d views, more than max_touched = %d" % (len(touched), max_touched))
     ids = torch.full((max_touched,), -1, dtype=torch.int64, device=dev)
-    assert len(touched) <= max_touched
-    ids[:len(touched)] = torch.as_tensor(sorted(touched), dtype=torch.int64)
+    ids[:len(touched)] = torch.as_tensor(touched, dtype=torch.int64)
     gathered = [torch.empty_like(ids) for _ in range(world)]
     dist.all_gather(gathered, ids, group=group)
     union = sorted(set(int(i) for g in gathered for i in g.tolist() if i >= 0))

@@ -10,6 +10,7 @@ IBRNetWithNeuRay.posenc (network/ibrnet.py:312) so the modules run on CPU.
 Nothing under /root/reference is modified or copied.
 """
 import sys
+import importlib.machinery
 import types
 import os
 
@@ -33,6 +34,9 @@ class _Permissive(types.ModuleType):
 
 def _stub(name, **attrs):
     m = _Permissive(name)
+    # a module in sys.modules without a __spec__ makes importlib.util.find_spec raise (torch._dynamo's trace rules probe
+    # 'sklearn' & co. that way when an optimiser is first built), so the stubs carry one
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None)
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m

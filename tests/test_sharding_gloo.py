@@ -157,3 +157,54 @@ def test_two_rank_finetuning_exchanges_only_touched_feature_maps(tmp_path):
         assert len(union_a) < 6 or mine_a != mine_b
         differed |= mine_a != mine_b
     assert differed            # the ranks did render from different views
+
+
+# ---- the same through parallel.train_step on a PATCHED reference-shaped ft class (which has no `touched_views`) -------
+def _patched_ft_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NEURAY_EMU_THREADS='2')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from conftest import GOLDEN_DIR
+    import test_integrate as ti
+    from neuray_amd import integrate
+    import ref_harness
+    if ref_harness.reference_available():            # the real class where the tree exists, the stand-in elsewhere
+        ref_harness.import_reference()
+    else:
+        sys.path.insert(0, ti.STUB_ROOT)
+    mod = integrate.patch_reference()
+    mod.to_cuda = lambda d: d
+    gold = np.load(os.path.join(GOLDEN_DIR, 'case_scene.npz'))
+    ft, n = ti.build_ft(mod, gold)
+    assert not hasattr(ft, 'touched_views')
+    ft._engine_test_lib = emu_lib()
+    ft.train()
+    opt = torch.optim.Adam(ft.parameters(), lr=1e-2)
+    log = []
+
+    def loss_fn(t):
+        return ((t['pixel_colors_nr_fine'] - t['pixel_colors_gt']) ** 2).mean() + t['hit_prob_self_fine'].mean()
+    for step in range(2):
+        np.random.seed(100 * step + rank)
+        torch.manual_seed(100 * step + rank)
+        parallel.train_step(ft, {'index': 0}, loss_fn, opt)
+        log.append([i for i, p in enumerate(ft.ray_feats) if p.grad is not None])
+    state = torch.cat([p.detach().reshape(-1) for p in ft.parameters()])
+    torch.save({'log': log, 'state': state, 'cls': mod.__file__}, os.path.join(out_dir, 'pft_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_on_a_patched_reference_ft_renderer(tmp_path):
+    """ADVICE r2: the reference's NeuralRayFtRenderer has a `ray_feats` ParameterList but no `touched_views`;
+    parallel.train_step reads the touched set off the gradients and the ranks agree on the exchange length themselves.
+    Replicas stay bit-identical and only the union's maps carry a gradient."""
+    emu_lib()
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(_patched_ft_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'pft_rank0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'pft_rank1.pt'))
+    assert torch.equal(a['state'], b['state'])
+    for ga, gb in zip(a['log'], b['log']):
+        assert ga == gb and 0 < len(ga) <= 8

@@ -166,8 +166,14 @@ def cpu_baseline(cfg, weights, que, ref, budget_s=20.0, rays_per_batch=4096, max
                       % (done, rays_per_batch, cfg['fine_depth_sample_num'], best, ' / '.join(str(t) for t in tried), dt)}
 
 
-def numpy_oracle_leg(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
-    """Parity of the rendered image against the numpy oracle on `sample_rays` strided rays (+ the oracle's own speed)."""
+# the gates of the tests (tests/test_render_parity.py, tests/test_full_size.py), applied to the bench's own sample as well
+PARITY_GATES = {'coarse_pixel_max': 2e-4, 'chained_frac_within_2e-4_min': 0.99, 'chained_max': 5e-3, 'chained_psnr_db_min': 70.0}
+
+
+def numpy_oracle_leg(cfg, weights, que, ref, got, sample_rays, chunk):
+    """Parity of the rendered image against the numpy oracle on `sample_rays` strided rays (+ the oracle's own speed):
+    the COARSE pixels (identical inputs: SURVEY 8(c)'s 2e-4) and the chained coarse -> fine pixels (distributional gates,
+    DESIGN.md 2.4 / tests/test_chained_parity.py).  `got`: {'pixel_colors_nr', 'pixel_colors_nr_fine'} of the whole image."""
     from oracle import neuray_oracle as orc
     try:
         from threadpoolctl import threadpool_info
@@ -182,15 +188,24 @@ def numpy_oracle_leg(cfg, weights, que, ref, got_pixels, sample_rays, chunk):
     for i in range(0, sample_rays, chunk):
         q = dict(que)
         q['coords'] = que['coords'][:, idx[i:i + chunk]]
-        outs.append(orc.render_impl(weights, ocfg, q, ref)['pixel_colors_nr_fine'])
+        o = orc.render_impl(weights, ocfg, q, ref)
+        outs.append((o['pixel_colors_nr'], o['pixel_colors_nr_fine']))
     dt = time.perf_counter() - t0
-    want = np.concatenate(outs, 1)
-    got = got_pixels[:, idx]
-    err = np.abs(got - want).max(-1)
+    want_c, want = (np.concatenate([o[i] for o in outs], 1) for i in (0, 1))
+    fine = got['pixel_colors_nr_fine'][:, idx]
+    err = np.abs(fine - want).max(-1)
+    err_c = np.abs(got['pixel_colors_nr'][:, idx] - want_c).max(-1)
+    parity = {'psnr_vs_oracle_db': synthetic.psnr_uint8(fine, want), 'max_abs_err_vs_oracle': float(err.max()),
+              'frac_rays_within_2e-4': float(np.mean(err <= 2e-4)),
+              'coarse_pixels': {'max_abs_err_vs_oracle': float(err_c.max()), 'p99.9': float(np.percentile(err_c, 99.9)),
+                                'median': float(np.median(err_c)), 'gate': PARITY_GATES['coarse_pixel_max']},
+              'rays': int(sample_rays), 'gates': PARITY_GATES,
+              'vs_gt_psnr': 'unmeasurable here: no datasets / checkpoints in the container (north_star asks <= 0.05 dB vs the '
+                            'reference on real scenes); ours-vs-oracle PSNR on the synthetic workload is the proxy'}
+    parity['pass'] = bool(err_c.max() <= PARITY_GATES['coarse_pixel_max'] and parity['frac_rays_within_2e-4'] >= PARITY_GATES['chained_frac_within_2e-4_min']
+                          and err.max() <= PARITY_GATES['chained_max'] and parity['psnr_vs_oracle_db'] >= PARITY_GATES['chained_psnr_db_min'])
     return {'value': sample_rays / dt, 'unit': 'rays/s', 'blas_threads': int(cores), 'kind': 'port (numpy oracle, the parity checker)',
-            'sample': '%d strided rays of the same image, %.1f s' % (sample_rays, dt)}, \
-           {'psnr_vs_oracle_db': synthetic.psnr_uint8(got, want), 'max_abs_err_vs_oracle': float(err.max()),
-            'frac_rays_within_2e-4': float(np.mean(err <= 2e-4))}
+            'sample': '%d strided rays of the same image, %.1f s' % (sample_rays, dt)}, parity
 
 
 def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch=4096):
@@ -658,7 +673,8 @@ def main(argv=None):
         if world == 1 and emu is None and not args.no_cpu_baseline:   # baselines: rank 0 at N = 1 only
             line['cpu_baseline'] = side(cpu_baseline, cfg, weights, que, ref)
             if args.cpu_sample_rays > 0:
-                res = side(numpy_oracle_leg, cfg, weights, que, ref, out['pixel_colors_nr_fine'].cpu().numpy(), args.cpu_sample_rays, 1024)
+                res = side(numpy_oracle_leg, cfg, weights, que, ref,
+                           {k: out[k].cpu().numpy() for k in ('pixel_colors_nr', 'pixel_colors_nr_fine')}, args.cpu_sample_rays, 1024)
                 if isinstance(res, tuple):
                     line['numpy_oracle'], line['parity'] = res
                 else:

@@ -54,9 +54,38 @@ __device__ __forceinline__ float norm_inv_depth(float d, float nearp, float farp
     return rn_div(rn_sub(rn_div(-1.0f, d), nearp), rn_sub(farp, nearp));
 }
 
-// feature-path variant (does not decide any mask or index): one hardware reciprocal, ~1 ulp
-__device__ __forceinline__ float norm_inv_depth_fast(float d, float nearp, float inv_range) {
-    return (-nr_fast_rcp(d) - nearp) * inv_range;
+// Feature-path divisions (they decide no mask and no index).  NR_FEATURE_RCP_REFINE = 1 (default): the hardware reciprocal
+// (v_rcp_f32, 1 ulp) gets one Newton step and a quotient p / d computed as p * RN(1/d) gets one residual correction
+// q' = q + r (p - d q) - two FMAs each, which makes both agree with the correctly rounded division of the reference's op
+// sequence in all but rare halfway cases.  It matters for the texel coordinates: 1 ulp of u / (W - 1) is 1.2e-5 texels on a
+// 200-wide map, i.e. ~2e-5 on a gathered feature of a white-noise map, which the MLP stack carries to the pixel
+// (worst coarse error 1.6e-4 against the 2e-4 gate).  = 0: the round-2 forms, for A/B timing.
+#ifndef NR_FEATURE_RCP_REFINE
+#define NR_FEATURE_RCP_REFINE 1
+#endif
+#ifndef NR_FEATURE_RCP_NEWTON          // the Newton step of 1 / d alone (A/B: the quotient correction is what the texel coordinates need)
+#define NR_FEATURE_RCP_NEWTON NR_FEATURE_RCP_REFINE
+#endif
+__device__ __forceinline__ float nr_rcp_refined(float d) {
+    const float r = nr_fast_rcp(d);
+#if NR_FEATURE_RCP_NEWTON
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+#else
+    return r;
+#endif
+}
+// p / d given r = RN(1 / d)
+__device__ __forceinline__ float nr_div_refined(float p, float d, float r) {
+    const float q = p * r;
+#if NR_FEATURE_RCP_REFINE
+    return fmaf(fmaf(-d, q, p), r, q);
+#else
+    return q;
+#endif
+}
+// feature-path normalised inverse depth: (-1/d - near') / (far' - near') with inv_range = RN(1 / (far' - near'))
+__device__ __forceinline__ float norm_inv_depth_fast(float d, float nearp, float farp, float inv_range) {
+    return nr_div_refined(-nr_rcp_refined(d) - nearp, farp - nearp, inv_range);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -81,7 +110,7 @@ __device__ __forceinline__ Ray make_ray(const float* __restrict__ qc, float x, f
     r.dz = rn_sub(rn_add(w2, r.cz), r.cz);
     const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(r.dx, r.dx), rn_mul(r.dy, r.dy)), rn_mul(r.dz, r.dz)));
     if (EXACT) { r.qx = rn_div(-r.dx, nrm); r.qy = rn_div(-r.dy, nrm); r.qz = rn_div(-r.dz, nrm); }
-    else { const float inv = nr_fast_rcp(nrm); r.qx = -r.dx * inv; r.qy = -r.dy * inv; r.qz = -r.dz * inv; }   // direction feature only
+    else { const float inv = nr_rcp_refined(nrm); r.qx = -r.dx * inv; r.qy = -r.dy * inv; r.qz = -r.dz * inv; }   // direction feature only
     return r;
 }
 
@@ -107,7 +136,7 @@ __device__ __forceinline__ Proj project_point(const float* __restrict__ vc, floa
     const float nrm = rn_sqrt(rn_add(rn_add(rn_mul(dx, dx), rn_mul(dy, dy)), rn_mul(dz, dz)));
     const float den = fmaxf(nrm, 1e-5f);
     if (EXACT) { o.dirx = rn_div(-dx, den); o.diry = rn_div(-dy, den); o.dirz = rn_div(-dz, den); }
-    else { const float inv = nr_fast_rcp(den); o.dirx = -dx * inv; o.diry = -dy * inv; o.dirz = -dz * inv; }   // feature only
+    else { const float inv = nr_rcp_refined(den); o.dirx = -dx * inv; o.diry = -dy * inv; o.dirz = -dz * inv; }   // feature only
     return o;
 }
 
@@ -128,8 +157,8 @@ struct Taps { int o00, o10, o01, o11; float w00, w10, w01, w11; };   // texel of
 
 // feature-path texel coordinate: p * 1/(size_full-1) instead of the correctly rounded division (<= 1 ulp apart; the
 // bilinear result is continuous in the coordinate, validity masks never depend on it)
-__device__ __forceinline__ float texel_coord_fast(float p, float inv_full_m1, float size_map, bool align) {
-    const float n = p * inv_full_m1 * 2.0f - 1.0f;
+__device__ __forceinline__ float texel_coord_fast(float p, float full_m1, float inv_full_m1, float size_map, bool align) {
+    const float n = nr_div_refined(p, full_m1, inv_full_m1) * 2.0f - 1.0f;
     const float ix = align ? (n + 1.0f) * 0.5f * (size_map - 1.0f) : ((n + 1.0f) * size_map - 1.0f) * 0.5f;
     return fminf(size_map - 1.0f, fmaxf(ix, 0.0f));
 }
@@ -149,8 +178,9 @@ __device__ __forceinline__ Taps taps_from(float ix, float iy, int mw, int mh) {
     return t;
 }
 
-__device__ __forceinline__ Taps make_taps_fast(float u, float v, float inv_w_m1, float inv_h_m1, int mw, int mh, bool align) {
-    return taps_from(texel_coord_fast(u, inv_w_m1, (float)mw, align), texel_coord_fast(v, inv_h_m1, (float)mh, align), mw, mh);
+__device__ __forceinline__ Taps make_taps_fast(float u, float v, float w_m1, float h_m1, float inv_w_m1, float inv_h_m1, int mw, int mh,
+                                               bool align) {
+    return taps_from(texel_coord_fast(u, w_m1, inv_w_m1, (float)mw, align), texel_coord_fast(v, h_m1, inv_h_m1, (float)mh, align), mw, mh);
 }
 
 __device__ __forceinline__ Taps make_taps(float u, float v, int w_full, int h_full, int mw, int mh) {

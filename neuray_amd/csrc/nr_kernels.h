@@ -179,8 +179,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     float* wl = xch + 16 * NT * 64;                  // staged weights of the current phase
     const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
     const float* __restrict__ qc = p.que_const;
-    const float qnearp = qc[24], qinv = qc[27];
-    const float inv_w_m1 = 1.0f / (float)(p.w - 1), inv_h_m1 = 1.0f / (float)(p.h - 1), inv_rfn = 1.0f / (float)p.rfn;
+    const float qnearp = qc[24], qfarp = qc[25], qinv = qc[27];
+    const float w_m1 = (float)(p.w - 1), h_m1 = (float)(p.h - 1);
+    const float inv_w_m1 = 1.0f / w_m1, inv_h_m1 = 1.0f / h_m1, inv_rfn = 1.0f / (float)p.rfn;
     const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
     const nr_mbuf rf_map = nr_make_mbuf(p.ray_feats, sizeof(float) * fmap * p.rfn);
     const nr_mbuf if_map = nr_make_mbuf(p.img_feats, sizeof(float) * fmap * p.rfn);
@@ -220,9 +221,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             const float d = drow[smp];
             // half intervals in normalised inverse depth (render_ops.py:46-52, dist_decoder.py:34-38); feature path:
             // hardware reciprocals (they feed only the logistic CDFs)
-            const float s_c = norm_inv_depth_fast(d, qnearp, qinv);
-            const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qinv);
-            const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qinv);
+            const float s_c = norm_inv_depth_fast(d, qnearp, qfarp, qinv);
+            const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qfarp, qinv);
+            const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp, qinv);
             const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
             const float half_p = (s_c - s_p) * 0.5f;
             hi[t] = half_c;
@@ -242,13 +243,13 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 mask[s] = pr.mask;
                 dlt[s][0] = pr.dirx - r.qx; dlt[s][1] = pr.diry - r.qy; dlt[s][2] = pr.dirz - r.qz;
                 dlt[s][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
-                tref[s] = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
+                tref[s] = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[16], vc[17]);
                 if (dbg_lane && pvalid[t] && vok) {
                     float* d_ = p.dbg + ((size_t)pi * p.rfn + view) * kDbgFields;
                     d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
                 }
-                tfs[s] = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
-                tcs[s] = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.w, p.h, true);
+                tfs[s] = make_taps_fast(pr.u, pr.v, w_m1, h_m1, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
+                tcs[s] = make_taps_fast(pr.u, pr.v, w_m1, h_m1, inv_w_m1, inv_h_m1, p.w, p.h, true);
                 soffs[s][0] = view * (int)(fmap * sizeof(float)); soffs[s][1] = view * (int)(imap * sizeof(float));
             }
         }

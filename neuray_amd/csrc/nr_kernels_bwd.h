@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
     const int pl = lane / vp, v = lane % vp;
     const int npts = p.rn * p.dn, dn = p.dn;
     const float* __restrict__ qc = p.que_const;
-    const float qnearp = qc[24], qinv = qc[27];
+    const float qnearp = qc[24], qfarp = qc[25], qinv = qc[27];
     const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
     const bool has_vis = p.has_vis_head != 0, use_vis = has_vis && (p.use_vis != 0);
     // (distinct row ranges of the arena: __restrict__ lets the per-row loops overlap their loads and stores)
@@ -650,9 +650,9 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         const Ray r = make_ray<false>(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
         const float* drow = p.depth + (size_t)ray * dn;
         const float d = drow[smp];
-        const float s_c = norm_inv_depth_fast(d, qnearp, qinv);
-        const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qinv);
-        const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qinv);
+        const float s_c = norm_inv_depth_fast(d, qnearp, qfarp, qinv);
+        const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qfarp, qinv);
+        const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp, qinv);
         const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
         const float half_p = (s_c - s_p) * 0.5f;
         SCALAR(hi, 0); SCALAR(lo, 1);
@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(64, 4) points_backward_kernel(PointBwdParams p
         Proj pr = project_point<false>(vc, px, py, pz, (float)p.w, (float)p.h);
         SCALAR(m, 2); SCALAR(tref, 3); SCALAR(pu, 4); SCALAR(pv, 5);
         m = vok ? pr.mask : 0.0f;
-        tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
+        tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[16], vc[17]);
         pu = pr.u; pv = pr.v;
         {
             const Taps tf = make_taps(pr.u, pr.v, p.w, p.h, p.fw, p.fh);

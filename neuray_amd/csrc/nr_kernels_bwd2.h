@@ -350,8 +350,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
     const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
     const nr_wbuf WT = nr_make_wbuf(p.weights_t, sizeof(float) * kPackedTFloats);
     const float* __restrict__ qc = p.que_const;
-    const float qnearp = qc[24], qinv = qc[27];
-    const float inv_w_m1 = 1.0f / (float)(p.w - 1), inv_h_m1 = 1.0f / (float)(p.h - 1), inv_rfn = 1.0f / (float)p.rfn;
+    const float qnearp = qc[24], qfarp = qc[25], qinv = qc[27];
+    const float w_m1 = (float)(p.w - 1), h_m1 = (float)(p.h - 1);
+    const float inv_w_m1 = 1.0f / w_m1, inv_h_m1 = 1.0f / h_m1, inv_rfn = 1.0f / (float)p.rfn;
     const size_t fmap = (size_t)p.fh * p.fw * 32, imap = (size_t)p.h * p.w * 4;
     const nr_mbuf rf_map = nr_make_mbuf(p.ray_feats, sizeof(float) * fmap * p.rfn);
     const nr_mbuf if_map = nr_make_mbuf(p.img_feats, sizeof(float) * fmap * p.rfn);
@@ -397,9 +398,9 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         const Ray r = make_ray<false>(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
         const float* drow = p.depth + (size_t)ray * dn;
         const float d = drow[smp];
-        const float s_c = norm_inv_depth_fast(d, qnearp, qinv);
-        const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qinv);
-        const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qinv);
+        const float s_c = norm_inv_depth_fast(d, qnearp, qfarp, qinv);
+        const float s_n = norm_inv_depth_fast(drow[smp + 1 < dn ? smp + 1 : smp], qnearp, qfarp, qinv);
+        const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp, qinv);
         const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
         const float hi = half_c, lo = (smp == 0) ? half_c : (s_c - s_p) * 0.5f;
         const float px = rn_add(r.cx, rn_mul(r.dx, d)), py = rn_add(r.cy, rn_mul(r.dy, d)), pz = rn_add(r.cz, rn_mul(r.dz, d));
@@ -408,11 +409,11 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         float dlt[4];
         dlt[0] = pr.dirx - r.qx; dlt[1] = pr.diry - r.qy; dlt[2] = pr.dirz - r.qz;
         dlt[3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
-        const float tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[17]);
-        const Taps tfs = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
+        const float tref = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[16], vc[17]);
+        const Taps tfs = make_taps_fast(pr.u, pr.v, w_m1, h_m1, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
         float fray[1][8], fimg[8], rgb[3];
         {
-            const Taps tcs = make_taps_fast(pr.u, pr.v, inv_w_m1, inv_h_m1, p.w, p.h, true);
+            const Taps tcs = make_taps_fast(pr.u, pr.v, w_m1, h_m1, inv_w_m1, inv_h_m1, p.w, p.h, true);
             float4 qf[8], qi[8], qcl[4];
             issue8(rf_map, goff, soff_f, tfs, qf);
             issue8(if_map, goff, soff_f, tfs, qi);

@@ -5,8 +5,8 @@ smooth scene, config 1 (400x400, 3 views, 32+32), config 3 (LLFF 756x1008 / 768x
 
 Stages are compared on IDENTICAL inputs (tight: SURVEY.md 8(c) tolerances) - the coarse pass; `sample_fine_depth` on the
 reference's coarse hit_prob; the fine pass on the reference's fine depths - and the chained coarse -> fine output
-statistically (the reference's `denom < 1e-5 -> 1` rule makes a few fine samples jump by a bin on fp32-level noise,
-DESIGN.md 2.4).  CPU legs run a slice of the rays through the numpy oracle (pins the oracle at these shapes) and through
+statistically (the inverse-CDF placement of the fine samples has condition number 1 / bin mass, down to the reference's
+`denom < 1e-5 -> 1` rule; tests/test_chained_parity.py holds the evidence, DESIGN.md 2.4 the argument).  CPU legs run a slice of the rays through the numpy oracle (pins the oracle at these shapes) and through
 the kernels on the emulator; the GPU legs run every ray of the tile through libneuray_hip.so."""
 import ast
 import os
@@ -124,9 +124,11 @@ def test_kernels_on_the_emulator_at_baseline_shapes(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', TILES)
 def test_tiles_against_the_reference_on_the_gpu(name):
-    """every ray of the tile; chained gates: what the evidence supports (the white-noise scenes are the pathological
-    input for the 1e-5 rule; the smooth scene is what encoder outputs of real images look like)"""
-    frac, psnr = (0.995, 70.0) if name == 'c2_smooth' else (0.97, 60.0)
+    """every ray of the tile; chained gates: what the evidence supports (tests/test_chained_parity.py: the fp32 reference
+    itself is 1.3 % beyond 2e-4 of its float64 evaluation on the white-noise scene, where a displaced fine sample lands on
+    an unrelated texel; the smooth scene is what encoder outputs of real images look like).  Round 3, with the
+    feature-path divisions refined: 99.7-99.8 % / >= 80 dB on the white-noise tiles, 100 % on the smooth one"""
+    frac, psnr = (0.999, 80.0) if name == 'c2_smooth' else (0.99, 70.0)
     staged_compare(name, 'hip', slice(None), frac, psnr)
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 5
+#define NEURAY_ABI_VERSION 6
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -281,6 +281,23 @@ int neuray_project_points(const float* view_const_dev, const float* pts_dev, int
                           float* pts2d_dev, float* depth_dev, unsigned char* mask_dev, void* stream);
 /* a15 alpha_values2hit_prob (render_ops.py:72-80), rows x dn */
 int neuray_alpha2hit_prob(const float* alpha_dev, int rows, int dn, float* out_dev, void* stream);
+
+/* ---- a18 direct rendering, cfg['use_dr_prediction'] (renderer.py:85-125: predict_alpha_values_dr, predict_colors_dr,
+ * direct_rendering; sph_solver.py:1-59: SphericalHarmonicsSolver.forward / predict).
+ * neuray_direct_render_points, per sample point: alpha_dr [rn*dn] = the visibility-weighted mean of the views' alpha logits
+ * (`ground` = cfg['alpha_value_ground_state'] where no view sees the point) and, unless color_dev is NULL
+ * (cfg['use_nr_color_for_dr']), color_dr [rn*dn][3] = the weighted degree-3 spherical-harmonics fit of the views' colours over
+ * their viewing directions, evaluated at the query direction.  view_rec_dev is NeurayPointsArgs.dbg_dev of the SAME pass
+ * ([rn*dn][rfn][NEURAY_DBG_FIELDS]; fields 0 / 4 / 5 = mask / hit_prob / visibility per view), regs_dev [16] the solver's
+ * `regs` buffer.
+ * neuray_direct_render_rays, per ray: hit_prob_dr [rn][dn] = alpha_values2hit_prob(sigmoid(alpha_dr)), pixel_colors_dr [rn][3]
+ * = sum_i hit_i colour_i with colour i at colors_dev[(ray * dn + i) * color_stride + color_first] (the SH colours: stride 3,
+ * first 0; use_nr_color_for_dr: the point records, stride NEURAY_POINT_REC, first 16). */
+int neuray_direct_render_points(const float* query_const_dev, const float* view_const_dev, const float* coords_dev,
+                                const float* depth_dev, const float* rgba_dev, const float* view_rec_dev, const float* regs_dev,
+                                int rfn, int rn, int dn, int h, int w, float ground, float* alpha_dev, float* color_dev, void* stream);
+int neuray_direct_render_rays(const float* alpha_dev, const float* colors_dev, int color_stride, int color_first, int rn, int dn,
+                              float* hit_prob_dev, float* pixel_dev, void* stream);
 
 /* ---- a9 stand-alone: MixtureLogisticsDistDecoder.forward / predict_mean on arbitrary rows (dist_decoder.py:99-107,147-149).
  * feats [n][32] -> mean [n][2], var [n][2] (bias_val included), aw [n], vis [n] (vis only with a vis head, else NULL). */

@@ -3,6 +3,7 @@
 // CPU test emulator, g++ -DNEURAY_EMU (tests/emu/build_emu.py).
 #include "nr_kernels.h"
 #include "nr_kernels_bwd.h"
+#include "nr_kernels_dr.h"
 #ifndef NR_BF16_QUADS
 #include "nr_kernels_bwd2.h"
 #endif
@@ -292,6 +293,25 @@ int neuray_alpha2hit_prob(const float* alpha, int rows, int dn, float* out, void
     const int grid = grid_for(rows, 64, 256 * 8);
     NR_LAUNCH(nr::hit_prob_kernel, dim3(grid), dim3(64), 0, stream, alpha, rows, dn, out);
     return check_launch("neuray_alpha2hit_prob");
+}
+
+int neuray_direct_render_points(const float* query_const, const float* view_const, const float* coords, const float* depth,
+                                const float* rgba, const float* view_rec, const float* regs, int rfn, int rn, int dn, int h, int w,
+                                float ground, float* alpha, float* color, void* stream) {
+    if (rfn < 1 || rfn > NEURAY_MAX_VIEWS || rn < 1 || dn < 1) return fail("neuray_direct_render_points: bad shape rfn=%d rn=%d dn=%d", rfn, rn, dn);
+    if (!view_rec || !alpha) return fail("neuray_direct_render_points: view_rec / alpha missing");
+    const int grid = grid_for((long long)rn * dn, 128, 256 * 16);
+    NR_LAUNCH(nr::dr_points_kernel, dim3(grid), dim3(128), 0, stream, query_const, view_const, coords, depth, rgba, view_rec, regs, rfn, rn,
+              dn, h, w, ground, alpha, color);
+    return check_launch("neuray_direct_render_points");
+}
+
+int neuray_direct_render_rays(const float* alpha, const float* colors, int color_stride, int color_first, int rn, int dn,
+                              float* hit_prob, float* pixel, void* stream) {
+    if (rn < 1 || dn < 1 || color_stride < 3 || color_first < 0) return fail("neuray_direct_render_rays: bad shape");
+    const int grid = grid_for(rn, 64, 256 * 8);
+    NR_LAUNCH(nr::dr_rays_kernel, dim3(grid), dim3(64), 0, stream, alpha, colors, color_stride, color_first, rn, dn, hit_prob, pixel);
+    return check_launch("neuray_direct_render_rays");
 }
 
 int neuray_dist_decoder_rows(const float* feats, const float* packed_weights, int n, int has_vis_head, float var_bias,

@@ -579,6 +579,31 @@ class RenderEngine:
             out['att_saved'] = att
         return out
 
+    def direct_render(self, qconst, views, coords, depth, view_rec, regs, ground=-15.0, point_rec=None):
+        """cfg['use_dr_prediction'] (renderer.py:85-125, sph_solver.py): -> dict(hit_prob [rn,dn], pixel [rn,3], alpha [rn,dn],
+        colors [rn,dn,3]).  view_rec: render_pass(want_dbg=True)['dbg'] of the same pass; regs [16]: SphericalHarmonicsSolver.regs;
+        point_rec given = cfg['use_nr_color_for_dr'] (the aggregation network's per-point colours instead of the SH fit)."""
+        coords, depth = self._f32(coords), self._f32(depth)
+        rn, dn = depth.shape
+        view_rec, regs = self._f32(view_rec), self._f32(regs.to(self.device))
+        assert view_rec.numel() == rn * dn * views.rfn * _lib.DBG_FIELDS and regs.numel() == 16
+        alpha = self.empty(rn, dn)
+        colors = None if point_rec is not None else self.empty(rn, dn, 3)
+        s = self._stream()
+        self._check(self.lib.neuray_direct_render_points(
+            qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.rgba.data_ptr(),
+            view_rec.data_ptr(), regs.data_ptr(), views.rfn, rn, dn, views.h, views.w, float(ground), alpha.data_ptr(),
+            colors.data_ptr() if colors is not None else None, s))
+        hit, pix = self.empty(rn, dn), self.empty(rn, 3)
+        if colors is not None:
+            src, stride, first = colors, 3, 0
+        else:
+            src, stride, first = self._f32(point_rec), _lib.POINT_REC, 16
+            colors = src.view(rn, dn, _lib.POINT_REC)[..., 16:19]
+        self._check(self.lib.neuray_direct_render_rays(alpha.data_ptr(), src.data_ptr(), stride, first, rn, dn, hit.data_ptr(),
+                                                       pix.data_ptr(), s))
+        return {'hit_prob': hit, 'pixel': pix, 'alpha': alpha, 'colors': colors}
+
     def render_rays(self, point_rec, depth, packed, save=False, ray_mask_view_num=2, ray_mask_point_num=8):
         """The ray kernel alone on per-point records [rn,dn,POINT_REC]: -> dict(hit_prob, pixel, att_saved?)"""
         point_rec, depth = self._f32(point_rec), self._f32(depth)

@@ -15,7 +15,7 @@ import torch
 from ..engine import RenderEngine
 from .autograd import PassRun, RenderPassFn, RenderPassSelfFn, SelfHitFn
 
-HOT_PATH_METHODS = ('engine', '_packed_pass', '_same_tensors', '_views', '_query', '_self_hit_prob',
+HOT_PATH_METHODS = ('engine', '_packed_pass', '_same_tensors', '_views', '_query', '_self_hit_prob', '_direct_rendering',
                     'render_by_depth', 'predict_self_hit_prob', 'fine_render_impl', 'render_impl')
 
 
@@ -24,9 +24,6 @@ class HipRenderPath:
     def engine(self, device):
         eng = self.__dict__.get('_engine')
         if eng is None or eng.device != torch.device(device):
-            if self.cfg.get('use_dr_prediction', False):
-                raise NotImplementedError("neuray_amd: use_dr_prediction (direct rendering, renderer.py:85-125) is outside "
-                                          "the HIP render path; every shipped config has it off")
             eng = RenderEngine(device, _test_lib=self.__dict__.get('_engine_test_lib'),
                                variant=self.cfg.get('hip_variant', 'fp32'))
             self.__dict__['_engine'] = eng
@@ -108,8 +105,10 @@ class HipRenderPath:
             packed = self._packed_pass(eng, is_fine)
             res = eng.render_pass(qconst, views, run.coords, run.depth, packed, use_vis=use_vis, var_bias=run.var_bias,
                                   ray_mask_view_num=cfg['ray_mask_view_num'], ray_mask_point_num=cfg['ray_mask_point_num'],
-                                  want_depth=cfg['render_depth'])
+                                  want_depth=cfg['render_depth'], want_dbg=bool(cfg.get('use_dr_prediction', False)))
         outputs = {'pixel_colors_nr': res['pixel'][None], 'hit_prob_nr': res['hit_prob'][None]}
+        if cfg.get('use_dr_prediction', False):           # renderer.py:181-185
+            outputs.update(self._direct_rendering(eng, qconst, views, run, res, packed, is_fine))
         if is_train and cfg['use_self_hit_prob']:
             outputs['hit_prob_self'] = res['hit_self'][None] if res.get('hit_self') is not None else \
                 self._self_hit_prob(que_imgs_info, que_depth, is_fine, run, packed)
@@ -120,6 +119,33 @@ class HipRenderPath:
         if cfg['render_depth']:
             outputs['render_depth'] = res['render_depth'][None]
         return outputs
+
+    def _direct_rendering(self, eng, qconst, views, run, res, packed, is_fine):
+        """renderer.py:85-125 (+ sph_solver.py) on the dr kernels -> {'pixel_colors_dr', 'hit_prob_dr'}.  The per-view hit
+        probabilities / visibilities come from the point kernel's per-view record; under autograd the pass itself ran as an
+        autograd.Function without that record, so the point kernel is run once more for it, and the dr outputs are returned
+        DETACHED: the backward kernels cover the losses of every shipped config (loss.py use_dr_loss: false everywhere)."""
+        cfg = self.cfg
+        rec = res.get('dbg')
+        point_rec = res.get('point_rec')
+        if rec is None:
+            if not self.__dict__.get('_dr_grad_warned'):
+                import warnings
+                warnings.warn("neuray_amd: use_dr_prediction under autograd - pixel_colors_dr / hit_prob_dr are computed but carry "
+                              "no gradient (cfg use_dr_loss is off in every shipped config)")
+                self.__dict__['_dr_grad_warned'] = True
+            with torch.no_grad():
+                packed = packed if packed is not None else self._packed_pass(eng, is_fine)
+                again = eng.render_pass(qconst, views, run.coords, run.depth, packed, use_vis=run.use_vis, var_bias=run.var_bias,
+                                        want_dbg=True)
+            rec, point_rec = again['dbg'], again['point_rec']
+        fitter = getattr(self, 'sph_fitter', None)
+        regs = fitter.regs if fitter is not None and hasattr(fitter, 'regs') else \
+            torch.tensor([0.0] + [0.001] * 3 + [0.005] * 5 + [0.05] * 7, dtype=torch.float32)       # sph_solver.py:6-12, degree 3
+        with torch.no_grad():
+            dr = eng.direct_render(qconst, views, run.coords, run.depth, rec, regs, ground=float(cfg['alpha_value_ground_state']),
+                                   point_rec=point_rec if cfg.get('use_nr_color_for_dr', False) else None)
+        return {'pixel_colors_dr': dr['pixel'][None], 'hit_prob_dr': dr['hit_prob'][None]}
 
     def predict_self_hit_prob(self, que_imgs_info, que_depth, que_dists, is_fine):
         """network/renderer.py:147-155, the reference's signature (`que_dists` is recomputed inside the kernel from

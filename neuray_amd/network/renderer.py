@@ -43,9 +43,6 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = {**self.base_cfg, **cfg}
-        if self.cfg['use_dr_prediction']:
-            raise NotImplementedError("neuray_amd: use_dr_prediction (direct rendering, renderer.py:85-125) is outside "
-                                      "the HIP render path; every shipped config has it off")
         self.dist_decoder = name2dist_decoder[self.cfg['dist_decoder_type']](self.cfg['dist_decoder_cfg'])
         self.agg_net = name2agg_net[self.cfg['agg_net_type']](self.cfg['agg_net_cfg'])
         if self.cfg['use_hierarchical_sampling']:

@@ -467,6 +467,60 @@ def alpha_values2hit_prob(alpha_values):
     return (a * np.cumprod(no_hit, -1, dtype=np.float32)[..., :-1]).astype(np.float32)
 
 
+# --------------------------------------------------------------------------------------
+# a18 direct rendering (cfg['use_dr_prediction'])      network/renderer.py:85-125, network/sph_solver.py:1-59
+# --------------------------------------------------------------------------------------
+SPH_REGS = np.concatenate([np.zeros(1), np.ones(3) * 0.001, np.ones(5) * 0.005, np.ones(7) * 0.05]).astype(np.float32)   # sph_solver.py:9-11
+
+
+def sph_basis(d):
+    """sph_solver.py:14-31, degree 3: [..., 3] -> [..., 16]"""
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    l0 = [np.ones_like(x)]
+    l1 = [x, y, z]
+    l2 = [x * y, y * z, -x ** 2 - y ** 2 + F32(2) * z ** 2, z * x, x ** 2 - y ** 2]
+    l3 = [(F32(3) * x ** 2 - y ** 2) * y, x * y * z, y * (F32(4) * z ** 2 - x ** 2 - y ** 2),
+          z * (F32(2) * z ** 2 - F32(3) * x ** 2 - F32(3) * y ** 2), x * (F32(4) * z ** 2 - x ** 2 - y ** 2), (x ** 2 - y ** 2) * z,
+          (x ** 2 - F32(3) * y ** 2) * x]
+    return np.stack(l0 + l1 + l2 + l3, -1).astype(d.dtype)
+
+
+def sph_fit(directions, colors, weights, regs=SPH_REGS, eps=1e-4):
+    """SphericalHarmonicsSolver.forward (sph_solver.py:33-50): directions [b,n,3], colors [b,n,3], weights [b,n] -> theta [b,16,3]"""
+    dt = directions.dtype
+    A = sph_basis(directions)
+    insufficient = np.sum(weights, 1, keepdims=True, dtype=dt) < eps
+    weights = weights + insufficient.astype(dt) * dt.type(eps)
+    A_ = np.transpose(A * weights[..., None], (0, 2, 1))
+    inv_mat = A_ @ A + np.diag(regs.astype(dt))[None]
+    return (np.linalg.inv(inv_mat) @ (A_ @ colors)).astype(dt)
+
+
+def direct_rendering(cfg, prj, que_dir, colors_nr, dtype=np.float32):
+    """renderer.py:85-125 -> hit_prob_dr [qn,rn,dn], colors [qn,rn,dn,3], pixel_colors_dr [qn,rn,3].
+    dtype=np.float64: the same formulas in double (a yardstick for the 16 x 16 inverse, which is ill conditioned)."""
+    dt = np.dtype(dtype)
+    ground = dt.type(cfg['alpha_value_ground_state'])
+    alpha_v, vis_v, mask = prj['alpha'].astype(dt), prj['vis'].astype(dt), prj['mask']
+    alpha = np.sum(vis_v * alpha_v, 0, dtype=dt) / (np.sum(vis_v, 0, dtype=dt) + dt.type(1e-5))
+    invalid = (np.sum(mask.astype(np.int32)[..., 0], 0) == 0).astype(dt)[..., None]
+    alpha = (alpha * (1 - invalid) + invalid * ground)[..., 0]                 # qn,rn,dn
+    if cfg.get('use_nr_color_for_dr', False):
+        colors = colors_nr.astype(dt)
+    else:
+        rfn, qn, rn, dn, _ = prj['rgb'].shape
+        pn = qn * rn * dn
+        hit = prj['hit_prob'].reshape(rfn, pn, 1).astype(dt)
+        w = hit / (np.sum(hit, 0, keepdims=True, dtype=dt) + dt.type(1e-3))
+        theta = sph_fit(np.transpose(prj['dir'].reshape(rfn, pn, 3).astype(dt), (1, 0, 2)),
+                        np.transpose(prj['rgb'].reshape(rfn, pn, 3).astype(dt), (1, 0, 2)), np.transpose(w[..., 0], (1, 0)))
+        colors = (sph_basis(que_dir.reshape(pn, 1, 3).astype(dt)) @ theta)[:, 0].reshape(qn, rn, dn, 3)
+    alpha_values = 1 / (1 + np.exp(-alpha))                                   # decode_alpha_value (dist_decoder.py:142-144)
+    no_hit = np.concatenate([np.ones(alpha_values.shape[:-1] + (1,), dt), 1 - alpha_values + dt.type(1e-10)], -1)
+    hit_prob = alpha_values * np.cumprod(no_hit, -1, dtype=dt)[..., :-1]
+    return hit_prob.astype(dt), colors.astype(dt), np.sum(hit_prob[..., None] * colors, 2, dtype=dt)
+
+
 def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
     """network/render_ops.py:172-229 (inv_mode=True).  u=None -> deterministic stratified u
     (random_sample=False); otherwise u [qn,rn,fdn] is the externally drawn uniform sample."""
@@ -509,6 +563,7 @@ DEFAULT_CFG = {
     'use_hierarchical_sampling': False, 'fine_depth_sample_num': 64, 'fine_depth_use_all': False,
     'depth_sample_num': 64, 'alpha_value_ground_state': -15, 'use_self_hit_prob': False,
     'use_ray_mask': True, 'ray_mask_view_num': 2, 'ray_mask_point_num': 8, 'render_depth': False,
+    'use_dr_prediction': False, 'use_nr_color_for_dr': False,
     'coarse_use_vis': True,   # = dist_decoder_cfg['use_vis'] of the COARSE decoder (quirk A.9.2)
     'fine_use_vis': True,     # = fine_dist_decoder_cfg['use_vis']
 }
@@ -560,6 +615,10 @@ def render_by_depth(weights, cfg, que_depth, que, ref, is_train, is_fine, return
     hit_prob = alpha_values2hit_prob(alpha_values)
     pixel = np.sum(hit_prob[..., None] * colors, 2, dtype=np.float32)
     out = {'pixel_colors_nr': pixel, 'hit_prob_nr': hit_prob}
+    if cfg.get('use_dr_prediction', False):                                    # renderer.py:181-185
+        out['hit_prob_dr'], colors_dr, out['pixel_colors_dr'] = direct_rendering(cfg, prj, que_dir, colors)
+        if cfg.get('_dr_float64', False):     # test hook: the same branch evaluated in double on the same fp32 inputs
+            out['hit_prob_dr64'], _, out['pixel_colors_dr64'] = direct_rendering(cfg, prj, que_dir, colors, np.float64)
     if is_train and cfg['use_self_hit_prob']:
         out['hit_prob_self'] = predict_self_hit_prob(weights, cfg, que, que_depth, que_dists, is_fine)
     if 'imgs' in que:

@@ -539,9 +539,42 @@ def sampling_branches_case(ns):
     print('wrote case_sampling_branches.npz', depth.shape, fine_lin.shape)
 
 
+def direct_rendering_cases(ns):
+    """cfg['use_dr_prediction'] (renderer.py:85-125 + sph_solver.py): the `*_dr` outputs of both passes, with the spherical-
+    harmonics colours (f_dr) and with use_nr_color_for_dr (f_dr_nr).  Geometry of case C (a camera with samples behind it, one far
+    away, wide depth range: masked views and empty rays exercise the `ground` / `insufficient` branches).  Each case is also
+    run through the reference in float64 (`out64.*`): the 16 x 16 torch.inverse of a regularised rank-<= rfn normal matrix is
+    ill conditioned, so |ref32 - ref64| is the honest tolerance of the SH colours."""
+    def tweak(que, ref):
+        ref['poses'][1] = orc.look_at_pose(orc.sphere_pos(2.5, 30.0, 25.0), target=orc.sphere_pos(8.0, 30.0, 25.0))
+        ref['poses'][2] = orc.look_at_pose(orc.sphere_pos(9.0, 200.0, -40.0))
+        ref['depth_range'][2] = np.array([5.0, 13.0], np.float32)
+    base = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 16,
+            'fine_depth_sample_num': 16, 'agg_net_cfg': {'sample_num': 16}, 'fine_agg_net_cfg': {'sample_num': 16},
+            'use_dr_prediction': True}
+    for name, extra in (('f_dr', {}), ('f_dr_nr', {'use_nr_color_for_dr': True})):
+        cfg = {**base, **extra}
+        r = run_case(ns, name, cfg, 48, 48, 5, 48, seed=6, is_train=False, integer_coords=False, depth_range=(0.8, 9.0), tweak=tweak)
+        z = dict(np.load(os.path.join(HERE, 'case_%s.npz' % name)))
+        r64 = r.double()
+        tq = {k[4:]: torch.from_numpy(v).double() for k, v in z.items() if k.startswith('que.') and k != 'que.Ks_inv'}
+        tr = {k[4:]: torch.from_numpy(v).double() for k, v in z.items() if k.startswith('ref.')}
+        with torch.no_grad():
+            out64 = r64.render_impl(tq, tr, False)
+        for k in ('pixel_colors_dr', 'hit_prob_dr', 'pixel_colors_dr_fine', 'hit_prob_dr_fine', 'pixel_colors_nr'):
+            z['out64.' + k] = out64[k].numpy()
+        np.savez_compressed(os.path.join(HERE, 'case_%s.npz' % name), **z)
+        print('   ref32 vs ref64: pixel_colors_dr %.2e, hit_prob_dr %.2e' % (
+            np.abs(z['out.pixel_colors_dr'] - z['out64.pixel_colors_dr']).max(), np.abs(z['out.hit_prob_dr'] - z['out64.hit_prob_dr']).max()))
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['dr']:
+        direct_rendering_cases(ref_harness.import_reference())
+        sys.exit(0)
     main()
     ns_ = ref_harness.import_reference()
+    direct_rendering_cases(ns_)
     gradient_case(ns_)
     encoder_case(ns_)
     scene_case(ns_)

@@ -163,7 +163,8 @@ def test_training_step_at_config4_shape_against_reference_autograd():
         g = z['grad.' + k]
         got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(g)
         rel = np.abs(got - g).max() / max(np.abs(g).max(), 1e-7)
-        worst = max(worst, rel)
+        if np.abs(g).max() >= 1e-6:      # (rgb_fc.4.bias: the softmax over views is shift invariant, its true gradient is 0 and
+            worst = max(worst, rel)      #  the reference's own value is 1e-10 of rounding noise - nothing to compare against)
         assert rel <= 5e-3 or np.abs(g).max() < 1e-6, (k, rel)
     for tag, t in (('ref.ray_feats', tr['ray_feats']), ('ref.img_feats', tr['img_feats']), ('que.ray_feats', tq['ray_feats'])):
         g = t.grad.cpu().numpy()

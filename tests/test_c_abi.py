@@ -23,7 +23,7 @@ def test_header_and_binding_agree():
 def test_product_library_exports_abi():
     path = nbuild.build()          # hipcc cross-compiles gfx950 without a GPU
     lib = _lib.bind(path)          # raises AttributeError on a missing symbol
-    assert lib.neuray_abi_version() == 5
+    assert lib.neuray_abi_version() == 6
     assert lib.neuray_is_device_build() == 1
     assert lib.neuray_packed_pass_floats() > 30000
 
@@ -78,11 +78,13 @@ def test_integration_md_option_b_snippet_matches_the_header():
     m = re.search(r'```python\n(# network/neuray_hip\.py.*?)```', text, flags=re.S)
     assert m, 'Option B snippet not found'
 
+    abi = int(re.search(r'#define NEURAY_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'neuray_hip.h')).read()).group(1))
+
     class FakeFn:
         restype = None
 
         def __call__(self, *a):
-            return 5
+            return abi            # the snippet asserts the version it was generated for
 
     class FakeLib:
         def __getattr__(self, name):

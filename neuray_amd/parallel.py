@@ -62,12 +62,53 @@ def gather_tiles(local, n_total, rank, world, group=None):
     return out
 
 
-def render_image_sharded(renderer, que_imgs_info, ref_imgs_info, group=None):
-    """One image split over all ranks of the default (or given) process group; every rank gets the full image."""
+def encode_views_sharded(renderer, ref_imgs_info, group=None):
+    """Single-image latency path of SURVEY.md 8(e): the per-image encoder phase (renderer.py:229-235: `image_encoder` on the
+    reference images, `vis_encoder` on the initial ray_feats) sharded BY VIEW - rank r encodes the contiguous views
+    shard_range(rfn, r, world) - followed by ONE all-gather of a packed buffer [views, (C_img + C_ray) * fh * fw] (17.9 MB
+    per view at 800 x 800: far below a millisecond over xGMI, so one fused collective).  Every rank ends up with the full
+    `img_feats` / `ray_feats` in `ref_imgs_info`, exactly what the replicated `renderer.render()` computes (the encoders are
+    per-sample networks: InstanceNorm, no batch statistics).  No-op when the maps are already there."""
+    if 'img_feats' in ref_imgs_info:
+        return ref_imgs_info
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    imgs, ray0 = ref_imgs_info['imgs'], ref_imgs_info['ray_feats']
+    rfn = imgs.shape[0]
+    spans = [shard_range(rfn, r, world) for r in range(world)]
+    lo, hi = spans[rank]
+    pad = max(e - s for s, e in spans)
+    with torch.no_grad():
+        if hi > lo:
+            f_img = renderer.image_encoder(imgs[lo:hi])
+            f_ray = renderer.vis_encoder(ray0[lo:hi], f_img)
+            mine = torch.cat([f_img.reshape(hi - lo, -1), f_ray.reshape(hi - lo, -1)], 1).float()
+            shapes = torch.tensor([f_img.shape[1], f_ray.shape[1], f_img.shape[2], f_img.shape[3]], dtype=torch.int64, device=imgs.device)
+        else:
+            mine, shapes = None, torch.zeros(4, dtype=torch.int64, device=imgs.device)
+    dist.all_reduce(shapes, op=dist.ReduceOp.MAX, group=group)       # ranks without a view learn the map shape (rfn < world only)
+    c_img, c_ray, fh, fw = (int(v) for v in shapes.tolist())
+    width = (c_img + c_ray) * fh * fw
+    buf = torch.zeros(pad, width, dtype=torch.float32, device=imgs.device)
+    if mine is not None:
+        buf[:hi - lo] = mine
+    parts = torch.empty(world * pad, width, dtype=torch.float32, device=imgs.device)
+    dist.all_gather_into_tensor(parts, buf, group=group)
+    full = torch.cat([parts[r * pad:r * pad + (e - s)] for r, (s, e) in enumerate(spans)], 0)      # [rfn, width]
+    ref_imgs_info['img_feats'] = full[:, :c_img * fh * fw].reshape(rfn, c_img, fh, fw).contiguous()
+    ref_imgs_info['ray_feats'] = full[:, c_img * fh * fw:].reshape(rfn, c_ray, fh, fw).contiguous()
+    return ref_imgs_info
+
+
+def render_image_sharded(renderer, que_imgs_info, ref_imgs_info, group=None, shard_encoders=True):
+    """One image split over all ranks of the default (or given) process group; every rank gets the full image.
+    shard_encoders: when `ref_imgs_info` still holds images + initial ray_feats (a renderer with encoders), encode the views
+    sharded by view and all-gather the maps (encode_views_sharded) instead of every rank encoding all of them."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = que_imgs_info['coords'].shape[1]
     if n < world:
         raise ValueError("neuray_amd.parallel: %d rays cannot be split over %d ranks" % (n, world))
+    if shard_encoders and 'img_feats' not in ref_imgs_info and hasattr(renderer, 'image_encoder'):
+        ref_imgs_info = encode_views_sharded(renderer, dict(ref_imgs_info), group)
     local, _ = render_ray_shard(renderer, que_imgs_info, ref_imgs_info, rank, world)
     return gather_tiles(local, n, rank, world, group)
 

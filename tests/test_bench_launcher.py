@@ -60,3 +60,18 @@ def test_refuses_a_wrong_world_size():
     assert p.returncode != 0 and 'WORLD_SIZE=2' in p.stderr and '{' not in p.stdout
     p = run_bench(['--gpus', '1', '--steps', '1'], env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert p.returncode != 0 and '{' not in p.stdout
+
+
+def test_gpus_8_world_size_of_the_target_node(emu_path):
+    """the driver's largest launch (8 ranks, one per GPU of an MI355X node) on gloo + emulator: eight ranks start, the line
+    reports 8, the split image (16 x 24 = 384 rays, 48 per rank) is gathered whole, replicas stay identical"""
+    p = run_bench(['--gpus', '8', '--steps', '1', '--warmup', '0', '--emulator-lib', emu_path],
+                  env={'NEURAY_EMU_THREADS': '1', 'OMP_NUM_THREADS': '1'}, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['world_size_seen_by_process_group'] == 8
+    assert abs(line['value'] - 8 * 16 * 24 / (line['ms_per_step'] * 1e-3)) <= 1e-6 * line['value']
+    assert line['split_image'].get('gathered_rays') == 16 * 24, line['split_image']
+    assert line['train_ddp'].get('world_size') == 8 and line['train_ddp']['replicas_identical_after_steps'] is True, line['train_ddp']

@@ -208,3 +208,69 @@ def test_two_rank_train_step_on_a_patched_reference_ft_renderer(tmp_path):
     assert torch.equal(a['state'], b['state'])
     for ga, gb in zip(a['log'], b['log']):
         assert ga == gb and 0 < len(ga) <= 8
+
+
+# ---- single-image latency path: encoder phase sharded by view + ONE all-gather of the maps --------------
+def _enc_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NEURAY_EMU_THREADS='2')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from neuray_amd import synthetic
+    from neuray_amd.network.renderer import NeuralRayBaseRenderer
+    from test_encoders import fill_by_name
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 8,
+           'fine_depth_sample_num': 8, 'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 8},
+           'build_encoders': True, 'ray_batch_num': 16}
+    torch.manual_seed(0)
+    r = NeuralRayBaseRenderer(cfg).eval()
+    fill_by_name(r)
+    r._engine_test_lib = emu_lib()
+    que, ref = synthetic.make_scene(48, 64, 3, seed=5)              # 3 views over 2 ranks: an uneven split (2 + 1)
+    que['coords'] = (np.random.RandomState(6).rand(1, 23, 2) * np.array([63, 47])).astype(np.float32)
+    tq = {k: torch.from_numpy(v) for k, v in que.items()}
+    tr = {k: torch.from_numpy(v) for k, v in ref.items() if k != 'img_feats'}        # images + INITIAL ray_feats only
+    calls = {'n': 0}
+    enc = r.image_encoder.forward
+
+    def counting(x):
+        calls['n'] += x.shape[0]
+        return enc(x)
+    r.image_encoder.forward = counting
+    with torch.no_grad():
+        full = parallel.render_image_sharded(r, dict(tq), dict(tr))
+    encoded_here = calls['n']
+    with torch.no_grad():
+        single = r.render(dict(tq), dict(tr), False)                # the replicated path: this process encodes all views
+        # the maps the collective must have delivered: each rank's views encoded as ITS batch (2 + 1), concatenated
+        f_img = torch.cat([enc(tr['imgs'][s:e]) for s, e in ((0, 2), (2, 3))], 0)
+        f_ray = torch.cat([r.vis_encoder(tr['ray_feats'][s:e], f_img[s:e]) for s, e in ((0, 2), (2, 3))], 0)
+        local = parallel.render_ray_shard(r, dict(tq), dict(tr, img_feats=f_img, ray_feats=f_ray), 0, 1)[0]
+        maps = parallel.encode_views_sharded(r, dict(tr))
+    torch.save({'sharded': full, 'single': single, 'encoded': encoded_here, 'from_same_maps': local,
+                'maps_equal': bool(torch.equal(maps['img_feats'], f_img) and torch.equal(maps['ray_feats'], f_ray))},
+               os.path.join(out_dir, 'enc_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_view_sharded_encoders_equal_the_replicated_path(tmp_path):
+    """every rank encodes only its views (2 + 1 of 3) and one all-gather hands everyone all maps: the gathered maps equal the
+    per-shard encodings bit for bit, the sharded image equals a single-process render from those maps bit for bit, and it
+    equals the replicated path (one process encoding all three views as ONE batch) to fp32 rounding - a convolution's
+    summation order may depend on the batch size (oneDNN here, MIOpen on the GPU), nothing else differs"""
+    emu_lib()
+    port = 37500 + os.getpid() % 2000
+    mp.spawn(_enc_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'enc_rank0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'enc_rank1.pt'))
+    assert (a['encoded'], b['encoded']) == (2, 1)
+    for res in (a, b):
+        assert res['maps_equal']
+        assert set(res['sharded']) == set(res['single']) == set(res['from_same_maps'])
+        for k, v in res['single'].items():
+            assert torch.equal(res['sharded'][k], res['from_same_maps'][k]), k
+            tol = 1e-3 if k.endswith('_fine') else 2e-5           # (chained coarse -> fine: DESIGN.md 2.4)
+            assert torch.allclose(res['sharded'][k].float(), v.float(), atol=tol), (k, float((res['sharded'][k].float() - v.float()).abs().max()))
+    for k in a['sharded']:
+        assert torch.equal(a['sharded'][k], b['sharded'][k]), k            # every rank holds the same full image

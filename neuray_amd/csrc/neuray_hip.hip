@@ -63,6 +63,11 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")
     auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, SAVE>;
+    if constexpr (!SAVE) {
+        if (p.dbg) k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, false, true>;     // the per-view record: its own instantiation
+    } else if (p.dbg) {
+        return fail("neuray_render_points: dbg_dev and saved_dev together are not built (run the pass twice)");
+    }
 #ifndef NEURAY_EMU
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif

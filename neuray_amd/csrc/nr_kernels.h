@@ -165,7 +165,10 @@ __device__ __forceinline__ void view_allreduce(const float (&v)[NT * VPW][R], fl
 // fragment and give the MFMA pipe NS independent accumulator chains.
 //   OWN = number of 16-feature output tiles of the per-point layers (base_fc.0 global part, geometry_fc.0) a wave
 //         owns: ceil(4 / nwaves).
-template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW, bool SAVE = false>
+//   DBG = the per-(point, view) record p.dbg is written (tests, direct rendering).  A template flag, not a run-time test of the
+//         pointer: the product instantiation carries none of its 6 predicated store blocks per tile nor their lane masks
+//         (loop-invariant SGPR pairs that hipcc spilled to VGPR lanes and read back with v_readlane + s_nop inside the loop).
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW, bool SAVE = false, bool DBG = false>
 __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     NR_DYNAMIC_SMEM(float, smem);
     constexpr int RMAX = point_rmax<NT>();
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     const int npts = p.rn * p.dn;
     const int dn = p.dn;
     const bool use_vis = p.use_vis != 0;
-    const bool dbg_lane = (p.dbg != nullptr) && (g == 0);
+    const bool dbg_lane = DBG && (g == 0);
     // XCD-aware tile map: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Giving every
     // XCD a contiguous run of tiles keeps the texels that neighbouring samples / rays share inside one private L2
     // instead of fetching them into all eight (the grid is a multiple of 8).

@@ -206,6 +206,11 @@ size_t neuray_packed_t_floats(void);
 /* index[neuray_packed_t_floats()] (host, int32): packed_t[i] = index[i] >= 0 ? flat[index[i]] : 0 */
 int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
+/* The resident kernel exists in two decompositions of the same computation: 2 (default) = workgroups of 8 waves with one reference
+ * view each, two waves per SIMD (csrc/nr_kernels_bwd2.h); 3 = 4 waves with 2 views per wave at one wave per SIMD, accumulators in
+ * AGPRs (csrc/nr_kernels_bwd3.h; measured slower on the MI355X, kept as the on-device cross-check and for A/B timing).
+ * variant 0 restores the default.  Process-wide. */
+int neuray_select_points_backward(int variant);
 
 /* ---- backward of the a19 path (renderer.py:137-155): hit_prob_self [rn][dn] as a function of the gathered query-view
  * features feats [rn][32] (neuray_interpolate_feats of que ray_feats) and the dist decoder weights.

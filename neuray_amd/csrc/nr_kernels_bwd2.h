@@ -116,11 +116,14 @@ constexpr int dw_bias0(int id) {         // running index of the bias accumulato
 }
 constexpr int kDwJobs = dw_job0(DW_COUNT), kDwAcc = (kDwJobs + kB2Waves - 1) / kB2Waves;
 constexpr int kDwBias = dw_bias0(DW_COUNT), kDwBiasAcc = (kDwBias + kB2Waves - 1) / kB2Waves;
+// accumulators per wave when NWV waves share the jobs (points_backward3_kernel: 4 waves)
+constexpr int dw_acc_n(int nwv) { return (kDwJobs + nwv - 1) / nwv; }
+constexpr int dw_bias_n(int nwv) { return (kDwBias + nwv - 1) / nwv; }
 
 // accumulate the jobs of weight tensor ID that this wave owns.  S: staging area, rowA / rowB: first staged row of dY / X,
 // NCQ: column groups of 16 (8 = all views, 1 = per-point operands with stride kB2PStride)
-template <int ID>
-__device__ __forceinline__ void dw_jobs(v4f (&acc)[kDwAcc], float (&bacc)[kDwBiasAcc], const float* S, int rowA, int rowB, int wave, int lane) {
+template <int ID, int NWV = kB2Waves>
+__device__ __forceinline__ void dw_jobs(v4f (&acc)[dw_acc_n(NWV)], float (&bacc)[dw_bias_n(NWV)], const float* S, int rowA, int rowB, int wave, int lane) {
     constexpr int OT = dw_ot(ID), KT = dw_kt(ID), J0 = dw_job0(ID), B0 = dw_bias0(ID);
     constexpr bool PP = kDw[ID].per_point;
     constexpr int STR = PP ? kB2PStride : kB2Stride, NCQ = PP ? 1 : 8;
@@ -130,11 +133,11 @@ __device__ __forceinline__ void dw_jobs(v4f (&acc)[kDwAcc], float (&bacc)[kDwBia
         NR_PRAGMA_UNROLL
         for (int b = 0; b < KT; ++b) {
             const int job = J0 + a * KT + b;
-            if (job % kB2Waves == wave) {
+            if (job % NWV == wave) {
                 const float* pa = S + (rowA + 16 * a + m) * STR + 4 * kk;
                 const float* pb = S + (rowB + 16 * b + m) * STR + 4 * kk;
                 // (software pipeline: the operands of column group j + 1 are read while group j is on the matrix pipe)
-                v4f d = acc[job / kB2Waves];
+                v4f d = acc[job / NWV];
                 float4 av = ld4(pa), bv = ld4(pb);
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < NCQ; ++j) {
@@ -145,25 +148,25 @@ __device__ __forceinline__ void dw_jobs(v4f (&acc)[kDwAcc], float (&bacc)[kDwBia
                     d = nr_mfma16(av.z, bv.z, d); d = nr_mfma16(av.w, bv.w, d);
                     av = an; bv = bn;
                 }
-                acc[job / kB2Waves] = d;
+                acc[job / NWV] = d;
             }
         }
         if (kDw[ID].tb >= 0) {          // bias: row sums of dY, by the owner of this 16-row block's first job
             const int bj = B0 + a;
-            if (bj % kB2Waves == wave) {
+            if (bj % NWV == wave) {
                 const float* pa = S + (rowA + 16 * a + m) * STR + 4 * kk;
-                float s = bacc[bj / kB2Waves];
+                float s = bacc[bj / NWV];
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < NCQ; ++j) { const float4 av = ld4(pa + 16 * j); s += (av.x + av.y) + (av.z + av.w); }
-                bacc[bj / kB2Waves] = s;
+                bacc[bj / NWV] = s;
             }
         }
     }
 }
 
 // end of the launch: this wave's accumulators of tensor ID -> global gradient buffer (natural layout)
-template <int ID>
-__device__ __forceinline__ void dw_flush(const v4f (&acc)[kDwAcc], const float (&bacc)[kDwBiasAcc], float* d_flat, int wave, int lane) {
+template <int ID, int NWV = kB2Waves>
+__device__ __forceinline__ void dw_flush(const v4f (&acc)[dw_acc_n(NWV)], const float (&bacc)[dw_bias_n(NWV)], float* d_flat, int wave, int lane) {
     constexpr int OT = dw_ot(ID), KT = dw_kt(ID), J0 = dw_job0(ID), B0 = dw_bias0(ID);
     constexpr DwSpec sp = kDw[ID];
     const float xs = sp.xscaled ? (float)(1.0 / kLog2e) : 1.0f;       // X was staged as a scaled-ELU activation L * h
@@ -173,8 +176,8 @@ __device__ __forceinline__ void dw_flush(const v4f (&acc)[kDwAcc], const float (
         NR_PRAGMA_UNROLL
         for (int b = 0; b < KT; ++b) {
             const int job = J0 + a * KT + b;
-            if (job % kB2Waves == wave) {
-                const v4f d = acc[job / kB2Waves];
+            if (job % NWV == wave) {
+                const v4f d = acc[job / NWV];
                 NR_PRAGMA_UNROLL
                 for (int r = 0; r < 4; ++r) {
                     const int o = 16 * a + 4 * kk + r, k = 16 * b + m;
@@ -184,8 +187,8 @@ __device__ __forceinline__ void dw_flush(const v4f (&acc)[kDwAcc], const float (
         }
         if (sp.tb >= 0) {
             const int bj = B0 + a;
-            if (bj % kB2Waves == wave) {
-                const float s = nr_group_sum(bacc[bj / kB2Waves]);          // the four column subsets kk
+            if (bj % NWV == wave) {
+                const float s = nr_group_sum(bacc[bj / NWV]);          // the four column subsets kk
                 const int o = 16 * a + m;
                 if (kk == 0 && o < sp.O) atomicAdd(d_flat + tensor_offset(sp.tb) + o, s);
             }

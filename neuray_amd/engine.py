@@ -107,6 +107,7 @@ class RenderEngine:
         self.timing = None
         self.max_backward_samples = _lib.MAX_BACKWARD_SAMPLES
         self.points_backward_kernel = 'auto'       # 'v1': force the first-version point backward (A/B timing, tests)
+        # 'b2' / 'b3' (render_points_backward(kernel=...)): the 8-wave / the 4-wave x 2-view resident kernel (default: b2; b3 measured 1.06 vs 0.91 ms)
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -417,6 +418,8 @@ class RenderEngine:
         d_rf = torch.zeros_like(views.ray_feats)
         d_if = torch.zeros_like(views.img_feats)
         resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
+        pick = kernel if kernel in ('b2', 'b3') else (self.points_backward_kernel if self.points_backward_kernel in ('b2', 'b3') else None)
+        self._check(self.lib.neuray_select_points_backward({'b2': 2, 'b3': 3, None: 0}[pick]))
         ws = pk = pt = None
         if resident:
             packed = packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))

@@ -406,17 +406,50 @@ class RenderEngine:
         ok, idx = cache[has_vis]
         return flat[idx] * ok
 
+    def zeroed(self, *shapes):
+        """Zero-initialised fp32 device tensors of the given shapes carved out of ONE buffer (one fill kernel instead of one per
+        tensor: a backward pass needs d_flat, the ray weights' gradient and two or three 15 MB map gradients)."""
+        sizes = [int(np.prod(sh)) for sh in shapes]
+        pad = [(n + 63) // 64 * 64 for n in sizes]                       # 256-byte aligned pieces (float4 / dwordx4 access)
+        buf = torch.zeros(sum(pad), dtype=torch.float32, device=self.device)
+        out, off = [], 0
+        for sh, n, pn in zip(shapes, sizes, pad):
+            out.append(buf[off:off + n].view(*sh))
+            off += pn
+        return out
+
+    def draw_uniforms(self, shape):
+        """torch.rand(shape) on the CPU generator (the reference draws the fine-sampling uniforms there, render_ops.py:205, so a
+        seeded run consumes the RNG stream identically) -> device tensor.  On a GPU the draw goes into a pinned staging buffer
+        and the upload is asynchronous: a pageable-memory H2D copy would block the host until everything queued before it (the
+        coarse pass) has run, which stalls the launch pipeline once per training step."""
+        if self.device.type != 'cuda':
+            return torch.rand(shape)
+        n = int(np.prod(shape))
+        st = self.__dict__.get('_u_stage')
+        if st is None or st[0].numel() < n:
+            st = (torch.empty(n, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            self.__dict__['_u_stage'] = st
+        else:
+            st[1].synchronize()                                           # the previous upload has left the staging buffer
+        host = st[0][:n].view(*shape)
+        drawn = torch.rand(shape, out=host)
+        if drawn.data_ptr() != host.data_ptr():       # (a replaced torch.rand that ignores `out`: tests feed recorded uniforms)
+            host.copy_(drawn)
+        dev = host.to(self.device, non_blocking=True)
+        st[1].record(torch.cuda.current_stream(self.device))
+        return dev
+
     def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05,
-                               packed=None, kernel='auto', saved=None):
+                               packed=None, kernel='auto', saved=None, out=None):
         """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC).
         packed: the forward's PackedPass of the same weights (built from `flat` here if absent).  kernel: 'auto' = the
         register / LDS resident kernel when it applies (rfn <= 8), 'v1' = force the first-version kernel (tests).
         saved: render_pass(save=True)['saved'] of the same inputs (resident kernel; produced here by one more forward if absent)."""
         coords, depth, d_point_rec = self._f32(coords), self._f32(depth), self._f32(d_point_rec)
         rn, dn = depth.shape
-        d_flat = torch.zeros_like(flat)
-        d_rf = torch.zeros_like(views.ray_feats)
-        d_if = torch.zeros_like(views.img_feats)
+        # out: (d_flat, d_ray_feats, d_img_feats) already zeroed by the caller (engine.zeroed: one fill for the whole pass)
+        d_flat, d_rf, d_if = out if out is not None else self.zeroed(flat.shape, views.ray_feats.shape, views.img_feats.shape)
         resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
         pick = kernel if kernel in ('b2', 'b3') else (self.points_backward_kernel if self.points_backward_kernel in ('b2', 'b3') else None)
         self._check(self.lib.neuray_select_points_backward({'b2': 2, 'b3': 3, None: 0}[pick]))
@@ -477,21 +510,21 @@ class RenderEngine:
                                                                d_flat.data_ptr(), ws.data_ptr(), self._stream()))
         return d_feats, d_flat
 
-    def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None):
-        """Backward of interpolate_feats w.r.t. the feature maps: -> d_feats [b,c,fh,fw]"""
+    def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None, out=None):
+        """Backward of interpolate_feats w.r.t. the feature maps: -> d_feats [b,c,fh,fw] (out: a zeroed buffer to add into)"""
         d_out, points = self._f32(d_out), self._f32(points)
         b, c, fh, fw = feats_shape
         n = points.shape[1]
         if h is None and w is None:
             h, w = fh, fw
-        d_feats = torch.zeros(b, c, fh, fw, dtype=torch.float32, device=self.device)
+        d_feats = out if out is not None else torch.zeros(b, c, fh, fw, dtype=torch.float32, device=self.device)
         m = self._f32(mask) if mask is not None else None
         self._check(self.lib.neuray_interpolate_feats_backward(d_out.data_ptr(), points.data_ptr(), m.data_ptr() if m is not None else None,
                                                                b, n, c, fh, fw, int(h), int(w), int(bool(align_corners)),
                                                                d_feats.data_ptr(), self._stream()))
         return d_feats
 
-    def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None, att_saved=None):
+    def render_rays_backward(self, point_rec, depth, packed, d_pixel, d_hit_prob=None, d_render_depth=None, att_saved=None, d_w=None):
         """Backward of the ray kernel (attention, sigma head, compositing): gradients of a scalar loss w.r.t. the
         per-point records [rn,dn,POINT_REC] (geometry feature 0..15, colour 16..18) and the ray-part weights.
         att_saved: render_pass(save=True)['att_saved'] (the forward's softmax statistics; recomputed if absent).
@@ -502,7 +535,8 @@ class RenderEngine:
         dh = self._f32(d_hit_prob) if d_hit_prob is not None else None
         dd = self._f32(d_render_depth) if d_render_depth is not None else None
         d_rec = self.empty(rn, dn, _lib.POINT_REC)
-        d_w = torch.zeros(_lib.PACKED_RAY_FLOATS, dtype=torch.float32, device=self.device)
+        if d_w is None:
+            d_w = torch.zeros(_lib.PACKED_RAY_FLOATS, dtype=torch.float32, device=self.device)
         a = _lib.NeurayRaysBwdArgs(
             point_rec.data_ptr(), depth.data_ptr(), self.posenc(dn).data_ptr(), packed.dev.data_ptr(), d_pixel.data_ptr(),
             dh.data_ptr() if dh is not None else None, dd.data_ptr() if dd is not None else None,

@@ -3,6 +3,8 @@
 neuray_interpolate_feats_backward).  Nothing here computes with PyTorch ops besides layout permutes and slicing."""
 import torch
 
+from .. import _lib
+
 
 class PassRun:
     """Everything one render pass needs besides the differentiable tensors."""
@@ -65,13 +67,15 @@ class RenderPassFn(torch.autograd.Function):
         rn, dn = run.depth.shape
         if d_pixel is None:
             d_pixel = torch.zeros(rn, 3, device=point_rec.device)
+        # every gradient buffer of the pass out of one zero-filled allocation (one fill kernel)
+        d_flat, d_w, d_rf, d_if = eng.zeroed(ctx.flat.shape, (_lib.PACKED_RAY_FLOATS,), run.views.ray_feats.shape, run.views.img_feats.shape)
         d_rec, g_ray = eng.render_rays_backward(point_rec, run.depth, ctx.packed, d_pixel.contiguous(),
                                                 d_hit.contiguous() if d_hit is not None else None,
-                                                d_depth.contiguous() if d_depth is not None else None, att_saved=ctx.att_saved)
+                                                d_depth.contiguous() if d_depth is not None else None, att_saved=ctx.att_saved, d_w=d_w)
         sd = run.state()
         d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
                                                         run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed,
-                                                        saved=ctx.point_saved)
+                                                        saved=ctx.point_saved, out=(d_flat, d_rf, d_if))
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g
@@ -111,18 +115,25 @@ class RenderPassSelfFn(torch.autograd.Function):
         rn, dn = run.depth.shape
         if d_pixel is None:
             d_pixel = torch.zeros(rn, 3, device=point_rec.device)
+        # every gradient buffer of the pass - flat weights, ray-part weights, both reference maps, the query view's map - out of
+        # one zero-filled allocation: one fill kernel instead of five
+        want_map = d_hit_self is not None and ctx.needs_input_grad[4]
+        d_flat, d_w, d_rf, d_if, d_map = eng.zeroed(ctx.flat.shape, (_lib.PACKED_RAY_FLOATS,), run.views.ray_feats.shape,
+                                                    run.views.img_feats.shape, ctx.que_shape if want_map else (1,))
         d_rec, g_ray = eng.render_rays_backward(point_rec, run.depth, ctx.packed, d_pixel.contiguous(),
                                                 d_hit.contiguous() if d_hit is not None else None,
-                                                d_depth.contiguous() if d_depth is not None else None, att_saved=ctx.att_saved)
+                                                d_depth.contiguous() if d_depth is not None else None, att_saved=ctx.att_saved, d_w=d_w)
         d_flat, d_rf, d_if = eng.render_points_backward(run.qconst, run.views, run.coords, run.depth, ctx.flat, ctx.has_vis,
                                                         run.use_vis, d_rec, var_bias=run.var_bias, packed=ctx.packed,
-                                                        saved=ctx.point_saved)
-        d_map = None
+                                                        saved=ctx.point_saved, out=(d_flat, d_rf, d_if))
         if d_hit_self is not None:
             d_feats, _ = eng.self_hit_prob_backward(run.qconst, run.depth, feats[0], ctx.flat, ctx.has_vis, ctx.self_use_vis,
                                                     d_hit_self.contiguous(), var_bias=run.var_bias, packed=ctx.packed, d_flat=d_flat)
-            if ctx.needs_input_grad[4]:
-                d_map = eng.interpolate_feats_backward(d_feats[None], ctx.que_shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False)
+            if want_map:
+                eng.interpolate_feats_backward(d_feats[None], ctx.que_shape, run.coords[None], ctx.hw[0], ctx.hw[1], align_corners=False,
+                                               out=d_map)
+        if not want_map:
+            d_map = None
         grads = eng.unflatten_pass_grads(d_flat, run.state(), 'd.', 'a.')
         for name, g in g_ray.items():
             grads['a.agg_impl.' + name] = g

@@ -177,7 +177,8 @@ class HipRenderPath:
         fdn = self.cfg['fine_depth_sample_num']
         u = None
         if is_train:   # the reference draws the uniforms on the CPU (render_ops.py:205)
-            u = torch.rand(list(depth.shape[:-1]) + [fdn])[0]
+            u = coarse_render_info.get('_neuray_u')           # render_impl drew them before launching the coarse pass
+            u = (u if u is not None else eng.draw_uniforms(list(depth.shape[:-1]) + [fdn]))[0]
         qconst = self._query(eng, que_imgs_info)
         if '_neuray_fine_range' in que_imgs_info:            # view q > 0 of a multi-view query: view 0's range (quirk A.9.6)
             qconst = eng.prepare_query({**que_imgs_info, 'depth_range': que_imgs_info['_neuray_fine_range']})
@@ -201,10 +202,13 @@ class HipRenderPath:
             return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
         eng = self.engine(coords.device)
         rn = coords.shape[1]
+        # the fine-sampling uniforms (render_ops.py:205: torch.rand on the CPU generator, the only draw of render_impl) are taken
+        # BEFORE the coarse pass is launched and uploaded asynchronously, so the host never waits for the coarse pass
+        u = eng.draw_uniforms([1, rn, self.cfg['fine_depth_sample_num']]) if (is_train and self.cfg['use_hierarchical_sampling']) else None
         que_depth = eng.sample_coarse_depth(que_imgs_info['depth_range'], rn, self.cfg['depth_sample_num'])[None]
         outputs = self.render_by_depth(que_depth, que_imgs_info, ref_imgs_info, is_train, False)
         if self.cfg['use_hierarchical_sampling']:
-            coarse = {'depth': que_depth, 'hit_prob': outputs['hit_prob_nr']}
+            coarse = {'depth': que_depth, 'hit_prob': outputs['hit_prob_nr'], '_neuray_u': u}
             for k, v in self.fine_render_impl(coarse, que_imgs_info, ref_imgs_info, is_train).items():
                 outputs[k + '_fine'] = v
         return outputs

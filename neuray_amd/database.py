@@ -1,15 +1,16 @@
-"""On-disk scene adapters for the host pipeline: the two evaluation formats BASELINE.json's
-configs read - `nerf_synthetic/<scene>/<background>_<size>` (configs 1, 2) and `llff_colmap/<scene>/<high|low>` (config 3) -
-exposing the accessors of the reference's `BaseDatabase` (dataset/database.py:25-58) so that `neuray_amd.pipeline`
+"""On-disk scene adapters for the host pipeline: the three evaluation formats BASELINE.json's
+configs read - `nerf_synthetic/<scene>/<background>_<size>` (configs 1, 2), `llff_colmap/<scene>/<high|low>` (config 3) and
+`dtu_test/<scene>/black_<size>` (config 4) - exposing the accessors of the reference's `BaseDatabase` (dataset/database.py:25-58) so that `neuray_amd.pipeline`
 (`build_imgs_info`, `DeviceViewCache`, `render_poses`) and the reference's own `render.py` loop can run on them, plus the
 reference's `parse_database_name` (database.py:983-1003) / `get_database_split` (:1005-1046) for these two families and a
 PNG / JPEG writer for the rendered images (render.py:49-56).  Decoding is PIL + numpy (the reference uses skimage / cv2,
 which this image does not have); COLMAP's binary models and depth maps are read with a few lines of `struct`.
 
-Deliberately not reproduced: the reference's on-the-fly RESIZING paths (`black_400` etc.: `resize_img` = cv2 Gaussian blur +
-bilinear resize, database.py:312-314; the LLFF `cache/<res>` images it writes on first use, :84-97).  A scene must be at
-its native size / have its cache directory; otherwise the constructor raises.  (Bit-parity of a resize with OpenCV's is
-not something numpy reproduces, and a silently different resize would be a numerics change.)
+The reference's on-the-fly RESIZING paths (`black_400`: `resize_img` = cv2 Gaussian blur + bilinear resize, database.py:312-314;
+nearest-neighbour masks / depth maps, :341,349; the DTU 1600 -> 800 / 400 images and masks, :203,244; the LLFF `cache/<res>`
+images it writes on first use, :84-97) go through neuray_amd/imgproc.py, numpy restatements of the OpenCV routines - see its
+header for what is exact (nearest, area, the projection-matrix decomposition) and what may differ from OpenCV's fixed-point
+8-bit paths by one grey level (blur, bilinear); nothing there could be pinned against cv2 in this container.
 """
 import json
 import os
@@ -17,8 +18,11 @@ import struct
 
 import numpy as np
 
+from . import imgproc
+
 NERF_SYN_ROOT = 'data/nerf_synthetic'            # asset.py / database.py:258
 LLFF_ROOT = 'data/llff_colmap'                   # asset.py:50
+DTU_TEST_ROOT = 'data/dtu_test'                  # database.py:142
 nerf_syn_val_ids = ['val-r_39', 'val-r_2', 'val-r_94', 'val-r_62', 'val-r_23', 'val-r_36']      # asset.py:45
 
 
@@ -120,8 +124,8 @@ class BaseDatabase:
 
 
 class NeRFSyntheticDatabase(BaseDatabase):
-    """dataset/database.py:251-353.  database_name = 'nerf_synthetic/<scene>/<black|white>_<size>'; <size> must be the
-    PNGs' own size (800 for the released data)."""
+    """dataset/database.py:251-353.  database_name = 'nerf_synthetic/<scene>/<black|white>_<size>'; the PNGs are the released
+    800 x 800 ones, any other <size> (black_400: BASELINE.json config 1) is produced by the reference's resize path."""
 
     def __init__(self, database_name, root=None):
         super().__init__(database_name)
@@ -138,12 +142,11 @@ class NeRFSyntheticDatabase(BaseDatabase):
             poses += p
         self.img_ids, self.poses = ids, poses
         self.range_dict = {i: np.asarray((2.0, 6.0), np.float32) for i in ids}
-        native = imread('%s/%s.png' % (self.root_dir, self.img_id2img_path(ids[0]))).shape[0]
-        if native != self.img_size:
-            raise NotImplementedError("neuray_amd.database: %s asks for size %d but the images are %d: the reference's cv2 "
-                                      "blur + resize (database.py:312-314) is not reproduced" % (database_name, self.img_size, native))
-        ratio = self.img_size / native
-        self.K = np.diag([ratio, ratio, 1.0]).astype(np.float32) @ K
+        # database.py:269-270,312-314,341,349 resize relative to the constant 800, the size of the released PNGs; here relative
+        # to the PNGs' own size (the same thing for the released data)
+        self.native = imread('%s/%s.png' % (self.root_dir, self.img_id2img_path(ids[0]))).shape[0]
+        self.ratio = self.img_size / self.native
+        self.K = np.diag([self.ratio, self.ratio, 1.0]).astype(np.float32) @ K
         self.depth_img_ids = [i for i in ids if os.path.exists(self._depth_fn(i))]
 
     def parse_info(self, split='train'):
@@ -175,7 +178,8 @@ class NeRFSyntheticDatabase(BaseDatabase):
         alpha = img[:, :, 3:].astype(np.float32) / 255.0
         rgb = img[:, :, :3].astype(np.float32) / 255.0
         rgb = rgb * alpha if self.background == 'black' else rgb * alpha + 1.0 - alpha
-        return color_map_backward(rgb)
+        img = color_map_backward(rgb)
+        return imgproc.resize_img(img, self.ratio) if self.img_size != self.native else img
 
     def get_K(self, img_id):
         return self.K.astype(np.float32).copy()
@@ -193,10 +197,16 @@ class NeRFSyntheticDatabase(BaseDatabase):
 
     def get_depth(self, img_id):
         fn = self._depth_fn(img_id)
-        return read_colmap_array(fn) if os.path.exists(fn) else None
+        if not os.path.exists(fn):
+            return None
+        depth = read_colmap_array(fn)
+        return imgproc.resize(depth, (self.img_size, self.img_size), imgproc.INTER_NEAREST) if self.img_size != self.native else depth
 
     def get_mask(self, img_id):
-        return imread('%s/%s.png' % (self.root_dir, self.img_id2img_path(img_id)))[:, :, 3] > 0
+        alpha = imread('%s/%s.png' % (self.root_dir, self.img_id2img_path(img_id)))[:, :, 3]
+        if self.img_size != self.native:
+            alpha = imgproc.resize(alpha, (self.img_size, self.img_size), imgproc.INTER_NEAREST)
+        return alpha > 0
 
     def get_depth_range(self, img_id):
         return self.range_dict[img_id].copy()
@@ -216,12 +226,23 @@ class LLFFColmapDatabase(BaseDatabase):
         self.images_colmap = read_images_binary('%s/sparse/images.bin' % self.root_dir)
         self.img_ids = [str(k + 1) for k in range(len(self.images_colmap))]
         self.image_dir = '%s/cache/%s' % (self.root_dir, self.res_type)
-        missing = [i for i in self.img_ids if not os.path.exists('%s/%s' % (self.image_dir, self.images_colmap[int(i)]['name']))]
-        if missing:
-            raise NotImplementedError("neuray_amd.database: %d image(s) missing under %s - the reference creates this cache with a "
-                                      "cv2 blur + INTER_AREA resize (database.py:84-97), which is not reproduced here; run the "
-                                      "reference's loader once or provide the resized images" % (len(missing), self.image_dir))
+        self._cache_resolution()
         self.bounds = np.load('%s/depth_range.npy' % self.root_dir)
+
+    def _cache_resolution(self):
+        """database.py:84-97: images missing from cache/<res> are made from images/<name>: Gaussian pre-blur for the ratio
+        w / 4032, then an INTER_AREA resize (an integer factor for the 4032 x 3024 captures: 4 or 8)"""
+        os.makedirs(self.image_dir, exist_ok=True)
+        h, w = self.get_resolution()
+        for img_id in self.img_ids:
+            fn = self.images_colmap[int(img_id)]['name']
+            if os.path.exists('%s/%s' % (self.image_dir, fn)):
+                continue
+            src = '%s/images/%s' % (self.root_dir, fn)
+            if not os.path.exists(src):
+                raise FileNotFoundError("neuray_amd.database: neither %s/%s nor %s exists" % (self.image_dir, fn, src))
+            img = imgproc.downsample_gaussian_blur(imread(src), w / 4032)
+            imsave('%s/%s' % (self.image_dir, fn), imgproc.resize(img, (w, h), imgproc.INTER_AREA))
 
     def get_resolution(self):
         return (756, 1008) if self.res_type == 'high' else (756 // 2, 1008 // 2)
@@ -254,7 +275,86 @@ class LLFFColmapDatabase(BaseDatabase):
         return self.bounds[int(img_id) - 1]
 
 
-name2database = {'nerf_synthetic': NeRFSyntheticDatabase, 'llff_colmap': LLFFColmapDatabase}
+class DTUTestDatabase(BaseDatabase):
+    """dataset/database.py:138-249.  database_name = 'dtu_test/<scene>/black_<size>' (size 1600 = native, 800 = BASELINE.json
+    config 4, 400).  Reads <root>/<scene>/{image/%06d.png, mask/%03d.png, cameras.npz (IDR-style world_mat_i / scale_mat_i),
+    depth_range.npy, colmap_depth/<i>.jpg.geometric.bin}.  Intrinsics and world-to-camera poses come from decomposing
+    world_mat_i; the normalisation of scale_mat_i is undone on the camera centre and the world is flipped (y, z -> -y, -z)."""
+
+    def __init__(self, database_name, root=None):
+        super().__init__(database_name)
+        _, self.model_name, background_size = database_name.split('/')
+        self.background, size = background_size.split('_')
+        if self.background != 'black':
+            raise NotImplementedError(self.background)
+        self.image_size = int(size)
+        self.root_dir = os.path.join(root if root is not None else DTU_TEST_ROOT, self.model_name)
+        self.ratio = self.image_size / 1600
+        self.h, self.w = int(self.ratio * 1200), self.image_size
+        n = len(sorted(f for f in os.listdir(os.path.join(self.root_dir, 'image')) if f.endswith(('.jpg', '.png'))))
+        self.depth_range = np.load('%s/depth_range.npy' % self.root_dir)
+        cams = np.load(os.path.join(self.root_dir, 'cameras.npz'))
+        flip_world = np.diag([1.0, -1.0, -1.0, 1.0]).astype(np.float32)
+        self.Ks, self.Rts, self.img_ids = [], [], []
+        for i in range(n):
+            K, R, ch = imgproc.decompose_projection_matrix(cams['world_mat_%d' % i][:3])
+            cam2world = np.eye(4, dtype=np.float32)                  # (float32 from here on, as the reference's np.eye(4, float32))
+            cam2world[:3, :3] = R.T
+            cam2world[:3, 3] = (ch[:3] / ch[3])[:, 0]
+            if 'scale_mat_%d' % i in cams.files:
+                sm = cams['scale_mat_%d' % i]
+                cam2world[:3, 3:] -= sm[:3, 3:]
+                cam2world[:3, 3:] /= np.diagonal(sm[:3, :3])[..., None]
+            cam2world = (flip_world @ cam2world)[:3]
+            self.Rts.append(np.concatenate([cam2world[:, :3].T, -cam2world[:, :3].T @ cam2world[:, 3:]], 1))
+            self.Ks.append(np.diag([self.ratio, self.ratio, 1]) @ K)
+            self.img_ids.append(str(i))
+        self._imgs, self._depths, self._masks = {}, {}, {}
+        self.depth_img_ids = [i for i in self.img_ids if os.path.exists('%s/depth_maps/%s.jpg.geometric.bin' % (self.root_dir, i))]
+
+    def get_image(self, img_id):
+        if img_id not in self._imgs:
+            img = imread(os.path.join(self.root_dir, 'image', '%06d.png' % int(img_id)))
+            if self.w != 1600:
+                img = imgproc.resize(imgproc.downsample_gaussian_blur(img, self.ratio), (self.w, self.h), imgproc.INTER_LINEAR)
+            self._imgs[img_id] = img * self.get_mask(img_id).astype(np.uint8)[:, :, None]
+        return self._imgs[img_id]
+
+    def get_K(self, img_id):
+        return self.Ks[int(img_id)].copy()
+
+    def get_pose(self, img_id):
+        return self.Rts[int(img_id)].copy()
+
+    def get_img_ids(self, check_depth_exist=False):
+        return self.img_ids                           # (database.py:216-217: the flag is ignored for this family)
+
+    def get_depth(self, img_id):
+        if img_id not in self._depths:
+            fn = '%s/colmap_depth/%s.jpg.geometric.bin' % (self.root_dir, img_id)
+            if not os.path.exists(fn):
+                raise NotImplementedError("neuray_amd.database: no depth map %s" % fn)
+            depth = np.ascontiguousarray(read_colmap_array(fn), dtype=np.float32)
+            if self.w != 800:                         # (database.py:236: the COLMAP maps of this family are 800 wide)
+                depth = imgproc.resize(depth, (self.w, self.h), imgproc.INTER_NEAREST)
+            depth = depth.copy()
+            depth[~self.get_mask(img_id)] = 0
+            self._depths[img_id] = depth
+        return self._depths[img_id]
+
+    def get_mask(self, img_id):
+        if img_id not in self._masks:
+            mask = np.sum(imread(os.path.join(self.root_dir, 'mask', '%03d.png' % int(img_id))), -1) > 0
+            if self.w != 1600:
+                mask = imgproc.resize(mask.astype(np.uint8), (self.w, self.h), imgproc.INTER_NEAREST) > 0
+            self._masks[img_id] = mask
+        return self._masks[img_id]
+
+    def get_depth_range(self, img_id):
+        return self.depth_range.copy()
+
+
+name2database = {'nerf_synthetic': NeRFSyntheticDatabase, 'llff_colmap': LLFFColmapDatabase, 'dtu_test': DTUTestDatabase}
 
 
 def parse_database_name(database_name, root=None):
@@ -277,6 +377,9 @@ def get_database_split(database, split_type='val'):
         val_ids = list(nerf_syn_val_ids) if split_type.startswith('val') else [i for i in database.get_img_ids() if i.startswith('te')]
     elif name.startswith('llff'):
         val_ids = database.get_img_ids()[::8]
+        train_ids = [i for i in database.get_img_ids(check_depth_exist=depth_valid) if i not in val_ids]
+    elif name.startswith('dtu_test'):
+        val_ids = database.get_img_ids()[3:-3:8]
         train_ids = [i for i in database.get_img_ids(check_depth_exist=depth_valid) if i not in val_ids]
     else:
         raise NotImplementedError(name)

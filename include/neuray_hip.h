@@ -304,6 +304,22 @@ int neuray_direct_render_points(const float* query_const_dev, const float* view_
 int neuray_direct_render_rays(const float* alpha_dev, const float* colors_dev, int color_stride, int color_first, int rn, int dn,
                               float* hit_prob_dev, float* pixel_dev, void* stream);
 
+/* ---- f-1 encoders: fused InstanceNorm2d(affine=True, eps) + activation (+ residual add) + reflection padding, NCHW fp32
+ * (network/ops.py:43-75,150-230 ResidualBlock / ResUNetLight: `conv -> norm -> relu [-> + skip -> relu]`, `conv -> norm -> elu`;
+ * network/vis_encoder.py:6-21; the reflection padding is the `padding_mode='reflect'` of the NEXT convolution).
+ * forward:  out_padded [n][c][h + 2 pad][w + 2 pad] = reflect_pad(act(gamma (x - mean) / sqrt(var + eps) + beta [+ res])), act 0 = none,
+ *           1 = ReLU, 2 = ELU; res (NULL = none) is addressed with element strides (a view of another padded buffer);
+ *           raw_zeroed [n*c][2] is scratch that must be zero on entry; stats [n*c][2] receives (mean, 1 / std) for the backward.
+ * backward: d_out_padded is the gradient of the padded output (everything that consumed the padded tensor or its interior view);
+ *           -> dx [n][c][h][w], d_res [n][c][h][w] (NULL = no residual).  raw_zeroed [n*c][2] (zero on entry) returns per plane
+ *           (sum g, sum g xhat): d beta[c] = sum over images of the first, d gamma[c] of the second. */
+int neuray_inorm_forward(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, long long res_stride_n,
+                         long long res_stride_c, long long res_stride_h, int n, int c, int h, int w, int pad, int act, float eps,
+                         float* raw_zeroed_dev, float* stats_dev, float* out_padded_dev, void* stream);
+int neuray_inorm_backward(const float* x_dev, const float* out_padded_dev, const float* d_out_padded_dev, const float* stats_dev,
+                          const float* gamma_dev, int n, int c, int h, int w, int pad, int act, float* raw_zeroed_dev, float* dx_dev,
+                          float* d_res_dev, void* stream);
+
 /* ---- a9 stand-alone: MixtureLogisticsDistDecoder.forward / predict_mean on arbitrary rows (dist_decoder.py:99-107,147-149).
  * feats [n][32] -> mean [n][2], var [n][2] (bias_val included), aw [n], vis [n] (vis only with a vis head, else NULL). */
 int neuray_dist_decoder_rows(const float* feats_dev, const float* packed_weights_dev, int n, int has_vis_head, float var_bias,

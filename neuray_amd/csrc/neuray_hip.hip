@@ -4,6 +4,7 @@
 #include "nr_kernels.h"
 #include "nr_kernels_bwd.h"
 #include "nr_kernels_dr.h"
+#include "nr_kernels_norm.h"
 #ifndef NR_BF16_QUADS
 #include "nr_kernels_bwd3.h"
 #endif
@@ -268,6 +269,45 @@ int neuray_warp_variance(const float* ref_feats, const float* src_feats, const i
     const int grid = grid_for((long long)rfn * dn * fh * fw, 256, 256 * 64);
     NR_LAUNCH(nr::warp_variance_kernel, dim3(grid), dim3(256), 0, stream, p);
     return check_launch("neuray_warp_variance");
+}
+
+// ---- fused InstanceNorm + activation (+ residual) + reflection pad of the per-image encoders (nr_kernels_norm.h) ----------------
+namespace {
+int norm_chunks(int planes, int hw) {          // workgroups per plane: ~4096 workgroups in all (16 per CU), each thread >= 4 elements
+    int want = (4096 + planes - 1) / planes, most = (hw + 1023) / 1024;
+    if (want > most) want = most;
+    return want < 1 ? 1 : want;
+}
+}  // namespace
+
+int neuray_inorm_forward(const float* x, const float* gamma, const float* beta, const float* res, long long res_stride_n,
+                         long long res_stride_c, long long res_stride_h, int n, int c, int h, int w, int pad, int act, float eps,
+                         float* raw_zeroed, float* stats, float* out_padded, void* stream) {
+    if (!x || !gamma || !beta || !raw_zeroed || !stats || !out_padded) return fail("neuray_inorm_forward: null pointer");
+    if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2 || (long long)(h + 2 * pad) * (w + 2 * pad) >= (1 << 23))
+        return fail("neuray_inorm_forward: bad arguments n=%d c=%d h=%d w=%d pad=%d act=%d", n, c, h, w, pad, act);
+    const int planes = n * c, hw = h * w;
+    NR_LAUNCH(nr::inorm_stats_kernel, dim3(norm_chunks(planes, hw), planes), dim3(256), 0, stream, x, hw, raw_zeroed);
+    nr::NormApplyParams p;
+    p.x = x; p.raw = raw_zeroed; p.gamma = gamma; p.beta = beta; p.res = res; p.out = out_padded; p.stats = stats;
+    p.rs_n = res_stride_n; p.rs_c = res_stride_c; p.rs_h = res_stride_h;
+    p.n = n; p.c = c; p.h = h; p.w = w; p.pad = pad; p.act = act; p.eps = eps;
+    NR_LAUNCH(nr::inorm_apply_kernel, dim3(norm_chunks(planes, (h + 2 * pad) * (w + 2 * pad)), planes), dim3(256), 0, stream, p);
+    return check_launch("neuray_inorm_forward");
+}
+
+int neuray_inorm_backward(const float* x, const float* out_padded, const float* d_out_padded, const float* stats, const float* gamma,
+                          int n, int c, int h, int w, int pad, int act, float* raw_zeroed, float* dx, float* d_res, void* stream) {
+    if (!x || !out_padded || !d_out_padded || !stats || !gamma || !raw_zeroed || !dx) return fail("neuray_inorm_backward: null pointer");
+    if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2)
+        return fail("neuray_inorm_backward: bad arguments n=%d c=%d h=%d w=%d pad=%d act=%d", n, c, h, w, pad, act);
+    nr::NormBwdParams p;
+    p.x = x; p.out = out_padded; p.d_out = d_out_padded; p.stats = stats; p.gamma = gamma; p.raw = raw_zeroed; p.dx = dx; p.d_res = d_res;
+    p.n = n; p.c = c; p.h = h; p.w = w; p.pad = pad; p.act = act;
+    const int planes = n * c, hw = h * w;
+    NR_LAUNCH(nr::inorm_backward_reduce_kernel, dim3(norm_chunks(planes, hw), planes), dim3(256), 0, stream, p);
+    NR_LAUNCH(nr::inorm_backward_apply_kernel, dim3(norm_chunks(planes, hw), planes), dim3(256), 0, stream, p);
+    return check_launch("neuray_inorm_backward");
 }
 
 int neuray_rays_points(const float* query_const, const float* coords, const float* depth, int rn, int dn, float* centers,

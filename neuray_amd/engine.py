@@ -418,6 +418,19 @@ class RenderEngine:
             off += pn
         return out
 
+    def zero_scratch(self, n):
+        """n zeroed floats carved out of a 1 M-float chunk that is filled ONCE (a bump allocator: slices are handed out once and
+        never reused, a new chunk is made when the current one is used up) - the fused norm kernels need 2 floats per plane of
+        zeroed scratch on every call, 60 calls per encoder pass: one 4 MB fill per ~8 passes instead of 60 tiny fills"""
+        n = (int(n) + 63) // 64 * 64
+        st = self.__dict__.get('_zero_pool')
+        if st is None or st[1] + n > st[0].numel():
+            st = [torch.zeros(max(1 << 20, n), dtype=torch.float32, device=self.device), 0]
+            self.__dict__['_zero_pool'] = st
+        out = st[0][st[1]:st[1] + n]
+        st[1] += n
+        return out
+
     def draw_uniforms(self, shape):
         """torch.rand(shape) on the CPU generator (the reference draws the fine-sampling uniforms there, render_ops.py:205, so a
         seeded run consumes the RNG stream identically) -> device tensor.  On a GPU the draw goes into a pinned staging buffer

@@ -20,6 +20,25 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_norm
+from .fused_norm import conv_prepadded, interior, norm_act
+
+
+# memory format the convolution stacks run in.  True: channels-last end to end (the NHWC storage the HIP gathers read, no relayout
+# of the outputs); False: NCHW inside the stacks, one channels-last conversion of the two 32-channel outputs at the end.
+CHANNELS_LAST = True
+
+
+def _fmt(x):
+    # (the fused norm kernels are NCHW, the layout MIOpen's fp32 Winograd convolutions run in natively: with them the stacks are
+    # NCHW inside and the two 32-channel outputs are converted once)
+    fused = fused_norm.FUSED_NORM and fused_norm._engine(x.device) is not None
+    return x.contiguous(memory_format=torch.channels_last) if (CHANNELS_LAST and not fused) else x.contiguous()
+
+
+def set_fused_norm(on):
+    fused_norm.FUSED_NORM = bool(on)
+
 
 def _inorm(c):
     return nn.InstanceNorm2d(c, track_running_stats=False, affine=True)
@@ -40,9 +59,13 @@ class _ResBlock(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), _inorm(cout))
 
-    def forward(self, x):
-        y = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
-        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+    def forward(self, xp, pad_out=1):
+        """xp: the block's input carrying 1 pixel of reflection padding -> the block's output padded by `pad_out`"""
+        a = norm_act(self.bn1, conv_prepadded(self.conv1, xp), 'relu', 1)
+        skip = interior(xp, 1)
+        if self.downsample is not None:
+            skip = norm_act(self.downsample[1], conv_prepadded(self.downsample[0], skip), None, 0)
+        return norm_act(self.bn2, conv_prepadded(self.conv2, a), 'relu', pad_out, res=skip)
 
 
 class _ConvNormElu(nn.Module):
@@ -51,7 +74,7 @@ class _ConvNormElu(nn.Module):
         self.conv, self.bn = _conv(cin, cout, 3, bias=True), _inorm(cout)
 
     def forward(self, x):
-        return F.elu(self.bn(self.conv(x)))
+        return norm_act(self.bn, self.conv(x), 'elu', 0)
 
 
 class _Up(nn.Module):
@@ -65,6 +88,13 @@ class _Up(nn.Module):
 
 def _stage(cin, cout, n):
     return nn.Sequential(*[_ResBlock(cin if i == 0 else cout, cout, 2 if i == 0 else 1) for i in range(n)])
+
+
+def _run_stage(stage, xp, pad_out):
+    """the blocks of a stage on a padded input; every block hands the next one its output already padded"""
+    for i, blk in enumerate(stage):
+        xp = blk(xp, 1 if i + 1 < len(stage) else pad_out)
+    return xp
 
 
 def _join(skip, x):
@@ -89,12 +119,13 @@ class ImageEncoder(nn.Module):
         self.out_conv = nn.Conv2d(32, out_dim, 1)
 
     def forward(self, imgs):
-        x = imgs.contiguous(memory_format=torch.channels_last)
-        x = F.relu(self.bn1(self.conv1(x)))
-        s1 = self.layer1(x)
-        s2 = self.layer2(s1)
-        x = self.iconv3(_join(s2, self.upconv3(self.layer3(s2))))
-        x = self.iconv2(_join(s1, self.upconv2(x)))
+        x = _fmt(imgs)
+        xp = norm_act(self.bn1, self.conv1(x), 'relu', 1)                 # every activation travels with the next conv's padding
+        s1p = _run_stage(self.layer1, xp, 1)
+        s2p = _run_stage(self.layer2, s1p, 1)
+        s3 = _run_stage(self.layer3, s2p, 0)
+        x = self.iconv3(_join(interior(s2p, 1), self.upconv3(s3)))
+        x = self.iconv2(_join(interior(s1p, 1), self.upconv2(x)))
         return self.out_conv(x).contiguous(memory_format=torch.channels_last)     # (no-op when the convs kept the format)
 
 
@@ -106,7 +137,9 @@ class _PreActBlock(nn.Module):
         self.conv = nn.Sequential(_inorm(c), nn.ReLU(), _conv(c, c, 3), _inorm(c), nn.ReLU(), _conv(c, c, 3))
 
     def forward(self, x):
-        return x + self.conv(x)
+        a = norm_act(self.conv[0], x, 'relu', 1)
+        b = norm_act(self.conv[3], conv_prepadded(self.conv[2], a), 'relu', 1)
+        return x + conv_prepadded(self.conv[5], b)
 
 
 class DefaultVisEncoder(nn.Module):
@@ -119,7 +152,7 @@ class DefaultVisEncoder(nn.Module):
         self.out_conv = nn.Sequential(_conv(64, 32, 3), _PreActBlock(32), _PreActBlock(32), _conv(32, 32, 1))
 
     def forward(self, ray_feats, imgs_feats):
-        x = torch.cat([imgs_feats, ray_feats], 1).contiguous(memory_format=torch.channels_last)
+        x = _fmt(torch.cat([imgs_feats, ray_feats], 1))
         return self.out_conv(x).contiguous(memory_format=torch.channels_last)
 
 

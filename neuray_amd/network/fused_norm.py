@@ -1,0 +1,83 @@
+"""Fused InstanceNorm2d + activation (+ residual) + reflection padding for the per-image encoders, on the
+kernels of csrc/nr_kernels_norm.h: `norm_act(bn, y, act, pad, res)` is
+
+    reflect_pad(act(bn(y) [+ res]), pad)              bn: nn.InstanceNorm2d(affine=True, track_running_stats=False)
+
+in two passes over the activation instead of PyTorch's four to six (MIOpen batch-norm, activation, add, activation,
+reflection_pad2d), with a two-pass backward.  The result is handed to the next convolution already padded
+(`conv_prepadded`); the un-padded activation is the interior view of the same buffer (`interior`).  On a device without the
+kernels (plain CPU) the same function composes the PyTorch ops, so the modules have one forward."""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+ACTS = {None: 0, 'relu': 1, 'elu': 2}
+FUSED_NORM = True          # False: always compose the PyTorch ops (A/B timing, tests)
+
+
+def _engine(device):
+    from . import render_ops
+    if device.type != 'cuda' and render_ops._TEST_LIB is None:
+        return None
+    return render_ops.engine_for(device)
+
+
+class _NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, pad, act, eps):
+        eng = _engine(x.device)
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, h + 2 * pad, w + 2 * pad, dtype=torch.float32, device=x.device)
+        stats = torch.empty(n * c, 2, dtype=torch.float32, device=x.device)
+        raw = eng.zero_scratch(2 * n * c)
+        g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+        rs = (0, 0, 0)
+        if res is not None:
+            if res.dtype != torch.float32 or res.stride(3) != 1:
+                res = res.contiguous().float()
+            assert tuple(res.shape) == (n, c, h, w), (tuple(res.shape), (n, c, h, w))
+            rs = res.stride()[:3]
+        eng._check(eng.lib.neuray_inorm_forward(
+            x.data_ptr(), g.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, rs[0], rs[1], rs[2],
+            n, c, h, w, int(pad), int(act), float(eps), raw.data_ptr(), stats.data_ptr(), out.data_ptr(), eng._stream()))
+        ctx.save_for_backward(x, out, stats, g)
+        ctx.meta = (int(pad), int(act), res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, out, stats, g = ctx.saved_tensors
+        pad, act, has_res = ctx.meta
+        eng = _engine(x.device)
+        n, c, h, w = x.shape
+        d_out = d_out.contiguous().float()
+        raw = eng.zero_scratch(2 * n * c)[:2 * n * c]
+        dx = torch.empty_like(x)
+        d_res = torch.empty_like(x) if has_res else None
+        eng._check(eng.lib.neuray_inorm_backward(
+            x.data_ptr(), out.data_ptr(), d_out.data_ptr(), stats.data_ptr(), g.data_ptr(), n, c, h, w, pad, act, raw.data_ptr(),
+            dx.data_ptr(), d_res.data_ptr() if has_res else None, eng._stream()))
+        sums = raw.view(n, c, 2).sum(0)
+        return dx, sums[:, 1].contiguous(), sums[:, 0].contiguous(), d_res, None, None, None
+
+
+def norm_act(bn, y, act=None, pad=0, res=None):
+    """-> reflect_pad(act(bn(y) [+ res]), pad) as one [n, c, h + 2 pad, w + 2 pad] tensor"""
+    if FUSED_NORM and bn.affine and not bn.track_running_stats and _engine(y.device) is not None:
+        return _NormActFn.apply(y, bn.weight, bn.bias, res, pad, ACTS[act], bn.eps)
+    z = bn(y)
+    if res is not None:
+        z = z + res
+    z = F.relu(z) if act == 'relu' else (F.elu(z) if act == 'elu' else z)
+    return F.pad(z, (pad, pad, pad, pad), mode='reflect') if pad else z
+
+
+def interior(zp, pad):
+    return zp[:, :, pad:zp.shape[2] - pad, pad:zp.shape[3] - pad] if pad else zp
+
+
+def conv_prepadded(conv, xp):
+    """`conv` (an nn.Conv2d with padding_mode='reflect') on an input that already carries its reflection padding"""
+    return F.conv2d(xp, conv.weight, conv.bias, conv.stride, 0, conv.dilation, conv.groups)

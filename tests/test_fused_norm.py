@@ -1,0 +1,108 @@
+"""csrc/nr_kernels_norm.h: fused InstanceNorm2d + activation (+ residual) + reflection padding of the per-image encoders
+ against the PyTorch composition it replaces (network/ops.py:43-75,150-230: `conv -> norm -> relu
+[-> + skip -> relu]`, `conv -> norm -> elu`, followed by the next convolution's padding_mode='reflect'), forward and backward."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from emu_util import emu_lib
+from neuray_amd.network import fused_norm
+from neuray_amd.network import render_ops as ro
+
+BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture
+def device(request):
+    backend = request.param
+    if backend == 'emu':
+        ro._TEST_LIB = emu_lib()
+        ro._ENGINES.clear()
+        yield torch.device('cpu')
+        ro._TEST_LIB = None
+        ro._ENGINES.clear()
+    else:
+        yield torch.device('cuda', 0)
+
+
+def composed(bn, y, act, pad, res):
+    z = bn(y)
+    if res is not None:
+        z = z + res
+    z = F.relu(z) if act == 'relu' else (F.elu(z) if act == 'elu' else z)
+    return F.pad(z, (pad, pad, pad, pad), mode='reflect') if pad else z
+
+
+@pytest.mark.parametrize('device', BACKENDS, indirect=True)
+@pytest.mark.parametrize('act,pad,with_res,shape', [
+    ('relu', 1, False, (2, 5, 9, 11)), ('relu', 1, True, (3, 4, 8, 6)), (None, 0, False, (2, 3, 7, 5)), ('elu', 0, False, (1, 6, 10, 13)),
+    ('relu', 0, True, (2, 4, 6, 6)), ('elu', 1, True, (2, 2, 2, 3)), ('relu', 1, False, (1, 16, 40, 50)),
+])
+def test_fused_norm_act_equals_the_pytorch_composition(device, act, pad, with_res, shape):
+    g = torch.Generator().manual_seed(sum(shape) + pad)
+    n, c, h, w = shape
+    bn = nn.InstanceNorm2d(c, affine=True, track_running_stats=False)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    bn = bn.to(device)
+    y0 = (torch.randn(n, c, h, w, generator=g) * 2 + 3 * torch.randn(1, c, 1, 1, generator=g)).to(device)     # planes with a large mean
+    base = torch.randn(n, c, h + 2, w + 2, generator=g).to(device)
+    dz = torch.randn(n, c, h + 2 * pad, w + 2 * pad, generator=g).to(device)
+    outs = []
+    for fused in (True, False):
+        fused_norm.FUSED_NORM = fused
+        try:
+            y = y0.clone().requires_grad_(True)
+            b = base.clone().requires_grad_(True)
+            res = b[:, :, 1:-1, 1:-1] if with_res else None             # a strided view, as the interior of a padded buffer is
+            for p_ in bn.parameters():
+                p_.grad = None
+            out = fused_norm.norm_act(bn, y, act, pad, res) if fused else composed(bn, y, act, pad, res)
+            (out * dz).sum().backward()
+            outs.append((out.detach().cpu(), y.grad.cpu(), bn.weight.grad.cpu().clone(), bn.bias.grad.cpu().clone(),
+                         b.grad.cpu() if with_res else None))
+        finally:
+            fused_norm.FUSED_NORM = True
+    (o1, gy1, gw1, gb1, gr1), (o0, gy0, gw0, gb0, gr0) = outs
+    assert o1.shape == (n, c, h + 2 * pad, w + 2 * pad)
+    assert float((o1 - o0).abs().max()) <= 2e-5
+    scale = lambda t: max(1.0, float(t.abs().max()))                      # noqa: E731
+    assert float((gy1 - gy0).abs().max()) <= 2e-4 * scale(gy0)
+    assert float((gw1 - gw0).abs().max()) <= 2e-4 * scale(gw0) and float((gb1 - gb0).abs().max()) <= 2e-4 * scale(gb0)
+    if with_res:
+        assert float((gr1 - gr0).abs().max()) <= 1e-5 * scale(gr0)
+
+
+@pytest.mark.parametrize('device', BACKENDS, indirect=True)
+def test_encoders_with_and_without_the_fused_kernels(device):
+    """the whole image_encoder + vis_encoder, forward and parameter gradients, fused path vs the PyTorch composition"""
+    from neuray_amd.network import encoders
+    from test_encoders import fill_by_name
+    torch.manual_seed(0)
+    enc, vis = encoders.ImageEncoder().to(device), encoders.DefaultVisEncoder({}).to(device)
+    fill_by_name(enc), fill_by_name(vis)
+    imgs = torch.rand(2, 3, 48, 64, device=device)
+    ray0 = torch.randn(2, 32, 12, 16, device=device)
+    res = []
+    for fused in (True, False):
+        encoders.set_fused_norm(fused)
+        try:
+            for p_ in list(enc.parameters()) + list(vis.parameters()):
+                p_.grad = None
+            f = enc(imgs)
+            r = vis(ray0, f)
+            (f.square().mean() + r.square().mean()).backward()
+            res.append((f.detach().cpu(), r.detach().cpu(), [p_.grad.cpu().clone() for p_ in list(enc.parameters()) + list(vis.parameters())]))
+        finally:
+            encoders.set_fused_norm(True)
+    (f1, r1, g1), (f0, r0, g0) = res
+    assert f1.shape == (2, 32, 12, 16) and float((f1 - f0).abs().max()) <= 1e-4 * max(1.0, float(f0.abs().max()))
+    assert float((r1 - r0).abs().max()) <= 1e-4 * max(1.0, float(r0.abs().max()))
+    # (a convolution bias in front of an InstanceNorm has a mathematically zero gradient - both sides hold rounding noise there -
+    # so every tensor is measured against the larger of its own scale and 1e-3 of the largest gradient of the model)
+    top = max(float(b.abs().max()) for b in g0)
+    worst = max(float((a - b).abs().max()) / max(1e-3 * top, float(b.abs().max())) for a, b in zip(g1, g0))
+    assert worst <= 2e-3, worst

@@ -288,9 +288,11 @@ def training_step_timing(device, steps=3):
         torch.cuda.synchronize(device)
         return 1e3 * (time.perf_counter() - t0) / n
 
-    a, b = timeit(ours, 40, 10 * steps), timeit(eager, 1, steps)
+    # the same policy for both legs: 10 warm-up steps, then the mean over 10 * steps timed ones
+    a, b = timeit(ours, 10, 10 * steps), timeit(eager, 10, 10 * steps)
     out = {'what': 'forward + backward, 512 rays x 8 views x 64+64 samples, HIP kernels vs autograd of the eager-PyTorch port',
-           'hip_ms_per_step': a, 'eager_torch_ms_per_step': b, 'speedup_vs_eager': b / a}
+           'hip_ms_per_step': a, 'eager_torch_ms_per_step': b, 'speedup_vs_eager': b / a,
+           'timing_policy': '10 warm-up steps, mean of %d timed steps, both legs' % (10 * steps)}
     # the dominant kernel of the step by HIP events on its launch stream: the point backward, one launch per pass
     eng = r.engine(device)
     eng.timing = []
@@ -306,6 +308,49 @@ def training_step_timing(device, steps=3):
                                  'tflops_by_3x_forward_convention': conv, 'frac_of_fp32_mfma_peak': conv / MFMA_F32_PEAK_TFLOPS,
                                  'note': 'a backward pass counted as 3 x the forward algorithmic FLOP of its 512 x 64 points (round-1 judge convention); '
                                          'the kernel reads the cross-view quantities the training forward saved and recomputes only per-view layers'}
+    return out
+
+
+def encoder_timing(device, n=9, hw=(800, 800), reps=5):
+    """Side measurement: image_encoder + vis_encoder on the fine-tuning step's 9 images of 800 x 800
+    (renderer.py:229-235), forward and forward + backward, with the fused InstanceNorm / activation / residual / reflection-pad
+    kernels (csrc/nr_kernels_norm.h) and with the PyTorch composition they replace (MIOpen batch-norm + element-wise + pad kernels).
+    The convolutions are MIOpen's fp32 kernels in both."""
+    from neuray_amd.network import encoders
+    torch.manual_seed(0)
+    img_enc, vis_enc = encoders.ImageEncoder().to(device), encoders.DefaultVisEncoder({}).to(device)
+    imgs = torch.rand(n, 3, hw[0], hw[1], device=device)
+    ray0 = torch.randn(n, 32, hw[0] // 4, hw[1] // 4, device=device, requires_grad=True)
+
+    def fwd():
+        f = img_enc(imgs)
+        return f, vis_enc(ray0, f)
+
+    def fwd_bwd():
+        f, r_ = fwd()
+        (f.square().mean() + r_.square().mean()).backward()
+        for p_ in list(img_enc.parameters()) + list(vis_enc.parameters()) + [ray0]:
+            p_.grad = None
+
+    def timeit(fn, grad):
+        with (torch.enable_grad() if grad else torch.no_grad()):
+            for _ in range(6):
+                fn()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(device)
+        return 1e3 * (time.perf_counter() - t0) / reps
+    out = {'what': 'image_encoder + vis_encoder, %d x 3 x %d x %d, fp32' % (n, hw[0], hw[1])}
+    try:
+        for tag, on in (('fused_norm', True), ('pytorch_norm', False)):
+            encoders.set_fused_norm(on)
+            out[tag] = {'forward_ms': timeit(fwd, False), 'forward_backward_ms': timeit(fwd_bwd, True)}
+    finally:
+        encoders.set_fused_norm(True)
+    out['speedup_forward'] = out['pytorch_norm']['forward_ms'] / out['fused_norm']['forward_ms']
+    out['speedup_forward_backward'] = out['pytorch_norm']['forward_backward_ms'] / out['fused_norm']['forward_backward_ms']
     return out
 
 
@@ -689,6 +734,7 @@ def main(argv=None):
                 'reference_cli_ray_batch_4096': side(extra_config_timing, device, args.fine_samples, 4096, tq, tr),
             }
             line['training_step'] = side(training_step_timing, device)
+            line['encoders'] = side(encoder_timing, device)
             line['init_net'] = side(init_net_timing, device)
             line['pipeline_pcie_inclusive'] = side(pipeline_timing, device, args.fine_samples)
             line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())

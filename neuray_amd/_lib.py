@@ -14,6 +14,7 @@ import torch  # noqa: F401  (first: the library must resolve libamdhip64 to the 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NEURAY_HIP_LIB', os.path.join(HERE, 'libneuray_hip.so'))   # env override: A/B debugging only
 BF16_LIB_PATH = os.path.join(HERE, 'libneuray_hip_bf16.so')     # the separately reported bf16-operand variant (inference only)
+BF16X3_LIB_PATH = os.path.join(HERE, 'libneuray_hip_bf16x3.so') # the split variant: hi + lo bf16 operands, 3 bf16 MFMAs per fp32 quad (inference only)
 
 PASS_TENSORS = 68
 POINT_REC = 20
@@ -160,7 +161,7 @@ def load(variant='fp32'):
     """The product library (HIP, gfx950), or with variant='bf16' the bf16-operand build.  Raises loudly if it has not
     been built."""
     if variant not in _LIBS:
-        path = {'fp32': LIB_PATH, 'bf16': BF16_LIB_PATH}[variant]
+        path = {'fp32': LIB_PATH, 'bf16': BF16_LIB_PATH, 'bf16x3': BF16X3_LIB_PATH}[variant]
         if not os.path.exists(path):
             raise NeurayLibError(
                 "neuray_amd: %s not found - build it with `python -m neuray_amd.build` (hipcc, gfx950). "
@@ -168,7 +169,7 @@ def load(variant='fp32'):
         lib = bind(path)
         if lib.neuray_is_device_build() != 1:
             raise NeurayLibError("neuray_amd: %s is not a device build" % path)
-        if lib.neuray_operand_precision() != {'fp32': 32, 'bf16': 16}[variant]:
+        if lib.neuray_operand_precision() != {'fp32': 32, 'bf16': 16, 'bf16x3': 48}[variant]:
             raise NeurayLibError("neuray_amd: %s is not the %s build" % (path, variant))
         _LIBS[variant] = lib
     return _LIBS[variant]

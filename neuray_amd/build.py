@@ -21,6 +21,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp
 
 
 OUT_BF16 = os.path.join(HERE, 'libneuray_hip_bf16.so')      # same sources with -DNR_BF16_QUADS (bf16 MFMA operands)
+OUT_BF16X3 = os.path.join(HERE, 'libneuray_hip_bf16x3.so')  # ... + -DNR_BF16_SPLIT (hi + lo bf16 operands, three bf16 MFMAs per fp32 quad)
 
 
 def needs_build(out=OUT):
@@ -29,7 +30,7 @@ def needs_build(out=OUT):
 
 def build(force=False, verbose=False):
     """-> path of the product library; also (re)builds the bf16-operand variant next to it"""
-    for out, extra in ((OUT, []), (OUT_BF16, ['-DNR_BF16_QUADS'])):
+    for out, extra in ((OUT, []), (OUT_BF16, ['-DNR_BF16_QUADS']), (OUT_BF16X3, ['-DNR_BF16_QUADS', '-DNR_BF16_SPLIT'])):
         if not force and not needs_build(out):
             continue
         cmd = [HIPCC] + FLAGS + extra + SOURCES + ['-o', out]

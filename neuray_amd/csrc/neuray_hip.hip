@@ -134,7 +134,9 @@ int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_hos
 }
 
 int neuray_operand_precision(void) {
-#ifdef NR_BF16_QUADS
+#if defined(NR_BF16_SPLIT)
+    return 48;         // hi + lo bf16 operands, three bf16 MFMAs per fp32 quad (libneuray_hip_bf16x3.so)
+#elif defined(NR_BF16_QUADS)
     return 16;
 #else
     return 32;

@@ -220,7 +220,7 @@ __device__ __forceinline__ float wld1(LdsW w, int voff, int soff) {
 }
 // one quad fragment (nr_layout.h): 16 bytes per lane; in the bf16-operand build only the first 8 carry data
 template <class WS> __device__ __forceinline__ float4 wldq(WS W, int voff, int soff) {
-#ifdef NR_BF16_QUADS
+#if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT)
     const float2 h = wld2(W, voff, soff);
     return make_float4(h.x, h.y, 0.0f, 0.0f);
 #else
@@ -335,7 +335,12 @@ __device__ __forceinline__ void layer_bias(WS W, int lane, v4f (&acc)[NT][kShape
 // One quad of A fragments feeds 4 K-steps x NT slots of MFMAs.
 template <int NT, int KQX>
 __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (&xq)[NT][KQX], v4f (&acc)[NT]) {
-#ifdef NR_BF16_QUADS      // the bf16-operand library: (a.x, a.y) hold the quad's four weights as bf16, one MFMA per slot
+#ifdef NR_BF16_SPLIT       // the split library: (a.x, a.y) = hi, (a.z, a.w) = lo bf16 halves of the quad's four weights, three MFMAs per slot
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        acc[t] = nr_mfma16_bf16q3(a.x, a.y, a.z, a.w, xq[t][4 * kq + 0], xq[t][4 * kq + 1], xq[t][4 * kq + 2], xq[t][4 * kq + 3], acc[t]);
+    return;
+#elif defined(NR_BF16_QUADS)      // the bf16-operand library: (a.x, a.y) hold the quad's four weights as bf16, one MFMA per slot
     NR_PRAGMA_UNROLL
     for (int t = 0; t < NT; ++t)
         acc[t] = nr_mfma16_bf16q(a.x, a.y, xq[t][4 * kq + 0], xq[t][4 * kq + 1], xq[t][4 * kq + 2], xq[t][4 * kq + 3], acc[t]);

@@ -35,6 +35,14 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
                     float* slot = q + ((mo * s.kq + kq) * 64 + lane) * 4;
 #ifdef NR_BF16_QUADS      // the four weights of the quad as bf16 in the slot's first two dwords (the rest stays zero)
                     reinterpret_cast<unsigned short*>(slot)[j] = to_bf16(v);
+#ifdef NR_BF16_SPLIT      // ... and what bf16 dropped, again as bf16, in the last two dwords: v = hi + lo to 2^-16
+                    {
+                        const unsigned hb = (unsigned)reinterpret_cast<unsigned short*>(slot)[j] << 16;
+                        float hf;
+                        std::memcpy(&hf, &hb, 4);
+                        reinterpret_cast<unsigned short*>(slot)[4 + j] = to_bf16(v - hf);
+                    }
+#endif
 #else
                     slot[j] = v;
 #endif

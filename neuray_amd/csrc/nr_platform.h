@@ -43,6 +43,29 @@ __device__ __forceinline__ v4f nr_mfma16_bf16q(float a01, float a23, float b0, f
     const uint2 bp = make_uint2(nr_pk_bf16(b0, b1), nr_pk_bf16(b2, b3));
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(nr_v4s, ap), __builtin_bit_cast(nr_v4s, bp), c, 0, 0, 0);
 }
+#ifdef NR_BF16_SPLIT
+// Error-compensated split (the third library, libneuray_hip_bf16x3.so): every operand is carried as hi + lo, both bf16
+// (x = hi + lo to 2^-16 relative), and a quad of four fp32 K-steps becomes THREE bf16 MFMAs  hi*hi + hi*lo + lo*hi  (the
+// dropped lo*lo term is 2^-16 of the product as well), fp32 accumulation.  ~3e-5 per product instead of bf16's 4e-3, at 3/7 of the
+// fp32 MFMA issue time.  The weights arrive split from the packer (hi pairs in the slot's first two dwords, lo pairs in the last
+// two); the activations are split here: hi = cvt_pk_bf16(x), lo = cvt_pk_bf16(x - float(hi)).
+__device__ __forceinline__ void nr_split_bf16(float b0, float b1, unsigned& hi, unsigned& lo) {
+    hi = nr_pk_bf16(b0, b1);
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = nr_pk_bf16(b0 - h0, b1 - h1);
+}
+__device__ __forceinline__ v4f nr_mfma16_bf16q3(float a01h, float a23h, float a01l, float a23l, float b0, float b1, float b2, float b3, v4f c) {
+    const uint2 ah = make_uint2(__builtin_bit_cast(unsigned, a01h), __builtin_bit_cast(unsigned, a23h));
+    const uint2 al = make_uint2(__builtin_bit_cast(unsigned, a01l), __builtin_bit_cast(unsigned, a23l));
+    uint2 bh, bl;
+    nr_split_bf16(b0, b1, bh.x, bl.x);
+    nr_split_bf16(b2, b3, bh.y, bl.y);
+    // (small terms first: the two cross terms, then the leading one, on the incoming accumulator)
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(nr_v4s, al), __builtin_bit_cast(nr_v4s, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(nr_v4s, ah), __builtin_bit_cast(nr_v4s, bl), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(nr_v4s, ah), __builtin_bit_cast(nr_v4s, bh), c, 0, 0, 0);
+}
+#endif
 #endif
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)

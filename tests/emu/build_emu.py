@@ -15,15 +15,17 @@ DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bw
 
 
 def build(force=False, variant='fp32'):
-    """variant 'bf16': the same sources with -DNR_BF16_QUADS (the bf16-operand library on the emulator)"""
+    """variant 'bf16': the same sources with -DNR_BF16_QUADS (the bf16-operand library on the emulator); 'bf16x3': + -DNR_BF16_SPLIT"""
     os.makedirs(OUT_DIR, exist_ok=True)
-    out = OUT if variant == 'fp32' else OUT.replace('.so', '_bf16.so')
+    out = OUT if variant == 'fp32' else OUT.replace('.so', '_%s.so' % variant)
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
         return out
     cmd = ['g++', '-std=c++17', '-O2', '-g', '-rdynamic', '-fPIC', '-shared', '-DNEURAY_EMU', '-ffp-contract=off',
            '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', out]
-    if variant == 'bf16':
+    if variant in ('bf16', 'bf16x3'):
         cmd.append('-DNR_BF16_QUADS')
+    if variant == 'bf16x3':
+        cmd.append('-DNR_BF16_SPLIT')
     for s in SOURCES:
         cmd += ['-x', 'c++', s]
     subprocess.check_call(cmd)

@@ -208,6 +208,26 @@ static inline v4f nr_mfma16_bf16q(float a01, float a23, float b0, float b1, floa
     return d;
 }
 
+// split library (NR_BF16_SPLIT): hi * hi + hi * lo + lo * hi with bf16 halves, fp32 accumulation (cross terms first)
+static inline v4f nr_mfma16_bf16q3(float a01h, float a23h, float a01l, float a23l, float b0, float b1, float b2, float b3, v4f c) {
+    float ah[4], al[4];
+    emu_bf16_unpack(a01h, ah[0], ah[1]); emu_bf16_unpack(a23h, ah[2], ah[3]);
+    emu_bf16_unpack(a01l, al[0], al[1]); emu_bf16_unpack(a23l, al[2], al[3]);
+    const float b[4] = {b0, b1, b2, b3};
+    float bh[4], bl[4];
+    for (int j = 0; j < 4; ++j) { bh[j] = emu_bf16_round(b[j]); bl[j] = emu_bf16_round(b[j] - bh[j]); }
+    v4f d = c;
+    const float* As[3] = {al, ah, ah};
+    const float* Bs[3] = {bh, bl, bh};
+    for (int term = 0; term < 3; ++term)
+        for (int j = 0; j < 4; ++j) {
+            v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+            v4f t = nr_mfma16(As[term][j], Bs[term][j], z);
+            for (int r = 0; r < 4; ++r) d[r] += t[r];
+        }
+    return d;
+}
+
 // ---- exact-rounding helpers (same names as the HIP device intrinsics) --------------------------
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }

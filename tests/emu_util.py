@@ -42,3 +42,17 @@ def emu_engine(**kw):
 
 def to_torch(d, device='cpu'):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in d.items()}
+
+
+_EMU_BF16X3 = None
+
+
+def emu_lib_bf16x3():
+    """the split variant (hi + lo bf16 operands, three bf16 MFMAs per fp32 quad) on the emulator"""
+    global _EMU_BF16X3
+    if _EMU_BF16X3 is None:
+        import build_emu
+        from neuray_amd import _lib
+        _EMU_BF16X3 = _lib.bind(build_emu.build(variant='bf16x3'))
+        assert _EMU_BF16X3.neuray_is_device_build() == 0 and _EMU_BF16X3.neuray_operand_precision() == 48
+    return _EMU_BF16X3

@@ -45,7 +45,14 @@ class PassRun:
 
 
 class RenderPassFn(torch.autograd.Function):
-    """(ray_feats NCHW, img_feats NCHW, *params) -> pixel [rn,3], hit_prob [rn,dn], ray_mask [rn], render_depth [rn]"""
+    """(ray_feats NCHW, img_feats NCHW, *params) -> pixel [rn,3], hit_prob [rn,dn], ray_mask [rn], render_depth [rn]
+
+    Memory: the training forward keeps, until the backward has run, the per-point records (80 B per sample point), the ray
+    kernel's softmax statistics (96 B per sample point) and - for <= 8 views - the point kernel's cross-view quantities
+    (`saved`, neuray_points_saved_floats: 29 KB per 16-point tile = 1.9 KB per sample point).  At the training shapes (512 rays
+    x 64 + 64 samples) that is 120 MB per step; a grad-enabled pass over an inference-sized batch (32 768 rays x 64 samples)
+    would hold 3.9 GB, so evaluation belongs under torch.no_grad(), as the reference's own callers do it
+    (renderer.py:244-246, :513)."""
 
     @staticmethod
     def forward(ctx, run, ray_feats, img_feats, *params):

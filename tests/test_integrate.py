@@ -219,6 +219,8 @@ def test_reference_ft_renderer_train_and_validate_steps(patched):
     scene_case sets them (the constructor reads a dataset from disk).  The stub legs run the stand-in ft class of
     tests/ref_stub (same surface, no `touched_views`), on the MI355X with the module's real `to_cuda`."""
     mod, dev = patched
+    if dev == 'cpu' and not hasattr(mod, 'compute_nearest_camera_indices') and ref_harness.reference_available():
+        pytest.skip('the stand-in on the CPU emulator repeats the reference leg (40 s); it runs where the reference tree is absent and on the GPU')
     gold = np.load(os.path.join(GOLDEN_DIR, 'case_scene.npz'))
     ft, n = build_ft(mod, gold)
     to_cuda = mod.to_cuda

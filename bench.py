@@ -137,14 +137,14 @@ def cpu_baseline(cfg, weights, que, ref, budget_s=20.0, rays_per_batch=4096, max
         with torch.no_grad():
             return tep.render_impl(w, ocfg, q, tr)
 
-    def timed(threads, budget):
+    def timed(threads, budget, min_batches=3):
         torch.set_num_threads(threads)
         run(int(starts[0]))
         done, t0 = 0, time.perf_counter()
         for st in starts[1:]:
             run(int(st))
             done += 1
-            if time.perf_counter() - t0 > budget:
+            if done >= min_batches and time.perf_counter() - t0 > budget:     # (at least 3 timed batches)
                 break
         dt = time.perf_counter() - t0
         return done * rays_per_batch / dt, done, dt

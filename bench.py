@@ -315,6 +315,40 @@ def training_step_timing(device, steps=3):
     return out
 
 
+def ft_step_timing(device, steps=10):
+    """Side measurement: one whole fine-tuning step as run_training.py's ft configs do it (BASELINE.json configs[3]) -
+    NeuralRayFtRenderer.train_step (a random query view of a 24-view 800 x 800 scene, 8 neighbours, 512 rays, 64 + 64 samples:
+    encoders on 9 images + per-ray forward) + loss.backward() (HIP backward kernels + encoder backward) + Adam on every parameter
+    incl. the touched per-view ray_feats maps."""
+    from neuray_amd import pipeline
+    from neuray_amd.network.renderer import NeuralRayFtRenderer
+    db = synthetic.MemoryDatabase(24, 800, 800, seed=0)
+    scene = {'ref_imgs_info': pipeline.build_imgs_info(db, db.get_img_ids(), -1, True, False, True, True)}
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'use_self_hit_prob': True, 'use_validation': False,
+           'train_ray_num': 512}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ft = NeuralRayFtRenderer(cfg, scene=scene).train().to(device)
+    opt = torch.optim.Adam(ft.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = ft.train_step()
+        loss = ((out['pixel_colors_nr'] - out['pixel_colors_gt']) ** 2).mean() + ((out['pixel_colors_nr_fine'] - out['pixel_colors_gt']) ** 2).mean() + \
+            out['hit_prob_self'].mean() + out['hit_prob_self_fine'].mean()
+        loss.backward()
+        opt.step()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    return {'what': 'NeuralRayFtRenderer.train_step + backward + Adam: 512 rays, 8 of 24 views of 800 x 800, 64+64 samples, encoders trained',
+            'ms_per_step': 1e3 * (time.perf_counter() - t0) / steps}
+
+
 def encoder_timing(device, n=9, hw=(800, 800), reps=5):
     """Side measurement: image_encoder + vis_encoder on the fine-tuning step's 9 images of 800 x 800
     (renderer.py:229-235), forward and forward + backward, with the fused InstanceNorm / activation / residual / reflection-pad
@@ -758,6 +792,7 @@ def main(argv=None):
             }
             line['training_step'] = side(training_step_timing, device)
             line['encoders'] = side(encoder_timing, device)
+            line['ft_step'] = side(ft_step_timing, device)
             line['init_net'] = side(init_net_timing, device)
             line['pipeline_pcie_inclusive'] = side(pipeline_timing, device, args.fine_samples)
             line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())

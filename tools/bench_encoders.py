@@ -22,10 +22,13 @@ def main():
     ap.add_argument('--fused', type=int, default=-1, help='1 / 0: force the fused InstanceNorm kernels on / off (default: the module default)')
     ap.add_argument('--fwd-only', action='store_true', help='time only the forward (kernel traces of the forward alone)')
     ap.add_argument('--cprofile', action='store_true', help='host-side profile of 20 forwards')
+    ap.add_argument('--benchmark', action='store_true', help='torch.backends.cudnn.benchmark = True (MIOpen find mode instead of the immediate heuristics)')
     ap.add_argument('--nchw', action='store_true', help='run the stacks in NCHW (encoders.CHANNELS_LAST = False)')
     a = ap.parse_args()
     if a.nchw:
         encoders.CHANNELS_LAST = False
+    if a.benchmark:
+        torch.backends.cudnn.benchmark = True
     dev = torch.device('cuda', 0)
     if a.fused >= 0 and hasattr(encoders, 'set_fused_norm'):
         encoders.set_fused_norm(bool(a.fused))
@@ -67,7 +70,7 @@ def main():
                 fwd()
             pr.disable(); torch.cuda.synchronize()
         pstats.Stats(pr).sort_stats('tottime').print_stats(18)
-    out = {'n': a.n, 'hw': a.hw, 'channels_last': encoders.CHANNELS_LAST, 'fused_norm': encoders.fused_norm.FUSED_NORM,
+    out = {'n': a.n, 'hw': a.hw, 'miopen_find': bool(a.benchmark), 'channels_last': encoders.CHANNELS_LAST, 'fused_norm': encoders.fused_norm.FUSED_NORM,
            'forward_ms': time(fwd, False), 'forward_backward_ms': None if a.fwd_only else time(fwd_bwd, True)}
     print(json.dumps(out))
 

@@ -205,6 +205,11 @@ typedef struct NeurayPointsBwdArgs {
 size_t neuray_packed_t_floats(void);
 /* index[neuray_packed_t_floats()] (host, int32): packed_t[i] = index[i] >= 0 ? flat[index[i]] : 0 */
 int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
+/* float ranges [begin, end) of the quad fragments inside the packed pass buffer (transposed = 0) or the transposed pack (= 1), as
+ * (begin, end) int pairs; returns MINUS the number of pairs (a positive value is an error).  The split library
+ * (neuray_operand_precision() == 48) stores a quad's four weights as (hi, hi | lo, lo) bf16 pairs in the same 16 bytes: a device-side
+ * packer gathers fp32 values with the index maps above and converts exactly these ranges. */
+int neuray_packed_quad_ranges(int transposed, int* ranges_host, int max_pairs);
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
 /* The resident kernel exists in two decompositions of the same computation: 2 (default) = workgroups of 8 waves with one reference
  * view each, two waves per SIMD (csrc/nr_kernels_bwd2.h); 3 = 4 waves with 2 views per wave at one wave per SIMD, accumulators in

@@ -123,6 +123,7 @@ SYMBOLS = {
     'neuray_packed_t_floats': (C.c_size_t, []),
     'neuray_pack_pass_t_index_map': (C.c_int, [C.c_int, C.c_void_p]),
     'neuray_select_points_backward': (C.c_int, [C.c_int]),
+    'neuray_packed_quad_ranges': (C.c_int, [C.c_int, C.c_void_p, C.c_int]),
     'neuray_render_points_backward': (C.c_int, [C.POINTER(NeurayPointsBwdArgs), C.c_void_p]),
     'neuray_self_hit_backward_workspace_floats': (C.c_size_t, [C.c_int]),
     'neuray_self_hit_prob_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,

@@ -5,7 +5,11 @@
 #include "nr_kernels_bwd.h"
 #include "nr_kernels_dr.h"
 #include "nr_kernels_norm.h"
-#ifndef NR_BF16_QUADS
+// the plain bf16-operand build is inference only; the fp32 build and the split build (hi + lo bf16 operands: fp32-grade products)
+// carry the training path
+#if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT)
+#define NR_INFERENCE_ONLY 1
+#else
 #include "nr_kernels_bwd3.h"
 #endif
 #include "nr_pack.h"
@@ -88,7 +92,7 @@ int launch_points(const nr::PointParams& p, void* stream) {
 // wave, one for a single view)
 template <bool HAS_VIS>
 int launch_points_save(const nr::PointParams& p, void* stream) {
-#ifdef NR_BF16_QUADS
+#ifdef NR_INFERENCE_ONLY
     return fail("neuray_render_points: saved_dev is a training feature; the bf16-operand variant is inference only");
 #else
     if (p.rfn > 8) return fail("neuray_render_points: saved_dev needs rfn <= 8 (rfn=%d)", p.rfn);
@@ -145,11 +149,27 @@ int neuray_operand_precision(void) {
 
 int neuray_pack_pass_index_map(int has_vis_head, int* index_host, float* scale_host) {
     if (!index_host || !scale_host) return fail("neuray_pack_pass_index_map: null argument");
-#ifdef NR_BF16_QUADS
+#ifdef NR_INFERENCE_ONLY
     return fail("neuray_pack_pass_index_map: the bf16-operand build packs on the host only (inference variant, no training path)");
 #endif
     if (nr::pack_pass_index_map(has_vis_head != 0, index_host, scale_host)) return fail("neuray_pack_pass_index_map: internal error");
     return 0;
+}
+
+// float ranges [begin, end) of the quad fragments inside the packed pass buffer (transposed = 0) or the transposed pack (= 1): what a
+// device-side packer of the split library converts from four fp32 weights to (hi pair, hi pair, lo pair, lo pair) after the gather
+int neuray_packed_quad_ranges(int transposed, int* ranges_host, int max_pairs) {
+    if (!ranges_host || max_pairs < 1) return fail("neuray_packed_quad_ranges: null argument");
+    int n = 0;
+    const int first = transposed ? (int)nr::L_FWD_COUNT : 0, last = transposed ? (int)nr::L_COUNT : (int)nr::L_FWD_COUNT;
+    for (int l = first; l < last; ++l) {
+        if (nr::quads_floats(l) == 0) continue;
+        if (n >= max_pairs) return fail("neuray_packed_quad_ranges: more than %d ranges", max_pairs);
+        ranges_host[2 * n] = nr::quads_offset(l);
+        ranges_host[2 * n + 1] = nr::quads_offset(l) + nr::quads_floats(l);
+        ++n;
+    }
+    return -n;          // (negative count on success: 0 is reserved for "no error" elsewhere, positive for failure)
 }
 
 int neuray_setup_views(const float* poses, const float* Ks, const float* depth_range, int n, float* out, void* stream) {
@@ -423,7 +443,7 @@ size_t neuray_packed_t_floats(void) { return (size_t)nr::kPackedTFloats; }
 size_t neuray_points_saved_floats(int npts) { return npts < 1 ? 0 : (size_t)((npts + 15) / 16) * nr::kSavedTileFloats; }
 int neuray_pack_pass_t_index_map(int has_vis_head, int* index) {
     if (!index) return fail("neuray_pack_pass_t_index_map: null argument");
-#ifdef NR_BF16_QUADS
+#ifdef NR_INFERENCE_ONLY
     return fail("neuray_pack_pass_t_index_map: the bf16-operand library is inference only");
 #else
     const int rc = nr::pack_pass_t_index_map(has_vis_head != 0, index);
@@ -463,7 +483,7 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
         return fail("neuray_render_points_backward: null argument");
     if (a->rfn < 1 || a->rfn > NEURAY_MAX_VIEWS) return fail("neuray_render_points_backward: rfn=%d outside [1,%d]", a->rfn, NEURAY_MAX_VIEWS);
     if (a->rn < 1 || a->dn < 3 || a->dn > NEURAY_MAX_SAMPLES) return fail("neuray_render_points_backward: rn=%d dn=%d", a->rn, a->dn);
-#ifdef NR_BF16_QUADS
+#ifdef NR_INFERENCE_ONLY
     if (a->packed_weights_dev || a->packed_t_weights_dev) return fail("neuray_render_points_backward: the bf16-operand library is inference only");
 #else
     if (a->packed_weights_dev && a->packed_t_weights_dev && a->rfn <= nr::kB2Waves) {      // register / LDS resident kernel
@@ -547,7 +567,7 @@ int neuray_self_hit_prob_backward(const float* qc, const float* depth, const flo
 int neuray_self_hit_prob_backward_resident(const float* qc, const float* depth, const float* feats, const float* packed, const float* packed_t,
                                            int has_vis_head, int use_vis, float var_bias, const float* d_hit, int rn, int dn,
                                            float* d_feats, float* d_flat, void* stream) {
-#ifdef NR_BF16_QUADS
+#ifdef NR_INFERENCE_ONLY
     return fail("neuray_self_hit_prob_backward_resident: the bf16-operand variant is inference only");
 #else
     if (!qc || !depth || !feats || !packed || !packed_t || !d_hit || !d_feats || !d_flat)

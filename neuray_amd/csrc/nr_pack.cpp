@@ -6,6 +6,7 @@
 namespace nr {
 
 static bool g_pack_unscaled = false;     // pack_pass_index_map: pack without the scaled-ELU factors
+static bool g_pack_fp32_quads = false;   // the index maps are built by packing POSITIONS: fp32 quad slots in every build
 
 #ifdef NR_BF16_QUADS
 static unsigned short to_bf16(float f) {          // round to nearest even, as v_cvt_pk_bf16_f32
@@ -34,6 +35,7 @@ void pack_layer(float* dst, int layer, const float* W, int ldw, const float* bia
                     const float v = (o >= 0 && i >= 0) ? (float)(W[o * ldw + i] * sw) : 0.0f;
                     float* slot = q + ((mo * s.kq + kq) * 64 + lane) * 4;
 #ifdef NR_BF16_QUADS      // the four weights of the quad as bf16 in the slot's first two dwords (the rest stays zero)
+                    if (g_pack_fp32_quads) { slot[j] = v; continue; }
                     reinterpret_cast<unsigned short*>(slot)[j] = to_bf16(v);
 #ifdef NR_BF16_SPLIT      // ... and what bf16 dropped, again as bf16, in the last two dwords: v = hi + lo to 2^-16
                     {
@@ -349,7 +351,9 @@ int pack_pass_t_index_map(bool has_vis, int* index) {
         const bool vis_slot = t >= T_VIS0_W && t <= T_VIS4_B;
         tp[t] = (vis_slot && !has_vis) ? nullptr : pos.data() + tensor_offset(t);
     }
+    g_pack_fp32_quads = true;
     const int rc = pack_pass_t_weights(tp, tmp.data());
+    g_pack_fp32_quads = false;
     if (rc) return rc;
     for (int i = 0; i < kPackedTFloats; ++i) index[i] = (int)tmp[i] - 1;
     return 0;
@@ -369,11 +373,13 @@ int pack_pass_index_map(bool has_vis, int* index, float* scale) {
         to[t] = (vis_slot && !has_vis) ? nullptr : ones.data() + tensor_offset(t);
     }
     g_pack_unscaled = true;
+    g_pack_fp32_quads = true;
     int rc = pack_pass_weights(tp, tmp.data());
     g_pack_unscaled = false;
-    if (rc) return rc;
+    if (rc) { g_pack_fp32_quads = false; return rc; }
     for (int i = 0; i < kPackedPassFloats; ++i) index[i] = (int)tmp[i] - 1;
     rc = pack_pass_weights(to, tmp.data());
+    g_pack_fp32_quads = false;
     if (rc) return rc;
     for (int i = 0; i < kPackedPassFloats; ++i) scale[i] = index[i] >= 0 ? tmp[i] : 0.0f;
     return 0;

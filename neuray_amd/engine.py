@@ -360,7 +360,30 @@ class RenderEngine:
             self._check(self.lib.neuray_pack_pass_index_map(int(has_vis), C.c_void_p(idx.data_ptr()), C.c_void_p(scale.data_ptr())))
             cache[has_vis] = (idx.clamp(min=0).long().to(self.device), scale.to(self.device))
         idx, scale = cache[has_vis]
-        return PackedPass(flat[idx] * scale, has_vis)
+        return PackedPass(self._split_quads(flat[idx] * scale, 0), has_vis)
+
+    def _split_quads(self, packed, transposed):
+        """The split library (variant 'bf16x3') keeps a quad's four weights as (hi, hi | lo, lo) bf16 pairs in the slot's 16 bytes
+        (nr_pack.cpp): after the fp32 gather the quad ranges are converted on the device - hi = bf16(w), lo = bf16(w - hi).  Other
+        variants: unchanged."""
+        if self.variant != 'bf16x3':
+            return packed
+        cache = self.__dict__.setdefault('_quad_ranges', {})
+        if transposed not in cache:
+            buf = np.zeros(2 * 128, np.int32)
+            n = -int(self.lib.neuray_packed_quad_ranges(int(transposed), C.c_void_p(buf.ctypes.data), 128))
+            if n <= 0:
+                raise RuntimeError("neuray_packed_quad_ranges failed: " + self.lib.neuray_last_error().decode())
+            mask = torch.zeros(packed.numel() // 4, dtype=torch.bool)
+            for b, e in buf[:2 * n].reshape(n, 2):
+                mask[b // 4:e // 4] = True
+            cache[transposed] = mask.to(self.device)
+        mask = cache[transposed]
+        q = packed.view(-1, 4)
+        hi = q.to(torch.bfloat16)
+        lo = (q - hi.float()).to(torch.bfloat16)
+        both = torch.cat([hi, lo], 1).view(torch.float32)                 # [slots, 8] bf16 = 16 bytes -> [slots, 4] fp32 bit patterns
+        return torch.where(mask[:, None], both, q).reshape(-1)
 
     def flat_pass(self, state_dict, dist_prefix, agg_prefix):
         """Flat natural-layout weights of a pass (include/neuray_hip.h, backward kernels) -> (device tensor, has_vis)."""
@@ -404,7 +427,7 @@ class RenderEngine:
             self._check(self.lib.neuray_pack_pass_t_index_map(int(has_vis), C.c_void_p(idx.data_ptr())))
             cache[has_vis] = ((idx >= 0).to(self.device), idx.clamp(min=0).long().to(self.device))
         ok, idx = cache[has_vis]
-        return flat[idx] * ok
+        return self._split_quads(flat[idx] * ok, 1)
 
     def zeroed(self, *shapes):
         """Zero-initialised fp32 device tensors of the given shapes carved out of ONE buffer (one fill kernel instead of one per
@@ -496,7 +519,7 @@ class RenderEngine:
         rn, dn = depth.shape
         d_feats = self.empty(rn, 32)
         d_flat = torch.zeros_like(flat) if d_flat is None else d_flat
-        if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant == 'fp32':
+        if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant in ('fp32', 'bf16x3'):
             pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
             pt = self.pack_pass_t_device(flat, bool(has_vis_head))
             self._check(self.lib.neuray_self_hit_prob_backward_resident(

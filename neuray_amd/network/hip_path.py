@@ -83,10 +83,10 @@ class HipRenderPath:
                       dist.cfg['bias_val'], cfg['ray_mask_view_num'], cfg['ray_mask_point_num'], cfg['render_depth'])
         diff = [p for _, p in run.named_params()] + [ref_imgs_info['ray_feats'], ref_imgs_info['img_feats']]
         if torch.is_grad_enabled() and any(t.requires_grad for t in diff):
-            if eng.variant != 'fp32':
+            if eng.variant not in ('fp32', 'bf16x3'):
                 raise NotImplementedError("neuray_amd: cfg['hip_variant'] = %r is inference only (the training forward's saved "
-                                          "quantities and the backward kernels are fp32); render under torch.no_grad() or "
-                                          "use the fp32 library" % eng.variant)
+                                          "quantities and the backward kernels exist in the fp32 and the split 'bf16x3' libraries); "
+                                          "render under torch.no_grad() or use one of those" % eng.variant)
             if que_depth.shape[-1] > eng.max_backward_samples:
                 raise NotImplementedError("neuray_amd: the backward kernels take at most %d samples per ray and pass"
                                           % eng.max_backward_samples)

@@ -82,3 +82,41 @@ def test_split_packing_is_hi_plus_lo():
     assert np.abs(hi + lo - q32).max() <= 2.0 ** -15 * np.abs(q32).max() and np.abs(lo).max() <= 2.0 ** -8 * np.abs(q32).max()
     assert np.abs(hi + lo - q32).max() < 0.02 * np.abs(hi - q32).max()      # two orders closer than bf16 alone
     del _lib
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_split_variant_trains_gradients_match_the_references_autograd(backend):
+    """BASELINE.json config 5 names bf16 training: the split library carries the whole training path (training forward with its saved
+    quantities, ray / point / self-hit backward kernels on device-packed hi + lo weights, fp32 weight-gradient accumulation, fp32
+    master weights).  Gate: the fp32 path's own - 5e-3 of each tensor's largest gradient entry against the REFERENCE's autograd
+    (tests/golden/case_g_grads.npz)."""
+    import os
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, 'case_g_grads.npz'))
+    cfg = __import__('ast').literal_eval(str(z['cfg_json']))
+    r, dev = split_renderer(cfg, backend)
+    r.train()
+    assert r.engine(dev).variant == 'bf16x3'
+    que = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith('que.') and k != 'que.Ks_inv'}
+    ref = {k[4:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith('ref.')}
+    for t_ in (ref['ray_feats'], ref['img_feats'], que['ray_feats']):
+        t_.requires_grad_(True)
+    torch.manual_seed(4321)
+    out = r.render_impl(que, ref, True)
+    keys = ('pixel_colors_nr', 'pixel_colors_nr_fine', 'hit_prob_self', 'hit_prob_self_fine')
+    for k in ('pixel_colors_nr', 'hit_prob_self'):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), z['out.' + k], atol=2e-4)
+    loss = sum((torch.from_numpy(z['lw.' + k]).to(dev) * out[k]).sum() for k in keys)
+    assert abs(float(loss.detach()) - float(z['loss'])) <= 5e-3
+    loss.backward()
+    worst = 0.0
+    for k, p_ in r.named_parameters():
+        want = z['grad.' + k]
+        g = p_.grad.cpu().numpy() if p_.grad is not None else np.zeros_like(want)
+        scale = max(1e-3, float(np.abs(want).max()))
+        err = float(np.abs(g - want).max()) / scale
+        worst = max(worst, err)
+        assert err <= 5e-3, (k, err)
+    for t_, k in ((ref['ray_feats'], 'grad.ref.ray_feats'), (ref['img_feats'], 'grad.ref.img_feats'), (que['ray_feats'], 'grad.que.ray_feats')):
+        assert np.abs(t_.grad.cpu().numpy() - z[k]).max() <= 5e-3 * np.abs(z[k]).max(), k
+    print('split variant [%s]: worst relative parameter-gradient error vs the reference autograd %.2e' % (backend, worst))

@@ -446,6 +446,8 @@ class RenderEngine:
         never reused, a new chunk is made when the current one is used up) - the fused norm kernels need 2 floats per plane of
         zeroed scratch on every call, 60 calls per encoder pass: one 4 MB fill per ~8 passes instead of 60 tiny fills"""
         n = (int(n) + 63) // 64 * 64
+        if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return torch.zeros(n, dtype=torch.float32, device=self.device)     # a replayed graph must zero its scratch itself, every replay
         st = self.__dict__.get('_zero_pool')
         if st is None or st[1] + n > st[0].numel():
             st = [torch.zeros(max(1 << 20, n), dtype=torch.float32, device=self.device), 0]

@@ -59,6 +59,13 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         self._engine_test_lib = None     # CPU test-suite hook (emulator build of the kernels)
         self._packed = {}
 
+    def encode_views(self, imgs, ray_feats):
+        """renderer.py:229-235: image_encoder, then vis_encoder on its output -> (img_feats, refined ray_feats).
+        (Capturing the two stacks' forward + backward as HIP graphs - torch.cuda.make_graphed_callables - was measured and is not
+        done: the replayed step is slower than launching the ~900 kernels one by one)"""
+        feats = self.image_encoder(imgs)
+        return feats, self.vis_encoder(ray_feats, feats)
+
     def render(self, que_imgs_info, ref_imgs_info, is_train):
         """network/renderer.py:228-254.  ref_imgs_info either carries 'img_feats' and the encoded 'ray_feats' already, or
         (cfg['build_encoders']) 'imgs' and the initial 'ray_feats', which go through image_encoder / vis_encoder first."""
@@ -67,11 +74,19 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
             if not self.cfg['build_encoders']:
                 raise NotImplementedError("neuray_amd: render() needs ref_imgs_info['img_feats'] (and the encoded 'ray_feats'), "
                                           "or a renderer built with cfg['build_encoders'] = True")
-            ref_img_feats = self.image_encoder(ref_imgs_info['imgs'])
-            ref_imgs_info['img_feats'] = ref_img_feats
-            ref_imgs_info['ray_feats'] = self.vis_encoder(ref_imgs_info['ray_feats'], ref_img_feats)
-            if is_train and self.cfg['use_self_hit_prob']:
-                que_imgs_info['ray_feats'] = self.vis_encoder(que_imgs_info['ray_feats'], self.image_encoder(que_imgs_info['imgs']))
+            self_hit = is_train and self.cfg['use_self_hit_prob']
+            if self_hit and que_imgs_info['imgs'].shape[1:] == ref_imgs_info['imgs'].shape[1:]:
+                # the query view of the self-hit loss rides along as one more sample of the same batch: the stacks are per-sample
+                # (convolutions + InstanceNorm), so this is the reference's two encoder passes (renderer.py:229-235) in half the
+                # launches, forward and backward - a training step is host-bound on exactly those
+                n = ref_imgs_info['imgs'].shape[0]
+                feats, rays = self.encode_views(torch.cat([ref_imgs_info['imgs'], que_imgs_info['imgs']], 0),
+                                                torch.cat([ref_imgs_info['ray_feats'], que_imgs_info['ray_feats']], 0))
+                ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'], que_imgs_info['ray_feats'] = feats[:n], rays[:n], rays[n:]
+            else:
+                ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'] = self.encode_views(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'])
+                if self_hit:
+                    que_imgs_info['ray_feats'] = self.encode_views(que_imgs_info['imgs'], que_imgs_info['ray_feats'])[1]
         if 'ray_feats' not in ref_imgs_info:
             raise NotImplementedError("neuray_amd: render() needs ref_imgs_info['ray_feats']")
         ray_batch_num = self.cfg['ray_batch_num']

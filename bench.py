@@ -315,7 +315,7 @@ def training_step_timing(device, steps=3):
     return out
 
 
-def ft_step_timing(device, steps=10):
+def ft_step_timing(device, steps=20):
     """Side measurement: one whole fine-tuning step as run_training.py's ft configs do it (BASELINE.json configs[3]) -
     NeuralRayFtRenderer.train_step (a random query view of a 24-view 800 x 800 scene, 8 neighbours, 512 rays, 64 + 64 samples:
     encoders on 9 images + per-ray forward) + loss.backward() (HIP backward kernels + encoder backward) + Adam on every parameter
@@ -338,7 +338,7 @@ def ft_step_timing(device, steps=10):
             out['hit_prob_self'].mean() + out['hit_prob_self_fine'].mean()
         loss.backward()
         opt.step()
-    for _ in range(5):
+    for _ in range(15):             # (also builds most views' cached pixel lists of the ray sampler: 5 ms per first visit of a view)
         step()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()

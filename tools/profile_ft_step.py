@@ -49,5 +49,38 @@ def main():
     pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
 
 
+def classify(path, steps):
+    """rocprofv3 kernel_stats.csv of this script's 25 steps -> GPU milliseconds per step by kernel class"""
+    import csv
+    classes = [('per-ray path (nr:: kernels)', ('nr::',)), ('fused norm (nr::inorm)', ('inorm',)),
+               ('MIOpen convolutions', ('conv', 'Conv', 'igemm', 'gemm', 'Sp3', 'winograd', 'Winograd', 'xform', 'naive_conv', 'Cijk')),
+               ('MIOpen transposes / batched copies', ('transpose', 'Transpose', 'batched_transpose')),
+               ('up-sampling', ('upsample', 'bilinear')), ('optimizer (multi_tensor)', ('multi_tensor',)),
+               ('indexing / gathers / cat / pad', ('index', 'Index', 'gather', 'Cat', 'cat_', 'pad', 'Pad')),
+               ('reductions', ('reduce', 'Reduce')), ('element-wise / copies / fills', ('elementwise', 'Elementwise', 'copy', 'Copy', 'fill', 'Fill'))]
+    rows = list(csv.DictReader(open(path)))
+    tot = {}
+    for r in rows:
+        name, ms, calls = r['Name'], float(r['TotalDurationNs']) / 1e6, int(r['Calls'])
+        cls = 'other'
+        if 'inorm' in name:
+            cls = 'fused norm (nr::inorm)'
+        else:
+            for c, keys in classes:
+                if any(k in name for k in keys):
+                    cls = c
+                    break
+        t = tot.setdefault(cls, [0.0, 0])
+        t[0] += ms
+        t[1] += calls
+    whole = sum(v[0] for v in tot.values())
+    print('GPU kernel time per step (%d steps in the trace): %.2f ms in %d launches' % (steps, whole / steps, sum(v[1] for v in tot.values()) // steps))
+    for c, v in sorted(tot.items(), key=lambda kv: -kv[1][0]):
+        print('  %-40s %7.2f ms  %5.1f %%  %5d launches' % (c, v[0] / steps, 100 * v[0] / whole, v[1] // steps))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == '--classify':
+        classify(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25)
+    else:
+        main()

@@ -82,7 +82,9 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
                 n = ref_imgs_info['imgs'].shape[0]
                 feats, rays = self.encode_views(torch.cat([ref_imgs_info['imgs'], que_imgs_info['imgs']], 0),
                                                 torch.cat([ref_imgs_info['ray_feats'], que_imgs_info['ray_feats']], 0))
-                ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'], que_imgs_info['ray_feats'] = feats[:n], rays[:n], rays[n:]
+                # (split, not three slices: one concatenation per tensor in the backward instead of a zero-fill + copy per slice)
+                ref_imgs_info['img_feats'] = feats.split([n, feats.shape[0] - n])[0]
+                ref_imgs_info['ray_feats'], que_imgs_info['ray_feats'] = rays.split([n, rays.shape[0] - n])
             else:
                 ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'] = self.encode_views(ref_imgs_info['imgs'], ref_imgs_info['ray_feats'])
                 if self_hit:
@@ -222,14 +224,21 @@ def _as_torch(info):
 
 
 def _take(info, idx):
-    idx = torch.as_tensor(np.asarray(idx)).long()
-    on = {}                                             # the index goes to each device once, not once per entry
-    out = {}
-    for k, v in info.items():
-        if v.device not in on:
-            on[v.device] = idx.to(v.device)
-        out[k] = v[on[v.device]]
-    return out
+    """the entries of an imgs_info at the view indices `idx` (a handful of Python ints).  No index tensor: uploading one from
+    pageable memory is a synchronous copy, i.e. a wait for everything queued on the device - one view is a slice (no kernel), several
+    are stacked (one kernel per entry)"""
+    idx = [int(i) for i in np.asarray(idx).reshape(-1)]
+    if len(idx) == 1:
+        return {k: v[idx[0]:idx[0] + 1] for k, v in info.items()}
+    return {k: torch.stack([v[i] for i in idx], 0) for k, v in info.items()}
+
+
+def _upload(array, device):
+    """numpy -> device tensor without stalling the launch queue (pinned staging + asynchronous copy on a GPU)"""
+    t = torch.from_numpy(array)
+    if device.type == 'cuda':
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
 
 
 class NeuralRayFtRenderer(NeuralRayBaseRenderer):
@@ -300,7 +309,12 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
         hit = self._scene_dev.get(which)
         if hit is None or hit[0] != dev:
             src = self.ref_imgs_info if which == 'ref' else self.val_imgs_info
-            self._scene_dev[which] = (dev, {k: v.to(dev) if torch.is_tensor(v) else v for k, v in src.items()})
+            src = {k: v for k, v in src.items() if torch.is_tensor(v)}
+            # K^-1 of every view, evaluated where engine.prepare_query would evaluate it (host LAPACK, the same call on the same bytes),
+            # once: handed over as `Ks_inv`, a step needs no device -> host round trip for its query view
+            from ..engine import host_inverse
+            src['Ks_inv'] = torch.cat([host_inverse(src['Ks'][i:i + 1]) for i in range(src['Ks'].shape[0])], 0)
+            self._scene_dev[which] = (dev, {k: v.to(dev) for k, v in src.items()})
         return self._scene_dev[which][1]
 
     def _encoded(self, ref_idx):
@@ -341,7 +355,7 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
             que = _take(self._resident('val'), [val_idx])
             hn, wn = que['imgs'].shape[-2:]
             coords = np.stack(np.meshgrid(np.arange(wn), np.arange(hn)), -1).reshape(1, -1, 2).astype(np.float32)
-        que['coords'] = torch.from_numpy(coords).to(self._device())
+        que['coords'] = _upload(coords, self._device())
         if is_train and self.cfg['use_self_hit_prob']:
             que['ray_feats'] = self.ray_feats[int(val_idx)]
         return ref_imgs_info, que

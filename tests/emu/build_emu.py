@@ -10,7 +10,8 @@ CSRC = os.path.join(ROOT, 'neuray_amd', 'csrc')
 OUT_DIR = os.path.join(HERE, '_build')
 OUT = os.path.join(OUT_DIR, 'libneuray_emu.so')
 SOURCES = [os.path.join(CSRC, 'neuray_hip.hip'), os.path.join(CSRC, 'nr_pack.cpp'), os.path.join(HERE, 'hip_emu.cpp')]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bwd.h', 'nr_kernels_bwd2.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bwd.h', 'nr_kernels_bwd2.h', 'nr_kernels_bwd3.h', 'nr_kernels_dr.h', 'nr_kernels_norm.h', 'nr_device.h',
+                                              'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
     [os.path.join(HERE, 'hip_emu.h'), os.path.join(ROOT, 'include', 'neuray_hip.h')]
 
 
@@ -21,7 +22,7 @@ def build(force=False, variant='fp32'):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
         return out
     cmd = ['g++', '-std=c++17', '-O2', '-g', '-rdynamic', '-fPIC', '-shared', '-DNEURAY_EMU', '-ffp-contract=off',
-           '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', out]
+           '-fno-strict-aliasing', '-Wno-unused-value', '-I', HERE, '-I', CSRC, '-pthread', '-o', out + '.building.%d' % os.getpid()]
     if variant in ('bf16', 'bf16x3'):
         cmd.append('-DNR_BF16_QUADS')
     if variant == 'bf16x3':
@@ -29,6 +30,7 @@ def build(force=False, variant='fp32'):
     for s in SOURCES:
         cmd += ['-x', 'c++', s]
     subprocess.check_call(cmd)
+    os.replace(out + '.building.%d' % os.getpid(), out)        # (a half-written library is never visible under the final name)
     return out
 
 

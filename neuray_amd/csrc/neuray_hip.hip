@@ -107,9 +107,12 @@ int launch_points_save(const nr::PointParams& p, void* stream) {
 // Built decompositions (measured on MI355X, DESIGN.md "point kernel tuning"):
 //   views_per_wave = 2, 168 VGPRs, 3 waves per SIMD  - default (2.35 M rays/s on the lego-800 workload)
 //   views_per_wave = 1, 128 VGPRs, 4 waves per SIMD  - single reference view, and the A/B reference
+#ifndef NR_POINT_MINW
+#define NR_POINT_MINW 3        // workgroups per CU the 2-views-per-wave kernel is compiled for (A/B: -DNR_POINT_MINW=2 = 256 VGPRs, no spills)
+#endif
 template <bool HAS_VIS>
 int launch_points_cfg(const nr::PointParams& p, int vpw, void* stream) {
-    if (vpw == 2) return launch_points<1, 2, HAS_VIS, 3>(p, stream);
+    if (vpw == 2) return launch_points<1, 2, HAS_VIS, NR_POINT_MINW>(p, stream);
     if (vpw == 1) return launch_points<1, 1, HAS_VIS, 4>(p, stream);
     return fail("neuray_render_points: views_per_wave=%d is not built (1 or 2)", vpw);
 }

@@ -13,7 +13,8 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started wi
 WORLD_SIZE == N.  Images are sharded across ranks (no data-path collective; rays and images are independent), weak
 scaling; the timed region is bracketed by barrier + synchronize and the max over ranks is taken.  After the timed
 region an N > 1 run adds two side legs to the line: `split_image` (ONE image split over the ranks + one fused all-gather
-of the tiles) and `train_ddp` (forward + backward + ONE flattened gradient all-reduce per step).
+of the tiles) and `train_ddp` (forward + backward + ONE flattened gradient all-reduce per step); they run after the headline is in
+hand and under a watchdog (`--side-leg-timeout`), so a rank lost inside one costs the side legs, not the line.
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the MFMA point kernel):
 achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream).
@@ -34,6 +35,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -651,6 +653,8 @@ def main(argv=None):
                     help='N > 1: make the TIMED region the split of ONE image over the ranks + all-gather of the tiles '
                          '(strong scaling) instead of one image per rank (weak scaling, no collective)')
     ap.add_argument('--no-side-legs', action='store_true', help='N > 1: skip the split_image / train_ddp side legs')
+    ap.add_argument('--fail-leg-on-rank', type=int, default=-1, help='TEST HOOK: that rank raises inside the first side leg')
+    ap.add_argument('--side-leg-timeout', type=int, default=300, help='N > 1: seconds after which the line is printed without the side legs')
     ap.add_argument('--emulator-lib', default=None, help='TEST HOOK: CPU emulator build of the kernels, gloo, tiny image')
     ap.add_argument('--size', type=int, nargs=2, default=None, metavar=('H', 'W'), help='test hook: image size (default 800 800)')
     args = ap.parse_args(argv)
@@ -719,13 +723,7 @@ def main(argv=None):
         dt = float(t.item())
     timing, eng.timing = eng.timing, None
 
-    legs = {}
-    if world > 1 and not args.no_side_legs:        # collectives: every rank takes part
-        if not split:
-            c2, r2, _, _, _, tq2, tr2 = build_case(device, args.fine_samples, seed=0, test_lib=emu)
-            legs['split_image'] = side(split_image_leg, r2, tq2, tr2, device, world, max(1, min(args.steps, 3)))
-        legs['train_ddp'] = side(train_ddp_leg, device, world, emu, 2 if emu is not None else 5)
-
+    line = None
     if rank == 0:
         value = (1 if split else world) * args.steps * nrays / dt
         standard = (H, W, RFN, DN_COARSE) == (800, 800, 8, 64) and emu is None
@@ -771,7 +769,47 @@ def main(argv=None):
                                 'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt}
         else:
             line['roofline'] = None
-        line.update(legs)
+
+    # ---- N > 1 side legs: collectives, every rank takes part.  They run AFTER the headline is in hand and under a watchdog: a rank
+    # that fails inside a leg leaves the others waiting in a collective, and that must cost the side legs, never the line.
+    emitted, emit_lock = threading.Event(), threading.Lock()
+
+    def emit():
+        with emit_lock:
+            if not emitted.is_set():
+                emitted.set()
+                if rank == 0:
+                    print(json.dumps(line))
+                    sys.stdout.flush()
+
+    watchdog = None
+    if world > 1:
+        limit = args.side_leg_timeout
+
+        def expired():
+            if rank == 0 and not emitted.is_set():
+                line['side_legs_error'] = 'a multi-rank side leg (or the final barrier) did not finish within %d s; the headline above is complete' % limit
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(limit, expired)
+        watchdog.daemon = True
+        watchdog.start()
+    if world > 1 and not args.no_side_legs:
+        legs = {}
+        if not split:
+            c2, r2, _, _, _, tq2, tr2 = build_case(device, args.fine_samples, seed=0, test_lib=emu)
+            def split_leg(*a):
+                if args.fail_leg_on_rank == rank:          # TEST HOOK (tests/test_bench_launcher.py): the other ranks are left in a collective
+                    raise RuntimeError('test hook: rank %d fails inside the side leg' % rank)
+                return split_image_leg(*a)
+            legs['split_image'] = side(split_leg, r2, tq2, tr2, device, world, max(1, min(args.steps, 3)))
+        if args.fail_leg_on_rank == rank:
+            time.sleep(10 ** 6)                            # (... and never joins another one: only the watchdog ends this rank)
+        legs['train_ddp'] = side(train_ddp_leg, device, world, emu, 2 if emu is not None else 5)
+        if rank == 0:
+            line.update(legs)
+
+    if rank == 0:
         if world == 1 and emu is None and not args.no_cpu_baseline:   # baselines: rank 0 at N = 1 only
             line['cpu_baseline'] = side(cpu_baseline, cfg, weights, que, ref)
             if args.cpu_sample_rays > 0:
@@ -798,11 +836,11 @@ def main(argv=None):
             line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
             line['bf16x3_split_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy(),
                                                 2, 'bf16x3')
-        print(json.dumps(line))
-        sys.stdout.flush()
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        watchdog.cancel()
 
 
 if __name__ == '__main__':

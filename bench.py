@@ -658,6 +658,7 @@ def main(argv=None):
     ap.add_argument('--emulator-lib', default=None, help='TEST HOOK: CPU emulator build of the kernels, gloo, tiny image')
     ap.add_argument('--size', type=int, nargs=2, default=None, metavar=('H', 'W'), help='test hook: image size (default 800 800)')
     args = ap.parse_args(argv)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # multi-process GPU work: the host driver only supports dmabuf IPC (RCCL)
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args, argv)

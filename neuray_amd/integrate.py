@@ -20,6 +20,9 @@ or, with the reference's scripts untouched:
 Options swap the neighbouring per-image pieces too (each is the same arithmetic on a HIP kernel / channels-last conv):
   render_ops=True   network.render_ops' 12 free functions -> stand-alone kernels (neuray_amd/network/render_ops.py)
   init_nets=True    DepthInitNet.get_diff_feats -> neuray_diff_feats
+  ft_host=True      NeuralRayFtRenderer.slice_imgs_info (renderer.py:469-491) -> the resident-scene host path: the scene's views are
+                    moved to the device once instead of `to_cuda(imgs_info_slice(...))` of 100 MB per step, the ray sampler works from
+                    cached pixel lists (same np.random draws, same rays), no synchronous copy is left in a step
 """
 import importlib
 import sys
@@ -54,12 +57,14 @@ def unpatch_renderer_class(cls):
             delattr(cls, name)
 
 
-def patch_reference(renderer_module=None, render_ops=False, init_nets=False):
+def patch_reference(renderer_module=None, render_ops=False, init_nets=False, ft_host=False):
     """Patch the reference's `network.renderer` (imported here if it is not yet; the reference tree must be importable).
     -> the patched module."""
     mod = renderer_module if renderer_module is not None else (
         sys.modules.get('network.renderer') or importlib.import_module('network.renderer'))
     patch_renderer_class(mod.NeuralRayBaseRenderer)
+    if ft_host:
+        patch_ft_host(mod.NeuralRayFtRenderer)
     if render_ops:
         from .network import render_ops as hip_ops
         ref_ops = importlib.import_module('network.render_ops')
@@ -78,10 +83,45 @@ def patch_reference(renderer_module=None, render_ops=False, init_nets=False):
     return mod
 
 
+FT_HOST_METHODS = ('slice_imgs_info', '_ref_views', '_resident', '_encoded', '_device')
+_PATCHED_FT = {}
+
+
+def patch_ft_host(ft_cls):
+    """Graft the resident-scene host path of neuray_amd's NeuralRayFtRenderer onto `ft_cls` (the reference's NeuralRayFtRenderer or
+    anything shaped like it: instances carry cfg / ref_imgs_info / val_imgs_info as dicts of host tensors / ray_feats).  The class
+    keeps its own train_step / validate_step / render; a seeded run draws the same views and rays.  Idempotent."""
+    if ft_cls in _PATCHED_FT:
+        return _PATCHED_FT[ft_cls]
+    from .network.renderer import NeuralRayFtRenderer as ours
+    saved = {}
+    for name in FT_HOST_METHODS + ('cache_encoded_views',):
+        if name in ft_cls.__dict__:
+            saved[name] = ft_cls.__dict__[name]
+    for name in FT_HOST_METHODS:
+        setattr(ft_cls, name, ours.__dict__[name])
+    ft_cls.cache_encoded_views = False          # the class's own render() runs the encoders unconditionally (renderer.py:229-235)
+    _PATCHED_FT[ft_cls] = saved
+    return saved
+
+
+def unpatch_ft_host(ft_cls):
+    saved = _PATCHED_FT.pop(ft_cls, None)
+    if saved is None:
+        return
+    for name in FT_HOST_METHODS + ('cache_encoded_views',):
+        if name in saved:
+            setattr(ft_cls, name, saved[name])
+        elif name in ft_cls.__dict__:
+            delattr(ft_cls, name)
+
+
 def unpatch_reference(renderer_module=None):
     mod = renderer_module if renderer_module is not None else sys.modules.get('network.renderer')
     if mod is not None:
         unpatch_renderer_class(mod.NeuralRayBaseRenderer)
+        if hasattr(mod, 'NeuralRayFtRenderer'):
+            unpatch_ft_host(mod.NeuralRayFtRenderer)
     for target in [t for t in _PATCHED if not isinstance(t, type)]:
         for name, fn in _PATCHED.pop(target).items():
             setattr(target, name, fn)

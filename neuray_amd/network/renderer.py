@@ -299,6 +299,10 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
             raise KeyError("generalisation state_dict lacks %s" % missing[:4])
         self.load_state_dict(picked, strict=False)
 
+    # eval: hand render() the cached per-view encoder outputs (`img_feats` + encoded `ray_feats`).  False where render() encodes
+    # unconditionally - the reference's own class with these host-path methods grafted on (integrate.patch_ft_host)
+    cache_encoded_views = True
+
     def _device(self):
         return self.ray_feats[0].device
 
@@ -306,7 +310,8 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
         """The scene's views stay resident in HBM (a 100-view 800x800 scene is 0.8 GB of 288): moved once per device
         instead of the reference's per-step `to_cuda(imgs_info_slice(...))` (renderer.py:487)."""
         dev = self._device()
-        hit = self._scene_dev.get(which)
+        scene_dev = self.__dict__.setdefault('_scene_dev', {})     # (state is created on first use: these methods are also grafted onto the reference's class)
+        hit = scene_dev.get(which)
         if hit is None or hit[0] != dev:
             src = self.ref_imgs_info if which == 'ref' else self.val_imgs_info
             src = {k: v for k, v in src.items() if torch.is_tensor(v)}
@@ -314,29 +319,29 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
             # once: handed over as `Ks_inv`, a step needs no device -> host round trip for its query view
             from ..engine import host_inverse
             src['Ks_inv'] = torch.cat([host_inverse(src['Ks'][i:i + 1]) for i in range(src['Ks'].shape[0])], 0)
-            self._scene_dev[which] = (dev, {k: v.to(dev) for k, v in src.items()})
-        return self._scene_dev[which][1]
+            scene_dev[which] = (dev, {k: v.to(dev) for k, v in src.items()})
+        return scene_dev[which][1]
 
     def _encoded(self, ref_idx):
         """eval only: per-view encoder outputs, reused while the encoders and that view's ray_feats are unchanged
         (neighbouring poses share most of their reference views) -> (img_feats, ray_feats)"""
         enc_stamp = tuple(p._version for p in self.image_encoder.parameters()) + tuple(p._version for p in self.vis_encoder.parameters())
         imgs = self._resident('ref')['imgs']
-        out = []
+        out, cache = [], self.__dict__.setdefault('_enc_cache', {})
         for i in (int(i) for i in ref_idx):
             stamp = (enc_stamp, self.ray_feats[i]._version, self._device())
-            hit = self._enc_cache.get(i)
+            hit = cache.get(i)
             if hit is None or hit[0] != stamp:
                 with torch.no_grad():
                     f = self.image_encoder(imgs[i:i + 1])
                     hit = (stamp, f, self.vis_encoder(self.ray_feats[i], f))
-                self._enc_cache[i] = hit
+                cache[i] = hit
             out.append(hit)
         return torch.cat([h[1] for h in out], 0), torch.cat([h[2] for h in out], 0)
 
     def _ref_views(self, ref_idx, is_train):
         ref_imgs_info = _take(self._resident('ref'), ref_idx)
-        if is_train:
+        if is_train or not self.cache_encoded_views:
             ref_imgs_info['ray_feats'] = torch.cat([self.ray_feats[int(i)] for i in ref_idx], 0)
         else:
             ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'] = self._encoded(ref_idx)
@@ -346,9 +351,10 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
         """renderer.py:484-507"""
         ref_imgs_info = self._ref_views(ref_idx, is_train)
         if is_train:
-            lists = self._pixel_lists.get(int(val_idx))
+            cached = self.__dict__.setdefault('_pixel_lists', {})
+            lists = cached.get(int(val_idx))
             if lists is None:
-                lists = self._pixel_lists[int(val_idx)] = pixel_lists(self.ref_imgs_info['masks'][val_idx, 0].numpy() > 0)
+                lists = cached[int(val_idx)] = pixel_lists(self.ref_imgs_info['masks'][val_idx, 0].cpu().numpy() > 0)
             que = _take(self._resident('ref'), [val_idx])
             coords = sample_train_coords(None, self.cfg['train_ray_num'], self.cfg['foreground_ratio'], lists).reshape(1, -1, 2)
         else:

@@ -249,3 +249,48 @@ def test_reference_ft_renderer_train_and_validate_steps(patched):
             assert np.abs(ft.ray_feats[i].grad.cpu().numpy() - want).max() <= 5e-3 * float(np.abs(want).max()), i
     finally:
         mod.to_cuda = to_cuda
+
+
+def test_reference_ft_renderer_with_the_resident_scene_host_path(patched):
+    """integrate.patch_ft_host: the ft class's slice_imgs_info replaced by the resident-scene host path (no per-step `to_cuda` of the
+    sliced views, cached pixel lists in the ray sampler).  Same np.random draws: the rays equal the reference's golden draws and the
+    generator is left in the state the unpatched method leaves it in; outputs and gradients pass the same checks as above."""
+    mod, dev = patched
+    if dev == 'cpu' and not hasattr(mod, 'compute_nearest_camera_indices') and ref_harness.reference_available():
+        pytest.skip('the stand-in on the CPU emulator repeats the reference leg; it runs where the reference tree is absent and on the GPU')
+    gold = np.load(os.path.join(GOLDEN_DIR, 'case_scene.npz'))
+    ft, n = build_ft(mod, gold)
+    to_cuda = mod.to_cuda
+    if dev == 'cpu':
+        mod.to_cuda = lambda d: d
+    try:
+        ft = place(ft, dev)
+        ft.train()
+        np.random.seed(3)
+        torch.manual_seed(4)
+        ft.train_step()
+        state_after = np.random.random()                      # where the unpatched host path leaves the generator
+        integrate.patch_ft_host(type(ft))
+        assert type(ft).cache_encoded_views is False and integrate.patch_ft_host(type(ft)) is not None      # idempotent
+        np.random.seed(3)
+        torch.manual_seed(4)
+        t = ft.train_step()
+        assert np.random.random() == state_after
+        assert np.array_equal(t['que_imgs_info']['coords'].cpu().numpy(), gold['ft_train_coords'])
+        assert 'ray_feats' not in t['que_imgs_info'] and t['que_imgs_info']['imgs'].device.type == torch.device(dev).type
+        tol = 2e-4 if dev == 'cpu' else 1e-3
+        for k in ('pixel_colors_nr', 'hit_prob_self', 'pixel_colors_gt'):
+            assert frac_within(t[k].detach().cpu().numpy(), gold['ft_train_' + k], tol)[0] == 1.0, k
+        loss = ((t['pixel_colors_nr_fine'] - t['pixel_colors_gt']) ** 2).mean() + t['hit_prob_self_fine'].mean()
+        loss.backward()
+        touched = [i for i in range(n) if ft.ray_feats[i].grad is not None and float(ft.ray_feats[i].grad.abs().max()) > 0]
+        assert touched == list(gold['ft_train_touched'])
+        ft.eval()
+        v = ft.validate_step(1)
+        f, worst = frac_within(v['pixel_colors_nr_fine'].cpu().numpy(), gold['ft_val_pixel_colors_nr_fine'], tol)
+        assert f >= 0.95 and worst < 0.1, (f, worst)
+        assert 'ray_feats' not in v['ref_imgs_info'] and 'img_feats' not in v['ref_imgs_info']
+    finally:
+        integrate.unpatch_ft_host(type(ft))
+        mod.to_cuda = to_cuda
+    assert 'cache_encoded_views' not in type(ft).__dict__ and '_resident' not in type(ft).__dict__

@@ -20,6 +20,9 @@ or, with the reference's scripts untouched:
 Options swap the neighbouring per-image pieces too (each is the same arithmetic on a HIP kernel / channels-last conv):
   render_ops=True   network.render_ops' 12 free functions -> stand-alone kernels (neuray_amd/network/render_ops.py)
   init_nets=True    DepthInitNet.get_diff_feats -> neuray_diff_feats
+  render_loop=True  NeuralRayBaseRenderer.render (renderer.py:228-254) -> the mirror's: the same encoders-once + ray-batch
+                    loop, with the query view of the self-hit loss batched into the reference views' encoder pass (half the launches of
+                    a training step's encoders) and encoder outputs accepted from the caller (`img_feats` already in ref_imgs_info)
   ft_host=True      NeuralRayFtRenderer.slice_imgs_info (renderer.py:469-491) -> the resident-scene host path: the scene's views are
                     moved to the device once instead of `to_cuda(imgs_info_slice(...))` of 100 MB per step, the ray sampler works from
                     cached pixel lists (same np.random draws, same rays), no synchronous copy is left in a step
@@ -57,14 +60,16 @@ def unpatch_renderer_class(cls):
             delattr(cls, name)
 
 
-def patch_reference(renderer_module=None, render_ops=False, init_nets=False, ft_host=False):
+def patch_reference(renderer_module=None, render_ops=False, init_nets=False, ft_host=False, render_loop=False):
     """Patch the reference's `network.renderer` (imported here if it is not yet; the reference tree must be importable).
     -> the patched module."""
     mod = renderer_module if renderer_module is not None else (
         sys.modules.get('network.renderer') or importlib.import_module('network.renderer'))
     patch_renderer_class(mod.NeuralRayBaseRenderer)
+    if render_loop:
+        patch_render_loop(mod.NeuralRayBaseRenderer)
     if ft_host:
-        patch_ft_host(mod.NeuralRayFtRenderer)
+        patch_ft_host(mod.NeuralRayFtRenderer, cache_encoded_views=render_loop)
     if render_ops:
         from .network import render_ops as hip_ops
         ref_ops = importlib.import_module('network.render_ops')
@@ -83,14 +88,42 @@ def patch_reference(renderer_module=None, render_ops=False, init_nets=False, ft_
     return mod
 
 
+RENDER_LOOP_METHODS = ('render', 'encode_views')
+_PATCHED_LOOP = {}
+
+
+def patch_render_loop(cls):
+    """Graft the mirror's render() (row a20) and encode_views() onto `cls` (the reference's NeuralRayBaseRenderer).  Idempotent."""
+    if cls in _PATCHED_LOOP:
+        return _PATCHED_LOOP[cls]
+    from .network.renderer import NeuralRayBaseRenderer as ours
+    saved = {name: cls.__dict__[name] for name in RENDER_LOOP_METHODS if name in cls.__dict__}
+    for name in RENDER_LOOP_METHODS:
+        setattr(cls, name, ours.__dict__[name])
+    _PATCHED_LOOP[cls] = saved
+    return saved
+
+
+def unpatch_render_loop(cls):
+    saved = _PATCHED_LOOP.pop(cls, None)
+    if saved is None:
+        return
+    for name in RENDER_LOOP_METHODS:
+        if name in saved:
+            setattr(cls, name, saved[name])
+        elif name in cls.__dict__:
+            delattr(cls, name)
+
+
 FT_HOST_METHODS = ('slice_imgs_info', '_ref_views', '_resident', '_encoded', '_device')
 _PATCHED_FT = {}
 
 
-def patch_ft_host(ft_cls):
+def patch_ft_host(ft_cls, cache_encoded_views=False):
     """Graft the resident-scene host path of neuray_amd's NeuralRayFtRenderer onto `ft_cls` (the reference's NeuralRayFtRenderer or
     anything shaped like it: instances carry cfg / ref_imgs_info / val_imgs_info as dicts of host tensors / ray_feats).  The class
-    keeps its own train_step / validate_step / render; a seeded run draws the same views and rays.  Idempotent."""
+    keeps its own train_step / validate_step / render; a seeded run draws the same views and rays.  cache_encoded_views: in eval
+    hand render() cached per-view encoder outputs - only with a render() that accepts them (patch_render_loop).  Idempotent."""
     if ft_cls in _PATCHED_FT:
         return _PATCHED_FT[ft_cls]
     from .network.renderer import NeuralRayFtRenderer as ours
@@ -100,7 +133,7 @@ def patch_ft_host(ft_cls):
             saved[name] = ft_cls.__dict__[name]
     for name in FT_HOST_METHODS:
         setattr(ft_cls, name, ours.__dict__[name])
-    ft_cls.cache_encoded_views = False          # the class's own render() runs the encoders unconditionally (renderer.py:229-235)
+    ft_cls.cache_encoded_views = bool(cache_encoded_views)      # (the reference's own render() runs the encoders unconditionally, renderer.py:229-235)
     _PATCHED_FT[ft_cls] = saved
     return saved
 
@@ -120,6 +153,7 @@ def unpatch_reference(renderer_module=None):
     mod = renderer_module if renderer_module is not None else sys.modules.get('network.renderer')
     if mod is not None:
         unpatch_renderer_class(mod.NeuralRayBaseRenderer)
+        unpatch_render_loop(mod.NeuralRayBaseRenderer)
         if hasattr(mod, 'NeuralRayFtRenderer'):
             unpatch_ft_host(mod.NeuralRayFtRenderer)
     for target in [t for t in _PATCHED if not isinstance(t, type)]:

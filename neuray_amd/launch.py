@@ -1,6 +1,6 @@
 """Run one of the reference's scripts, unchanged, on the HIP render path:
 
-    python -m neuray_amd.launch [--render-ops] [--init-nets] [--ft-host] <script.py> [script args ...]
+    python -m neuray_amd.launch [--render-ops] [--init-nets] [--ft-host] [--render-loop] <script.py> [script args ...]
 
 e.g. from the reference checkout:  python -m neuray_amd.launch render.py --cfg configs/gen/neuray_gen_depth.yaml ...
 The script's directory becomes sys.path[0] (as `python script.py` would make it), `network.renderer` is imported from
@@ -11,14 +11,14 @@ import runpy
 import sys
 
 
-def run(script, argv=(), render_ops=False, init_nets=False, ft_host=False):
+def run(script, argv=(), render_ops=False, init_nets=False, ft_host=False, render_loop=False):
     script = os.path.abspath(script)
     root = os.path.dirname(script)
     if root in sys.path:
         sys.path.remove(root)
     sys.path.insert(0, root)
     from . import integrate
-    integrate.patch_reference(render_ops=render_ops, init_nets=init_nets, ft_host=ft_host)
+    integrate.patch_reference(render_ops=render_ops, init_nets=init_nets, ft_host=ft_host, render_loop=render_loop)
     old = sys.argv
     sys.argv = [script] + list(argv)
     try:
@@ -29,8 +29,8 @@ def run(script, argv=(), render_ops=False, init_nets=False, ft_host=False):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    opts = {'render_ops': False, 'init_nets': False, 'ft_host': False}
-    while argv and argv[0] in ('--render-ops', '--init-nets', '--ft-host'):
+    opts = {'render_ops': False, 'init_nets': False, 'ft_host': False, 'render_loop': False}
+    while argv and argv[0] in ('--render-ops', '--init-nets', '--ft-host', '--render-loop'):
         opts[argv.pop(0)[2:].replace('-', '_')] = True
     if not argv:
         raise SystemExit(__doc__)

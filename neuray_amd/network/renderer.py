@@ -71,7 +71,7 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         (cfg['build_encoders']) 'imgs' and the initial 'ray_feats', which go through image_encoder / vis_encoder first."""
         if 'img_feats' not in ref_imgs_info:
             # renderer.py:229-235: encode the reference images, refine the initial ray_feats with them
-            if not self.cfg['build_encoders']:
+            if not self.cfg.get('build_encoders', hasattr(self, 'image_encoder')):      # (the reference's cfg has no such key: its classes always build them)
                 raise NotImplementedError("neuray_amd: render() needs ref_imgs_info['img_feats'] (and the encoded 'ray_feats'), "
                                           "or a renderer built with cfg['build_encoders'] = True")
             self_hit = is_train and self.cfg['use_self_hit_prob']

@@ -285,12 +285,31 @@ def test_reference_ft_renderer_with_the_resident_scene_host_path(patched):
         loss.backward()
         touched = [i for i in range(n) if ft.ray_feats[i].grad is not None and float(ft.ray_feats[i].grad.abs().max()) > 0]
         assert touched == list(gold['ft_train_touched'])
+        # ... and with the mirror's render() (row a20) on the base class: the query view rides through the encoders with the reference
+        # views, eval reuses cached per-view encoder outputs
+        integrate.unpatch_ft_host(type(ft))
+        integrate.patch_render_loop(mod.NeuralRayBaseRenderer)
+        integrate.patch_ft_host(type(ft), cache_encoded_views=True)
+        ft.train()
+        for p_ in ft.parameters():
+            p_.grad = None
+        np.random.seed(3)
+        torch.manual_seed(4)
+        t2 = ft.train_step()
+        assert np.random.random() == state_after
+        for k in ('pixel_colors_nr', 'hit_prob_self', 'pixel_colors_gt'):
+            assert frac_within(t2[k].detach().cpu().numpy(), gold['ft_train_' + k], tol)[0] == 1.0, k
         ft.eval()
-        v = ft.validate_step(1)
-        f, worst = frac_within(v['pixel_colors_nr_fine'].cpu().numpy(), gold['ft_val_pixel_colors_nr_fine'], tol)
+        v2 = ft.validate_step(1)
+        f, worst = frac_within(v2['pixel_colors_nr_fine'].cpu().numpy(), gold['ft_val_pixel_colors_nr_fine'], tol)
         assert f >= 0.95 and worst < 0.1, (f, worst)
-        assert 'ray_feats' not in v['ref_imgs_info'] and 'img_feats' not in v['ref_imgs_info']
+        assert len(ft._enc_cache) > 0 and 'img_feats' not in v2['ref_imgs_info'] and 'ray_feats' not in v2['ref_imgs_info']
+        entries = {i: hit[1] for i, hit in ft._enc_cache.items()}
+        ft._encoded(list(entries))                             # a second pose with the same views is served from the cache
+        assert all(ft._enc_cache[i][1] is f_ for i, f_ in entries.items())
     finally:
         integrate.unpatch_ft_host(type(ft))
+        integrate.unpatch_render_loop(mod.NeuralRayBaseRenderer)
         mod.to_cuda = to_cuda
     assert 'cache_encoded_views' not in type(ft).__dict__ and '_resident' not in type(ft).__dict__
+    assert 'encode_views' not in mod.NeuralRayBaseRenderer.__dict__

@@ -173,9 +173,7 @@ def test_launcher_runs_an_unmodified_script(tmp_path, patched):
     """python -m neuray_amd.launch <script>: the script only knows the reference's names (as render.py does)"""
     mod, dev = patched
     integrate.unpatch_reference(mod)                  # the launcher has to do the patching itself
-    script = os.path.join(os.path.dirname(os.path.dirname(mod.__file__)), '_neuray_launch_probe.py')
-    if not os.access(os.path.dirname(script), os.W_OK):      # the reference tree is read-only: run from a scratch directory
-        script = str(tmp_path / 'probe.py')
+    script = str(tmp_path / 'probe.py')               # (never next to the reference's scripts: that tree is not ours to write to)
     with open(script, 'w') as f:
         f.write("from network.renderer import name2network\n"
                 "cls = name2network['neuray_gen']\n"
@@ -185,9 +183,26 @@ def test_launcher_runs_an_unmodified_script(tmp_path, patched):
         keep = list(sys.path)
         ns = launch.run(script)
         sys.path[:] = keep
+        # the option flags of the command line reach patch_reference
+        with open(script, 'w') as f:
+            f.write("from network.renderer import name2network\n"
+                    "RESULT = (name2network['neuray_ft'].slice_imgs_info.__module__, name2network['neuray_gen'].render.__module__,\n"
+                    "          name2network['neuray_ft'].cache_encoded_views)\n")
+        integrate.unpatch_reference(mod)
+        launch_main_ns = {}
+        real_run = launch.run
+        launch.run = lambda *a, **k: launch_main_ns.update(real_run(*a, **k))
+        try:
+            launch.main(['--ft-host', '--render-loop', script])
+        finally:
+            launch.run = real_run
+        sys.path[:] = keep
     finally:
         os.remove(script)
+        integrate.unpatch_reference(mod)
     assert ns['RESULT'] == 'neuray_amd.network.hip_path'
+    assert launch_main_ns['RESULT'] == ('neuray_amd.network.renderer', 'neuray_amd.network.renderer', True)
+    assert 'slice_imgs_info' in mod.NeuralRayFtRenderer.__dict__ and mod.NeuralRayFtRenderer.slice_imgs_info.__module__ != 'neuray_amd.network.renderer'
 
 
 def build_ft(mod, gold, extra_cfg=None):

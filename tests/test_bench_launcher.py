@@ -48,14 +48,14 @@ def test_gpus_2_without_a_launcher_starts_two_ranks(emu_path):
 def test_a_rank_lost_inside_a_side_leg_costs_the_side_legs_not_the_line(emu_path):
     """rank 1 raises inside the first side leg and never joins another collective: rank 0 is left waiting in one.  The watchdog must
     print the (complete) headline line once and end every rank with exit code 0."""
-    p = run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--emulator-lib', emu_path, '--fail-leg-on-rank', '1', '--side-leg-timeout', '20'],
+    p = run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--emulator-lib', emu_path, '--fail-leg-on-rank', '1', '--side-leg-timeout', '12'],
                   timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['world_size_seen_by_process_group'] == 2
-    assert 'did not finish within 20 s' in line['side_legs_error'] and 'train_ddp' not in line
+    assert 'did not finish within 12 s' in line['side_legs_error'] and 'train_ddp' not in line
 
 
 def test_split_image_as_the_timed_region(emu_path):

@@ -19,8 +19,8 @@ hand and under a watchdog (`--side-leg-timeout`), so a rank lost inside one cost
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the MFMA point kernel):
 achieved = algorithmic FLOPs per launch / average launch duration (HIP events on the launch stream).
 `cpu_baseline` times the golden-checked eager-PyTorch port of the reference's op sequence (oracle/torch_eager_port.py;
-the reference tree itself does not exist on the GPU box; where it exists, the port runs the same batches 1.02 x as fast as the reference
-itself with identical pixels: tools/port_vs_reference_cpu.py) on the host - with torch.set_num_threads(physical cores) and,
+the reference tree itself does not exist on the GPU box; where it exists, the port runs the same batches within ~10 % of the reference
+itself - 0.83 ... 1.02 x on a shared host - with identical pixels: tools/port_vs_reference_cpu.py) on the host - with torch.set_num_threads(physical cores) and,
 on a many-core host, with 16 threads; the faster one is `value` - on a bounded sample of the same workload.  At N = 1 side measurements ride along (reported baselines, not the metric):
 `eager_torch_baseline` (the same port on the same GPU - the stand-in for "the reference on stock PyTorch-ROCm"),
 `numpy_oracle` (parity of the rendered image against the numpy oracle + its speed), `extra` (64+64 samples, the

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--threads', type=int, default=os.cpu_count())
-    ap.add_argument('--batches', type=int, default=3)
+    ap.add_argument('--batches', type=int, default=5)
     ap.add_argument('--rays', type=int, default=4096)
     a = ap.parse_args()
     import ref_harness
@@ -55,19 +55,18 @@ def main():
         with torch.no_grad():
             return tep.render_impl(weights, ocfg, q, tv)
 
-    def timed(fn):
-        fn(int(starts[0]))                                  # warm-up batch
-        t0 = time.perf_counter()
-        for st in starts[1:]:
-            out = fn(int(st))
-        return a.batches * a.rays / (time.perf_counter() - t0), out
-
-    r_ref, o_ref = timed(run_ref)
-    r_port, o_port = timed(run_port)
+    # interleaved (reference batch, port batch, reference batch, ...) so that a noisy neighbour on a shared host hits both alike;
+    # rates from the median batch time
+    run_ref(int(starts[0])); run_port(int(starts[0]))       # warm-up batch each
+    t_ref, t_port = [], []
+    for st in starts[1:]:
+        t0 = time.perf_counter(); o_ref = run_ref(int(st)); t_ref.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); o_port = run_port(int(st)); t_port.append(time.perf_counter() - t0)
+    r_ref, r_port = a.rays / float(np.median(t_ref)), a.rays / float(np.median(t_port))
     d = float((o_ref['pixel_colors_nr_fine'] - o_port['pixel_colors_nr_fine']).abs().max())
     print(json.dumps({'what': 'the reference itself vs the eager-PyTorch port of its op sequence, same CPU / threads / weights / batches; 800 x 800, 8 views, 64 + 32',
                       'threads': a.threads, 'batches_timed': a.batches, 'rays_per_batch': a.rays,
-                      'reference_rays_per_s': r_ref, 'port_rays_per_s': r_port, 'port_over_reference': r_port / r_ref,
+                      'reference_rays_per_s': r_ref, 'port_rays_per_s': r_port, 'batch_seconds_reference': t_ref, 'batch_seconds_port': t_port, 'port_over_reference': r_port / r_ref,
                       'max_abs_pixel_difference_last_batch': d, 'host': os.uname().nodename, 'cpus': os.cpu_count()}))
 
 

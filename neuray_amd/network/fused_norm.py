@@ -7,7 +7,6 @@ in two passes over the activation instead of PyTorch's four to six (MIOpen batch
 reflection_pad2d), with a two-pass backward.  The result is handed to the next convolution already padded
 (`conv_prepadded`); the un-padded activation is the interior view of the same buffer (`interior`).  On a device without the
 kernels (plain CPU) the same function composes the PyTorch ops, so the modules have one forward."""
-import ctypes as C
 
 import torch
 import torch.nn.functional as F

@@ -56,14 +56,23 @@ RAY_BATCH = 32768
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA dense peak
 
 
-def algorithmic_macs_per_point(rfn, vis_head_used):
-    """MACs of the point kernel per sample point (factored base_fc; SURVEY.md 8(d) 'minimal' count
-    minus the attention / sigma head that live in the ray kernel)."""
+def point_macs(vis_head_used, folded=True):
+    """-> (MACs per (sample point, reference view), MACs per sample point) of the point kernel (DESIGN.md 4.1, factored base_fc;
+    SURVEY.md 8(d) 'minimal' count minus the attention / sigma head that live in the ray kernel).  folded (the inference packs since
+    round 4): prob_embed.2, a Linear with no activation behind it (aggregate_net.py:27-31), is multiplied into neuray_fc.0 and
+    base_fc.0 at pack time - 32 x 32 MACs per (point, view) that no longer exist in the network the kernel evaluates."""
     dist = 3 * (32 * 32 * 2) + 32 * 2 + 32 * 2 + 32 * 1 + (32 * 32 * 2 + 32 if vis_head_used else 0)
-    per_view = (dist + (34 * 32 + 32 * 32) + (4 * 16 + 16 * 35) + (32 * 8 + 8) + ((35 + 32) * 64 + 64 * 32)
+    per_view = (dist + (34 * 32 + (0 if folded else 32 * 32)) + (4 * 16 + 16 * 35) + (32 * 8 + 8) + ((35 + 32) * 64 + 64 * 32)
                 + (32 * 32 + 32 * 33) + (32 * 32 + 32) + (37 * 16 + 16 * 8 + 8))
     per_point = 140 * 64 + (65 * 64 + 64 * 16)
-    return rfn * per_view + per_point
+    return per_view, per_point
+
+
+def algorithmic_macs_per_point(rfn, vis_head_used, folded=True, slots_run_share=1.0):
+    """MACs per sample point; slots_run_share < 1: the EXECUTED count when the kernel skipped that share of fully masked
+    (16-point tile, view) slots (their per-view layers are multiplied by the zero mask downstream: csrc/nr_kernels.h points_kernel)."""
+    per_view, per_point = point_macs(vis_head_used, folded)
+    return rfn * per_view * slots_run_share + per_point
 
 
 def build_case(device, fdn, seed, test_lib=None):
@@ -310,7 +319,7 @@ def training_step_timing(device, steps=3):
     eng.timing = None
     if ts:
         ms = float(np.median(ts))
-        conv = 3 * 2.0 * algorithmic_macs_per_point(8, vis_head_used=False) * 512 * 64 / (ms * 1e-3) / 1e12
+        conv = 3 * 2.0 * algorithmic_macs_per_point(8, vis_head_used=False, folded=False) * 512 * 64 / (ms * 1e-3) / 1e12
         out['point_backward'] = {'ms_per_pass': ms, 'launches_timed': len(ts),
                                  'tflops_by_3x_forward_convention': conv, 'frac_of_fp32_mfma_peak': conv / MFMA_F32_PEAK_TFLOPS,
                                  'note': 'a backward pass counted as 3 x the forward algorithmic FLOP of its 512 x 64 points (round-1 judge convention); '
@@ -350,6 +359,66 @@ def ft_step_timing(device, steps=20):
     torch.cuda.synchronize(device)
     return {'what': 'NeuralRayFtRenderer.train_step + backward + Adam: 512 rays, 8 of 24 views of 800 x 800, 64+64 samples, encoders trained',
             'ms_per_step': 1e3 * (time.perf_counter() - t0) / steps}
+
+
+def gen_train_case(device, h=416, w=608, rfn=8, extra_src=4, rays=512):
+    """One generalisation-training step at the shape of BASELINE.json configs[4] (configs/train/gen/neuray_gen_cost_volume_train.yaml;
+    dataset/train_dataset.py:78-102,304-378): NeuralRayGenRenderer with the cost-volume init net (`init_net_type: cost_volume`, frozen
+    MVSNet + trained heads), image / visibility encoders, 8 working views of a 400 x 600 crop padded to the ref_pad_interval of 32
+    (416 x 608), 3 cost-volume neighbours per view out of 8 + `extra_src` source views, 512 rays, 64 + 64 samples, render + depth loss
+    (network/loss.py:46-77,79-130), Adam on every trainable parameter.  -> (model, optimiser, step function)"""
+    from neuray_amd.network.renderer import NeuralRayGenRenderer
+    cfg = {'init_net_type': 'cost_volume', 'use_hierarchical_sampling': True, 'use_depth_loss': True, 'dist_decoder_cfg': {'use_vis': False},
+           'fine_dist_decoder_cfg': {'use_vis': False}, 'ray_batch_num': 2048, 'depth_loss_coords_num': 8192}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = NeuralRayGenRenderer(cfg).train().to(device)
+    n_src = rfn + extra_src
+    que, scene = synthetic.make_scene(h, w, n_src, seed=0, que_imgs=True, smooth=True)
+    cams = {k: torch.from_numpy(scene[k]).to(device) for k in ('imgs', 'poses', 'Ks', 'depth_range')}
+    src = dict(cams)
+    ref = {k: v[:rfn].contiguous() for k, v in cams.items()}
+    ref['nn_ids'] = torch.tensor([[(v + 1) % n_src, (v + 2) % n_src, (v + 5) % n_src] for v in range(rfn)], device=device)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    ref['true_depth'] = torch.from_numpy(np.stack([3.6 + 0.7 * np.sin(xx / 90.0 + v) * np.cos(yy / 70.0 - v)
+                                                   for v in range(rfn)])[:, None].astype(np.float32)).to(device)
+    tq = {k: torch.from_numpy(v).to(device) for k, v in que.items() if k != 'ray_feats'}
+    tq['coords'] = torch.from_numpy((np.random.RandomState(0).rand(1, rays, 2) * np.array([w - 1, h - 1])).astype(np.float32)).to(device)
+    opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=4e-4)
+    near, far = -1 / ref['depth_range'][:, 0:1], -1 / ref['depth_range'][:, 1:2]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model({'que_imgs_info': dict(tq), 'ref_imgs_info': dict(ref), 'src_imgs_info': dict(src), 'scene_name': 'synthetic'})
+        gt = out['pixel_colors_gt']
+        loss = ((out['pixel_colors_nr'] - gt) ** 2).mean() + ((out['pixel_colors_nr_fine'] - gt) ** 2).mean()
+        # depth loss (loss.py:79-130, l2): decoded mixture means of every view at random pixels against the normalised inverse true depth
+        c = out['depth_coords'].long()                          # [rfn, pn, 2]
+        d = ref['true_depth'][torch.arange(rfn, device=device)[:, None], 0, c[..., 1].clamp(max=h - 1), c[..., 0].clamp(max=w - 1)]
+        d = (((-1 / d.clamp(min=1e-5)) - near) / (far - near)).clamp(0, 1)
+        loss = loss + ((d - out['depth_mean']) ** 2).mean() + ((d - out['depth_mean_fine']) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return loss
+    return model, opt, step
+
+
+def gen_train_step_timing(device, steps=10):
+    """Side measurement (VERDICT r3 missing #1 / next #5): the whole config-5-shaped training step (gen_train_case)."""
+    model, opt, step = gen_train_case(device)
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(device)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    # the init net alone, forward only (what an evaluation pays per image at this size)
+    return {'what': 'NeuralRayGenRenderer(cost_volume init net + encoders) forward + render/depth loss + backward + Adam: 512 rays, 8 views of '
+                    '416 x 608 (+ 4 source views), 64+64 samples, fp32',
+            'ms_per_step': ms, 'loss_is_finite': bool(torch.isfinite(loss).item()),
+            'kernel_classes': 'profiles/r04_*_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
 
 
 def encoder_timing(device, n=9, hw=(800, 800), reps=5):
@@ -543,6 +612,7 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     eng = r.engine(device)
     render_image(r, tq, tr)
     eng.timing = []
+    eng.slot_stats = stats = torch.zeros(2, dtype=torch.int64, device=device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -550,9 +620,11 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in eng.timing if name == 'points']
-    eng.timing = None
-    achieved = 2.0 * algorithmic_macs_per_point(RFN, False) * sum(n for _, n in pts) / sum(t for t, _ in pts) / 1e12
-    return {'samples': '64+%d' % fdn, 'ray_batch': ray_batch, 'value': steps * H * W / dt, 'unit': 'rays/s',
+    eng.timing, eng.slot_stats = None, None
+    st = stats.cpu().numpy()
+    share = float(st[0] / st[1]) if st[1] > 0 else 1.0
+    achieved = 2.0 * algorithmic_macs_per_point(RFN, False, True, share) * sum(n for _, n in pts) / sum(t for t, _ in pts) / 1e12     # executed FLOPs
+    return {'samples': '64+%d' % fdn, 'ray_batch': ray_batch, 'value': steps * H * W / dt, 'unit': 'rays/s', 'view_slots_run_share': share,
             'point_kernel_ms_per_launch': 1e3 * sum(t for t, _ in pts) / len(pts), 'point_kernel_frac_of_fp32_mfma_peak': achieved / MFMA_F32_PEAK_TFLOPS}
 
 
@@ -713,12 +785,15 @@ def main(argv=None):
             sync()
 
     eng.timing = []
+    slot_stats = torch.zeros(2, dtype=torch.int64, device=device) if device.type == 'cuda' else None
+    eng.slot_stats = slot_stats           # the point kernel counts the (tile, view) slots it ran / skipped (two atomics per wave and launch)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = render_image(renderer, tq, tr, split)
     fence()
     dt = time.perf_counter() - t0
+    eng.slot_stats = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -749,7 +824,15 @@ def main(argv=None):
             rays_k = [e0.elapsed_time(e1) * 1e-3 for name, e0, e1, n in timing if name == 'rays']
             t_pts = sum(t for t, _ in pts)
             n_pts = sum(n for _, n in pts)
-            flops_pt = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False)
+            # FLOP accounting: `achieved` counts what the kernel EXECUTES - the folded network (prob_embed.2 folded into
+            # its consumers at pack time) on the (tile, view) slots that were not skipped as fully masked (counted by the kernel itself:
+            # NeurayPointsArgs.slot_stats_dev) - so that skipping work does not inflate the fraction of the matrix peak; the rate the same
+            # launches represent in terms of the reference's unfolded network on every (point, view) is reported next to it.
+            st = slot_stats.cpu().numpy() if slot_stats is not None else None
+            share = float(st[0] / st[1]) if st is not None and st[1] > 0 else 1.0
+            flops_exec = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False, folded=True, slots_run_share=share)
+            flops_folded = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False, folded=True)
+            flops_ref = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False, folded=False)
             # HBM/fabric traffic of the point kernel per launch: PMC passes are run separately (rocprofv3 --pmc cannot run
             # inside this process); the committed summary of the same command is reported here (profiles/README.md)
             traffic, tsrc = None, None
@@ -761,13 +844,19 @@ def main(argv=None):
                 traffic = tj.get('bytes_per_launch')
                 tsrc = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; collected on tree %s)' % (
                     os.path.basename(tfiles[-1]), tj.get('commit', 'of that profile run'))
-            achieved = flops_pt * n_pts / t_pts / 1e12
+            achieved = flops_exec * n_pts / t_pts / 1e12
             line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
                                 'kernel': 'nr::points_kernel', 'launches': len(pts),
                                 'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
-                                'algorithmic_flops_per_point': flops_pt,
-                                'gather_demand_tb_per_s': 1088.0 * RFN * n_pts / t_pts / 1e12,
+                                'flops_counted': 'executed: folded network (prob_embed.2 folded into neuray_fc.0 / base_fc.0), per-view layers only on '
+                                                 'the (16-point tile, view) slots the kernel ran (fully masked slots are skipped)',
+                                'view_slots_run_share': share,
+                                'executed_flops_per_point': flops_exec,
+                                'algorithmic_flops_per_point': flops_folded,
+                                'algorithmic_flops_per_point_unfolded_reference_network': flops_ref,
+                                'equivalent_tflops_of_the_unfolded_network_on_every_view': flops_ref * n_pts / t_pts / 1e12,
+                                'gather_demand_tb_per_s': 1088.0 * RFN * n_pts * share / t_pts / 1e12,
                                 'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt}
         else:
             line['roofline'] = None
@@ -784,15 +873,22 @@ def main(argv=None):
                     print(json.dumps(line))
                     sys.stdout.flush()
 
+    def put(key, val):
+        with emit_lock:
+            if line is not None and not emitted.is_set():
+                line[key] = val
+
     watchdog = None
     if world > 1:
         limit = args.side_leg_timeout
 
         def expired():
-            if rank == 0 and not emitted.is_set():
-                line['side_legs_error'] = 'a multi-rank side leg (or the final barrier) did not finish within %d s; the headline above is complete' % limit
+            if rank == 0:
+                with emit_lock:                      # (the main thread only touches `line` under the same lock: put())
+                    if not emitted.is_set():
+                        line['side_legs_error'] = 'a multi-rank side leg (or the final barrier) did not finish within %d s; the headline above is complete' % limit
             emit()
-            os._exit(0)
+            os._exit(0)                              # the headline is out; the launcher must not discard it over a lost side leg
         watchdog = threading.Timer(limit, expired)
         watchdog.daemon = True
         watchdog.start()
@@ -809,35 +905,38 @@ def main(argv=None):
             time.sleep(10 ** 6)                            # (... and never joins another one: only the watchdog ends this rank)
         legs['train_ddp'] = side(train_ddp_leg, device, world, emu, 2 if emu is not None else 5)
         if rank == 0:
-            line.update(legs)
+            for k_, v_ in legs.items():
+                put(k_, v_)
 
     if rank == 0:
         if world == 1 and emu is None and not args.no_cpu_baseline:   # baselines: rank 0 at N = 1 only
-            line['cpu_baseline'] = side(cpu_baseline, cfg, weights, que, ref)
+            put('cpu_baseline', side(cpu_baseline, cfg, weights, que, ref))
             if args.cpu_sample_rays > 0:
                 res = side(numpy_oracle_leg, cfg, weights, que, ref,
                            {k: out[k].cpu().numpy() for k in ('pixel_colors_nr', 'pixel_colors_nr_fine')}, args.cpu_sample_rays, 1024)
                 if isinstance(res, tuple):
-                    line['numpy_oracle'], line['parity'] = res
+                    put('numpy_oracle', res[0])
+                    put('parity', res[1])
                 else:
-                    line['numpy_oracle'] = res
+                    put('numpy_oracle', res)
         if world == 1 and emu is None and not args.no_eager_baseline and not args.no_cpu_baseline:
             eb = side(eager_torch_baseline, cfg, weights, tq, tr, device)
             if 'value' in eb:
                 eb['speedup_vs_eager'] = value / eb['value']
-            line['eager_torch_baseline'] = eb
-            line['extra'] = {
+            put('eager_torch_baseline', eb)
+            put('extra', {
                 'reference_default_64+64': side(extra_config_timing, device, 64, RAY_BATCH, tq, tr),
                 'reference_cli_ray_batch_4096': side(extra_config_timing, device, args.fine_samples, 4096, tq, tr),
-            }
-            line['training_step'] = side(training_step_timing, device)
-            line['encoders'] = side(encoder_timing, device)
-            line['ft_step'] = side(ft_step_timing, device)
-            line['init_net'] = side(init_net_timing, device)
-            line['pipeline_pcie_inclusive'] = side(pipeline_timing, device, args.fine_samples)
-            line['bf16_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy())
-            line['bf16x3_split_variant'] = side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy(),
-                                                2, 'bf16x3')
+            })
+            put('training_step', side(training_step_timing, device))
+            put('encoders', side(encoder_timing, device))
+            put('ft_step', side(ft_step_timing, device))
+            put('gen_train_step', side(gen_train_step_timing, device))
+            put('init_net', side(init_net_timing, device))
+            put('pipeline_pcie_inclusive', side(pipeline_timing, device, args.fine_samples))
+            put('bf16_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy()))
+            put('bf16x3_split_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy(),
+                                             2, 'bf16x3'))
     emit()
     if world > 1:
         dist.barrier()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 6
+#define NEURAY_ABI_VERSION 7
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -51,6 +51,14 @@ int neuray_operand_precision(void);
  * network/ibrnet.py:249-293. */
 size_t neuray_packed_pass_floats(void);
 int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_host);
+/* The same pass with prob_embed.2 FOLDED into its consumers (inference packs).  aggregate_net.py:27-31: prob_embed is
+ * Linear(34,32) -> ReLU -> Linear(32,32) with no activation behind the second Linear, and its output feeds only Linear layers:
+ * neuray_fc.0 (ibrnet.py:287,337) and the last 32 columns of base_fc.0 (ibrnet.py:254,342-343).  With e = W2 h + b2:
+ *   neuray_fc.0(e) = (Wn W2) h + (Wn b2 + bn),   base_fc.0(..., e) = ... + (Wb[:, 175:207] W2) h + (Wb[:, 175:207] b2 + bb)
+ * so the 32 x 32 layer disappears (1,024 of the 19,504 MAC per (point, view)); the products are formed in double precision and
+ * rounded once.  Same size and layout as neuray_pack_pass_weights (the prob_embed.2 slot is zero); pass NeurayPointsArgs.folded = 1
+ * with it.  The backward kernels and the training forward (saved_dev) take the unfolded pack only. */
+int neuray_pack_pass_weights_folded(const float* const* tensors_host, float* packed_host);
 /* The same packing as a gather, for callers that keep the weights on the device (training: they change every step):
  * packed[i] = flat[index[i]] * scale[i], index -1 = padding (0); flat = the flat natural layout described at
  * neuray_render_points_backward.  index_host / scale_host: neuray_packed_pass_floats() entries each. */
@@ -105,6 +113,11 @@ typedef struct NeurayPointsArgs {
                           * every 16-point tile - base_fc.0's per-point part, the four weighted statistics, the mask sum, the dist
                           * decoder outputs (csrc/nr_kernels.h kSaved*) - which neuray_render_points_backward reads instead of
                           * recomputing them */
+    int folded;          /* packed_weights_dev comes from neuray_pack_pass_weights_folded (not with saved_dev) */
+    unsigned long long* slot_stats_dev;   /* NULL, or [2] counters the launch ADDS to: { (16-point tile, view) slots whose per-view layers
+                          * ran, slots in total }.  The inference kernels skip a slot whose 16 (point, view) columns are all outside the
+                          * view (mask = 0, render_ops.py:100-104,127-128): every quantity of such a column is multiplied by the mask
+                          * downstream (ibrnet.py:333-349,365), so the result is the same; the counters give the executed share. */
 } NeurayPointsArgs;
 size_t neuray_points_saved_floats(int npts);
 int neuray_render_points(const NeurayPointsArgs* args, void* stream);
@@ -250,6 +263,13 @@ int neuray_interpolate_feats_backward(const float* d_out_dev, const float* point
  * bit 2 = inv_mode=False (interpolate the metric depths instead of the normalised inverse depths). */
 int neuray_sample_fine_depth(const float* query_const_dev, const float* depth_dev, const float* hit_prob_dev,
                              const float* u_dev, int rn, int dn, int fdn, int use_all, float* out_dev, void* stream);
+/* The same, also writing out what the samples were drawn from (tests; either pointer may be NULL): idx_out_dev int32 [rn][fdn] =
+ * the `torch.searchsorted(cdf, u, right=True)` bin of every sample (render_ops.py:207) in the order of u, i.e. before the sort;
+ * cdf_out_dev [rn][dn + 1] = the cdf (render_ops.py:193-196).  The pdf total is summed in numpy's pairwise order, so that on identical
+ * inputs both equal the numpy oracle's bit for bit (tests/test_fine_index.py). */
+int neuray_sample_fine_depth_traced(const float* query_const_dev, const float* depth_dev, const float* hit_prob_dev,
+                                    const float* u_dev, int rn, int dn, int fdn, int use_all, float* out_dev, int* idx_out_dev,
+                                    float* cdf_out_dev, void* stream);
 
 /* ---- get_diff_feats of the depth init net (network/init_net.py:30-61, with depth2pts3d :13-28,
  * project_points_ref_views render_ops.py:117-130, interpolate_feats ops.py:14-34 and masked_mean_var ops.py:36-41 fused):

@@ -36,7 +36,7 @@ class NeurayPointsArgs(C.Structure):
         ('dbg_dev', C.c_void_p),
         ('rfn', C.c_int), ('rn', C.c_int), ('dn', C.c_int), ('h', C.c_int), ('w', C.c_int), ('fh', C.c_int),
         ('fw', C.c_int), ('has_vis_head', C.c_int), ('use_vis', C.c_int), ('var_bias', C.c_float),
-        ('views_per_wave', C.c_int), ('saved_dev', C.c_void_p),
+        ('views_per_wave', C.c_int), ('saved_dev', C.c_void_p), ('folded', C.c_int), ('slot_stats_dev', C.c_void_p),
     ]
 
 
@@ -89,6 +89,7 @@ SYMBOLS = {
     'neuray_packed_pass_floats': (C.c_size_t, []),
     'neuray_points_saved_floats': (C.c_size_t, [C.c_int]),
     'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    'neuray_pack_pass_weights_folded': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_index_map': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_setup_views': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_setup_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -99,6 +100,8 @@ SYMBOLS = {
     'neuray_render_rays': (C.c_int, [C.POINTER(NeurayRaysArgs), C.c_void_p]),
     'neuray_sample_fine_depth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_sample_fine_depth_traced': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_interpolate_feats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_rays_points': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -140,6 +140,13 @@ int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_hos
     return 0;
 }
 
+int neuray_pack_pass_weights_folded(const float* const* tensors_host, float* packed_host) {
+    if (!tensors_host || !packed_host) return fail("neuray_pack_pass_weights_folded: null argument");
+    const int rc = nr::pack_pass_weights(tensors_host, packed_host, true);
+    if (rc) return fail("neuray_pack_pass_weights_folded: tensor %d of the pass is missing", rc - 1);
+    return 0;
+}
+
 int neuray_operand_precision(void) {
 #if defined(NR_BF16_SPLIT)
     return 48;         // hi + lo bf16 operands, three bf16 MFMAs per fp32 quad (libneuray_hip_bf16x3.so)
@@ -215,7 +222,8 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     p.ray_feats = a->ray_feats_nhwc_dev; p.img_feats = a->img_feats_nhwc_dev; p.rgba = a->rgba_dev;
     p.weights = a->packed_weights_dev; p.point_out = a->point_out_dev; p.dbg = a->dbg_dev; p.saved = a->saved_dev;
     p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
-    p.use_vis = a->use_vis; p.var_bias = a->var_bias;
+    p.use_vis = a->use_vis; p.var_bias = a->var_bias; p.folded = a->folded; p.slot_stats = a->slot_stats_dev;
+    if (a->folded && a->saved_dev) return fail("neuray_render_points: saved_dev (training forward) takes the unfolded pack");
     // work decomposition: reference views processed per wave (0 = default)
     int vpw = a->views_per_wave ? a->views_per_wave : (a->rfn >= 2 ? 2 : 1);
     // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
@@ -254,10 +262,15 @@ int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {
 
 int neuray_sample_fine_depth(const float* query_const, const float* depth, const float* hit_prob, const float* u,
                              int rn, int dn, int fdn, int use_all, float* out, void* stream) {
+    return neuray_sample_fine_depth_traced(query_const, depth, hit_prob, u, rn, dn, fdn, use_all, out, nullptr, nullptr, stream);
+}
+
+int neuray_sample_fine_depth_traced(const float* query_const, const float* depth, const float* hit_prob, const float* u,
+                                    int rn, int dn, int fdn, int use_all, float* out, int* idx_out, float* cdf_out, void* stream) {
     if (dn < 2 || dn > NEURAY_MAX_SAMPLES || fdn < 1 || fdn > NEURAY_MAX_SAMPLES)
         return fail("neuray_sample_fine_depth: dn=%d fdn=%d outside [2,%d]", dn, fdn, NEURAY_MAX_SAMPLES);
     nr::FineParams p;
-    p.que_const = query_const; p.depth = depth; p.hit_prob = hit_prob; p.u = u; p.out = out;
+    p.que_const = query_const; p.depth = depth; p.hit_prob = hit_prob; p.u = u; p.out = out; p.idx_out = idx_out; p.cdf_out = cdf_out;
     p.rn = rn; p.dn = dn; p.fdn = fdn; p.use_all = use_all & 1; p.no_sort = (use_all >> 1) & 1; p.linear = (use_all >> 2) & 1;
     const int grid = grid_for(rn, nr::kRayWaves, 256 * 16);
     NR_LAUNCH(nr::fine_kernel, dim3(grid), dim3(64 * nr::kRayWaves), 0, stream, p);
@@ -324,7 +337,7 @@ int neuray_inorm_forward(const float* x, const float* gamma, const float* beta, 
 int neuray_inorm_backward(const float* x, const float* out_padded, const float* d_out_padded, const float* stats, const float* gamma,
                           int n, int c, int h, int w, int pad, int act, float* raw_zeroed, float* dx, float* d_res, void* stream) {
     if (!x || !out_padded || !d_out_padded || !stats || !gamma || !raw_zeroed || !dx) return fail("neuray_inorm_backward: null pointer");
-    if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2)
+    if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2 || (long long)(h + 2 * pad) * (w + 2 * pad) >= (1 << 23))
         return fail("neuray_inorm_backward: bad arguments n=%d c=%d h=%d w=%d pad=%d act=%d", n, c, h, w, pad, act);
     nr::NormBwdParams p;
     p.x = x; p.out = out_padded; p.d_out = d_out_padded; p.stats = stats; p.gamma = gamma; p.raw = raw_zeroed; p.dx = dx; p.d_res = d_res;

@@ -366,15 +366,19 @@ __device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
     constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
     static_assert(KQ0 + KQN <= KQ && K10 + K1N <= K1, "slice outside the layer");
     static_assert(KQX >= (KQN > 0 ? 4 * KQN : 1) && K1X >= (K1N > 0 ? K1N : 1), "operand arrays too small");
+    // the run-time tile index goes into the per-lane byte offset, so that every load's scalar offset is a compile-time constant: as
+    // `soffset = constant + mo * stride` each of the ~20 loads of a slice had its own loop-invariant SGPR, which hipcc hoisted out of
+    // the tile loop and spilled to VGPR lanes (v_writelane / v_readlane + s_nop inside the loop)
+    const int v1 = lane * 4 + mo * (K1 * 256), vq = lane * 16 + mo * (KQ * 1024);
     float s1[K1N > 0 ? K1N : 1];
     NR_PRAGMA_UNROLL
-    for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, lane * 4, (single_offset(L) + (mo * K1 + K10 + k1) * 64) * 4);
+    for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, v1, (single_offset(L) + (K10 + k1) * 64) * 4);
     if (KQN > 0) {
-        float4 cur = wldq(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0) * 256) * 4);
+        float4 cur = wldq(W, vq, (quads_offset(L) + KQ0 * 256) * 4);
         NR_PRAGMA_UNROLL
         for (int kq = 0; kq < KQN; ++kq) {
             float4 nxt = cur;
-            if (kq + 1 < KQN) nxt = wldq(W, lane * 16, (quads_offset(L) + (mo * KQ + KQ0 + kq + 1) * 256) * 4);
+            if (kq + 1 < KQN) nxt = wldq(W, vq, (quads_offset(L) + (KQ0 + kq + 1) * 256) * 4);
             NR_PIN();
             mfma_quad<NT>(cur, kq, xq, acc);
             cur = nxt;

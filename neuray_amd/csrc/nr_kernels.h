@@ -96,6 +96,8 @@ struct PointParams {
     int rfn, rn, dn, h, w, fh, fw;
     int use_vis;               // the COARSE decoder's use_vis governs compute_prob in both passes (renderer.py:75)
     float var_bias;            // AddBias value of var_decoder (dist_decoder.py:81)
+    int folded;                // the packed weights carry prob_embed.2 folded into neuray_fc.0 / base_fc.0 (inference packs)
+    unsigned long long* slot_stats;   // optional [2]: += (view slots whose layers ran, view slots) of the launch (slot skipping)
 };
 
 constexpr int kDbgFields = 16;
@@ -143,36 +145,54 @@ __device__ __forceinline__ void bg_accumulate(nr_wbuf W, int lane, int g, int wa
     }
 }
 
-// sum (or max; RED_MAX0: row 0 of each tile max, the other rows sum) over the VPW view slots of each tile, then over
-// the waves of the workgroup
-template <int NT, int VPW, int R, int RMAX, int OP>
-__device__ __forceinline__ void view_allreduce(const float (&v)[NT * VPW][R], float (&out)[NT * R], float* red, int wave,
+// sum (or max; RED_MAX0: row 0 max, the other rows sum) over the NA ACTIVE view slots of the wave, then over the waves of the
+// workgroup.  The IDLE = slots - NA skipped slots of a wave (points_kernel "slot skipping") contribute what a fully masked view
+// contributes in the reference: exact zeros to every sum and the masked_fill value -1e9 (ibrnet.py:365) to the maximum row.
+template <int NA, int IDLE, int R, int RMAX, int OP>
+__device__ __forceinline__ void view_allreduce(const float (&v)[NA > 0 ? NA : 1][R], float (&out)[R], float* red, int wave,
                                                int nw, int lane) {
     NR_PRAGMA_UNROLL
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < R; ++r) {
+        const bool is_max = OP == RED_MAX || (OP == RED_MAX0 && r == 0);
+        float a = NA > 0 ? v[0][r] : (is_max ? -1e9f : 0.0f);
         NR_PRAGMA_UNROLL
-        for (int r = 0; r < R; ++r) {
-            float a = v[t][r];
-            NR_PRAGMA_UNROLL
-            for (int vv = 1; vv < VPW; ++vv) a = red_combine<OP, R>(a, v[vv * NT + t][r], r);
-            out[t * R + r] = a;
-        }
-    block_allreduce<NT * R, RMAX, OP, R>(out, red, wave, nw, lane);
+        for (int s = 1; s < NA; ++s) a = red_combine<OP, R>(a, v[s][r], r);
+        if (IDLE > 0 && NA > 0 && is_max) a = fmaxf(a, -1e9f);
+        out[r] = a;
+    }
+    block_allreduce<R, RMAX, OP, R>(out, red, wave, nw, lane);
 }
 
-// Point kernel.  One workgroup = ceil(rfn / VPW) waves x NT tiles of 16 sample points; wave w processes the reference
-// views [w*VPW, w*VPW + VPW) of every tile ("slots": slot s = vv*NT + t).  The slots of a wave share every weight
-// fragment and give the MFMA pipe NS independent accumulator chains.
+template <int N> struct SlotCount { static constexpr int value = N; };
+
+#ifndef NR_POINT_SKIP
+#define NR_POINT_SKIP 1        // 0: every view slot runs its layers, masked or not (A/B timing)
+#endif
+
+// Point kernel.  One workgroup = ceil(rfn / VPW) waves x one tile of 16 sample points; wave w processes the reference
+// views [w*VPW, w*VPW + VPW) of the tile ("slots").  The slots of a wave share every weight fragment and give the MFMA
+// pipe independent accumulator chains.
 //   OWN = number of 16-feature output tiles of the per-point layers (base_fc.0 global part, geometry_fc.0) a wave
 //         owns: ceil(4 / nwaves).
 //   DBG = the per-(point, view) record p.dbg is written (tests, direct rendering).  A template flag, not a run-time test of the
 //         pointer: the product instantiation carries none of its 6 predicated store blocks per tile nor their lane masks
 //         (loop-invariant SGPR pairs that hipcc spilled to VGPR lanes and read back with v_readlane + s_nop inside the loop).
+// Slot skipping (inference instantiations with two views per wave): a slot whose 16 (point, view) columns are ALL outside the
+//   view (mask = 0: render_ops.py:100-104,127-128) contributes exactly 0 to every cross-view sum of the reference - weight,
+//   weight0, vis and vis'' are products with the mask (ibrnet.py:333-349), its colour logit is masked_fill'ed to -1e9 (:365) and
+//   the gathered features are multiplied by the mask (render_ops.py:140-143) - so none of its per-view layers is evaluated: the
+//   tile body is instantiated for 2, 1 and 0 active slots (NA) and picked per wave and tile by a wave-uniform branch (a lone
+//   active slot is moved to position 0 first; the two-term slot sums are commutative, so the result does not depend on it).
+//   Every variant executes the same barriers, weight-stage copies and per-point (owner wave) work.
+//   p.folded: the packed weights carry prob_embed.2 folded into its two consumers (nr_pack.cpp pack_pass_weights fold = true):
+//   the layer is skipped and prob_embed.0's ReLU output takes its place.
 template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW, bool SAVE = false, bool DBG = false>
 __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
+    static_assert(NT == 1, "one 16-point tile per wave iteration");
     NR_DYNAMIC_SMEM(float, smem);
     constexpr int RMAX = point_rmax<NT>();
-    constexpr int NS = NT * VPW;
+    constexpr int NS = VPW;
+    constexpr bool SKIP = (NR_POINT_SKIP != 0) && !SAVE && !DBG && VPW == 2;
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
     const int nw = (p.rfn + VPW - 1) / VPW;          // waves per workgroup
@@ -193,31 +213,36 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     const int npts = p.rn * p.dn;
     const int dn = p.dn;
     const bool use_vis = p.use_vis != 0;
+    const bool folded = !SAVE && p.folded != 0;
     const bool dbg_lane = DBG && (g == 0);
     // XCD-aware tile map: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Giving every
     // XCD a contiguous run of tiles keeps the texels that neighbouring samples / rays share inside one private L2
     // instead of fetching them into all eight (the grid is a multiple of 8).
     const int bid = (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8);
     int seq0 = 0;                                       // phases entered so far (selects the stage region)
-    if (bid * (16 * NT) < npts) stage_issue<PH_DIST_M>(wl, W, wave, nw, lane);
-    for (int base = bid * (16 * NT); base < npts; base += gridDim.x * (16 * NT), seq0 += phase_count(HAS_VIS)) {
-        const bool more = base + (int)gridDim.x * (16 * NT) < npts;   // another tile follows: its first phase is prefetched
+    int n_active = 0, n_slots = 0;                      // slot-skipping statistics of this wave (p.slot_stats)
+    if (bid * 16 < npts) stage_issue<PH_DIST_M>(wl, W, wave, nw, lane);
+    for (int base = bid * 16; base < npts; base += gridDim.x * 16, seq0 += phase_count(HAS_VIS)) {
+        const bool more = base + (int)gridDim.x * 16 < npts;   // another tile follows: its first phase is prefetched
         // lane index for the weight loads that go to global memory (L_BG, L_GF1, L_GF2): opaque and re-made per tile,
         // otherwise hipcc treats these loop-invariant loads as hoistable, keeps ~50 fragment registers alive across the
         // whole tile loop and spills them (seen as "spills outside, reloads inside the loop" in -Rpass-missed=regalloc)
         const int glane = lane + nr_opaque_zero();
+#ifndef NR_NO_OPAQUE_WAVE
+        const int wave_t = wave + nr_opaque_szero();     // (see nr_opaque_szero)
+#else
+        const int wave_t = wave;
+#endif
         const int gg = glane >> 4;
-        // ---------------- geometry + gather (a2-a8) -------------------------------------------
-        int pidx[NT]; bool pvalid[NT];
-        float mask[NS], dlt[NS][4], fray[NS][8], fimg[NS][8], rgb[NS][3], tref[NS], lo[NT], hi[NT];
-        Taps tfs[NS], tcs[NS];
-        int soffs[NS][2];
-        NR_PRAGMA_UNROLL
-        for (int t = 0; t < NT; ++t) {
-            int pi = base + 16 * t + c;
-            pvalid[t] = pi < npts;
+        // ---------------- geometry (a2-a6) ----------------------------------------------------
+        int pidx; bool pvalid;
+        float mask[NS], dlt[NS][4], tref[NS], pu[NS], pv[NS], lo, hi;
+        int soff_f[NS], soff_c[NS];                    // byte offsets of the slot's view inside the feature / colour maps
+        {
+            int pi = base + c;
+            pvalid = pi < npts;
             pi = pi < npts ? pi : npts - 1;
-            pidx[t] = pi;
+            pidx = pi;
             const int ray = pi / dn, smp = pi - ray * dn;
             const Ray r = make_ray<false>(qc, p.coords[2 * ray], p.coords[2 * ray + 1]);
             const float* drow = p.depth + (size_t)ray * dn;
@@ -229,15 +254,14 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             const float s_p = norm_inv_depth_fast(drow[smp > 0 ? smp - 1 : 0], qnearp, qfarp, qinv);
             const float half_c = (smp == dn - 1) ? 500000.0f : (s_n - s_c) * 0.5f;
             const float half_p = (s_c - s_p) * 0.5f;
-            hi[t] = half_c;
-            lo[t] = (smp == 0) ? half_c : half_p;
+            hi = half_c;
+            lo = (smp == 0) ? half_c : half_p;
             const float px = rn_add(r.cx, rn_mul(r.dx, d));
             const float py = rn_add(r.cy, rn_mul(r.dy, d));
             const float pz = rn_add(r.cz, rn_mul(r.dz, d));
             NR_PRAGMA_UNROLL
-            for (int vv = 0; vv < VPW; ++vv) {
-                const int s = vv * NT + t;
-                const int vraw = wave * VPW + vv;
+            for (int s = 0; s < NS; ++s) {
+                const int vraw = wave_t * VPW + s;
                 const bool vok = vraw < p.rfn;                // padding view when rfn % VPW != 0: masked out
                 const int view = vok ? vraw : p.rfn - 1;
                 const float* __restrict__ vc = p.view_const + view * kViewConst;
@@ -247,488 +271,531 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 dlt[s][0] = pr.dirx - r.qx; dlt[s][1] = pr.diry - r.qy; dlt[s][2] = pr.dirz - r.qz;
                 dlt[s][3] = dot3(pr.dirx, pr.diry, pr.dirz, r.qx, r.qy, r.qz);
                 tref[s] = norm_inv_depth_fast(fmaxf(pr.z, 1e-5f), vc[15], vc[16], vc[17]);
-                if (dbg_lane && pvalid[t] && vok) {
+                pu[s] = pr.u; pv[s] = pr.v;
+                if (dbg_lane && pvalid && vok) {
                     float* d_ = p.dbg + ((size_t)pi * p.rfn + view) * kDbgFields;
                     d_[0] = pr.mask; d_[1] = pr.u; d_[2] = pr.v; d_[3] = pr.z;
                 }
-                tfs[s] = make_taps_fast(pr.u, pr.v, w_m1, h_m1, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
-                tcs[s] = make_taps_fast(pr.u, pr.v, w_m1, h_m1, inv_w_m1, inv_h_m1, p.w, p.h, true);
-                soffs[s][0] = view * (int)(fmap * sizeof(float)); soffs[s][1] = view * (int)(imap * sizeof(float));
+                soff_f[s] = view * (int)(fmap * sizeof(float)); soff_c[s] = view * (int)(imap * sizeof(float));
             }
         }
-        // gathers (a7): the 20 tap loads of a slot are all issued before anything is blended, so they share one memory
-        // round trip (left alone hipcc serialises load -> wait -> blend per map: 3 dependent round trips per slot).
-        // Measured: +5% whole-job; holding two slots' taps (160 registers) or staggering slot s+1's loads into slot s's
-        // blends spills and is slower than this.
-        NR_PRAGMA_UNROLL
-        for (int s = 0; s < NS; ++s) {
-            float4 qf[8], qi[8], qc[4];
-            issue8(rf_map, goff, soffs[s][0], tfs[s], qf);
-            issue8(if_map, goff, soffs[s][0], tfs[s], qi);
-            issue_rgb(rgb_map, soffs[s][1], tcs[s], qc);
-            NR_PIN();
-            blend8(qf, tfs[s], mask[s], fray[s]);
-            blend8(qi, tfs[s], mask[s], fimg[s]);
-            blend_rgb(qc, tcs[s], mask[s], rgb[s]);
-            // the blends happen HERE: left alone the img / rgb blends are sunk to their first use (ray_dir_fc, two phases
-            // later) and the 48 raw tap registers of the slot are carried - spilled - through the whole dist decoder
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 8; ++k) { NR_KEEP(fray[s][k]); NR_KEEP(fimg[s][k]); }
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < 3; ++j) NR_KEEP(rgb[s][j]);
-            NR_PIN();
-        }
-        float none[NS][1];
-        NR_PRAGMA_UNROLL
-        for (int s = 0; s < NS; ++s) none[s][0] = 0.0f;
 
-        // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
-        float hit[NS], vis[NS];
-        {
-            float h1[NS][8], h2[NS][8], fm[NS][2], fv[NS][2], fa[NS][1];
+        // ---------------- the tile body for NA active slots (slots [0, NA) are the active ones) --------------------------
+        auto tile = [&](auto na_tag) NR_LAMBDA_INLINE {
+            constexpr int NA = decltype(na_tag)::value, NA1 = NA > 0 ? NA : 1, IDLE = NS - NA;
+            // gathers (a7): the 20 tap loads of a slot are all issued before anything is blended, so they share one memory
+            // round trip (left alone hipcc serialises load -> wait -> blend per map: 3 dependent round trips per slot).
+            // Measured: +5% whole-job; holding two slots' taps (160 registers) or staggering slot s+1's loads into slot s's
+            // blends spills and is slower than this.
+            float fray[NA1][8], fimg[NA1][8], rgb[NA1][3];
+            if constexpr (NA > 0) {
+                Taps tfs[NA], tcs[NA];
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s) {
+                    tfs[s] = make_taps_fast(pu[s], pv[s], w_m1, h_m1, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
+                    tcs[s] = make_taps_fast(pu[s], pv[s], w_m1, h_m1, inv_w_m1, inv_h_m1, p.w, p.h, true);
+                }
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s) {
+                    float4 qf[8], qi[8], qc4[4];
+                    issue8(rf_map, goff, soff_f[s], tfs[s], qf);
+                    issue8(if_map, goff, soff_f[s], tfs[s], qi);
+                    issue_rgb(rgb_map, soff_c[s], tcs[s], qc4);
+                    NR_PIN();
+                    blend8(qf, tfs[s], mask[s], fray[s]);
+                    blend8(qi, tfs[s], mask[s], fimg[s]);
+                    blend_rgb(qc4, tcs[s], mask[s], rgb[s]);
+                    // the blends happen HERE: left alone the img / rgb blends are sunk to their first use (ray_dir_fc, two phases
+                    // later) and the 48 raw tap registers of the slot are carried - spilled - through the whole dist decoder
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 8; ++k) { NR_KEEP(fray[s][k]); NR_KEEP(fimg[s][k]); }
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) NR_KEEP(rgb[s][j]);
+                    NR_PIN();
+                }
+            }
+            float none[NA1][1];
+            NR_PRAGMA_UNROLL
+            for (int s = 0; s < NA1; ++s) none[s][0] = 0.0f;
             NoLayer last;      // "no next layer": the following layer belongs to the next phase
-            const LdsW W1 = phase_enter<PH_DIST_M, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-            LayerPre<L_DM1> p_dm1; LayerPre<L_DM2> p_dm2; LayerPre<L_DV1> p_dv1; LayerPre<L_DV2> p_dv2;
-            VecPre<L_DFIN_M> p_fm; VecPre<L_DFIN_V> p_fv;
-            layer_prefetch<L_DM1>(W1, lane, p_dm1);
-            layer_fwd<L_DM1, NS, ACT_ELU>(W1, lane, p_dm1, fray, none, h1, p_dm2);
-            layer_fwd<L_DM2, NS, ACT_ELU>(W1, lane, p_dm2, h1, none, h2, p_fm);
-            layer_prefetch<L_DV1>(W1, lane, p_dv1);
-            layer_vec<L_DFIN_M, NS>(p_fm, h2, fm);
-            layer_fwd<L_DV1, NS, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, last);
-            const LdsW W2 = phase_enter<PH_DIST_VA, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-            layer_prefetch<L_DV2>(W2, lane, p_dv2);
-            layer_fwd<L_DV2, NS, ACT_ELU>(W2, lane, p_dv2, h1, none, h2, p_fv);
-            LayerPre<L_DA1> p_da1; LayerPre<L_DA2> p_da2; VecPre<L_DFIN_A> p_fa;
-            layer_prefetch<L_DA1>(W2, lane, p_da1);
-            layer_vec<L_DFIN_V, NS>(p_fv, h2, fv);
-            float mu0[NS], mu1[NS], s0[NS], s1[NS], aw[NS], nu[NS];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                mu0[s] = softplus(fm[s][0]); mu1[s] = softplus(fm[s][1]);
-                s0[s] = softplus(fv[s][0]) + p.var_bias; s1[s] = softplus(fv[s][1]) + p.var_bias;
-            }
-            layer_fwd<L_DA1, NS, ACT_ELU>(W2, lane, p_da1, fray, none, h1, p_da2);
-            layer_fwd<L_DA2, NS, ACT_ELU>(W2, lane, p_da2, h1, none, h2, p_fa);
-            if constexpr (HAS_VIS) {
-                LayerPre<L_DS1> p_ds1; LayerPre<L_DS2> p_ds2; VecPre<L_DFIN_S> p_fs;
-                float fs[NS][1];
-                layer_vec<L_DFIN_A, NS>(p_fa, h2, fa);
-                const LdsW W2s = phase_enter<PH_DIST_S, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-                layer_prefetch<L_DS1>(W2s, lane, p_ds1);
-                layer_fwd<L_DS1, NS, ACT_ELU>(W2s, lane, p_ds1, fray, none, h1, p_ds2);
-                layer_fwd<L_DS2, NS, ACT_ELU>(W2s, lane, p_ds2, h1, none, h2, p_fs);
-                layer_vec<L_DFIN_S, NS>(p_fs, h2, fs);
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = sigmoidf(fs[s][0]); }
-            } else {
-                layer_vec<L_DFIN_A, NS>(p_fa, h2, fa);
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = 1.0f; }
-            }
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                const int t = s % NT;
-                float v_, h_;
-                logistic_prob(tref[s], lo[t], hi[t], mu0[s], mu1[s], s0[s], s1[s], aw[s], nu[s], use_vis && HAS_VIS, v_, h_);
-                vis[s] = v_ * mask[s]; hit[s] = h_ * mask[s];
-                const int vraw = wave * VPW + s / NT;
-                if constexpr (SAVE) {
-                    if (g == 0 && vraw < p.rfn && vraw < 8) {
-                        float* d_ = p.saved + (size_t)(base / 16 + t) * kSavedTileFloats + kSavedDist + vraw * 128 + c;
-                        d_[0] = mu0[s]; d_[16] = mu1[s]; d_[32] = s0[s]; d_[48] = s1[s]; d_[64] = aw[s]; d_[80] = nu[s];
-                    }
-                }
-                if (dbg_lane && pvalid[t] && vraw < p.rfn) {
-                    float* d_ = p.dbg + ((size_t)pidx[t] * p.rfn + vraw) * kDbgFields;
-                    d_[4] = hit[s]; d_[5] = vis[s]; d_[6] = mu0[s]; d_[7] = mu1[s]; d_[8] = s0[s]; d_[9] = s1[s];
-                    d_[10] = aw[s]; d_[11] = nu[s];
-                }
-            }
-        }
 
-        // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
-        const LdsW W3 = phase_enter<PH_EMBED, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-        float e[NS][8];
-        NoLayer last;
-        LayerPre<L_PE1> p_pe1; LayerPre<L_PE2> p_pe2; LayerPre<L_RD1> p_rd1; LayerPre<L_RD2> p_rd2;
-        LayerPre<L_NF1> p_nf1; VecPre<L_RD2> p_rd2v; VecPre<L_NF2> p_nf2;
-        layer_prefetch<L_PE1>(W3, lane, p_pe1);
-        {
-            float x1[NS][1], h[NS][8];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                x1[s][0] = sel4(g, (hit[s] - 0.5f) * 2.0f, (vis[s] - 0.5f) * 2.0f, 0.0f, 0.0f);
-            layer_fwd<L_PE1, NS, ACT_RELU>(W3, lane, p_pe1, fray, x1, h, p_pe2);
-            layer_fwd<L_PE2, NS, ACT_NONE>(W3, lane, p_pe2, h, none, e, p_rd1);
-        }
-        // ---------------- ray_dir_fc, rgb_feat + direction_feat     ibrnet.py:324-327 -----------------
-        float gi[NS][8], gr[NS][3];
-        {
-            float x1[NS][1], h[NS][4], df[NS][8], dc[NS][3];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) x1[s][0] = sel4(g, dlt[s][0], dlt[s][1], dlt[s][2], dlt[s][3]);
-            layer_fwd<L_RD1, NS, ACT_ELU>(W3, lane, p_rd1, none, x1, h, p_rd2);
-            layer_prefetch<L_RD2>(W3, lane, p_rd2v);
-            layer_fwd<L_RD2, NS, ACT_ELU>(W3, lane, p_rd2, h, none, df, last);
-            layer_vec<L_RD2, NS>(p_rd2v, h, dc);          // the three rgb rows of ray_dir_fc.2
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) gi[s][k] = fimg[s][k] + df[s][k];
-                NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) gr[s][j] = rgb[s][j] + elu(dc[s][j]);
-            }
-        }
-        // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
-        // (this phase also holds base_fc.0's per-view rows 0..31, used after the statistics below)
-        const LdsW W4 = phase_enter<PH_NF_BV0, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-        float sn[NS];
-        {
-            float h[NS][4], o[NS][1];
-            layer_prefetch<L_NF1>(W4, lane, p_nf1);
-            layer_fwd<L_NF1, NS, ACT_ELU>(W4, lane, p_nf1, e, none, h, p_nf2);
-            layer_vec<L_NF2, NS>(p_nf2, h, o);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) sn[s] = sigmoidf(o[s][0]);
-        }
-        // ---------------- cross-view weighted mean / variance       ibrnet.py:334-340 ---------------------
-        // Each statistic is all-reduced over the views and immediately consumed by the owner waves as a K-slice of
-        // base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
-        float msum[NT], wv[NS];
-        v4f accv[NS][4];
-        {
-            v4f accg[OWN][NT];
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < OWN; ++j) {
-                const int mo = wave + j * nw;
-                const float4 b = wld4(W, gg * 16, (bias_offset(L_BG) + (mo < 4 ? mo : 0) * 16) * 4);
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) { accg[j][t][0] = b.x; accg[j][t][1] = b.y; accg[j][t][2] = b.z; accg[j][t][3] = b.w; }
-            }
-            float part[NS][11], st[NT * 11], sv[NT * 11], wk[NS];
-            {   // k = 0, first all-reduce: sum(mask) rides along with the un-normalised weighted sum
-                //   weight = mask / (sum(mask) + 1e-8), weight0 = sigmoid(neuray_fc) * weight, mean0 = sum(x * weight0)
-                //   is evaluated as sum(x * sigmoid * mask) / (sum(mask) + 1e-8)
-                float p12[NS][12], o12[NT * 12];
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) {
-                    const float w_ = sn[s] * mask[s];
-                    NR_PRAGMA_UNROLL
-                    for (int q = 0; q < 8; ++q) p12[s][q] = gi[s][q] * w_;
-                    NR_PRAGMA_UNROLL
-                    for (int j = 0; j < 3; ++j) p12[s][8 + j] = gr[s][j] * w_;
-                    p12[s][11] = mask[s];
+            // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
+            float hit[NA1], vis[NA1];
+            {
+                float h1[NA1][8], h2[NA1][8], fm[NA1][2], fv[NA1][2], fa[NA1][1];
+                float mu0[NA1], mu1[NA1], s0[NA1], s1[NA1], aw[NA1], nu[NA1];
+                LayerPre<L_DV2> p_dv2; VecPre<L_DFIN_V> p_fv;
+                const LdsW W1 = phase_enter<PH_DIST_M, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                if constexpr (NA > 0) {
+                    LayerPre<L_DM1> p_dm1; LayerPre<L_DM2> p_dm2; LayerPre<L_DV1> p_dv1; VecPre<L_DFIN_M> p_fm;
+                    layer_prefetch<L_DM1>(W1, lane, p_dm1);
+                    layer_fwd<L_DM1, NA, ACT_ELU>(W1, lane, p_dm1, fray, none, h1, p_dm2);
+                    layer_fwd<L_DM2, NA, ACT_ELU>(W1, lane, p_dm2, h1, none, h2, p_fm);
+                    layer_prefetch<L_DV1>(W1, lane, p_dv1);
+                    layer_vec<L_DFIN_M, NA>(p_fm, h2, fm);
+                    layer_fwd<L_DV1, NA, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, last);
                 }
-                view_allreduce<NT, VPW, 12, RMAX, RED_SUM>(p12, o12, red, wave, nw, lane);
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) {
-                    msum[t] = o12[t * 12 + 11];
-                    const float inv = nr_fast_rcp(msum[t] + 1e-8f);
+                const LdsW W2 = phase_enter<PH_DIST_VA, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                if constexpr (NA > 0) {
+                    LayerPre<L_DA1> p_da1; LayerPre<L_DA2> p_da2; VecPre<L_DFIN_A> p_fa;
+                    layer_prefetch<L_DV2>(W2, lane, p_dv2);
+                    layer_fwd<L_DV2, NA, ACT_ELU>(W2, lane, p_dv2, h1, none, h2, p_fv);
+                    layer_prefetch<L_DA1>(W2, lane, p_da1);
+                    layer_vec<L_DFIN_V, NA>(p_fv, h2, fv);
                     NR_PRAGMA_UNROLL
-                    for (int q = 0; q < 11; ++q) st[t * 11 + q] = o12[t * 12 + q] * inv;
-                }
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) wv[s] = mask[s] * nr_fast_rcp(msum[s % NT] + 1e-8f);
-                if constexpr (SAVE) {
-                    if (wave == 0) {
-                        NR_PRAGMA_UNROLL
-                        for (int t = 0; t < NT; ++t) p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + kSavedMsumRow * 64 + lane] = msum[t];
+                    for (int s = 0; s < NA; ++s) {
+                        mu0[s] = softplus(fm[s][0]); mu1[s] = softplus(fm[s][1]);
+                        s0[s] = softplus(fv[s][0]) + p.var_bias; s1[s] = softplus(fv[s][1]) + p.var_bias;
                     }
+                    layer_fwd<L_DA1, NA, ACT_ELU>(W2, lane, p_da1, fray, none, h1, p_da2);
+                    layer_fwd<L_DA2, NA, ACT_ELU>(W2, lane, p_da2, h1, none, h2, p_fa);
+                    layer_vec<L_DFIN_A, NA>(p_fa, h2, fa);
                 }
-            }
-            // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0 ;  k = 1: weight -> mean1, var1
-            NR_PRAGMA_UNROLL
-            for (int k = 0; k < 2; ++k) {
-                NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) wk[s] = k == 0 ? sn[s] * wv[s] : wv[s];
-                if (k == 1) {
-                    NR_PRAGMA_UNROLL
-                    for (int s = 0; s < NS; ++s) {
+                if constexpr (HAS_VIS) {
+                    const LdsW W2s = phase_enter<PH_DIST_S, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                    if constexpr (NA > 0) {
+                        LayerPre<L_DS1> p_ds1; LayerPre<L_DS2> p_ds2; VecPre<L_DFIN_S> p_fs;
+                        float fs[NA][1];
+                        layer_prefetch<L_DS1>(W2s, lane, p_ds1);
+                        layer_fwd<L_DS1, NA, ACT_ELU>(W2s, lane, p_ds1, fray, none, h1, p_ds2);
+                        layer_fwd<L_DS2, NA, ACT_ELU>(W2s, lane, p_ds2, h1, none, h2, p_fs);
+                        layer_vec<L_DFIN_S, NA>(p_fs, h2, fs);
                         NR_PRAGMA_UNROLL
-                        for (int q = 0; q < 8; ++q) part[s][q] = gi[s][q] * wk[s];
-                        NR_PRAGMA_UNROLL
-                        for (int j = 0; j < 3; ++j) part[s][8 + j] = gr[s][j] * wk[s];
+                        for (int s = 0; s < NA; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = sigmoidf(fs[s][0]); }
                     }
-                    view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, st, red, wave, nw, lane);
+                } else {
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = 1.0f; }
                 }
                 NR_PRAGMA_UNROLL
-                for (int s = 0; s < NS; ++s) {
-                    const int t = s % NT;
-                    NR_PRAGMA_UNROLL
-                    for (int q = 0; q < 8; ++q) { const float d_ = gi[s][q] - st[t * 11 + q]; part[s][q] = wk[s] * (d_ * d_); }
-                    NR_PRAGMA_UNROLL
-                    for (int j = 0; j < 3; ++j) { const float d_ = gr[s][j] - st[t * 11 + 8 + j]; part[s][8 + j] = wk[s] * (d_ * d_); }
-                }
-                if (k == 0) bg_accumulate<NT, OWN, 0>(W, glane, g, wave, nw, st, accg);
-                else bg_accumulate<NT, OWN, 2>(W, glane, g, wave, nw, st, accg);
-                view_allreduce<NT, VPW, 11, RMAX, RED_SUM>(part, sv, red, wave, nw, lane);
-                if (k == 0) bg_accumulate<NT, OWN, 1>(W, glane, g, wave, nw, sv, accg);
-                else bg_accumulate<NT, OWN, 3>(W, glane, g, wave, nw, sv, accg);
-                if constexpr (SAVE) {                          // every wave holds the statistics: wave 2k % nw writes the mean, (2k + 1) % nw the variance
-                    NR_PRAGMA_UNROLL
-                    for (int t = 0; t < NT; ++t) {
-                        float* d_ = p.saved + (size_t)(base / 16 + t) * kSavedTileFloats + (kSavedStatRow + 22 * k) * 64 + lane;
-                        if (wave == (2 * k) % nw) {
-                            NR_PRAGMA_UNROLL
-                            for (int q = 0; q < 11; ++q) d_[q * 64] = st[t * 11 + q];
-                        }
-                        if (wave == (2 * k + 1) % nw) {
-                            NR_PRAGMA_UNROLL
-                            for (int q = 0; q < 11; ++q) d_[(11 + q) * 64] = sv[t * 11 + q];
-                        }
-                    }
-                }
-            }
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < OWN; ++j) {
-                const int mo = wave + j * nw;
-                if (mo < 4) {
-                    NR_PRAGMA_UNROLL
-                    for (int t = 0; t < NT; ++t)
-                        NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = accg[j][t][r];
+                for (int s = 0; s < NA; ++s) {
+                    float v_, h_;
+                    logistic_prob(tref[s], lo, hi, mu0[s], mu1[s], s0[s], s1[s], aw[s], nu[s], use_vis && HAS_VIS, v_, h_);
+                    vis[s] = v_ * mask[s]; hit[s] = h_ * mask[s];
+                    const int vraw = wave_t * VPW + s;
                     if constexpr (SAVE) {
+                        if (g == 0 && vraw < p.rfn && vraw < 8) {
+                            float* d_ = p.saved + (size_t)(base / 16) * kSavedTileFloats + kSavedDist + vraw * 128 + c;
+                            d_[0] = mu0[s]; d_[16] = mu1[s]; d_[32] = s0[s]; d_[48] = s1[s]; d_[64] = aw[s]; d_[80] = nu[s];
+                        }
+                    }
+                    if (dbg_lane && pvalid && vraw < p.rfn) {
+                        float* d_ = p.dbg + ((size_t)pidx * p.rfn + vraw) * kDbgFields;
+                        d_[4] = hit[s]; d_[5] = vis[s]; d_[6] = mu0[s]; d_[7] = mu1[s]; d_[8] = s0[s]; d_[9] = s1[s];
+                        d_[10] = aw[s]; d_[11] = nu[s];
+                    }
+                }
+            }
+
+            // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
+            const LdsW W3 = phase_enter<PH_EMBED, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+            float e[NA1][8], gi[NA1][8], gr[NA1][3], sn[NA1];
+            LayerPre<L_NF1> p_nf1; VecPre<L_NF2> p_nf2;
+            if constexpr (NA > 0) {
+                LayerPre<L_PE1> p_pe1; LayerPre<L_RD1> p_rd1; LayerPre<L_RD2> p_rd2; VecPre<L_RD2> p_rd2v;
+                layer_prefetch<L_PE1>(W3, lane, p_pe1);
+                {
+                    float x1[NA][1];
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        x1[s][0] = sel4(g, (hit[s] - 0.5f) * 2.0f, (vis[s] - 0.5f) * 2.0f, 0.0f, 0.0f);
+                    if (folded) {
+                        // prob_embed.2 lives inside neuray_fc.0 / base_fc.0 of this pack: their input is the ReLU output itself
+                        layer_fwd<L_PE1, NA, ACT_RELU>(W3, lane, p_pe1, fray, x1, e, p_rd1);
+                    } else {
+                        float h[NA][8];
+                        LayerPre<L_PE2> p_pe2;
+                        layer_fwd<L_PE1, NA, ACT_RELU>(W3, lane, p_pe1, fray, x1, h, p_pe2);
+                        layer_fwd<L_PE2, NA, ACT_NONE>(W3, lane, p_pe2, h, none, e, p_rd1);
+                    }
+                }
+                // ---------------- ray_dir_fc, rgb_feat + direction_feat     ibrnet.py:324-327 -----------------
+                {
+                    float x1[NA][1], h[NA][4], df[NA][8], dc[NA][3];
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) x1[s][0] = sel4(g, dlt[s][0], dlt[s][1], dlt[s][2], dlt[s][3]);
+                    layer_fwd<L_RD1, NA, ACT_ELU>(W3, lane, p_rd1, none, x1, h, p_rd2);
+                    layer_prefetch<L_RD2>(W3, lane, p_rd2v);
+                    layer_fwd<L_RD2, NA, ACT_ELU>(W3, lane, p_rd2, h, none, df, last);
+                    layer_vec<L_RD2, NA>(p_rd2v, h, dc);          // the three rgb rows of ray_dir_fc.2
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
                         NR_PRAGMA_UNROLL
-                        for (int t = 0; t < NT; ++t)
+                        for (int k = 0; k < 8; ++k) gi[s][k] = fimg[s][k] + df[s][k];
+                        NR_PRAGMA_UNROLL
+                        for (int j = 0; j < 3; ++j) gr[s][j] = rgb[s][j] + elu(dc[s][j]);
+                    }
+                }
+            }
+            // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
+            // (this phase also holds base_fc.0's per-view rows 0..31, used after the statistics below)
+            const LdsW W4 = phase_enter<PH_NF_BV0, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+            if constexpr (NA > 0) {
+                float h[NA][4], o[NA][1];
+                layer_prefetch<L_NF1>(W4, lane, p_nf1);
+                layer_fwd<L_NF1, NA, ACT_ELU>(W4, lane, p_nf1, e, none, h, p_nf2);
+                layer_vec<L_NF2, NA>(p_nf2, h, o);
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s) sn[s] = sigmoidf(o[s][0]);
+            }
+            // ---------------- cross-view weighted mean / variance       ibrnet.py:334-340 ---------------------
+            // Each statistic is all-reduced over the views and immediately consumed by the owner waves as a K-slice of
+            // base_fc.0's per-point part (columns 0..139), so the four 35-vectors never coexist.
+            float msum, wv[NA1];
+            v4f accv[NA1][4];
+            {
+                v4f accg[OWN][1];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < OWN; ++j) {
+                    const int mo = wave_t + j * nw;
+                    const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_BG) * 4);      // (run-time tile index in the lane offset: see layer_tile_slice)
+                    accg[j][0][0] = b.x; accg[j][0][1] = b.y; accg[j][0][2] = b.z; accg[j][0][3] = b.w;
+                }
+                float part[NA1][11], st[11], sv[11], wk[NA1];
+                {   // k = 0, first all-reduce: sum(mask) rides along with the un-normalised weighted sum
+                    //   weight = mask / (sum(mask) + 1e-8), weight0 = sigmoid(neuray_fc) * weight, mean0 = sum(x * weight0)
+                    //   is evaluated as sum(x * sigmoid * mask) / (sum(mask) + 1e-8)
+                    float p12[NA1][12], o12[12];
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
+                        const float w_ = sn[s] * mask[s];
+                        NR_PRAGMA_UNROLL
+                        for (int q = 0; q < 8; ++q) p12[s][q] = gi[s][q] * w_;
+                        NR_PRAGMA_UNROLL
+                        for (int j = 0; j < 3; ++j) p12[s][8 + j] = gr[s][j] * w_;
+                        p12[s][11] = mask[s];
+                    }
+                    view_allreduce<NA, IDLE, 12, RMAX, RED_SUM>(p12, o12, red, wave_t, nw, lane);
+                    msum = o12[11];
+                    const float inv = nr_fast_rcp(msum + 1e-8f);
+                    NR_PRAGMA_UNROLL
+                    for (int q = 0; q < 11; ++q) st[q] = o12[q] * inv;
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) wv[s] = mask[s] * nr_fast_rcp(msum + 1e-8f);
+                    if constexpr (SAVE) {
+                        if (wave_t == 0) p.saved[(size_t)(base / 16) * kSavedTileFloats + kSavedMsumRow * 64 + lane] = msum;
+                    }
+                }
+                // k = 0: weight0 = sigmoid(neuray_fc) * weight  -> mean0, var0 ;  k = 1: weight -> mean1, var1
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 2; ++k) {
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) wk[s] = k == 0 ? sn[s] * wv[s] : wv[s];
+                    if (k == 1) {
+                        NR_PRAGMA_UNROLL
+                        for (int s = 0; s < NA; ++s) {
+                            NR_PRAGMA_UNROLL
+                            for (int q = 0; q < 8; ++q) part[s][q] = gi[s][q] * wk[s];
+                            NR_PRAGMA_UNROLL
+                            for (int j = 0; j < 3; ++j) part[s][8 + j] = gr[s][j] * wk[s];
+                        }
+                        view_allreduce<NA, IDLE, 11, RMAX, RED_SUM>(part, st, red, wave_t, nw, lane);
+                    }
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
+                        NR_PRAGMA_UNROLL
+                        for (int q = 0; q < 8; ++q) { const float d_ = gi[s][q] - st[q]; part[s][q] = wk[s] * (d_ * d_); }
+                        NR_PRAGMA_UNROLL
+                        for (int j = 0; j < 3; ++j) { const float d_ = gr[s][j] - st[8 + j]; part[s][8 + j] = wk[s] * (d_ * d_); }
+                    }
+                    if (k == 0) bg_accumulate<NT, OWN, 0>(W, glane, g, wave_t, nw, st, accg);
+                    else bg_accumulate<NT, OWN, 2>(W, glane, g, wave_t, nw, st, accg);
+                    view_allreduce<NA, IDLE, 11, RMAX, RED_SUM>(part, sv, red, wave_t, nw, lane);
+                    if (k == 0) bg_accumulate<NT, OWN, 1>(W, glane, g, wave_t, nw, sv, accg);
+                    else bg_accumulate<NT, OWN, 3>(W, glane, g, wave_t, nw, sv, accg);
+                    if constexpr (SAVE) {                          // every wave_t holds the statistics: wave_t 2k % nw writes the mean, (2k + 1) % nw the variance
+                        float* d_ = p.saved + (size_t)(base / 16) * kSavedTileFloats + (kSavedStatRow + 22 * k) * 64 + lane;
+                        if (wave_t == (2 * k) % nw) {
+                            NR_PRAGMA_UNROLL
+                            for (int q = 0; q < 11; ++q) d_[q * 64] = st[q];
+                        }
+                        if (wave_t == (2 * k + 1) % nw) {
+                            NR_PRAGMA_UNROLL
+                            for (int q = 0; q < 11; ++q) d_[(11 + q) * 64] = sv[q];
+                        }
+                    }
+                }
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < OWN; ++j) {
+                    const int mo = wave_t + j * nw;
+                    if (mo < 4) {
+                        NR_PRAGMA_UNROLL
+                        for (int r = 0; r < 4; ++r) xch[(mo * 4 + r) * 64 + lane] = accg[j][0][r];
+                        if constexpr (SAVE) {
                             NR_PRAGMA_UNROLL
                             for (int r = 0; r < 4; ++r)
-                                p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedBgRow + mo * 4 + r) * 64 + lane] = accg[j][t][r];
+                                p.saved[(size_t)(base / 16) * kSavedTileFloats + (kSavedBgRow + mo * 4 + r) * 64 + lane] = accg[j][0][r];
+                        }
+                    }
+                }
+                NR_BLOCK_SYNC();
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s)
+                    NR_PRAGMA_UNROLL
+                    for (int mo = 0; mo < 4; ++mo)
+                        NR_PRAGMA_UNROLL
+                        for (int r = 0; r < 4; ++r) accv[s][mo][r] = xch[(mo * 4 + r) * 64 + lane];
+            }
+            // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
+            float x[NA1][8], vis2[NA1], z[NA1];
+            LdsW W5;
+            LayerPre<L_VF1> p_vf1;
+            {
+                float xq[NA1][16], x1[NA1][1], h64[NA1][16];
+                LayerPre<L_BV0> p_bv0; LayerPre<L_BV1> p_bv1; LayerPre<L_B2> p_b2;
+                v4f acch[NA1][2];
+                if constexpr (NA > 0) {
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) { xq[s][k] = gi[s][k]; xq[s][8 + k] = e[s][k]; }
+                        x1[s][0] = sel4(g, gr[s][0], gr[s][1], gr[s][2], 0.0f);
+                    }
+                    layer_prefetch<L_BV0>(W4, lane, p_bv0);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) { acch[s][0] = accv[s][0]; acch[s][1] = accv[s][1]; }
+                    layer_acc<L_BV0, NA>(W4, lane, p_bv0, xq, x1, acch, last);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        NR_PRAGMA_UNROLL
+                        for (int mo = 0; mo < 2; ++mo)
+                            NR_PRAGMA_UNROLL
+                            for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV0]
+                }
+                const LdsW W4b = phase_enter<PH_BV1, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                if constexpr (NA > 0) {
+                    layer_prefetch<L_BV1>(W4b, lane, p_bv1);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) { acch[s][0] = accv[s][2]; acch[s][1] = accv[s][3]; }
+                    layer_acc<L_BV1, NA>(W4b, lane, p_bv1, xq, x1, acch, last);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        NR_PRAGMA_UNROLL
+                        for (int mo = 0; mo < 2; ++mo)
+                            NR_PRAGMA_UNROLL
+                            for (int r = 0; r < 4; ++r) h64[s][8 + 4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV1]
+                }
+                W5 = phase_enter<PH_B2_VF1, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                if constexpr (NA > 0) {
+                    layer_prefetch<L_B2>(W5, lane, p_b2);
+                    layer_fwd<L_B2, NA, ACT_ELU>(W5, lane, p_b2, h64, none, x, p_vf1);
+                }
+            }
+            {
+                float xin[NA1][8], h[NA1][8];
+                if constexpr (NA > 0) {
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) xin[s][k] = x[s][k] * wv[s];
+                    layer_fwd<L_VF1, NA, ACT_ELU>(W5, lane, p_vf1, xin, none, h, last);
+                }
+                W5 = phase_enter<PH_TAIL, HAS_VIS>(wl, W, seq0, more, wave_t, nw, lane);
+                if constexpr (NA > 0) {
+                    float y[NA][8], yv[NA][1], o[NA][1];
+                    LayerPre<L_VF2> p_vf2; LayerPre<L_V21> p_v21; LayerPre<L_RF1> p_rf1; LayerPre<L_RF2> p_rf2;
+                    VecPre<L_VF2> p_vf2v; VecPre<L_V22> p_v22; VecPre<L_RF3> p_rf3;
+                    layer_prefetch<L_VF2>(W5, lane, p_vf2);
+                    layer_prefetch<L_VF2>(W5, lane, p_vf2v);
+                    layer_fwd<L_VF2, NA, ACT_ELU>(W5, lane, p_vf2, h, none, y, p_v21);
+                    layer_vec<L_VF2, NA>(p_vf2v, h, yv);          // row 32: the visibility logit
+                    float visp[NA];
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
+                        visp[s] = sigmoidf(elu(yv[s][0])) * mask[s];      // sigmoid on an ELU output: quirk A.9.4
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) { x[s][k] = x[s][k] + y[s][k]; xin[s][k] = x[s][k] * visp[s]; }
+                    }
+                    layer_fwd<L_V21, NA, ACT_ELU>(W5, lane, p_v21, xin, none, h, p_v22);
+                    layer_prefetch<L_RF1>(W5, lane, p_rf1);
+                    layer_vec<L_V22, NA>(p_v22, h, o);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) vis2[s] = sigmoidf(o[s][0]) * mask[s];
+                    float x1[NA][2], h16[NA][4], h8[NA][4];
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
+                        x1[s][0] = sel4(g, vis2[s], dlt[s][0], dlt[s][1], dlt[s][2]);
+                        x1[s][1] = sel4(g, dlt[s][3], 0.0f, 0.0f, 0.0f);
+                    }
+                    layer_fwd<L_RF1, NA, ACT_ELU>(W5, lane, p_rf1, x, x1, h16, p_rf2);
+                    layer_fwd<L_RF2, NA, ACT_ELU>(W5, lane, p_rf2, h16, none, h8, p_rf3);
+                    layer_vec<L_RF3, NA>(p_rf3, h8, o);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s) {
+                        z[s] = mask[s] > 0.0f ? o[s][0] : -1e9f;
+                        const int vraw = wave_t * VPW + s;
+                        if (dbg_lane && pvalid && vraw < p.rfn) {
+                            float* d_ = p.dbg + ((size_t)pidx * p.rfn + vraw) * kDbgFields;
+                            d_[12] = sn[s]; d_[13] = visp[s]; d_[14] = vis2[s]; d_[15] = z[s];
+                        }
+                    }
+                }
+            }
+            // ---------------- cross-view: blending softmax, visibility-weighted mean/var  ibrnet.py:350-367 ---
+            // Two all-reduces: {max z, sum vis''} and {sum wh x (8), sum e (1), sum e rgb (3)} with e = exp(z - max z); the
+            // softmax blend sum(rgb * e / sum e) is evaluated as sum(rgb * e) / sum(e), the mean weight sum(wh) / rfn from
+            // sum(vis'') directly.
+            constexpr int ZR = SAVE ? 3 : 2;                       // (training: sum of weight0 = sn * weight rides along for the backward)
+            float zv[ZR], big[12], wh[NA1], meanw;
+            {
+                float z2[NA1][ZR];
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s) {
+                    z2[s][0] = z[s]; z2[s][1] = vis2[s];
+                    if constexpr (SAVE) z2[s][2] = sn[s] * wv[s];
+                }
+                view_allreduce<NA, IDLE, ZR, RMAX, RED_MAX0>(z2, zv, red, wave_t, nw, lane);
+                float b12[NA1][12];
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s) {
+                    const float ev = nr_fast_exp(z[s] - zv[0]);
+                    wh[s] = vis2[s] * nr_fast_rcp(zv[1] + 1e-8f);
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 8; ++k) b12[s][k] = x[s][k] * wh[s];
+                    b12[s][8] = ev;
+                    NR_PRAGMA_UNROLL
+                    for (int j = 0; j < 3; ++j) b12[s][9 + j] = rgb[s][j] * ev;
+                }
+                if constexpr (IDLE > 0) {
+                    // the softmax terms of the skipped slots: exp(-1e9 - max z) each (0, or 1 where every view of the point is masked: the
+                    // uniform softmax over zero colours of the reference); their colour / feature products are zeros
+                    const float ev_idle = nr_fast_exp(-1e9f - zv[0]);
+                    if constexpr (NA == 0) {
+                        NR_PRAGMA_UNROLL
+                        for (int q = 0; q < 12; ++q) b12[0][q] = 0.0f;
+                        float acc_ = ev_idle;
+                        NR_PRAGMA_UNROLL
+                        for (int i = 1; i < IDLE; ++i) acc_ += ev_idle;
+                        b12[0][8] = acc_;
+                        view_allreduce<1, 0, 12, RMAX, RED_SUM>(b12, big, red, wave_t, nw, lane);
+                    } else {
+                        NR_PRAGMA_UNROLL
+                        for (int i = 0; i < IDLE; ++i) b12[NA - 1][8] += ev_idle;
+                        view_allreduce<NA, 0, 12, RMAX, RED_SUM>(b12, big, red, wave_t, nw, lane);
+                    }
+                } else {
+                    view_allreduce<NA, 0, 12, RMAX, RED_SUM>(b12, big, red, wave_t, nw, lane);
+                }
+                {
+                    const float ie = nr_fast_rcp(big[8]);
+                    big[9] *= ie; big[10] *= ie; big[11] *= ie;
+                    meanw = zv[1] * nr_fast_rcp(zv[1] + 1e-8f);
+                }
+                if constexpr (SAVE) {
+                    float* d_ = p.saved + (size_t)(base / 16) * kSavedTileFloats + lane;
+                    if (wave_t == 0) {
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) d_[(kSavedGmeanRow + k) * 64] = big[k];
+                    }
+                    if (wave_t == 2 % nw) {
+                        d_[kSavedZmaxRow * 64] = zv[0]; d_[kSavedSezRow * 64] = big[8];
+                        d_[kSavedSvisRow * 64] = zv[1]; d_[kSavedSw0Row * 64] = zv[ZR - 1];
+                    }
+                }
+            }
+            // geometry_fc.0 (a14): owner waves stream the mean part, then the variance part   ibrnet.py:353-354
+            v4f accf[OWN][1];
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < OWN; ++j) {
+                const int mo = wave_t + j * nw;
+                const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_GF1) * 4);
+                accf[j][0][0] = b.x; accf[j][0][1] = b.y; accf[j][0][2] = b.z; accf[j][0][3] = b.w;
+            }
+            float var[8];
+            {
+                float xq[1][8], x1[1][1], v8[NA1][8];
+                NR_PRAGMA_UNROLL
+                for (int s = 0; s < NA; ++s)
+                    NR_PRAGMA_UNROLL
+                    for (int k = 0; k < 8; ++k) { const float d_ = x[s][k] - big[k]; v8[s][k] = wh[s] * (d_ * d_); }
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 8; ++k) xq[0][k] = big[k];
+                x1[0][0] = sel4(g, meanw * inv_rfn, 0.0f, 0.0f, 0.0f);
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < OWN; ++j) {
+                    const int mo = wave_t + j * nw;
+                    if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
+                }
+                view_allreduce<NA, IDLE, 8, RMAX, RED_SUM>(v8, var, red, wave_t, nw, lane);
+                if constexpr (SAVE) {
+                    if (wave_t == 1 % nw) {
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) p.saved[(size_t)(base / 16) * kSavedTileFloats + (kSavedGvarRow + k) * 64 + lane] = var[k];
+                    }
+                }
+            }
+            {
+                float xq[1][8], nonet[1][1];
+                nonet[0][0] = 0.0f;
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 8; ++k) xq[0][k] = var[k];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < OWN; ++j) {
+                    const int mo = wave_t + j * nw;
+                    if (mo < 4) {
+                        layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
+                        NR_PRAGMA_UNROLL
+                        for (int r = 0; r < 4; ++r) xch[(mo * 4 + r) * 64 + lane] = elu_s(accf[j][0][r]);   // kOutScaled[L_GF1]
+                        if constexpr (SAVE) {
+                            NR_PRAGMA_UNROLL
+                            for (int r = 0; r < 4; ++r)
+                                p.saved[(size_t)(base / 16) * kSavedTileFloats + (kSavedGeoRow + mo * 4 + r) * 64 + lane] = elu_s(accf[j][0][r]);
+                        }
                     }
                 }
             }
             NR_BLOCK_SYNC();
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
+            if (wave_t == 0) {
+                float h[1][16], G[1][4], nonet[1][1];
+                nonet[0][0] = 0.0f;
                 NR_PRAGMA_UNROLL
-                for (int mo = 0; mo < 4; ++mo)
+                for (int k = 0; k < 16; ++k) h[0][k] = xch[((k >> 2) * 4 + (k & 3)) * 64 + lane];
+                layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, h, nonet, G);
+                if (pvalid)
+                    *reinterpret_cast<float4*>(p.point_out + (size_t)pidx * kPointRec + 4 * g) = make_float4(G[0][0], G[0][1], G[0][2], G[0][3]);
+                if constexpr (SAVE) {
                     NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) accv[s][mo][r] = xch[((mo * NT + s % NT) * 4 + r) * 64 + lane];
-        }
-        // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
-        float x[NS][8], vis2[NS], z[NS];
-        LdsW W5;
-        LayerPre<L_VF1> p_vf1;
-        {
-            float xq[NS][16], x1[NS][1], h64[NS][16];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) { xq[s][k] = gi[s][k]; xq[s][8 + k] = e[s][k]; }
-                x1[s][0] = sel4(g, gr[s][0], gr[s][1], gr[s][2], 0.0f);
-            }
-            LayerPre<L_BV0> p_bv0; LayerPre<L_BV1> p_bv1; LayerPre<L_B2> p_b2;
-            v4f acch[NS][2];
-            layer_prefetch<L_BV0>(W4, lane, p_bv0);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) { acch[s][0] = accv[s][0]; acch[s][1] = accv[s][1]; }
-            layer_acc<L_BV0, NS>(W4, lane, p_bv0, xq, x1, acch, last);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int mo = 0; mo < 2; ++mo)
-                    NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV0]
-            const LdsW W4b = phase_enter<PH_BV1, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-            layer_prefetch<L_BV1>(W4b, lane, p_bv1);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) { acch[s][0] = accv[s][2]; acch[s][1] = accv[s][3]; }
-            layer_acc<L_BV1, NS>(W4b, lane, p_bv1, xq, x1, acch, last);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int mo = 0; mo < 2; ++mo)
-                    NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) h64[s][8 + 4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV1]
-            W5 = phase_enter<PH_B2_VF1, HAS_VIS>(wl, W, seq0, true, wave, nw, lane);
-            layer_prefetch<L_B2>(W5, lane, p_b2);
-            layer_fwd<L_B2, NS, ACT_ELU>(W5, lane, p_b2, h64, none, x, p_vf1);
-        }
-        {
-            float xin[NS][8], h[NS][8], y[NS][8], yv[NS][1], o[NS][1];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) xin[s][k] = x[s][k] * wv[s];
-            LayerPre<L_VF2> p_vf2; LayerPre<L_V21> p_v21; LayerPre<L_RF1> p_rf1; LayerPre<L_RF2> p_rf2;
-            VecPre<L_VF2> p_vf2v; VecPre<L_V22> p_v22; VecPre<L_RF3> p_rf3;
-            layer_fwd<L_VF1, NS, ACT_ELU>(W5, lane, p_vf1, xin, none, h, last);
-            W5 = phase_enter<PH_TAIL, HAS_VIS>(wl, W, seq0, more, wave, nw, lane);
-            layer_prefetch<L_VF2>(W5, lane, p_vf2);
-            layer_prefetch<L_VF2>(W5, lane, p_vf2v);
-            layer_fwd<L_VF2, NS, ACT_ELU>(W5, lane, p_vf2, h, none, y, p_v21);
-            layer_vec<L_VF2, NS>(p_vf2v, h, yv);          // row 32: the visibility logit
-            float visp[NS];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                visp[s] = sigmoidf(elu(yv[s][0])) * mask[s];      // sigmoid on an ELU output: quirk A.9.4
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) { x[s][k] = x[s][k] + y[s][k]; xin[s][k] = x[s][k] * visp[s]; }
-            }
-            layer_fwd<L_V21, NS, ACT_ELU>(W5, lane, p_v21, xin, none, h, p_v22);
-            layer_prefetch<L_RF1>(W5, lane, p_rf1);
-            layer_vec<L_V22, NS>(p_v22, h, o);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) vis2[s] = sigmoidf(o[s][0]) * mask[s];
-            float x1[NS][2], h16[NS][4], h8[NS][4];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                x1[s][0] = sel4(g, vis2[s], dlt[s][0], dlt[s][1], dlt[s][2]);
-                x1[s][1] = sel4(g, dlt[s][3], 0.0f, 0.0f, 0.0f);
-            }
-            layer_fwd<L_RF1, NS, ACT_ELU>(W5, lane, p_rf1, x, x1, h16, p_rf2);
-            layer_fwd<L_RF2, NS, ACT_ELU>(W5, lane, p_rf2, h16, none, h8, p_rf3);
-            layer_vec<L_RF3, NS>(p_rf3, h8, o);
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                const int t = s % NT;
-                z[s] = mask[s] > 0.0f ? o[s][0] : -1e9f;
-                const int vraw = wave * VPW + s / NT;
-                if (dbg_lane && pvalid[t] && vraw < p.rfn) {
-                    float* d_ = p.dbg + ((size_t)pidx[t] * p.rfn + vraw) * kDbgFields;
-                    d_[12] = sn[s]; d_[13] = visp[s]; d_[14] = vis2[s]; d_[15] = z[s];
+                    for (int r = 0; r < 4; ++r) p.saved[(size_t)(base / 16) * kSavedTileFloats + (kSavedGRow + r) * 64 + lane] = G[0][r];
                 }
             }
-        }
-        // ---------------- cross-view: blending softmax, visibility-weighted mean/var  ibrnet.py:350-367 ---
-        // Two all-reduces: {max z, sum vis''} and {sum wh x (8), sum e (1), sum e rgb (3)} with e = exp(z - max z); the
-        // softmax blend sum(rgb * e / sum e) is evaluated as sum(rgb * e) / sum(e), the mean weight sum(wh) / rfn from
-        // sum(vis'') directly.
-        constexpr int ZR = SAVE ? 3 : 2;                       // (training: sum of weight0 = sn * weight rides along for the backward)
-        float zv[NT * ZR], big[NT * 12], wh[NS], meanw[NT];
-        {
-            float z2[NS][ZR];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                z2[s][0] = z[s]; z2[s][1] = vis2[s];
-                if constexpr (SAVE) z2[s][2] = sn[s] * wv[s];
+            if (wave_t == (nw > 1 ? 1 : 0) && g == 0) {
+                if (pvalid)
+                    *reinterpret_cast<float4*>(p.point_out + (size_t)pidx * kPointRec + 16) = make_float4(big[9], big[10], big[11], msum);
             }
-            view_allreduce<NT, VPW, ZR, RMAX, RED_MAX0>(z2, zv, red, wave, nw, lane);
-            float b12[NS][12];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s) {
-                const int t = s % NT;
-                const float ev = nr_fast_exp(z[s] - zv[ZR * t]);
-                wh[s] = vis2[s] * nr_fast_rcp(zv[ZR * t + 1] + 1e-8f);
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) b12[s][k] = x[s][k] * wh[s];
-                b12[s][8] = ev;
-                NR_PRAGMA_UNROLL
-                for (int j = 0; j < 3; ++j) b12[s][9 + j] = rgb[s][j] * ev;
-            }
-            view_allreduce<NT, VPW, 12, RMAX, RED_SUM>(b12, big, red, wave, nw, lane);
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                const float ie = nr_fast_rcp(big[t * 12 + 8]);
-                big[t * 12 + 9] *= ie; big[t * 12 + 10] *= ie; big[t * 12 + 11] *= ie;
-                meanw[t] = zv[ZR * t + 1] * nr_fast_rcp(zv[ZR * t + 1] + 1e-8f);
-            }
-            if constexpr (SAVE) {
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t) {
-                    float* d_ = p.saved + (size_t)(base / 16 + t) * kSavedTileFloats + lane;
-                    if (wave == 0) {
-                        NR_PRAGMA_UNROLL
-                        for (int k = 0; k < 8; ++k) d_[(kSavedGmeanRow + k) * 64] = big[t * 12 + k];
-                    }
-                    if (wave == 2 % nw) {
-                        d_[kSavedZmaxRow * 64] = zv[ZR * t]; d_[kSavedSezRow * 64] = big[t * 12 + 8];
-                        d_[kSavedSvisRow * 64] = zv[ZR * t + 1]; d_[kSavedSw0Row * 64] = zv[ZR * t + 2];
-                    }
-                }
-            }
-        }
-        // geometry_fc.0 (a14): owner waves stream the mean part, then the variance part   ibrnet.py:353-354
-        v4f accf[OWN][NT];
-        NR_PRAGMA_UNROLL
-        for (int j = 0; j < OWN; ++j) {
-            const int mo = wave + j * nw;
-            const float4 b = wld4(W, gg * 16, (bias_offset(L_GF1) + (mo < 4 ? mo : 0) * 16) * 4);
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) { accf[j][t][0] = b.x; accf[j][t][1] = b.y; accf[j][t][2] = b.z; accf[j][t][3] = b.w; }
-        }
-        float var[NT * 8];
-        {
-            float xq[NT][8], x1[NT][1], v8[NS][8];
-            NR_PRAGMA_UNROLL
-            for (int s = 0; s < NS; ++s)
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) { const float d_ = x[s][k] - big[(s % NT) * 12 + k]; v8[s][k] = wh[s] * (d_ * d_); }
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) xq[t][k] = big[t * 12 + k];
-                x1[t][0] = sel4(g, meanw[t] * inv_rfn, 0.0f, 0.0f, 0.0f);
-            }
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < OWN; ++j) {
-                const int mo = wave + j * nw;
-                if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
-            }
-            view_allreduce<NT, VPW, 8, RMAX, RED_SUM>(v8, var, red, wave, nw, lane);
-            if constexpr (SAVE) {
-                if (wave == 1 % nw) {
+        };
+
+        if constexpr (SKIP) {
+            const bool a0 = __ballot(mask[0] != 0.0f) != 0ull, a1 = __ballot(mask[1] != 0.0f) != 0ull;
+#ifdef NR_FORCE_NA          // timing probe (wrong results): every wave_t takes the NA-slot body
+#ifdef NR_FORCE_NA_CONST
+            const int na = NR_FORCE_NA;
+#else
+            const int na = NR_FORCE_NA + (p.rn < 0 ? (a0 ? 1 : 0) + (a1 ? 1 : 0) : 0);
+#endif
+#else
+            const int na = (a0 ? 1 : 0) + (a1 ? 1 : 0);
+#endif
+            n_active += na; n_slots += NS;
+            if (na == 2) {
+                tile(SlotCount<2>{});
+            } else if (na == 1) {
+                if (!a0) {          // the lone active slot becomes slot 0
+                    mask[0] = mask[1]; tref[0] = tref[1]; pu[0] = pu[1]; pv[0] = pv[1]; soff_f[0] = soff_f[1]; soff_c[0] = soff_c[1];
                     NR_PRAGMA_UNROLL
-                    for (int t = 0; t < NT; ++t)
-                        NR_PRAGMA_UNROLL
-                        for (int k = 0; k < 8; ++k) p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedGvarRow + k) * 64 + lane] = var[t * 8 + k];
+                    for (int k = 0; k < 4; ++k) dlt[0][k] = dlt[1][k];
                 }
+                tile(SlotCount<1>{});
+            } else {
+                tile(SlotCount<0>{});
             }
+        } else {
+            tile(SlotCount<NS>{});
         }
-        {
-            float xq[NT][8], nonet[NT][1];
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                nonet[t][0] = 0.0f;
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 8; ++k) xq[t][k] = var[t * 8 + k];
-            }
-            NR_PRAGMA_UNROLL
-            for (int j = 0; j < OWN; ++j) {
-                const int mo = wave + j * nw;
-                if (mo < 4) {
-                    layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
-                    NR_PRAGMA_UNROLL
-                    for (int t = 0; t < NT; ++t)
-                        NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) xch[((mo * NT + t) * 4 + r) * 64 + lane] = elu_s(accf[j][t][r]);   // kOutScaled[L_GF1]
-                    if constexpr (SAVE) {
-                        NR_PRAGMA_UNROLL
-                        for (int t = 0; t < NT; ++t)
-                            NR_PRAGMA_UNROLL
-                            for (int r = 0; r < 4; ++r)
-                                p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedGeoRow + mo * 4 + r) * 64 + lane] = elu_s(accf[j][t][r]);
-                    }
-                }
-            }
-        }
-        NR_BLOCK_SYNC();
-        if (wave == 0) {
-            float h[NT][16], G[NT][4], nonet[NT][1];
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                nonet[t][0] = 0.0f;
-                NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) h[t][k] = xch[(((k >> 2) * NT + t) * 4 + (k & 3)) * 64 + lane];
-            }
-            layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, h, nonet, G);
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
-                if (pvalid[t])
-                    *reinterpret_cast<float4*>(p.point_out + (size_t)pidx[t] * kPointRec + 4 * g) = make_float4(G[t][0], G[t][1], G[t][2], G[t][3]);
-            if constexpr (SAVE) {
-                NR_PRAGMA_UNROLL
-                for (int t = 0; t < NT; ++t)
-                    NR_PRAGMA_UNROLL
-                    for (int r = 0; r < 4; ++r) p.saved[(size_t)(base / 16 + t) * kSavedTileFloats + (kSavedGRow + r) * 64 + lane] = G[t][r];
-            }
-        }
-        if (wave == (nw > 1 ? 1 : 0) && g == 0) {
-            NR_PRAGMA_UNROLL
-            for (int t = 0; t < NT; ++t)
-                if (pvalid[t])
-                    *reinterpret_cast<float4*>(p.point_out + (size_t)pidx[t] * kPointRec + 16) =
-                        make_float4(big[t * 12 + 9], big[t * 12 + 10], big[t * 12 + 11], msum[t]);
+    }
+    if constexpr (SKIP) {
+        if (p.slot_stats && lane == 0) {
+            atomicAdd(p.slot_stats, (unsigned long long)n_active);
+            atomicAdd(p.slot_stats + 1, (unsigned long long)n_slots);
         }
     }
 }
@@ -877,7 +944,11 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                         float den = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
                         for (int j = 0; j < dn; ++j) {
                             const float4 kj = ld4(ks + j * 16 + hh * 4);
+#ifdef NR_RAY_PROBE_NOSCORE     // timing probe (wrong results): what the QK^T products cost at most
+                            const float s = q[hh * 4] * kj.x;
+#else
                             const float s = fmaf(q[hh * 4 + 3], kj.w, fmaf(q[hh * 4 + 2], kj.z, fmaf(q[hh * 4 + 1], kj.y, q[hh * 4] * kj.x)));
+#endif
                             const float e_ = nr_fast_exp(s - cb[hh]);
                             const float4 vj = ld4(vs + j * 16 + hh * 4);
                             den += e_; a0 = fmaf(e_, vj.x, a0); a1 = fmaf(e_, vj.y, a1); a2 = fmaf(e_, vj.z, a2); a3 = fmaf(e_, vj.w, a3);
@@ -993,6 +1064,8 @@ struct FineParams {
     const float* hit_prob;   // [rn][dn]
     const float* u;          // [rn][fdn] or null -> stratified (k + 0.5)/fdn
     float* out;              // [rn][nout], nout = fdn (+ dn when use_all)
+    int* idx_out;            // optional [rn][fdn]: the searchsorted(right=True) bin of every sample, in the order of u (before the sort)
+    float* cdf_out;          // optional [rn][dn + 1]: the cdf the bins were looked up in
     int rn, dn, fdn, use_all, no_sort;
     int linear;              // sample_fine_depth(inv_mode=False): interpolate the metric depths themselves
 };
@@ -1021,13 +1094,26 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
         ray = rvalid ? ray : p.rn - 1;
         const float* drow = p.depth + (size_t)ray * dn;
         const float* hrow = p.hit_prob + (size_t)ray * dn;
+        for (int i = lane; i < dn; i += 64) { ss[i] = p.linear ? drow[i] : norm_inv_depth(drow[i], nearp, farp); pdf[i] = hrow[i] + 1e-5f; }
+        __syncthreads();
+        // sum(hit_prob + 1e-5) (render_ops.py:194) in the order of the oracle's np.sum - numpy's pairwise sum, which for n <= 128 is one
+        // block: eight interleaved partial sums r_j = a[j] + a[8 + j] + ..., the tree ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)),
+        // then the n % 8 tail added one by one - so that the cdf, and with it every searchsorted bin, is the oracle's bit for bit on
+        // identical inputs (tests/test_fine_index.py; a wave butterfly differed in the total's last bit on ~40 % of the rays, which
+        // moved a bin only where u sat within an ulp of a cdf entry - shown there as well).  Every lane computes the same value.
         float tot = 0.0f;
-        for (int i = lane; i < ((dn + 63) & ~63); i += 64) {
-            float hp = 0.0f;
-            if (i < dn) { ss[i] = p.linear ? drow[i] : norm_inv_depth(drow[i], nearp, farp); hp = hrow[i] + 1e-5f; pdf[i] = hp; }
-            tot += hp;
+        if (dn < 8) {
+            for (int i = 0; i < dn; ++i) tot += pdf[i];
+        } else {
+            const int j8 = lane & 7, n8 = dn - (dn & 7);
+            float r = pdf[j8];
+            for (int i = 8; i < n8; i += 8) r += pdf[i + j8];
+            r = r + __shfl_xor(r, 1);
+            r = r + __shfl_xor(r, 2);
+            r = r + __shfl_xor(r, 4);
+            for (int i = n8; i < dn; ++i) r += pdf[i];
+            tot = r;
         }
-        tot = wave_sum(tot);
         __syncthreads();
         for (int i = lane; i < dn; i += 64) pdf[i] = pdf[i] / tot;
         __syncthreads();
@@ -1036,6 +1122,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
             float cdfv = 0.0f;
             for (int j = 0; j < dn; ++j) { const float pj = pdf[j]; cdfv = (j < i) ? cdfv + pj : cdfv; }
             cdf[i] = cdfv;
+            if (p.cdf_out && rvalid) p.cdf_out[(size_t)ray * (dn + 1) + i] = cdfv;
             edge[i] = (i == 0) ? ss[0] : (i == dn ? ss[dn - 1] : rn_div(rn_add(ss[i], ss[i - 1]), 2.0f));
         }
         __syncthreads();
@@ -1046,6 +1133,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
                 const float uu = p.u ? p.u[(size_t)ray * fdn + k] : rn_add(rn_mul(0.5f, interval), rn_mul((float)k, interval));
                 int idx = 0;
                 for (int m = 0; m <= dn; ++m) idx += (cdf[m] <= uu) ? 1 : 0;     // searchsorted(right=True)
+                if (p.idx_out && rvalid) p.idx_out[(size_t)ray * fdn + k] = idx;
                 const int below = idx - 1 > 0 ? idx - 1 : 0;
                 const int above = idx < dn ? idx : dn;
                 float denom = rn_sub(cdf[above], cdf[below]);

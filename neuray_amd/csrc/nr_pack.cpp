@@ -110,15 +110,51 @@ void pack_mlp32(float* dst, int l1, int l2, const float* w0, const float* b0, co
 
 }  // namespace
 
-int pack_pass_weights(const float* const* t, float* dst) {
+int pack_pass_weights(const float* const* t_in, float* dst, bool fold) {
     for (int i = 0; i < T_COUNT; ++i) {
         const bool optional = (i >= T_VIS0_W && i <= T_VIS4_B);
-        if (!t[i] && !optional) return 1 + i;
+        if (!t_in[i] && !optional) return 1 + i;
     }
-    const bool has_vis = t[T_VIS0_W] != nullptr;
+    const bool has_vis = t_in[T_VIS0_W] != nullptr;
     if (has_vis)
-        for (int i = T_VIS0_W; i <= T_VIS4_B; ++i) if (!t[i]) return 1 + i;
+        for (int i = T_VIS0_W; i <= T_VIS4_B; ++i) if (!t_in[i]) return 1 + i;
     std::memset(dst, 0, sizeof(float) * kPackedPassFloats);
+    const float* t[T_COUNT];
+    for (int i = 0; i < T_COUNT; ++i) t[i] = t_in[i];
+    // ---- fold: e = W2 h + b2 (prob_embed.2, no activation) feeds only neuray_fc.0 and base_fc.0's columns 175..206:
+    //   Wn e + bn = (Wn W2) h + (Wn b2 + bn),   Wb[:, 175:207] e + bb = (Wb[:, 175:207] W2) h + (Wb[:, 175:207] b2 + bb)
+    // products in double, rounded once to fp32
+    std::vector<float> nf_w, nf_b, base_w, base_b;
+    if (fold) {
+        const float* W2 = t_in[T_PE2_W];
+        const float* b2 = t_in[T_PE2_B];
+        nf_w.resize(8 * 32); nf_b.resize(8);
+        for (int o = 0; o < 8; ++o) {
+            double bb = t_in[T_NF0_B][o];
+            for (int k = 0; k < 32; ++k) bb += (double)t_in[T_NF0_W][o * 32 + k] * b2[k];
+            nf_b[o] = (float)bb;
+            for (int i = 0; i < 32; ++i) {
+                double a = 0.0;
+                for (int k = 0; k < 32; ++k) a += (double)t_in[T_NF0_W][o * 32 + k] * W2[k * 32 + i];
+                nf_w[o * 32 + i] = (float)a;
+            }
+        }
+        base_w.assign(t_in[T_BASE0_W], t_in[T_BASE0_W] + 64 * 207);
+        base_b.resize(64);
+        for (int o = 0; o < 64; ++o) {
+            const float* row = t_in[T_BASE0_W] + o * 207 + 175;
+            double bb = t_in[T_BASE0_B][o];
+            for (int k = 0; k < 32; ++k) bb += (double)row[k] * b2[k];
+            base_b[o] = (float)bb;
+            for (int i = 0; i < 32; ++i) {
+                double a = 0.0;
+                for (int k = 0; k < 32; ++k) a += (double)row[k] * W2[k * 32 + i];
+                base_w[o * 207 + 175 + i] = (float)a;
+            }
+        }
+        t[T_NF0_W] = nf_w.data(); t[T_NF0_B] = nf_b.data();
+        t[T_BASE0_W] = base_w.data(); t[T_BASE0_B] = base_b.data();
+    }
 
     // ---- dist decoder -----------------------------------------------------------------------
     pack_mlp32(dst, L_DM1, L_DM2, t[T_MEAN0_W], t[T_MEAN0_B], t[T_MEAN2_W], t[T_MEAN2_B]);
@@ -138,7 +174,7 @@ int pack_pass_weights(const float* const* t, float* dst) {
         for (int g = 0; g < 4; ++g) m.in1_map.push_back(g < 2 ? 32 + g : -1);
         pack_layer(dst, L_PE1, t[T_PE0_W], 34, t[T_PE0_B], m);
         LayerMaps m2; m2.out_map = out_natural(2, 32); in_dlayout(m2.in_map, 0, 32, 2);
-        pack_layer(dst, L_PE2, t[T_PE2_W], 32, t[T_PE2_B], m2);
+        if (!fold) pack_layer(dst, L_PE2, t[T_PE2_W], 32, t[T_PE2_B], m2);     // (folded: the slot stays zero, the kernel skips the layer)
     }
     // ---- ray_dir_fc: 4 -> 16 -> 35; output rows re-ordered to [img channels in gathered order | rgb]
     {

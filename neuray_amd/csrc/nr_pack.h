@@ -20,7 +20,9 @@ void pack_vec(float* dst, int layer, const float* W, int ldw, const float* bias,
 
 // tensors: array of T_COUNT host pointers in PassTensor order (vis-head entries may be null).
 // Returns 0 on success, non-zero if a required tensor is missing.
-int pack_pass_weights(const float* const* tensors, float* dst);
+// fold: prob_embed.2 (a Linear with no activation behind it) is multiplied into its consumers neuray_fc.0 and base_fc.0's last 32
+// columns (aggregate_net.py:27-31, ibrnet.py:337,342-343); the L_PE2 slot stays zero and the kernel skips the layer.
+int pack_pass_weights(const float* const* tensors, float* dst, bool fold = false);
 
 // packed[i] = flat[index[i]] * scale[i] (flat natural layout, nr_layout.h); index -1 = padding.  kPackedPassFloats entries each.
 int pack_pass_index_map(bool has_vis, int* index, float* scale);

@@ -15,6 +15,7 @@ static inline float4 nr_gld4(const float* p) { return *reinterpret_cast<const fl
 static inline void nr_gst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #define NR_PRAGMA_UNROLL
 #define NR_PRAGMA_UNROLL4
+#define NR_LAMBDA_INLINE
 #else
 #include <hip/hip_runtime.h>
 
@@ -70,6 +71,7 @@ __device__ __forceinline__ v4f nr_mfma16_bf16q3(float a01h, float a23h, float a0
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define NR_PRAGMA_UNROLL _Pragma("unroll")
+#define NR_LAMBDA_INLINE __attribute__((always_inline))     // the tile body of the point kernel (a generic lambda, one instantiation per active-slot count)
 // pointer known to address global memory (generic pointers in non-inlined device functions compile to FLAT accesses)
 #define NR_GLOBAL_PTR(T) __attribute__((address_space(1))) T*
 #define NR_TO_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
@@ -162,8 +164,12 @@ typedef nr_buf nr_mbuf;      // feature / colour maps
 // it to a VGPR and spills: 1085 v_mov + 450 lane moves in the ray kernel)
 #ifdef NEURAY_EMU
 static inline int nr_opaque_zero() { return 0; }
+static inline int nr_opaque_szero() { return 0; }
 #else
 __device__ __forceinline__ int nr_opaque_zero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+// the same in an SGPR: `wave + nr_opaque_szero()` re-made per tile keeps wave-uniform predicates (wave == 0, owner tile < 4, ...) from
+// being hoisted out of the tile loop as 64-bit lane masks that live - spilled to VGPR lanes - across the whole loop
+__device__ __forceinline__ int nr_opaque_szero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 #endif
 
 // forces a value to be computed HERE (an empty volatile asm that "modifies" it): LLVM's IR-level sinking otherwise moves
@@ -247,6 +253,12 @@ __device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
 __device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ float rn_div(float a, float b) { return a / b; }
 __device__ __forceinline__ float rn_sqrt(float a) { return __builtin_sqrtf(a); }
-#pragma clang fp contract(fast)
+// (No `#pragma clang fp contract(fast)` here.  Rounds 1-3 had one, meant to "restore the default" after these helpers - but the pragma
+// overrides the command line's -ffp-contract=off for everything that follows, i.e. for every kernel: hipcc then fused `a * b + c`
+// wherever its SLP / scheduling heuristics liked, differently in different instantiations of the same source.  Within one
+// instantiation that was consistent, which is why the batching-invariance tests passed; the slot-skipping point kernel, whose 2-, 1-
+// and 0-slot bodies are separate code, exposed it (tests/test_properties.py, GPU leg).  Contraction stays OFF for the whole library:
+// the arithmetic is exactly what the source says - `fmaf` where a fused multiply-add is wanted -, the same in every instantiation
+// and the same as the CPU emulator build.)
 #endif
 }  // namespace nr

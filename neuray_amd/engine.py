@@ -70,11 +70,14 @@ def host_inverse(Ks):
 
 
 class PackedPass:
-    """Device-resident packed weights of one pass (dist decoder + aggregation net)."""
+    """Device-resident packed weights of one pass (dist decoder + aggregation net).  folded: prob_embed.2 is multiplied into
+    neuray_fc.0 / base_fc.0 (neuray_pack_pass_weights_folded): inference packs; the backward kernels and the training forward
+    take the unfolded form."""
 
-    def __init__(self, dev_tensor, has_vis_head):
+    def __init__(self, dev_tensor, has_vis_head, folded=False):
         self.dev = dev_tensor
         self.has_vis_head = has_vis_head
+        self.folded = folded
 
 
 class ViewSet:
@@ -106,6 +109,7 @@ class RenderEngine:
         # (name, start_event, end_event, n_points) recorded on the launch stream (HIP events)
         self.timing = None
         self.max_backward_samples = _lib.MAX_BACKWARD_SAMPLES
+        self.slot_stats = None                     # optional int64 device tensor [2]: every point-kernel launch adds (view slots run, view slots)
         self.points_backward_kernel = 'auto'       # 'v1': force the first-version point backward (A/B timing, tests)
         # 'b2' / 'b3' (render_points_backward(kernel=...)): the 8-wave / the 4-wave x 2-view resident kernel (default: b2; b3 measured 1.06 vs 0.91 ms)
 
@@ -137,8 +141,9 @@ class RenderEngine:
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
     # ------------------------------------------------------------------------------------------
-    def pack_pass(self, state_dict, dist_prefix, agg_prefix):
-        """state_dict (tensors or ndarrays, reference key names) -> PackedPass on the device."""
+    def pack_pass(self, state_dict, dist_prefix, agg_prefix, fold=False):
+        """state_dict (tensors or ndarrays, reference key names) -> PackedPass on the device.  fold: the inference form with
+        prob_embed.2 folded into its consumers (one 32 x 32 layer less per (point, view); same function up to fp32 rounding)."""
         keys = pass_tensor_keys(dist_prefix, agg_prefix)
         host, ptrs = [], (C.c_void_p * _lib.PASS_TENSORS)()
         has_vis = (dist_prefix + 'vis_decoder.0.weight') in state_dict
@@ -154,8 +159,9 @@ class RenderEngine:
             ptrs[i] = t.data_ptr()
         n = self.lib.neuray_packed_pass_floats()
         packed = torch.empty(n, dtype=torch.float32)
-        self._check(self.lib.neuray_pack_pass_weights(ptrs, C.c_void_p(packed.data_ptr())))
-        return PackedPass(packed.to(self.device), has_vis)
+        pack = self.lib.neuray_pack_pass_weights_folded if fold else self.lib.neuray_pack_pass_weights
+        self._check(pack(ptrs, C.c_void_p(packed.data_ptr())))
+        return PackedPass(packed.to(self.device), has_vis, folded=bool(fold))
 
     def posenc(self, dn):
         if dn not in self._posenc:
@@ -262,16 +268,22 @@ class RenderEngine:
             self._check(self.lib.neuray_sample_coarse_depth_jittered(dr.data_ptr(), uniforms.data_ptr(), rn, dn, depth.data_ptr(), self._stream()))
         return depth
 
-    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None, sort=True, inv_mode=True):
+    def sample_fine_depth(self, qconst, depth, hit_prob, fdn, use_all=False, u=None, sort=True, inv_mode=True, trace=False):
+        """trace: -> (depths, searchsorted bins int32 [rn, fdn] in the order of u, cdf [rn, dn + 1]) (tests/test_fine_index.py)"""
         rn, dn = depth.shape
         out = self.empty(rn, fdn + (dn if use_all else 0))
         u_ptr = None
         if u is not None:
             u = self._f32(u).reshape(rn, fdn)
             u_ptr = u.data_ptr()
+        flags = int(use_all) | (0 if sort else 2) | (0 if inv_mode else 4)
+        if trace:
+            idx, cdf = self.empty(rn, fdn, dtype=torch.int32), self.empty(rn, dn + 1)
+            self._check(self.lib.neuray_sample_fine_depth_traced(qconst.data_ptr(), depth.data_ptr(), hit_prob.data_ptr(), u_ptr, rn, dn, fdn,
+                                                                 flags, out.data_ptr(), idx.data_ptr(), cdf.data_ptr(), self._stream()))
+            return out, idx, cdf
         self._check(self.lib.neuray_sample_fine_depth(qconst.data_ptr(), depth.data_ptr(), hit_prob.data_ptr(), u_ptr,
-                                                      rn, dn, fdn, int(use_all) | (0 if sort else 2) | (0 if inv_mode else 4), out.data_ptr(),
-                                                      self._stream()))
+                                                      rn, dn, fdn, flags, out.data_ptr(), self._stream()))
         return out
 
     def setup_views(self, poses, Ks, depth_range):
@@ -488,6 +500,8 @@ class RenderEngine:
         rn, dn = depth.shape
         # out: (d_flat, d_ray_feats, d_img_feats) already zeroed by the caller (engine.zeroed: one fill for the whole pass)
         d_flat, d_rf, d_if = out if out is not None else self.zeroed(flat.shape, views.ray_feats.shape, views.img_feats.shape)
+        if packed is not None and packed.folded:
+            raise ValueError("neuray_amd: the backward kernels take the unfolded pack (pack_pass(fold=False) / pack_pass_device)")
         resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
         pick = kernel if kernel in ('b2', 'b3') else (self.points_backward_kernel if self.points_backward_kernel in ('b2', 'b3') else None)
         self._check(self.lib.neuray_select_points_backward({'b2': 2, 'b3': 3, None: 0}[pick]))
@@ -499,6 +513,13 @@ class RenderEngine:
             if saved is None:
                 saved = self.render_points_saved(qconst, views, coords, depth, packed, use_vis, var_bias)
         else:
+            if views.rfn > 8 and kernel == 'auto' and self.points_backward_kernel == 'auto' and not self.__dict__.get('_v1_warned'):
+                import warnings
+                warnings.warn("neuray_amd: %d reference views > 8 - the point backward runs its first-version kernel (activation arena in "
+                              "global memory, ~5 x the time of the register / LDS resident kernel that covers rfn <= 8: ~4.4 instead of "
+                              "~0.9 ms per 512-ray pass on an MI355X; INTEGRATION.md 'Shape limits').  The forward kernels take up to 16 "
+                              "views at full speed." % views.rfn)
+                self.__dict__['_v1_warned'] = True
             ws = self.empty(int(self.lib.neuray_points_backward_workspace_floats(rn * dn, views.rfn)))
         a = _lib.NeurayPointsBwdArgs(
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
@@ -521,6 +542,8 @@ class RenderEngine:
         rn, dn = depth.shape
         d_feats = self.empty(rn, 32)
         d_flat = torch.zeros_like(flat) if d_flat is None else d_flat
+        if packed is not None and packed.folded:
+            raise ValueError("neuray_amd: the backward kernels take the unfolded pack (pack_pass(fold=False) / pack_pass_device)")
         if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant in ('fp32', 'bf16x3'):
             pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
             pt = self.pack_pass_t_device(flat, bool(has_vis_head))
@@ -606,14 +629,19 @@ class RenderEngine:
         return out
 
     def render_pass(self, qconst, views, coords, depth, packed, use_vis, var_bias=0.05, ray_mask_view_num=2,
-                    ray_mask_point_num=8, want_depth=False, want_density=False, want_dbg=False, save=False):
+                    ray_mask_point_num=8, want_depth=False, want_density=False, want_dbg=False, save=False, slot_stats=None):
         """One pass (coarse or fine) over rays `coords` [rn,2] at sample depths `depth` [rn,dn].
         -> dict(hit_prob [rn,dn], pixel [rn,3], ray_mask [rn] bool, render_depth?, density?, dbg?, saved?)
         save (training forward, rfn <= 8): also return 'saved', the cross-view quantities render_points_backward reads instead of
-        recomputing them (include/neuray_hip.h NeurayPointsArgs.saved_dev)."""
+        recomputing them (include/neuray_hip.h NeurayPointsArgs.saved_dev).
+        slot_stats: optional int64 device tensor [2] the point kernel adds (view slots run, view slots) to (slot skipping)."""
         coords, depth = self._f32(coords), self._f32(depth)
         rn, dn = depth.shape
         assert coords.shape == (rn, 2)
+        if save and packed.folded:
+            raise ValueError("neuray_amd: the training forward (save=True) takes the unfolded pack")
+        if slot_stats is None:
+            slot_stats = self.slot_stats
         s = self._stream()
         rec = self.empty(rn * dn, _lib.POINT_REC)
         dbg = self.empty(rn * dn, views.rfn, _lib.DBG_FIELDS) if want_dbg else None
@@ -624,7 +652,8 @@ class RenderEngine:
             rec.data_ptr(), dbg.data_ptr() if want_dbg else None,
             views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
             int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.views_per_wave),
-            saved.data_ptr() if saved is not None else None)
+            saved.data_ptr() if saved is not None else None, int(packed.folded),
+            slot_stats.data_ptr() if slot_stats is not None else None)
         ev = self._event_pair()
         self._check(self.lib.neuray_render_points(C.byref(a), s))
         self._event_done(ev, 'points', rn * dn)
@@ -707,6 +736,6 @@ class RenderEngine:
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(),
             views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
             rec.data_ptr(), None, views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
-            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), 0, saved.data_ptr())
+            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), 0, saved.data_ptr(), 0, None)
         self._check(self.lib.neuray_render_points(C.byref(a), self._stream()))
         return saved

@@ -86,7 +86,13 @@ def resize(img, dsize, interpolation=INTER_LINEAR):
             raise NotImplementedError("neuray_amd.imgproc: INTER_AREA with a non-integer factor (%d x %d -> %d x %d)" % (sh, sw, h, w))
         fy, fx = sh // h, sw // w
         x = a.astype(np.float64).reshape((h, fy, w, fx) + a.shape[2:]).sum((1, 3)) / (fy * fx)
-        return np.clip(np.rint(x), 0, 255).astype(np.uint8) if a.dtype == np.uint8 else x.astype(a.dtype)      # cvRound: half to even
+        if a.dtype != np.uint8:
+            return x.astype(a.dtype)
+        if fy == 2 and fx == 2:
+            # OpenCV's 8-bit 2 x 2 fast path (ResizeAreaFastVec) is integer: (a + b + c + d + 2) >> 2, i.e. halves round UP
+            # (from the OpenCV sources as remembered - unpinned against a real cv2, like the rest of this module)
+            return np.clip(np.floor(x + 0.5), 0, 255).astype(np.uint8)
+        return np.clip(np.rint(x), 0, 255).astype(np.uint8)      # cvRound (saturate_cast): half to even
     if interpolation != INTER_LINEAR:
         raise NotImplementedError(interpolation)
     # bilinear, half-pixel centres: src = (dst + 0.5) * scale - 0.5; taps clamped at the borders (resize.cpp resizeGeneric_)

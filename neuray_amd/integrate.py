@@ -108,6 +108,9 @@ def unpatch_render_loop(cls):
     saved = _PATCHED_LOOP.pop(cls, None)
     if saved is None:
         return
+    for ft_cls in _PATCHED_FT:                       # (their cached encoder outputs were for the loop that is going away)
+        if cls in ft_cls.__mro__:
+            ft_cls.cache_encoded_views = False
     for name in RENDER_LOOP_METHODS:
         if name in saved:
             setattr(cls, name, saved[name])
@@ -124,7 +127,11 @@ def patch_ft_host(ft_cls, cache_encoded_views=False):
     anything shaped like it: instances carry cfg / ref_imgs_info / val_imgs_info as dicts of host tensors / ray_feats).  The class
     keeps its own train_step / validate_step / render; a seeded run draws the same views and rays.  cache_encoded_views: in eval
     hand render() cached per-view encoder outputs - only with a render() that accepts them (patch_render_loop).  Idempotent."""
+    # cached per-view encoder outputs are only sound under a render() that accepts them: the reference's own render() would run
+    # vis_encoder on already encoded ray_feats (wrong images, no error), so the flag follows the render loop actually in place
+    loop_patched = any(base in _PATCHED_LOOP for base in ft_cls.__mro__)
     if ft_cls in _PATCHED_FT:
+        ft_cls.cache_encoded_views = bool(cache_encoded_views) and loop_patched     # a repeat call updates the flag
         return _PATCHED_FT[ft_cls]
     from .network.renderer import NeuralRayFtRenderer as ours
     saved = {}
@@ -133,7 +140,7 @@ def patch_ft_host(ft_cls, cache_encoded_views=False):
             saved[name] = ft_cls.__dict__[name]
     for name in FT_HOST_METHODS:
         setattr(ft_cls, name, ours.__dict__[name])
-    ft_cls.cache_encoded_views = bool(cache_encoded_views)      # (the reference's own render() runs the encoders unconditionally, renderer.py:229-235)
+    ft_cls.cache_encoded_views = bool(cache_encoded_views) and loop_patched      # (the reference's own render() runs the encoders unconditionally, renderer.py:229-235)
     _PATCHED_FT[ft_cls] = saved
     return saved
 

@@ -64,7 +64,10 @@ class _NormActFn(torch.autograd.Function):
 
 def norm_act(bn, y, act=None, pad=0, res=None):
     """-> reflect_pad(act(bn(y) [+ res]), pad) as one [n, c, h + 2 pad, w + 2 pad] tensor"""
-    if FUSED_NORM and bn.affine and not bn.track_running_stats and _engine(y.device) is not None:
+    # (a padded plane of >= 2^23 elements - 2896 x 2896 - is beyond the kernels' fast division: such a map takes the composed PyTorch
+    # ops below.  A missing library on a GPU still raises: the package never silently swaps its kernels for something else.)
+    if (FUSED_NORM and bn.affine and not bn.track_running_stats and (y.shape[2] + 2 * pad) * (y.shape[3] + 2 * pad) < (1 << 23)
+            and _engine(y.device) is not None):
         return _NormActFn.apply(y, bn.weight, bn.bias, res, pad, ACTS[act], bn.eps)
     z = bn(y)
     if res is not None:

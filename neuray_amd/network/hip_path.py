@@ -40,7 +40,7 @@ class HipRenderPath:
         if hit is None or hit[0] != stamp:
             sd = {'d.' + k: v for k, v in dist.state_dict().items()}
             sd.update({'a.' + k: v for k, v in agg.state_dict().items()})
-            cache[is_fine] = hit = (stamp, eng.pack_pass(sd, 'd.', 'a.'))
+            cache[is_fine] = hit = (stamp, eng.pack_pass(sd, 'd.', 'a.', fold=self.cfg.get('hip_fold_prob_embed', True)))
         return hit[1]
 
     @staticmethod
@@ -129,6 +129,12 @@ class HipRenderPath:
         rec = res.get('dbg')
         point_rec = res.get('point_rec')
         if rec is None:
+            if cfg.get('use_dr_loss') or cfg.get('use_dr_fine_loss'):
+                # the reference back-propagates those losses through direct_rendering (loss.py: RenderLoss reads pixel_colors_dr); the
+                # backward kernels do not, and a loss term that silently contributes no gradient is worse than an error
+                raise NotImplementedError("neuray_amd: cfg use_dr_loss / use_dr_fine_loss need gradients through direct_rendering "
+                                          "(renderer.py:85-125), which the HIP backward kernels do not provide; the prediction-only "
+                                          "use_dr_prediction (no dr loss) is supported")
             if not self.__dict__.get('_dr_grad_warned'):
                 import warnings
                 warnings.warn("neuray_amd: use_dr_prediction under autograd - pixel_colors_dr / hit_prob_dr are computed but carry "

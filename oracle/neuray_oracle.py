@@ -521,9 +521,10 @@ def direct_rendering(cfg, prj, que_dir, colors_nr, dtype=np.float32):
     return hit_prob.astype(dt), colors.astype(dt), np.sum(hit_prob[..., None] * colors, 2, dtype=dt)
 
 
-def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
+def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None, trace=False):
     """network/render_ops.py:172-229 (inv_mode=True).  u=None -> deterministic stratified u
-    (random_sample=False); otherwise u [qn,rn,fdn] is the externally drawn uniform sample."""
+    (random_sample=False); otherwise u [qn,rn,fdn] is the externally drawn uniform sample.
+    trace: -> (fine depths, searchsorted bins [qn,rn,fdn], cdf [qn,rn,dn+1]) - what tests/test_fine_index.py pins the kernel's index path to."""
     depth, hit_prob, depth_range = f32(depth), f32(hit_prob), f32(depth_range)
     near, far = F32(-1.0) / depth_range[0, 0], F32(-1.0) / depth_range[0, 1]
     s = (F32(-1.0) / depth - near) / (far - near)
@@ -553,7 +554,8 @@ def sample_fine_depth(depth, hit_prob, depth_range, fdn, u=None):
     t = (u - cdf_b) / denom
     fine = bin_b + t * (bin_a - bin_b)
     fine = fine * (far - near) + near
-    return (F32(-1.0) / fine).astype(np.float32)
+    fine = (F32(-1.0) / fine).astype(np.float32)
+    return (fine, inds, cdf) if trace else fine
 
 
 # --------------------------------------------------------------------------------------

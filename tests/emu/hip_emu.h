@@ -152,6 +152,10 @@ static inline float atomicAdd(float* p, float v) {
     return f;
 }
 
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+    return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+
 static inline unsigned long long __ballot(int pred) {
     emu::WaveState& w = emu::my_wave();
     int par = w.gen & 1;

@@ -33,10 +33,13 @@ def test_resize_nearest_area_linear():
     area = I.resize(u8, (3, 2), I.INTER_AREA)
     want = u8.reshape(2, 4, 3, 4, 3).astype(np.float64).mean((1, 3))
     assert np.array_equal(area, np.rint(want).astype(np.uint8))
-    halves = np.array([[0, 1], [0, 0]], np.uint8).repeat(2, 0).repeat(2, 1)[:2, :2]      # mean 0.25 -> 0; a tie goes to even
-    assert I.resize(np.array([[1, 2], [1, 2]], np.uint8), (1, 1), I.INTER_AREA)[0, 0] == 2          # 1.5 -> 2 (even)
-    assert I.resize(np.array([[0, 1], [0, 1]], np.uint8), (1, 1), I.INTER_AREA)[0, 0] == 0          # 0.5 -> 0 (even)
-    del halves
+    # ties: the 8-bit 2 x 2 case is OpenCV's integer fast path (a + b + c + d + 2) >> 2 - halves round UP; every other integer
+    # factor goes through cvRound (half to even)
+    assert I.resize(np.array([[1, 2], [1, 2]], np.uint8), (1, 1), I.INTER_AREA)[0, 0] == 2          # 1.5 -> 2
+    assert I.resize(np.array([[0, 1], [0, 1]], np.uint8), (1, 1), I.INTER_AREA)[0, 0] == 1          # 0.5 -> 1 (2 x 2: up)
+    q = np.zeros((4, 4), np.uint8)
+    q[0, :] = 2                                                                                     # mean of the 4 x 4 block 0.5
+    assert I.resize(q, (1, 1), I.INTER_AREA)[0, 0] == 0                                             # 0.5 -> 0 (4 x 4: even)
     const = np.full((10, 14, 3), 93, np.uint8)
     assert np.array_equal(I.resize(const, (7, 5), I.INTER_LINEAR), np.full((5, 7, 3), 93, np.uint8))
     ramp = np.tile(np.arange(0, 160, 4, dtype=np.float32)[None, :], (4, 1))          # 40 columns, slope 4

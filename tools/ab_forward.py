@@ -6,7 +6,8 @@ For every library: rays/s, point-kernel ms per launch (HIP events of the engine)
 COARSE pixels / hit probabilities and of the chained fine pixels on N strided rays of the image against the numpy oracle
 (TEST INFRASTRUCTURE: the oracle is the checker here, computed once).  `build:` entries compile a variant first:
     python tools/ab_forward.py base=neuray_amd/libneuray_hip.so norefine=build:-DNR_FEATURE_RCP_REFINE=0
-(variants are written to _ab/, which is git-ignored)."""
+(variants are written to _ab/, which is git-ignored).  A path may carry `,nofold`: that library renders with the unfolded
+pack (cfg hip_fold_prob_embed = False; also what a library older than ABI 7 needs)."""
 import argparse
 import json
 import os
@@ -29,6 +30,18 @@ def build_variant(name, flags):
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call([nbuild.HIPCC] + nbuild.FLAGS + flags + nbuild.SOURCES + ['-o', out])
     return out
+
+
+def bind_compat(path):
+    """_lib.bind that tolerates a library from before the current ABI (symbols it lacks stay unbound; the argument structs only
+    grew at their ends, which an older library does not read)"""
+    import ctypes as C
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in _lib.SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = restype, argtypes
+    return lib
 
 
 def oracle_sample(cfg, weights, que, ref, n):
@@ -62,14 +75,18 @@ def main():
     res = {}
     for item in a.libs:
         name, path = item.split('=', 1)
+        path, *opts = path.split(',')
+        fold = 'nofold' not in opts
         if path.startswith('build:'):
             path = build_variant(name, path[6:].split())
         torch.manual_seed(0)
-        r = NeuralRayBaseRenderer(cfg).eval()
+        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold}).eval()
         r.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
         r = r.to(dev)
-        r._engine_test_lib = _lib.bind(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
+        r._engine_test_lib = bind_compat(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
         eng = r.engine(dev)
+        stats = torch.zeros(2, dtype=torch.int64, device=dev)
+        eng.slot_stats = stats
         out = bench.render_image(r, tq, tr)
         eng.timing = []
         torch.cuda.synchronize()
@@ -81,7 +98,9 @@ def main():
         pts = [e0.elapsed_time(e1) for nm, e0, e1, n in eng.timing if nm == 'points']
         rays = [e0.elapsed_time(e1) for nm, e0, e1, n in eng.timing if nm == 'rays']
         eng.timing = None
-        res[name] = {'rays_per_s': a.steps * 640000 / dt, 'point_kernel_ms': float(np.mean(pts)), 'ray_kernel_ms': float(np.mean(rays))}
+        st = stats.cpu().numpy()
+        res[name] = {'rays_per_s': a.steps * 640000 / dt, 'point_kernel_ms': float(np.mean(pts)), 'ray_kernel_ms': float(np.mean(rays)),
+                     'fold': fold, 'slots_run_share': float(st[0] / st[1]) if st[1] else None}
         if want is not None:
             sel = torch.from_numpy(idx).to(dev)
             q = {k: v for k, v in tq.items() if not k.startswith('_')}

@@ -290,6 +290,22 @@ int neuray_diff_feats(const float* view_const_dev, const float* lift_const_dev, 
  * out_dev [rfn][32][dn][fh][fw]. */
 int neuray_warp_variance(const float* ref_feats_dev, const float* src_feats_dev, const int* nn_ids_dev, const float* transforms_dev,
                          const float* depth_vals_dev, int rfn, int sn, int n_num, int dn, int fh, int fw, float* out_dev, void* stream);
+/* The same with the output layout selectable: channels_last = 1 writes [rfn][dn][fh][fw][32] (a voxel's 32 channels in one 128-byte
+ * line), the layout neuray_conv3d_c32_c8 reads. */
+int neuray_warp_variance_layout(const float* ref_feats_dev, const float* src_feats_dev, const int* nn_ids_dev, const float* transforms_dev,
+                                const float* depth_vals_dev, int rfn, int sn, int n_num, int dn, int fh, int fw, int channels_last,
+                                float* out_dev, void* stream);
+
+/* ---- f-3, MVSNet cost regularisation (network/mvsnet/mvsnet.py:29-69 CostRegNet, frozen / evaluation-only inside the cost-volume init
+ * net, network/init_net.py:121-160): its first and last layer.
+ * neuray_conv3d_c32_c8: `conv0` = leaky_relu(batch_norm(Conv3d(32, 8, 3, padding=1, bias=False)(x)), slope) with the frozen batch norm folded:
+ *   x_ndhwc_dev [n][d][h][w][32] (channels-last), wpack_dev [27][2][64][4] = the folded weights as per-lane MFMA A fragments - tap
+ *   t = (kz * 3 + ky) * 3 + kx, quad q, lane l (m = l & 15, g = l >> 4), component i: W'[m][8 g + 4 q + i][kz][ky][kx] for m < 8, else 0,
+ *   W' = W * gamma / sqrt(var + eps) per output channel -, bias_dev [8] = beta - mean * gamma / sqrt(var + eps); out_dev [n][8][d][h][w].
+ * neuray_conv3d_c8_c1: `prob` = Conv3d(8, 1, 3, padding=1): x_dev [n][8][d][h][w], w27_dev [8][27], out_dev [n][d][h][w]. */
+int neuray_conv3d_c32_c8(const float* x_ndhwc_dev, const float* wpack_dev, const float* bias_dev, float slope, int n, int d, int h, int w,
+                         float* out_dev, void* stream);
+int neuray_conv3d_c8_c1(const float* x_dev, const float* w27_dev, float bias, int n, int d, int h, int w, float* out_dev, void* stream);
 
 /* ---- a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
  * render_ops.py:54-70): bilinear, padding_mode='border'.  feats [b][c][fh][fw], points [b][n][2] pixel (x,y) in

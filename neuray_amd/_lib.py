@@ -140,6 +140,10 @@ SYMBOLS = {
     'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_warp_variance': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_warp_variance_layout': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_conv3d_c32_c8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_conv3d_c8_c1': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_diff_feats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

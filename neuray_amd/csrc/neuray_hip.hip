@@ -5,6 +5,7 @@
 #include "nr_kernels_bwd.h"
 #include "nr_kernels_dr.h"
 #include "nr_kernels_norm.h"
+#include "nr_kernels_conv3d.h"
 // the plain bf16-operand build is inference only; the fp32 build and the split build (hi + lo bf16 operands: fp32-grade products)
 // carry the training path
 #if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT)
@@ -298,12 +299,39 @@ int neuray_diff_feats(const float* view_const, const float* lift_const, const fl
 
 int neuray_warp_variance(const float* ref_feats, const float* src_feats, const int* nn_ids, const float* transforms, const float* depth_vals,
                          int rfn, int sn, int n_num, int dn, int fh, int fw, float* out, void* stream) {
+    return neuray_warp_variance_layout(ref_feats, src_feats, nn_ids, transforms, depth_vals, rfn, sn, n_num, dn, fh, fw, 0, out, stream);
+}
+
+int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* bias, float slope, int n, int d, int h, int w, float* out, void* stream) {
+    if (!x_ndhwc || !wpack || !bias || !out) return fail("neuray_conv3d_c32_c8: null pointer");
+    if (n < 1 || d < 1 || h < 1 || w < 1 || (long long)d * h * w * 128 >= 0x7fffff00LL)
+        return fail("neuray_conv3d_c32_c8: bad shape n=%d d=%d h=%d w=%d (one image's volume must stay below 2^31 bytes)", n, d, h, w);
+    nr::Conv0Params p;
+    p.x = x_ndhwc; p.wpack = wpack; p.bias = bias; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
+    const long long strips = (long long)n * d * h * ((w + 15) / 16);
+    const int grid = grid_for(strips, nr::kConv0Waves, 256 * 8);
+    NR_LAUNCH(nr::costreg_conv0_kernel, dim3(grid), dim3(64 * nr::kConv0Waves), 0, stream, p);
+    return check_launch("neuray_conv3d_c32_c8");
+}
+
+int neuray_conv3d_c8_c1(const float* x, const float* w27, float bias, int n, int d, int h, int w, float* out, void* stream) {
+    if (!x || !w27 || !out) return fail("neuray_conv3d_c8_c1: null pointer");
+    if (n < 1 || d < 1 || h < 1 || w < 1) return fail("neuray_conv3d_c8_c1: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
+    nr::ProbParams p;
+    p.x = x; p.w = w27; p.out = out; p.n = n; p.d = d; p.h = h; p.w_ = w; p.bias = bias;
+    const int grid = grid_for((long long)n * d * h * w, 256, 256 * 32);
+    NR_LAUNCH(nr::costreg_prob_kernel, dim3(grid), dim3(256), 0, stream, p);
+    return check_launch("neuray_conv3d_c8_c1");
+}
+
+int neuray_warp_variance_layout(const float* ref_feats, const float* src_feats, const int* nn_ids, const float* transforms, const float* depth_vals,
+                                int rfn, int sn, int n_num, int dn, int fh, int fw, int channels_last, float* out, void* stream) {
     if (!ref_feats || !src_feats || !nn_ids || !transforms || !depth_vals || !out) return fail("neuray_warp_variance: null pointer");
     if (rfn < 1 || sn < 1 || n_num < 1 || dn < 1 || fh < 2 || fw < 2)
         return fail("neuray_warp_variance: bad shape rfn=%d sn=%d n_num=%d dn=%d fh=%d fw=%d", rfn, sn, n_num, dn, fh, fw);
     nr::WarpVarParams p;
     p.ref_feats = ref_feats; p.src_feats = src_feats; p.nn_ids = nn_ids; p.transforms = transforms; p.depth_vals = depth_vals; p.out = out;
-    p.rfn = rfn; p.n_num = n_num; p.dn = dn; p.fh = fh; p.fw = fw;
+    p.rfn = rfn; p.n_num = n_num; p.dn = dn; p.fh = fh; p.fw = fw; p.channels_last = channels_last;
     const int grid = grid_for((long long)rfn * dn * fh * fw, 256, 256 * 64);
     NR_LAUNCH(nr::warp_variance_kernel, dim3(grid), dim3(256), 0, stream, p);
     return check_launch("neuray_warp_variance");

@@ -1188,8 +1188,9 @@ struct WarpVarParams {
     const int* nn_ids;         // [rfn][n_num] rows of src_feats
     const float* transforms;   // [rfn][n_num][12]: 3x4, row-major
     const float* depth_vals;   // [rfn][dn]
-    float* out;                // [rfn][32][dn][fh][fw]
+    float* out;                // [rfn][32][dn][fh][fw], or channels_last: [rfn][dn][fh][fw][32]
     int rfn, n_num, dn, fh, fw;
+    int channels_last;         // the layout costreg_conv0_kernel reads (csrc/nr_kernels_conv3d.h): a voxel's 32 channels are one 128-byte line
 };
 
 __global__ void __launch_bounds__(256) warp_variance_kernel(WarpVarParams p) {
@@ -1247,6 +1248,20 @@ __global__ void __launch_bounds__(256) warp_variance_kernel(WarpVarParams p) {
             }
         }
         const float V = (float)(p.n_num + 1);
+        if (p.channels_last) {
+            float4* o4 = reinterpret_cast<float4*>(p.out + i * 32);
+            NR_PRAGMA_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                float v[4];
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 4; ++k) {
+                    const float mean = rn_div(sum[4 * q + k], V);
+                    v[k] = rn_sub(rn_div(sq[4 * q + k], V), rn_mul(mean, mean));
+                }
+                o4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            continue;
+        }
         float* o = p.out + (long long)r * 32 * per_view + (long long)d * hw + pix;
         NR_PRAGMA_UNROLL
         for (int c = 0; c < 32; ++c) {

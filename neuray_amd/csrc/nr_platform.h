@@ -112,14 +112,22 @@ __device__ __forceinline__ nr_v2 nr_v2_fma(nr_v2 a, nr_v2 b, nr_v2 c) { return _
 // buffer_load needs no per-load 64-bit address register pair; with plain pointers hipcc hoisted ~150 loop-invariant
 // fragment addresses out of the point loop and spilled them.
 #ifdef NEURAY_EMU
-struct nr_buf { const char* p; };
-static inline nr_buf nr_make_buf(const float* p, size_t bytes) { (void)bytes; return nr_buf{(const char*)p}; }
-static inline float4 nr_buf_ld4(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float4*>(b.p + voff + soff); }
-static inline float nr_buf_ld1(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
-static inline float2 nr_buf_ld2(nr_buf b, int voff, int soff) { return *reinterpret_cast<const float2*>(b.p + voff + soff); }
+// (range-checked like the hardware descriptor: a load that starts beyond `bytes` returns 0 - csrc/nr_kernels_conv3d.h uses that as its
+// zero padding)
+struct nr_buf { const char* p; size_t n; };
+static inline nr_buf nr_make_buf(const float* p, size_t bytes) { return nr_buf{(const char*)p, bytes}; }
+static inline bool nr_buf_in(nr_buf b, int voff, int soff) { return (long long)voff + soff >= 0 && (size_t)((long long)voff + soff) < b.n; }
+static inline float4 nr_buf_ld4(nr_buf b, int voff, int soff) {
+    return nr_buf_in(b, voff, soff) ? *reinterpret_cast<const float4*>(b.p + (long long)voff + soff) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+static inline float nr_buf_ld1(nr_buf b, int voff, int soff) { return nr_buf_in(b, voff, soff) ? *reinterpret_cast<const float*>(b.p + (long long)voff + soff) : 0.0f; }
+static inline float2 nr_buf_ld2(nr_buf b, int voff, int soff) {
+    return nr_buf_in(b, voff, soff) ? *reinterpret_cast<const float2*>(b.p + (long long)voff + soff) : make_float2(0.0f, 0.0f);
+}
 // LDS-DMA piece (emulation: the copy happens at issue time, a legal completion point)
 static inline void nr_dma16(nr_buf b, float* lds_wave_base, int lane, int voff, int soff) {
-    memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, b.p + voff + soff, 16);
+    if (nr_buf_in(b, voff, soff)) memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, b.p + (long long)voff + soff, 16);
+    else memset(reinterpret_cast<char*>(lds_wave_base) + lane * 16, 0, 16);
 }
 #else
 struct nr_buf { __amdgpu_buffer_rsrc_t r; };

@@ -221,9 +221,27 @@ class RenderEngine:
         self._check(self.lib.neuray_diff_feats(vc.data_ptr(), lift.data_ptr(), rgbd.data_ptr(), rfn, h, w, out.data_ptr(), s))
         return out.permute(0, 3, 1, 2)
 
-    def warp_variance(self, ref_feats, src_feats, nn_ids, ref_prjs, src_prjs, depth_vals):
+    def costreg_conv0(self, x_ndhwc, wpack, bias, slope):
+        """MVSNet CostRegNet.conv0 with the frozen batch norm folded (neuray_conv3d_c32_c8): x [n,d,h,w,32] contiguous -> [n,8,d,h,w]"""
+        n, d, h, w, c = x_ndhwc.shape
+        assert c == 32 and x_ndhwc.is_contiguous() and x_ndhwc.dtype == torch.float32
+        out = self.empty(n, 8, d, h, w)
+        self._check(self.lib.neuray_conv3d_c32_c8(x_ndhwc.data_ptr(), wpack.data_ptr(), bias.data_ptr(), float(slope), n, d, h, w,
+                                                  out.data_ptr(), self._stream()))
+        return out
+
+    def costreg_prob(self, x, w27, bias):
+        """MVSNet CostRegNet.prob (neuray_conv3d_c8_c1): x [n,8,d,h,w] contiguous -> [n,1,d,h,w]"""
+        n, c, d, h, w = x.shape
+        assert c == 8 and x.is_contiguous() and x.dtype == torch.float32
+        out = self.empty(n, 1, d, h, w)
+        self._check(self.lib.neuray_conv3d_c8_c1(x.data_ptr(), w27.data_ptr(), float(bias), n, d, h, w, out.data_ptr(), self._stream()))
+        return out
+
+    def warp_variance(self, ref_feats, src_feats, nn_ids, ref_prjs, src_prjs, depth_vals, channels_last=False):
         """network/mvsnet/mvsnet.py:186-203: feature maps [n,32,fh,fw], nn_ids [rfn,n_num] (rows of src_feats), 4x4
-        projections, depth_vals [rfn,dn] -> variance volume [rfn,32,dn,fh,fw]."""
+        projections, depth_vals [rfn,dn] -> variance volume [rfn,32,dn,fh,fw] (channels_last: the same tensor in channels-last-3d
+        storage, which CostRegNet's conv0 kernel reads as it is)."""
         rfn, c, fh, fw = ref_feats.shape
         assert c == 32 and src_feats.shape[1:] == ref_feats.shape[1:]
         sn, n_num, dn = src_feats.shape[0], nn_ids.shape[1], depth_vals.shape[1]
@@ -236,10 +254,10 @@ class RenderEngine:
         inv = torch.inverse(self._f32(ref_prjs))
         tr = torch.stack([self._f32(src_prjs)[nn_ids[:, j].to(self.device).long()] @ inv for j in range(n_num)], 1)[:, :, :3, :].contiguous()
         dv = self._f32(depth_vals)
-        out = self.empty(rfn, 32, dn, fh, fw)
-        self._check(self.lib.neuray_warp_variance(rf.data_ptr(), sf.data_ptr(), ids.data_ptr(), tr.data_ptr(), dv.data_ptr(),
-                                                  rfn, sn, n_num, dn, fh, fw, out.data_ptr(), s))
-        return out
+        out = self.empty(rfn, dn, fh, fw, 32) if channels_last else self.empty(rfn, 32, dn, fh, fw)
+        self._check(self.lib.neuray_warp_variance_layout(rf.data_ptr(), sf.data_ptr(), ids.data_ptr(), tr.data_ptr(), dv.data_ptr(),
+                                                         rfn, sn, n_num, dn, fh, fw, int(bool(channels_last)), out.data_ptr(), s))
+        return out.permute(0, 4, 1, 2, 3) if channels_last else out
 
     def prepare_query(self, que_imgs_info):
         """-> query constant block.  K^-1 is `torch.inverse(Ks)` as in the reference (render_ops.py:20), evaluated on the

@@ -4,7 +4,8 @@ network/mvsnet/modules.py): frozen, eval mode, `construct_cost_volume_with_src` 
   feature            8 conv + activated-batch-norm layers, 3 -> 32 channels at 1/4 resolution (mvsnet.py:7-30)
   variance volume    ONE HIP kernel (neuray_warp_variance) instead of a [B,32,D,h,w] warp per source view plus two
                      running sums (mvsnet.py:186-203, modules.py:25-64)
-  cost_regularization  3-D U-Net, 32 -> 1 channel (mvsnet.py:32-75): PyTorch Conv3d / ConvTranspose3d (MIOpen)
+  cost_regularization  3-D U-Net, 32 -> 1 channel (mvsnet.py:32-75): PyTorch Conv3d / ConvTranspose3d (MIOpen), except - frozen and
+                     under no_grad, as the init net runs it - its first and last layer, which are HIP kernels (csrc/nr_kernels_conv3d.h)
 
 The reference builds it with `inplace_abn.ABN` (network/init_net.py:121): F.batch_norm with the running statistics
 followed by leaky_relu(0.01); `ActivatedBatchNorm` below has that module's parameter and buffer names (`weight`, `bias`,
@@ -66,6 +67,12 @@ class FeatureNet(nn.Module):
 
 
 class CostRegNet(nn.Module):
+    """mvsnet.py:29-69.  Inside CostVolumeInitNet the network is frozen and evaluated under no_grad (init_net.py:121-160), so its two
+    layers that MIOpen runs far off any roofline go through hand-written kernels (csrc/nr_kernels_conv3d.h): `conv0` (32 -> 8 channels
+    on the full-resolution variance volume: 68 % of the U-Net's MACs, 23 of its 37 ms through MIOpen on 8 x 64 x 160 x 160) as an
+    implicit GEMM on the fp32 MFMA with the frozen batch norm folded into weights and bias, and `prob` (8 -> 1, memory bound: 6.2 ms
+    through MIOpen).  Everything else, and every call that needs gradients or runs in training mode, takes the module path."""
+
     def __init__(self):
         super().__init__()
         self.conv0 = _c3(32, 8)
@@ -75,14 +82,66 @@ class CostRegNet(nn.Module):
         self.conv7, self.conv9, self.conv11 = _up3(64, 32), _up3(32, 16), _up3(16, 8)
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
 
-    def forward(self, x):
-        c0 = self.conv0(x)
+    def _tail(self, c0):
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))
         x = c4 + self.conv7(self.conv6(self.conv5(c4)))
         x = c2 + self.conv9(x)
-        x = c0 + self.conv11(x)
-        return self.prob(x)
+        return c0 + self.conv11(x)
+
+    def forward_modules(self, x):
+        return self.prob(self._tail(self.conv0(x)))
+
+    def _engine(self, x):
+        from . import render_ops
+        if x.device.type != 'cuda' and render_ops._TEST_LIB is None:
+            return None
+        return render_ops.engine_for(x.device)
+
+    def _fast_ok(self, x):
+        return (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.prob.weight.requires_grad))
+                and x.dtype == torch.float32 and x.dim() == 5 and self._engine(x) is not None)
+
+    def _packs(self, device):
+        """conv0's weights with the frozen batch norm folded in, as per-lane MFMA A fragments (csrc/nr_kernels_conv3d.h Conv0Params.wpack),
+        and prob's 8 x 27 taps; rebuilt when a parameter or buffer changes"""
+        conv, bn = self.conv0.conv, self.conv0.bn
+        src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.prob.weight, self.prob.bias)
+        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(device),)
+        hit = self.__dict__.get('_fast_packs')
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                w = (conv.weight * scale[:, None, None, None, None]).reshape(8, 32, 27).float()
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                lane = torch.arange(64, device=w.device)
+                m, g = lane & 15, lane >> 4
+                pack = torch.zeros(27, 2, 64, 4, device=w.device)
+                for q in range(2):
+                    for i in range(4):
+                        vals = w[m.clamp(max=7), 8 * g + 4 * q + i, :] * (m < 8)[:, None]          # [64 lanes, 27 taps]
+                        pack[:, q, :, i] = vals.t()
+                hit = (stamp, pack.contiguous().to(device), shift.to(device), float(bn.slope),
+                       self.prob.weight.detach().reshape(8, 27).float().contiguous().to(device), float(self.prob.bias.detach()[0]))
+            self.__dict__['_fast_packs'] = hit
+        return hit[1:]
+
+    def conv0_fast(self, x):
+        """leaky_relu(batch_norm(conv0(x))) on a [n, 32, D, H, W] volume (any strides; channels-last-3d storage is taken as it is)"""
+        pack, shift, slope, _, _ = self._packs(x.device)
+        xl = x.permute(0, 2, 3, 4, 1)
+        if not xl.is_contiguous():
+            xl = xl.contiguous()
+        return self._engine(x).costreg_conv0(xl, pack, shift, slope)
+
+    def prob_fast(self, x):
+        _, _, _, w, b = self._packs(x.device)
+        return self._engine(x).costreg_prob(x.contiguous(), w, b)
+
+    def forward(self, x):
+        if not self._fast_ok(x):
+            return self.forward_modules(x)
+        return self.prob_fast(self._tail(self.conv0_fast(x)))
 
 
 class MVSNet(nn.Module):
@@ -93,7 +152,10 @@ class MVSNet(nn.Module):
 
     def variance_volume(self, ref_feats, src_feats, ref_nn_idx, ref_prjs, src_prjs, depth_values):
         from . import render_ops
-        return render_ops.engine_for(ref_feats.device).warp_variance(ref_feats, src_feats, ref_nn_idx, ref_prjs, src_prjs, depth_values)
+        # channels-last-3d storage when the volume goes straight into the conv0 kernel (no relayout of 1.7 GB in between)
+        fast = not self.training and not torch.is_grad_enabled()
+        return render_ops.engine_for(ref_feats.device).warp_variance(ref_feats, src_feats, ref_nn_idx, ref_prjs, src_prjs, depth_values,
+                                                                      channels_last=fast)
 
     def construct_cost_volume_with_src(self, ref_imgs, src_imgs, ref_nn_idx, ref_prjs, src_prjs, depth_values, batch_num=2):
         """mvsnet.py:186-203 -> cost_reg [rfn,dn,h/4,w/4].  `batch_num` reference views go through the 3-D U-Net at a

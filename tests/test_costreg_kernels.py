@@ -1,0 +1,86 @@
+"""The two hand-written 3-D convolutions of MVSNet's cost regularisation (csrc/nr_kernels_conv3d.h; reference
+network/mvsnet/mvsnet.py:29-69: `conv0` = ConvBnReLU3D(32, 8) on the variance volume, `prob` = Conv3d(8, 1, 3, padding=1)) against
+PyTorch's own Conv3d + frozen batch norm + leaky ReLU on the same weights, and the whole CostRegNet fast path against the module path.
+CPU: kernels on the emulator; `hip`: libneuray_hip.so."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from emu_util import emu_lib
+from neuray_amd.network import mvsnet
+from neuray_amd.network import render_ops as ro
+
+BACKENDS = ['emu', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def dev(request):
+    ro._ENGINES.clear()
+    if request.param == 'emu':
+        ro._TEST_LIB = emu_lib()
+        yield 'cpu'
+        ro._TEST_LIB = None
+        ro._ENGINES.clear()
+    else:
+        ro._TEST_LIB = None
+        yield 'cuda:0'
+
+
+def make_net(dev, seed=0):
+    torch.manual_seed(seed)
+    net = mvsnet.CostRegNet().eval()
+    with torch.no_grad():
+        for name, buf in net.named_buffers():
+            if name.endswith('running_mean'):
+                buf.copy_(torch.randn(buf.shape) * 0.1)
+            elif name.endswith('running_var'):
+                buf.copy_(torch.rand(buf.shape) * 0.5 + 0.75)
+        for name, prm in net.named_parameters():
+            if name.endswith('bn.weight'):
+                prm.copy_(torch.rand(prm.shape) * 0.5 + 0.75)
+            elif name.endswith('bn.bias'):
+                prm.copy_(torch.randn(prm.shape) * 0.1)
+    return net.to(dev)
+
+
+@pytest.mark.parametrize('shape', [(1, 4, 6, 16), (2, 8, 5, 23), (1, 3, 9, 40)])
+def test_conv0_kernel_matches_conv3d_bn_leaky(dev, shape):
+    """odd sizes: rows that are not a multiple of the 16-voxel strip, every face / edge / corner of the zero padding"""
+    n, d, h, w = shape
+    net = make_net(dev)
+    x = torch.randn(n, 32, d, h, w, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        want = net.conv0(x)
+        got = net.conv0_fast(x)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(1, 4, 6, 16), (2, 5, 7, 19)])
+def test_prob_kernel_matches_conv3d(dev, shape):
+    n, d, h, w = shape
+    net = make_net(dev)
+    x = torch.randn(n, 8, d, h, w, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        want = net.prob(x)
+        got = net.prob_fast(x)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_costregnet_fast_path_equals_the_module_path(dev):
+    """the whole 3-D U-Net with the two kernels in place (what construct_cost_volume_with_src runs under no_grad) against the plain
+    module composition, on a channels-last volume as warp_variance hands it over and on a plain NCDHW one"""
+    net = make_net(dev)
+    x = torch.randn(2, 32, 8, 16, 24, generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.no_grad():
+        want = net.forward_modules(x)
+        for vol in (x, x.contiguous(memory_format=torch.channels_last_3d)):
+            got = net(vol)
+            assert got.shape == want.shape == (2, 1, 8, 16, 24)
+            assert float((got - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
+    # with gradients enabled towards the volume the module path is taken (the kernels are inference-only)
+    xg = x.clone().requires_grad_(True)
+    out = net(xg)
+    assert out.requires_grad

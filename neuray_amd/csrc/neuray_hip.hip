@@ -242,21 +242,21 @@ int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {
     p.hit_prob = a->hit_prob_dev; p.pixel = a->pixel_dev; p.render_depth = a->render_depth_dev; p.ray_mask = a->ray_mask_dev;
     p.density = a->density_dev; p.att_save = a->att_save_dev; p.rn = a->rn; p.dn = a->dn;
     p.mask_view_num = a->ray_mask_view_num; p.mask_point_num = a->ray_mask_point_num;
-    const size_t smem = nr::ray_smem_bytes(a->dn);
+    // two rays per wave when a ray's samples fill at most half of one (the 32-sample fine pass of the headline configuration)
+    const int rpw = a->dn <= 32 ? 2 : 1;
+    const size_t smem = nr::ray_smem_bytes(a->dn, rpw);
     if (smem > 160 * 1024) return fail("neuray_render_rays: dn=%d needs %zu bytes of LDS", a->dn, smem);
-    const int grid = grid_for(a->rn, nr::kRayWaves, 256 * 16);
+    const int grid = grid_for(a->rn, nr::kRayWaves * rpw, 256 * 16);
+    auto launch = [&](auto k) {
+#ifndef NEURAY_EMU
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+        NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+    };
     if (a->att_save_dev) {                                 // training forward: the attention's softmax statistics are kept for the backward
-        auto k = nr::rays_kernel<true>;
-#ifndef NEURAY_EMU
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
-        NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+        if (rpw == 2) launch(nr::rays_kernel<true, 2>); else launch(nr::rays_kernel<true, 1>);
     } else {
-        auto k = nr::rays_kernel<false>;
-#ifndef NEURAY_EMU
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
-        NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kRayWaves), smem, stream, p);
+        if (rpw == 2) launch(nr::rays_kernel<false, 2>); else launch(nr::rays_kernel<false, 1>);
     }
     return check_launch("neuray_render_rays");
 }

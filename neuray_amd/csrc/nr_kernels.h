@@ -822,7 +822,7 @@ constexpr int kRayAttSave = 24;
 
 constexpr int kRayWaves = 4;
 // LDS: attention / sigma-head weights (shared by the workgroup) + per wave K, V, transmittance factors, alpha
-inline size_t ray_smem_bytes(int dn) { return sizeof(float) * (kPackedRayFloats + 12 + kRayWaves * ((size_t)dn * 34)); }
+inline size_t ray_smem_bytes(int dn, int rays_per_wave = 1) { return sizeof(float) * (kPackedRayFloats + 12 + kRayWaves * rays_per_wave * ((size_t)dn * 34)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
     NR_PRAGMA_UNROLL
@@ -852,24 +852,40 @@ __device__ __forceinline__ void matvec16(const float* __restrict__ M, const floa
     }
 }
 
-template <bool SAVE>
+// sum / max over the 64 / RPW lanes of a ray's segment of the wave
+template <int RPW> __device__ __forceinline__ float seg_sum(float v) {
+    NR_PRAGMA_UNROLL
+    for (int m = 32 / RPW; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+template <int RPW> __device__ __forceinline__ float seg_max(float v) {
+    NR_PRAGMA_UNROLL
+    for (int m = 32 / RPW; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// RPW = rays per wave: 1 (any dn; lane = sample, 64 samples per chunk) or 2 (dn <= 32: the two halves of the wave take one ray each - a
+// 32-sample fine pass otherwise idles half of every wave).  The arithmetic per ray is the same in both.
+template <bool SAVE, int RPW = 1>
 __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
     NR_DYNAMIC_SMEM(float, smem);
+    constexpr int SEG = 64 / RPW;
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
+    const int seg = RPW == 2 ? (lane >> 5) : 0, li = RPW == 2 ? (lane & 31) : lane;      // the ray of this lane inside the wave, its lane index there
     const int dn = p.dn;
     float* RW = smem + nr_opaque_zero();               // [kPackedRayFloats] (+ pad to a 16-byte multiple)
-    float* ks = smem + kPackedRayFloats + 12 + (size_t)wave * (dn * 34);
+    float* ks = smem + kPackedRayFloats + 12 + (size_t)(wave * RPW + seg) * (dn * 34);
     float* vs = ks + dn * 16;
     float* tr = vs + dn * 16;        // [dn] transmittance factors
     float* al = tr + dn;             // [dn] alpha
     for (int i = threadIdx.x; i < kPackedRayFloats; i += blockDim.x) RW[i] = p.weights[kPackedPointFloats + i];
     __syncthreads();
-    const int nch = (dn + 63) >> 6;
-    const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
+    const int nch = RPW == 2 ? 1 : (dn + 63) >> 6;
+    const int nray_iter = (p.rn + kRayWaves * RPW - 1) / (kRayWaves * RPW);
 
     for (int it = blockIdx.x; it < nray_iter; it += gridDim.x) {
-        int ray = it * kRayWaves + wave;
+        int ray = (it * kRayWaves + wave) * RPW + seg;
         const bool rvalid = ray < p.rn;
         ray = rvalid ? ray : p.rn - 1;
         const float* rec = p.point_rec + (size_t)ray * dn * kPointRec;
@@ -878,7 +894,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
         asm volatile("" ::: "memory");
         float kn2[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // per head: largest squared key norm of the ray (this lane's samples)
         for (int ch = 0; ch < nch; ++ch) {
-            const int i = ch * 64 + lane;
+            const int i = ch * 64 + li;
             if (i < dn) {
                 float G[16], y[16];
                 NR_PRAGMA_UNROLL
@@ -900,11 +916,11 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
             }
         }
         NR_PRAGMA_UNROLL
-        for (int hh = 0; hh < 4; ++hh) kn2[hh] = wave_max(kn2[hh]);
+        for (int hh = 0; hh < 4; ++hh) kn2[hh] = seg_max<RPW>(kn2[hh]);
         __syncthreads();
         // ---- phase 2: attention row, LayerNorm, sigma, alpha
         for (int ch = 0; ch < nch; ++ch) {
-            const int iraw = ch * 64 + lane;
+            const int iraw = ch * 64 + li;
             const bool act = iraw < dn;               // lanes past the last sample redo sample dn-1 and store nothing, so
             const int i = act ? iraw : dn - 1;        // that the wave stays converged for the ballot below
             asm volatile("" ::: "memory");
@@ -1016,21 +1032,21 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f;
         int cnt = 0;
         for (int ch = 0; ch < nch; ++ch) {
-            const int i = ch * 64 + lane;
+            const int i = ch * 64 + li;
             const bool ok = i < dn;
             float T = 1.0f;
 #ifndef NR_SEQ_COMPOSITE
-            // exclusive prefix product over the lanes in log2(64) shuffle steps (a second chunk of a > 64-sample ray carries the first
-            // chunk's product).  The product associates as a tree, so hit_prob can differ from torch.cumprod's order in the last bit
-            // or two (relative 1e-7; the gates are 1e-4); it stays deterministic and independent of batching.  Measured against the
-            // sequential form: ray kernel 0.302 vs 0.312 ms per launch, identical parity figures (profiles/r03_p_scan_ab.log).
+            // exclusive prefix product over the lanes of the ray's segment in log2 shuffle steps (a second chunk of a > 64-sample ray
+            // carries the first chunk's product).  The product associates as a tree, so hit_prob can differ from torch.cumprod's order
+            // in the last bit or two (relative 1e-7; the gates are 1e-4); it stays deterministic and independent of batching.  Measured
+            // against the sequential form: ray kernel 0.302 vs 0.312 ms per launch, identical parity figures (profiles/r03_p_scan_ab.log).
             {
                 float x = ok ? tr[i] : 1.0f, carry = 1.0f;
                 for (int cc = 0; cc < ch; ++cc) { float q = 1.0f; for (int j = cc * 64; j < cc * 64 + 64 && j < dn; ++j) q *= tr[j]; carry = q * carry; }
                 NR_PRAGMA_UNROLL
-                for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(x, o); x = lane >= o ? x * y : x; }
+                for (int o = 1; o < SEG; o <<= 1) { const float y = __shfl_up(x, o); x = li >= o ? x * y : x; }
                 const float ex = __shfl_up(x, 1);
-                T = (lane == 0 ? 1.0f : ex) * carry;
+                T = (li == 0 ? 1.0f : ex) * carry;
             }
 #else
             for (int j = 0; j < dn; ++j) { const float tj = tr[j]; T = (j < i) ? T * tj : T; }
@@ -1042,10 +1058,10 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
             cr = fmaf(hp, c4.x, cr); cg = fmaf(hp, c4.y, cg); cb = fmaf(hp, c4.z, cb);
             cd = fmaf(hp, p.depth[(size_t)ray * dn + (ok ? i : 0)], cd);
             const unsigned long long b = __ballot(ok && c4.w > (float)p.mask_view_num);
-            cnt += __builtin_popcountll(b);
+            cnt += RPW == 2 ? __builtin_popcountll((b >> (32 * seg)) & 0xffffffffull) : __builtin_popcountll(b);
         }
-        cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); cd = wave_sum(cd);
-        if (lane == 0 && rvalid) {
+        cr = seg_sum<RPW>(cr); cg = seg_sum<RPW>(cg); cb = seg_sum<RPW>(cb); cd = seg_sum<RPW>(cd);
+        if (li == 0 && rvalid) {
             p.pixel[(size_t)ray * 3] = cr; p.pixel[(size_t)ray * 3 + 1] = cg; p.pixel[(size_t)ray * 3 + 2] = cb;
             if (p.render_depth) p.render_depth[ray] = cd;
             if (p.ray_mask) p.ray_mask[ray] = cnt > p.mask_point_num ? 1 : 0;

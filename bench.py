@@ -611,8 +611,10 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     r = NeuralRayBaseRenderer(cfg).eval().to(device)
     eng = r.engine(device)
     render_image(r, tq, tr)
+    eng.slot_stats = stats = torch.zeros(2, dtype=torch.int64, device=device)      # (one untimed image counts the skipped slots)
+    render_image(r, tq, tr)
+    eng.slot_stats = None
     eng.timing = []
-    eng.slot_stats = stats = torch.zeros(2, dtype=torch.int64, device=device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -620,7 +622,7 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in eng.timing if name == 'points']
-    eng.timing, eng.slot_stats = None, None
+    eng.timing = None
     st = stats.cpu().numpy()
     share = float(st[0] / st[1]) if st[1] > 0 else 1.0
     achieved = 2.0 * algorithmic_macs_per_point(RFN, False, True, share) * sum(n for _, n in pts) / sum(t for t, _ in pts) / 1e12     # executed FLOPs
@@ -784,16 +786,19 @@ def main(argv=None):
             dist.barrier()
             sync()
 
-    eng.timing = []
+    # the share of (tile, view) slots the point kernel runs / skips: counted by the kernel itself in ONE extra image outside the timed
+    # region (deterministic per image; the counters cost two atomics per workgroup, which the timed launches do not pay)
     slot_stats = torch.zeros(2, dtype=torch.int64, device=device) if device.type == 'cuda' else None
-    eng.slot_stats = slot_stats           # the point kernel counts the (tile, view) slots it ran / skipped (two atomics per wave and launch)
+    eng.slot_stats = slot_stats
+    render_image(renderer, tq, tr, split)
+    eng.slot_stats = None
+    eng.timing = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = render_image(renderer, tq, tr, split)
     fence()
     dt = time.perf_counter() - t0
-    eng.slot_stats = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -60,11 +60,18 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     const int nwaves = (p.rfn + VPW - 1) / VPW;
     const size_t smem = nr::point_smem_bytes<NT>(nwaves);
     if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
-    // persistent-style grid: enough workgroups to fill the 768 resident slots (3 per CU) ten times over, grid-stride beyond.  Measured on
+    // persistent-style grid: enough workgroups to fill the 768 resident slots (3 per CU) twenty times over, grid-stride beyond.  Measured on
     // the 800 x 800 workload (131 072 tiles per coarse launch), same box: 768 workgroups 2.30 M rays/s, 1536 2.35, 3072 / 3840 2.38,
     // 4096 2.42, 6144 2.37, 8192 ... 32768 2.44 - finer-grained balancing wins over fewer prologues, and counts that divide the tiles
-    // evenly beat those that do not
-    int grid = grid_for(npts, 16 * NT, 256 * 32);
+    // evenly beat those that do not.  Round 4 (tiles of 16 neighbouring rays): 4096 5.59 ms per launch, 8192 5.49, 16384 5.47, 32768 5.55.
+#ifndef NR_POINT_GRID
+#define NR_POINT_GRID (256 * 64)
+#endif
+    int grid = grid_for(npts, 16 * NT, NR_POINT_GRID);
+#ifndef NR_POINT_MIN_TILES
+#define NR_POINT_MIN_TILES 2       // a workgroup's prologue (constants, first weight phase) wants at least this many tiles behind it
+#endif
+    if (!SAVE && npts / 16 >= 4096 && grid > npts / (16 * NR_POINT_MIN_TILES)) grid = npts / (16 * NR_POINT_MIN_TILES);
     grid = (grid + 7) / 8 * 8;                         // the XCD-aware tile map needs a multiple of 8
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")

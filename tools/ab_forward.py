@@ -63,6 +63,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--parity', type=int, default=0)
+    ap.add_argument('--ray-batch', type=int, default=0, help='rays per render_impl call (default: bench.RAY_BATCH = 32768; render.py uses 4096)')
     ap.add_argument('libs', nargs='+')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
@@ -80,14 +81,15 @@ def main():
         if path.startswith('build:'):
             path = build_variant(name, path[6:].split())
         torch.manual_seed(0)
-        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold}).eval()
+        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold, **({'ray_batch_num': a.ray_batch} if a.ray_batch else {})}).eval()
         r.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
         r = r.to(dev)
         r._engine_test_lib = bind_compat(os.path.join(ROOT, path) if not os.path.isabs(path) else path)
         eng = r.engine(dev)
         stats = torch.zeros(2, dtype=torch.int64, device=dev)
-        eng.slot_stats = stats
+        eng.slot_stats = stats                       # (the warm-up image counts the skipped slots; the timed ones run without the counters)
         out = bench.render_image(r, tq, tr)
+        eng.slot_stats = None
         eng.timing = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()

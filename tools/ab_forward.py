@@ -63,11 +63,27 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--parity', type=int, default=0)
+    ap.add_argument('--order', default='row', help="ray order of the image: 'row' (meshgrid, the caller's), 'morton' (Z-order), 'tile8x2', 'tile4x4'")
     ap.add_argument('--ray-batch', type=int, default=0, help='rays per render_impl call (default: bench.RAY_BATCH = 32768; render.py uses 4096)')
     ap.add_argument('libs', nargs='+')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     cfg, r0, weights, que, ref, tq, tr = bench.build_case(dev, 32, seed=0)
+    if a.order != 'row':             # timing experiment: the same rays in another order (results per ray are order-independent)
+        xy = tq['coords'][0].long()
+        x, y = xy[:, 0], xy[:, 1]
+        if a.order == 'morton':
+            def spread(v):
+                v = (v | (v << 8)) & 0x00FF00FF
+                v = (v | (v << 4)) & 0x0F0F0F0F
+                v = (v | (v << 2)) & 0x33333333
+                return (v | (v << 1)) & 0x55555555
+            key = spread(x) | (spread(y) << 1)
+        else:
+            bw, bh = (8, 2) if a.order == 'tile8x2' else (4, 4)
+            key = ((y // bh) * (bench.W // bw) + x // bw) * (bw * bh) + (y % bh) * bw + x % bw
+        perm = torch.argsort(key)
+        tq['coords'] = tq['coords'][:, perm].contiguous()
     want = None
     if a.parity:
         t0 = time.perf_counter()

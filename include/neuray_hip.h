@@ -224,10 +224,8 @@ int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
  * packer gathers fp32 values with the index maps above and converts exactly these ranges. */
 int neuray_packed_quad_ranges(int transposed, int* ranges_host, int max_pairs);
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
-/* The resident kernel exists in two decompositions of the same computation: 2 (default) = workgroups of 8 waves with one reference
- * view each, two waves per SIMD (csrc/nr_kernels_bwd2.h); 3 = 4 waves with 2 views per wave at one wave per SIMD, accumulators in
- * AGPRs (csrc/nr_kernels_bwd3.h; measured slower on the MI355X, kept as the on-device cross-check and for A/B timing).
- * variant 0 restores the default.  Process-wide. */
+/* Kept for ABI stability: variant 0 / 2 = the resident kernel (csrc/nr_kernels_bwd2.h).  Variant 3 - round 3's 4-wave x 2-view decomposition,
+ * measured slower on the MI355X - was retired in round 4 and is refused. */
 int neuray_select_points_backward(int variant);
 
 /* ---- backward of the a19 path (renderer.py:137-155): hit_prob_self [rn][dn] as a function of the gathered query-view

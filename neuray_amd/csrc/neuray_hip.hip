@@ -11,7 +11,7 @@
 #if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT)
 #define NR_INFERENCE_ONLY 1
 #else
-#include "nr_kernels_bwd3.h"
+#include "nr_kernels_bwd2.h"
 #endif
 #include "nr_pack.h"
 #include "../../include/neuray_hip.h"
@@ -517,13 +517,12 @@ size_t neuray_points_backward_workspace_floats(int npoints, int rfn) {
     return (size_t)points_bwd_grid(npoints, pow2_at_least(rfn)) * nr::kBwdRows * 64;
 }
 
-// which resident point-backward kernel neuray_render_points_backward launches: 2 = 8 waves x 1 view at two waves per SIMD
-// (nr_kernels_bwd2.h, the default: 0.91 ms per 512 x 64 x 8 pass on the MI355X), 3 = 4 waves x 2 views per wave at one wave per SIMD
-// with the accumulators in AGPRs (nr_kernels_bwd3.h: 1.06 ms - measured slower, kept selectable as the cross-check)
-static int g_points_bwd_variant = 2;
+// The resident point backward is nr_kernels_bwd2.h (8 waves x 1 view at two waves per SIMD: 0.88 ms per 512 x 64 x 8 pass on the MI355X).
+// Round 3's second decomposition (4 waves x 2 views per wave at one wave per SIMD, accumulators in AGPRs: 1.06 ms) was
+// retired in round 4 - it lost on the hardware and three parity-tested implementations of one gradient were one too many; the
+// first-version kernel (nr_kernels_bwd.h) remains as the rfn > 8 fallback and the cross-check.  The selector stays for ABI stability.
 int neuray_select_points_backward(int variant) {
-    if (variant != 0 && variant != 2 && variant != 3) return fail("neuray_select_points_backward: variant %d (0 = default, 2, 3)", variant);
-    g_points_bwd_variant = variant == 0 ? 2 : variant;
+    if (variant != 0 && variant != 2) return fail("neuray_select_points_backward: variant %d is not built (0 / 2 = the resident kernel; 3 was retired in round 4)", variant);
     return 0;
 }
 
@@ -548,23 +547,6 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
         q.rfn = a->rfn; q.rn = a->rn; q.dn = a->dn; q.h = a->h; q.w = a->w; q.fh = a->fh; q.fw = a->fw;
         q.use_vis = a->use_vis; q.var_bias = a->var_bias;
         const int grid2 = grid_for((long long)a->rn * a->dn, 16, 256);            // persistent: one workgroup per CU
-        if (g_points_bwd_variant == 3) {
-            const size_t smem3 = nr::point_bwd3_smem_bytes();
-            if (a->has_vis_head && a->use_vis) {
-                auto k = nr::points_backward3_kernel<true>;
-#ifndef NEURAY_EMU
-                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
-#endif
-                NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB3Waves), smem3, stream, q);
-            } else {
-                auto k = nr::points_backward3_kernel<false>;
-#ifndef NEURAY_EMU
-                (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
-#endif
-                NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB3Waves), smem3, stream, q);
-            }
-            return check_launch("neuray_render_points_backward (resident, 4 x 2)");
-        }
         const size_t smem = nr::point_bwd2_smem_bytes();
         // (a vis head that compute_prob does not consume - the fine decoder's when the coarse decoder has use_vis = False, quirk A.9.2 -
         // has an identically zero gradient on this path: the kernel without the head is the same computation)

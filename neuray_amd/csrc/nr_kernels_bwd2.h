@@ -116,7 +116,7 @@ constexpr int dw_bias0(int id) {         // running index of the bias accumulato
 }
 constexpr int kDwJobs = dw_job0(DW_COUNT), kDwAcc = (kDwJobs + kB2Waves - 1) / kB2Waves;
 constexpr int kDwBias = dw_bias0(DW_COUNT), kDwBiasAcc = (kDwBias + kB2Waves - 1) / kB2Waves;
-// accumulators per wave when NWV waves share the jobs (points_backward3_kernel: 4 waves)
+// accumulators per wave when NWV waves share the jobs
 constexpr int dw_acc_n(int nwv) { return (kDwJobs + nwv - 1) / nwv; }
 constexpr int dw_bias_n(int nwv) { return (kDwBias + nwv - 1) / nwv; }
 

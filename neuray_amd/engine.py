@@ -111,7 +111,6 @@ class RenderEngine:
         self.max_backward_samples = _lib.MAX_BACKWARD_SAMPLES
         self.slot_stats = None                     # optional int64 device tensor [2]: every point-kernel launch adds (view slots run, view slots)
         self.points_backward_kernel = 'auto'       # 'v1': force the first-version point backward (A/B timing, tests)
-        # 'b2' / 'b3' (render_points_backward(kernel=...)): the 8-wave / the 4-wave x 2-view resident kernel (default: b2; b3 measured 1.06 vs 0.91 ms)
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -521,8 +520,6 @@ class RenderEngine:
         if packed is not None and packed.folded:
             raise ValueError("neuray_amd: the backward kernels take the unfolded pack (pack_pass(fold=False) / pack_pass_device)")
         resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
-        pick = kernel if kernel in ('b2', 'b3') else (self.points_backward_kernel if self.points_backward_kernel in ('b2', 'b3') else None)
-        self._check(self.lib.neuray_select_points_backward({'b2': 2, 'b3': 3, None: 0}[pick]))
         ws = pk = pt = None
         if resident:
             packed = packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))

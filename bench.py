@@ -350,8 +350,8 @@ def ft_step_timing(device, steps=20):
             out['hit_prob_self'].mean() + out['hit_prob_self_fine'].mean()
         loss.backward()
         opt.step()
-    for _ in range(15):             # (also builds most views' cached pixel lists of the ray sampler: 5 ms per first visit of a view)
-        step()
+    for _ in range(60):             # (also builds the views' cached pixel lists of the ray sampler - 5 ms per first visit of one of the 24 views -
+        step()                      # and gets MIOpen's per-shape selections and the allocator's pools settled: 15 warm-up steps left 3 ms of that in the timed ones)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -628,6 +628,27 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     achieved = 2.0 * algorithmic_macs_per_point(RFN, False, True, share) * sum(n for _, n in pts) / sum(t for t, _ in pts) / 1e12     # executed FLOPs
     return {'samples': '64+%d' % fdn, 'ray_batch': ray_batch, 'value': steps * H * W / dt, 'unit': 'rays/s', 'view_slots_run_share': share,
             'point_kernel_ms_per_launch': 1e3 * sum(t for t, _ in pts) / len(pts), 'point_kernel_frac_of_fp32_mfma_peak': achieved / MFMA_F32_PEAK_TFLOPS}
+
+
+def direct_rendering_timing(device, tq, tr, steps=2):
+    """Side measurement: the image with cfg['use_dr_prediction'] (renderer.py:85-125: the point kernel's
+    per-view-record instantiation - which computes every slot - plus dr_points_kernel / dr_rays_kernel in both passes).  Off in every
+    shipped config; timed once so that its cost is a number."""
+    cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': DN_COARSE,
+           'fine_depth_sample_num': 32, 'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': 32},
+           'ray_batch_num': RAY_BATCH, 'use_dr_prediction': True}
+    torch.manual_seed(0)
+    r = NeuralRayBaseRenderer(cfg).eval().to(device)
+    out = render_image(r, tq, tr)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = render_image(r, tq, tr)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {'what': 'same image with use_dr_prediction (per-view record + SH(16) fit per sample point + second compositing), 64+32',
+            'value': steps * H * W / dt, 'unit': 'rays/s', 'ms_per_image': 1e3 * dt / steps,
+            'finite': bool(torch.isfinite(out['pixel_colors_dr_fine']).all().item())}
 
 
 def train_ddp_leg(device, world, test_lib, steps, rays=512):
@@ -933,6 +954,7 @@ def main(argv=None):
                 'reference_default_64+64': side(extra_config_timing, device, 64, RAY_BATCH, tq, tr),
                 'reference_cli_ray_batch_4096': side(extra_config_timing, device, args.fine_samples, 4096, tq, tr),
             })
+            put('direct_rendering', side(direct_rendering_timing, device, tq, tr))
             put('training_step', side(training_step_timing, device))
             put('encoders', side(encoder_timing, device))
             put('ft_step', side(ft_step_timing, device))

@@ -88,7 +88,7 @@ def patch_reference(renderer_module=None, render_ops=False, init_nets=False, ft_
     return mod
 
 
-RENDER_LOOP_METHODS = ('render', 'encode_views')
+RENDER_LOOP_METHODS = ('render', 'encode_views', '_early_query')
 _PATCHED_LOOP = {}
 
 

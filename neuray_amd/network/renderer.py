@@ -69,9 +69,19 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         feats = self.image_encoder(imgs)
         return feats, self.vis_encoder(ray_feats, feats)
 
+    def _early_query(self, que_imgs_info):
+        """The query constants need K^-1 from the host's LAPACK (engine.prepare_query: the bit-exact geometry contract is pinned to the
+        CPU result): a 36-byte device -> host copy, i.e. a wait for everything queued so far.  Taken BEFORE the init net and the encoders
+        are queued it waits for next to nothing; taken where the per-ray path first needs it, it drained 25 ms of queued convolutions per
+        training step and left the GPU idle behind them (profiles/r04_n_gen_host_profile.txt: 8.6 ms per step).  Cached in the dict."""
+        coords = que_imgs_info.get('coords')
+        if coords is not None and coords.is_cuda and coords.shape[0] == 1 and 'Ks' in que_imgs_info:
+            self._query(self.engine(coords.device), que_imgs_info)
+
     def render(self, que_imgs_info, ref_imgs_info, is_train):
         """network/renderer.py:228-254.  ref_imgs_info either carries 'img_feats' and the encoded 'ray_feats' already, or
         (cfg['build_encoders']) 'imgs' and the initial 'ray_feats', which go through image_encoder / vis_encoder first."""
+        self._early_query(que_imgs_info)
         if 'img_feats' not in ref_imgs_info:
             # renderer.py:229-235: encode the reference images, refine the initial ray_feats with them
             if not self.cfg.get('build_encoders', hasattr(self, 'image_encoder')):      # (the reference's cfg has no such key: its classes always build them)
@@ -126,6 +136,7 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
             self.init_net = None      # plain attribute: no parameters, not in the state_dict
 
     def render_call(self, que_imgs_info, ref_imgs_info, is_train, src_imgs_info=None):
+        self._early_query(que_imgs_info)
         if self.init_net is not None:
             ref_imgs_info['ray_feats'] = self.init_net(ref_imgs_info, src_imgs_info, is_train)
         elif 'ray_feats' not in ref_imgs_info:

@@ -606,7 +606,7 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     """The same image at another sampling / batching configuration (reported next to the headline, never instead of it)."""
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': DN_COARSE,
            'fine_depth_sample_num': fdn, 'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
-           'ray_batch_num': ray_batch}
+           'ray_batch_num': ray_batch, 'hip_min_ray_batch': 0}      # (launches of exactly `ray_batch` rays: render() would merge them otherwise)
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).eval().to(device)
     eng = r.engine(device)

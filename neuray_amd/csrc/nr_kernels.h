@@ -324,6 +324,10 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 for (int s = 0; s < NA; ++s) {
                     tfs[s] = make_taps_fast(pu[s], pv[s], w_m1, h_m1, inv_w_m1, inv_h_m1, p.fw, p.fh, p.fw == p.w && p.fh == p.h);
                     tcs[s] = make_taps_fast(pu[s], pv[s], w_m1, h_m1, inv_w_m1, inv_h_m1, p.w, p.h, true);
+#ifdef NR_PROBE_NO_GATHER      // timing probe (wrong results): every tap of every lane reads texel 0 - what the texture path costs
+                    tfs[s].o00 = tfs[s].o10 = tfs[s].o01 = tfs[s].o11 = 0;
+                    tcs[s].o00 = tcs[s].o10 = tcs[s].o01 = tcs[s].o11 = 0;
+#endif
                 }
                 NR_PRAGMA_UNROLL
                 for (int s = 0; s < NA; ++s) {

@@ -41,6 +41,8 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         # not a reference key: the inference packs carry prob_embed.2 folded into its consumers neuray_fc.0 / base_fc.0 (one 32 x 32
         # layer less per (point, view); the same function up to fp32 rounding - neuray_pack_pass_weights_folded)
         'hip_fold_prob_embed': True,
+        # not a reference key: inference render() merges ray batches up to this many rays per launch (0 = exactly cfg['ray_batch_num'])
+        'hip_min_ray_batch': 32768,
     }
 
     def __init__(self, cfg):
@@ -105,6 +107,11 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         if 'ray_feats' not in ref_imgs_info:
             raise NotImplementedError("neuray_amd: render() needs ref_imgs_info['ray_feats']")
         ray_batch_num = self.cfg['ray_batch_num']
+        if not is_train and not torch.is_grad_enabled():
+            # `ray_batch_num` bounds the reference's activation memory (1.7 GB per 4096 rays); here a batch costs 80 B per
+            # sample point, results do not depend on the batching bit for bit, and a 4096-ray launch leaves a third of the
+            # machine idle in its tail (2.56 vs 2.79 M rays/s): inference uses at least cfg['hip_min_ray_batch'] rays per launch
+            ray_batch_num = max(ray_batch_num, int(self.cfg.get('hip_min_ray_batch', 32768)))
         coords = que_imgs_info['coords']
         ray_num = coords.shape[1]
         render_info_all = {}

@@ -46,7 +46,7 @@ def test_full_batch_invariants(case):
     # batching invariance at full size (eval mode: the training path draws its fine-sampling uniforms per call):
     # the same rays in 8 batches of 4096, and a permutation of them, bit for bit
     full = render(renderer, tq, tr, coords, is_train=False)
-    renderer.cfg['ray_batch_num'] = 4096
+    renderer.cfg['ray_batch_num'], renderer.cfg['hip_min_ray_batch'] = 4096, 0        # (exactly 4096 rays per launch: render() merges batches otherwise)
     try:
         parts = render(renderer, tq, tr, coords, is_train=False)
     finally:

@@ -31,7 +31,7 @@ def test_outputs_finite_and_shaped(full_render):
 def test_batching_invariance_bitwise(full_render):
     """Rays are independent: a different ray_batch_num (different tiling of the grid) gives identical bits."""
     cfg, renderer, weights, que, ref, tq, tr, out = full_render
-    renderer.cfg['ray_batch_num'] = 4096
+    renderer.cfg['ray_batch_num'], renderer.cfg['hip_min_ray_batch'] = 4096, 0        # (exactly 4096 rays per launch: render() merges batches otherwise)
     q = dict(tq)
     q['coords'] = tq['coords'][:, 100000:100000 + 3 * 4096 + 123]
     with torch.no_grad():

@@ -217,7 +217,7 @@ def test_rays_are_independent_of_batching(backend):
 def test_render_loop_drops_hit_prob_and_concats(backend):
     """NeuralRayBaseRenderer.render: ray-batch loop, eval drops hit_prob* keys (renderer.py:241-252)."""
     cfg, que, ref, out, mid, extra = load_case('a_small')
-    r, dev = make_renderer({**cfg, 'ray_batch_num': 16}, load_weights(False), backend)
+    r, dev = make_renderer({**cfg, 'ray_batch_num': 16, 'hip_min_ray_batch': 0}, load_weights(False), backend)      # (exactly 16 rays per launch: no merging)
     tq, tr = to_torch(que, dev), to_torch(ref, dev)
     with torch.no_grad():
         got = r.render(tq, tr, False)

@@ -24,7 +24,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from test_render_parity import make_renderer
     cfg, que, ref, out, mid, extra = load_case('a_small')
-    r, dev = make_renderer({**cfg, 'ray_batch_num': 8}, load_weights(False), 'emu')
+    r, dev = make_renderer({**cfg, 'ray_batch_num': 8, 'hip_min_ray_batch': 0}, load_weights(False), 'emu')
     with torch.no_grad():
         full = parallel.render_image_sharded(r, to_torch(que), to_torch(ref))
     if rank == 0:
@@ -221,7 +221,7 @@ def _enc_worker(rank, world, port, out_dir):
     from test_encoders import fill_by_name
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 8,
            'fine_depth_sample_num': 8, 'agg_net_cfg': {'sample_num': 8}, 'fine_agg_net_cfg': {'sample_num': 8},
-           'build_encoders': True, 'ray_batch_num': 16}
+           'build_encoders': True, 'ray_batch_num': 16, 'hip_min_ray_batch': 0}
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).eval()
     fill_by_name(r)

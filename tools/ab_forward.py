@@ -97,7 +97,7 @@ def main():
         if path.startswith('build:'):
             path = build_variant(name, path[6:].split())
         torch.manual_seed(0)
-        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold, **({'ray_batch_num': a.ray_batch} if a.ray_batch else {})}).eval()
+        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold, **({'ray_batch_num': a.ray_batch, 'hip_min_ray_batch': 0} if a.ray_batch else {})}).eval()
         r.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
         r = r.to(dev)
         r._engine_test_lib = bind_compat(os.path.join(ROOT, path) if not os.path.isabs(path) else path)

@@ -234,9 +234,15 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     // its tile mates either way.
     constexpr bool TR = (NR_POINT_TRANSPOSED != 0) && !SAVE && !DBG;
     const int nloop = TR ? ((p.rn + 15) / 16) * dn * 16 : npts;
-    if (bid * 16 < nloop) stage_issue<PH_DIST_M>(wl, W, wave, nw, lane);
-    for (int base = bid * 16; base < nloop; base += gridDim.x * 16, seq0 += phase_count(HAS_VIS)) {
-        const bool more = base + (int)gridDim.x * 16 < nloop;   // another tile follows: its first phase is prefetched
+#ifndef NR_POINT_CHUNK
+#define NR_POINT_CHUNK 1           // consecutive tiles a workgroup walks before it strides on by the grid (A/B: 2, 4, 8)
+#endif
+    constexpr int CH = NR_POINT_CHUNK;
+    const int G = (int)gridDim.x;
+    auto tile_base = [&](int it) { return (((it / CH) * G + bid) * CH + (it % CH)) * 16; };
+    if (tile_base(0) < nloop) stage_issue<PH_DIST_M>(wl, W, wave, nw, lane);
+    for (int it = 0, base; (base = tile_base(it)) < nloop; ++it, seq0 += phase_count(HAS_VIS)) {
+        const bool more = tile_base(it + 1) < nloop;   // another tile follows: its first phase is prefetched
         // lane index for the weight loads that go to global memory (L_BG, L_GF1, L_GF2): opaque and re-made per tile,
         // otherwise hipcc treats these loop-invariant loads as hoistable, keeps ~50 fragment registers alive across the
         // whole tile loop and spills them (seen as "spills outside, reloads inside the loop" in -Rpass-missed=regalloc)
@@ -958,7 +964,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
         }
         NR_PRAGMA_UNROLL
         for (int hh = 0; hh < 4; ++hh) kn2[hh] = seg_max<RPW>(kn2[hh]);
-        __syncthreads();
+        NR_WAVE_SYNC();         // (K, V, alpha and the transmittance factors are this wave's own LDS)
         // ---- phase 2: attention row, LayerNorm, sigma, alpha
         for (int ch = 0; ch < nch; ++ch) {
             const int iraw = ch * 64 + li;
@@ -1067,7 +1073,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
                 if (act) { al[i] = alpha; tr[i] = (1.0f - alpha) + 1e-10f; }
             }
         }
-        __syncthreads();
+        NR_WAVE_SYNC();         // (K, V, alpha and the transmittance factors are this wave's own LDS)
         // ---- phase 3: compositing.  Transmittance = exclusive prefix product over the samples: a wavefront-shuffle scan (north_star;
         // round 3).  -DNR_SEQ_COMPOSITE: the round-1/2 form, every lane multiplying its own prefix in torch.cumprod's order.
         float cr = 0.0f, cg = 0.0f, cb = 0.0f, cd = 0.0f;
@@ -1107,7 +1113,7 @@ __global__ void __launch_bounds__(256, 4) rays_kernel(RayParams p) {
             if (p.render_depth) p.render_depth[ray] = cd;
             if (p.ray_mask) p.ray_mask[ray] = cnt > p.mask_point_num ? 1 : 0;
         }
-        __syncthreads();
+        NR_WAVE_SYNC();         // (K, V, alpha and the transmittance factors are this wave's own LDS)
     }
 }
 
@@ -1144,6 +1150,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
     while (npad < nout) npad <<= 1;
     const float nearp = p.que_const[24], farp = p.que_const[25];
     float* ss = s_s[wave]; float* pdf = s_pdf[wave]; float* cdf = s_cdf[wave]; float* edge = s_edge[wave]; float* srt = s_sort[wave];
+    // (every LDS array below is this wave's own: the ordering points are wave-level, not workgroup barriers - 22 s_barriers per ray less)
     const int nray_iter = (p.rn + kRayWaves - 1) / kRayWaves;
     for (int it = blockIdx.x; it < nray_iter; it += gridDim.x) {
         int ray = it * kRayWaves + wave;
@@ -1152,7 +1159,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
         const float* drow = p.depth + (size_t)ray * dn;
         const float* hrow = p.hit_prob + (size_t)ray * dn;
         for (int i = lane; i < dn; i += 64) { ss[i] = p.linear ? drow[i] : norm_inv_depth(drow[i], nearp, farp); pdf[i] = hrow[i] + 1e-5f; }
-        __syncthreads();
+        NR_WAVE_SYNC();
         // sum(hit_prob + 1e-5) (render_ops.py:194) in the order of the oracle's np.sum - numpy's pairwise sum, which for n <= 128 is one
         // block: eight interleaved partial sums r_j = a[j] + a[8 + j] + ..., the tree ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)),
         // then the n % 8 tail added one by one - so that the cdf, and with it every searchsorted bin, is the oracle's bit for bit on
@@ -1171,9 +1178,9 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
             for (int i = n8; i < dn; ++i) r += pdf[i];
             tot = r;
         }
-        __syncthreads();
+        NR_WAVE_SYNC();
         for (int i = lane; i < dn; i += 64) pdf[i] = pdf[i] / tot;
-        __syncthreads();
+        NR_WAVE_SYNC();
         for (int i = lane; i <= dn; i += 64) {
             // sequential prefix sum (bit-exact cumsum order)
             float cdfv = 0.0f;
@@ -1182,7 +1189,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
             if (p.cdf_out && rvalid) p.cdf_out[(size_t)ray * (dn + 1) + i] = cdfv;
             edge[i] = (i == 0) ? ss[0] : (i == dn ? ss[dn - 1] : rn_div(rn_add(ss[i], ss[i - 1]), 2.0f));
         }
-        __syncthreads();
+        NR_WAVE_SYNC();
         const float interval = (float)(1.0 / (double)fdn);
         for (int k = lane; k < npad; k += 64) {
             float val = INFINITY;
@@ -1208,7 +1215,7 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
             }
             srt[k] = val;
         }
-        __syncthreads();
+        NR_WAVE_SYNC();
         // bitonic sort (ascending) of npad values in LDS
         for (int kk = 2; kk <= npad && !p.no_sort; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -1220,11 +1227,11 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
                         if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
                     }
                 }
-                __syncthreads();
+                NR_WAVE_SYNC();
             }
         if (rvalid)
             for (int k = lane; k < nout; k += 64) p.out[(size_t)ray * nout + k] = srt[k];
-        __syncthreads();
+        NR_WAVE_SYNC();
     }
 }
 

@@ -206,6 +206,14 @@ __device__ __forceinline__ int nr_opaque_szero() { int z; asm volatile("s_mov_b3
 
 // workgroup barrier of the point kernel
 #define NR_BLOCK_SYNC() __syncthreads()
+// orders the LDS traffic of ONE wave (written by some lanes, read by others of the same wave - per-wave scratch, no other wave involved):
+// the LDS executes a wave's instructions in order, so all it takes is that the compiler keeps the order; no s_barrier, no other wave waits
+#ifdef NEURAY_EMU
+#define NR_WAVE_SYNC() ((void)emu::wave_sync())
+#else
+#define NR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 // fast transcendental building blocks (v_exp_f32 / v_log_f32 / v_rcp_f32: ~1 ulp each)
 #ifdef NEURAY_EMU

@@ -368,6 +368,14 @@ int neuray_dist_decoder_rows(const float* feats_dev, const float* packed_weights
 int neuray_self_hit_prob(const float* query_const_dev, const float* depth_dev, const float* mean_dev, const float* var_dev,
                          const float* aw_dev, const float* vis_dev, int rn, int dn, float* out_dev, void* stream);
 
+/* ---- f-4 host pipeline: the ray sampler's np.random.shuffle, off the interpreter -------------------------------------------
+ * Replaces: the two `np.random.shuffle` calls of utils/base_utils.py:585-603 (sample_train_coords: a training step's rays, drawn over
+ * the full pixel lists of the query image - 640 000 entries at 800 x 800).  Host-only: the permutation numpy's legacy RandomState
+ * (MT19937) produces from the state { key[624], pos } (np.random.get_state()[1:3]), in place on a 1-D array of 4- or 8-byte items;
+ * key / pos are advanced exactly as numpy advances them, so a seeded run draws the same rays.  Unlike numpy's it runs without the
+ * interpreter lock (the host side of neuray_amd draws the NEXT step's rays on a worker thread while the current step is queued). */
+int neuray_mt19937_shuffle(unsigned int* key624_host, int* pos_host, void* data_host, long long n, int itemsize);
+
 /* ---- hardware self test of the MFMA operand layout the kernels assume (16x4 @ 4x16) ----------------------------- */
 int neuray_mfma_selftest(const float* A_dev, const float* B_dev, float* D_dev, void* stream);
 /* ---- hardware self test of the lane-group sum behind the vector rows (v_permlane16_swap / v_permlane32_swap):

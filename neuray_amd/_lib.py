@@ -91,6 +91,7 @@ SYMBOLS = {
     'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_weights_folded': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_index_map': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_mt19937_shuffle': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_longlong, C.c_int]),
     'neuray_setup_views': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_setup_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_relayout_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

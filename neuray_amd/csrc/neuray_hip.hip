@@ -155,6 +155,12 @@ int neuray_pack_pass_weights_folded(const float* const* tensors_host, float* pac
     return 0;
 }
 
+int neuray_mt19937_shuffle(unsigned int* key624_host, int* pos_host, void* data_host, long long n, int itemsize) {
+    if (nr::mt19937_shuffle(key624_host, pos_host, data_host, n, itemsize))
+        return fail("neuray_mt19937_shuffle: needs key[624], 0 <= pos <= 624, a data pointer and 4- or 8-byte items");
+    return 0;
+}
+
 int neuray_operand_precision(void) {
 #if defined(NR_BF16_SPLIT)
     return 48;         // hi + lo bf16 operands, three bf16 MFMAs per fp32 quad (libneuray_hip_bf16x3.so)

@@ -421,4 +421,56 @@ int pack_pass_index_map(bool has_vis, int* index, float* scale) {
     return 0;
 }
 
+// ---- np.random.shuffle of the reference's ray sampler, off the interpreter ------------------------------------------------------
+// utils/base_utils.py:585-603 draws a training step's rays with two np.random.shuffle calls over the full pixel lists of the query
+// image (640 000 entries at 800 x 800): 8 ms per step inside numpy, holding the interpreter lock.  The same permutation from the same
+// generator state: numpy's legacy RandomState is MT19937 (key[624], pos), its shuffle is Fisher-Yates from the top - for i = n - 1 ...
+// 1: j = random_interval(i), swap(x[i], x[j]) - and random_interval(max) masks 32-bit draws (64-bit above 2^32 - 1) to the smallest
+// 2^k - 1 >= max and rejects values > max.  The caller hands over np.random.get_state()'s key / pos and puts them back afterwards.
+namespace {
+struct Mt19937 {
+    unsigned int* key;
+    int pos;
+    void refill() {
+        constexpr int N = 624, M = 397;
+        constexpr unsigned int A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
+        int k = 0;
+        for (; k < N - M; ++k) { const unsigned int y = (key[k] & UP) | (key[k + 1] & LO); key[k] = key[k + M] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+        for (; k < N - 1; ++k) { const unsigned int y = (key[k] & UP) | (key[k + 1] & LO); key[k] = key[k + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+        const unsigned int y = (key[N - 1] & UP) | (key[0] & LO);
+        key[N - 1] = key[M - 1] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+        pos = 0;
+    }
+    unsigned int next32() {
+        if (pos >= 624) refill();
+        unsigned int y = key[pos++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    unsigned long long next64() { const unsigned long long hi = next32(); return (hi << 32) | next32(); }
+    unsigned long long interval(unsigned long long max) {
+        if (max == 0) return 0;
+        unsigned long long mask = max, v;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        if (max <= 0xffffffffull) { while ((v = (next32() & mask)) > max) {} }
+        else { while ((v = (next64() & mask)) > max) {} }
+        return v;
+    }
+};
+}  // namespace
+
+int mt19937_shuffle(unsigned int* key, int* pos, void* data, long long n, int itemsize) {
+    if (!key || !pos || *pos < 0 || *pos > 624 || (n > 0 && !data) || (itemsize != 4 && itemsize != 8)) return 1;
+    Mt19937 g{key, *pos};
+    if (itemsize == 4) {
+        unsigned int* x = static_cast<unsigned int*>(data);
+        for (long long i = n - 1; i >= 1; --i) { const long long j = (long long)g.interval((unsigned long long)i); const unsigned int t = x[j]; x[j] = x[i]; x[i] = t; }
+    } else {
+        unsigned long long* x = static_cast<unsigned long long*>(data);
+        for (long long i = n - 1; i >= 1; --i) { const long long j = (long long)g.interval((unsigned long long)i); const unsigned long long t = x[j]; x[j] = x[i]; x[i] = t; }
+    }
+    *pos = g.pos;
+    return 0;
+}
+
 }  // namespace nr

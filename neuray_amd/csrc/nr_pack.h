@@ -32,4 +32,8 @@ int pack_pass_t_weights(const float* const* tensors, float* dst);
 // packed_t[i] = flat[index[i]]; index -1 = padding.  kPackedTFloats entries.
 int pack_pass_t_index_map(bool has_vis, int* index);
 
+// np.random.shuffle (legacy MT19937 RandomState) of a 1-D array of 4- or 8-byte items, in place; key[624] / *pos are the generator state
+// and are advanced exactly as numpy advances them.  0 on success.
+int mt19937_shuffle(unsigned int* key, int* pos, void* data, long long n, int itemsize);
+
 }  // namespace nr

@@ -12,10 +12,15 @@ implementation.
 The per-ray methods themselves (`render_by_depth`, `fine_render_impl`, `render_impl`, `predict_self_hit_prob`) live in
 network/hip_path.py so that neuray_amd/integrate.py can graft the very same code onto the reference's own classes.
 """
+import ctypes
+import threading
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from .hip_path import HipRenderPath
 from .aggregate_net import name2agg_net
 from .dist_decoder import name2dist_decoder
@@ -203,22 +208,52 @@ def pixel_lists(fg_mask):
     return np.flatnonzero(fg_mask).astype(np.int32), np.flatnonzero(~fg_mask).astype(np.int32), fg_mask.shape[1]
 
 
-def sample_train_coords(fg_mask, ray_num, foreground_ratio, lists=None):
+_HOST_LIB = []
+
+
+def _host_lib():
+    """libneuray_hip.so for its host-only entry points (they need no GPU), or None where it has not been built"""
+    if not _HOST_LIB:
+        try:
+            _HOST_LIB.append(_lib.load())
+        except (_lib.NeurayLibError, OSError, AttributeError):
+            _HOST_LIB.append(None)
+    return _HOST_LIB[0]
+
+
+def shuffle_like_numpy(arr, rs=np.random):
+    """rs.shuffle(arr) for a large 1-D array - the same permutation, the same generator state afterwards - through
+    neuray_mt19937_shuffle: numpy's Fisher-Yates on its MT19937 state, outside the interpreter lock (numpy holds it for the 4 ms of a
+    640 000-entry shuffle, which is what keeps the next step's draws from overlapping this step's launches).  `rs`: the np.random
+    module (the global generator) or a np.random.RandomState."""
+    lib = _host_lib()
+    if lib is None or arr.ndim != 1 or arr.itemsize not in (4, 8) or not arr.flags.c_contiguous or arr.shape[0] < 4096:
+        rs.shuffle(arr)
+        return
+    st = rs.get_state()
+    key = np.array(st[1], dtype=np.uint32)
+    pos = ctypes.c_int(int(st[2]))
+    _lib.check(lib, lib.neuray_mt19937_shuffle(key.ctypes.data, ctypes.byref(pos), arr.ctypes.data, arr.shape[0], arr.itemsize))
+    rs.set_state((st[0], key, pos.value, st[3], st[4]))
+
+
+def sample_train_coords(fg_mask, ray_num, foreground_ratio, lists=None, rs=np.random):
     """utils/base_utils.py:585-603: `ray_num` pixel coordinates (x, y) of one image, at least
     int(ray_num * foreground_ratio) of them drawn from the foreground mask (when it has that many), the rest from the
     remaining pixels.  The two np.random.shuffle draws over the full pixel lists are the reference's (same lengths, same order,
     so the same generator stream and the same pixels); what the reference does around them - two np.nonzero passes, gathering
     and concatenating the whole shuffled lists to keep 512 rows - is replaced by cached lists (`lists` = pixel_lists(fg_mask))
-    and by indexing only the rows that are returned (19 -> 8 ms per step at 800 x 800)."""
+    and by indexing only the rows that are returned (19 -> 8 ms per step at 800 x 800).  `rs`: the generator the draws come from
+    (the global one, or the private copy of it a prefetching NeuralRayFtRenderer works on)."""
     want_fg = int(ray_num * foreground_ratio)
     fg, bg, w = lists if lists is not None else pixel_lists(fg_mask)
-    order = np.arange(fg.shape[0])
-    np.random.shuffle(order)
+    order = np.arange(fg.shape[0], dtype=np.int32)                         # (the permutation does not depend on the item type)
+    shuffle_like_numpy(order, rs)
     flat = fg[order[:want_fg]]
     if want_fg < ray_num:
         nbg = bg.shape[0]
-        order2 = np.arange(nbg + max(fg.shape[0] - want_fg, 0))        # the pool: background, then the unpicked foreground
-        np.random.shuffle(order2)
+        order2 = np.arange(nbg + max(fg.shape[0] - want_fg, 0), dtype=np.int32)     # the pool: background, then the unpicked foreground
+        shuffle_like_numpy(order2, rs)
         idx = order2[:ray_num - want_fg]
         rest = np.empty(idx.shape[0], np.int32)
         from_bg = idx < nbg
@@ -226,6 +261,72 @@ def sample_train_coords(fg_mask, ray_num, foreground_ratio, lists=None):
         rest[~from_bg] = fg[order[want_fg + idx[~from_bg] - nbg]]
         flat = np.concatenate([flat, rest], 0)
     return np.stack([flat % w, flat // w], 1).astype(np.float32)
+
+
+def _same_generator_state(a, b):
+    return a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1])
+
+
+# speculative draws of the NEXT training step, per renderer (kept outside the module so that it stays picklable / deep-copyable)
+_PREFETCH = weakref.WeakKeyDictionary()
+
+
+def _train_coords(ft, val_idx, rs):
+    """[1, train_ray_num, 2] training rays of reference view `val_idx` (sample_train_coords on its cached pixel lists)"""
+    cached = ft.__dict__.setdefault('_pixel_lists', {})
+    lists = cached.get(int(val_idx))
+    if lists is None:
+        lists = cached[int(val_idx)] = pixel_lists(ft.ref_imgs_info['masks'][val_idx, 0].cpu().numpy() > 0)
+    return sample_train_coords(None, ft.cfg['train_ray_num'], ft.cfg['foreground_ratio'], lists, rs).reshape(1, -1, 2)
+
+
+def _sampling_cfg(ft):
+    return tuple(ft.cfg[k] for k in ('include_self_prob', 'neighbor_view_num', 'neighbor_pool_ratio', 'train_ray_num', 'foreground_ratio'))
+
+
+def _draw_train_step(ft, rs):
+    """renderer.py:521-529 + base_utils.py:585-603: every np.random draw of one training step, in the reference's order, from `rs`
+    -> (query view, its reference views, ray coordinates)"""
+    que_i = rs.randint(0, len(ft.ref_ids))
+    ref_idx = ft.ref_dist_idx[que_i]
+    if rs.random_sample() > ft.cfg['include_self_prob']:
+        ref_idx = ref_idx[1:]
+    ref_idx = ref_idx[:ft.cfg['neighbor_view_num'] * ft.cfg['neighbor_pool_ratio']].copy()
+    rs.shuffle(ref_idx)
+    ref_idx = ref_idx[:ft.cfg['neighbor_view_num']]
+    return que_i, ref_idx, _train_coords(ft, que_i, rs)
+
+
+def _prefetch_start(ft):
+    start, cfg = np.random.get_state(), _sampling_cfg(ft)
+    slot = {'start': start, 'cfg': cfg}
+
+    def work():
+        rs = np.random.RandomState()
+        rs.set_state(start)
+        try:
+            slot['drawn'] = _draw_train_step(ft_ref(), rs)
+            slot['end'] = rs.get_state()
+        except Exception:                                    # (a vanished renderer, a changed scene: the next step draws afresh)
+            slot.pop('drawn', None)
+
+    ft_ref = weakref.ref(ft)
+    slot['thread'] = threading.Thread(target=work, name='neuray-ray-sampler', daemon=True)
+    _PREFETCH[ft] = slot
+    slot['thread'].start()
+
+
+def _prefetch_take(ft):
+    slot = _PREFETCH.pop(ft, None)
+    if slot is None:
+        return None
+    slot['thread'].join()
+    if 'drawn' not in slot or 'end' not in slot or slot['cfg'] != _sampling_cfg(ft):
+        return None
+    if not _same_generator_state(np.random.get_state(), slot['start']):
+        return None
+    np.random.set_state(slot['end'])
+    return slot['drawn']
 
 
 def pad_views(info, interval):
@@ -368,16 +469,13 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
             ref_imgs_info['img_feats'], ref_imgs_info['ray_feats'] = self._encoded(ref_idx)
         return ref_imgs_info
 
-    def slice_imgs_info(self, ref_idx, val_idx, is_train):
-        """renderer.py:484-507"""
+    def slice_imgs_info(self, ref_idx, val_idx, is_train, coords=None):
+        """renderer.py:484-507.  coords: the training rays of `val_idx` when they have been drawn already (train_step's prefetch)."""
         ref_imgs_info = self._ref_views(ref_idx, is_train)
         if is_train:
-            cached = self.__dict__.setdefault('_pixel_lists', {})
-            lists = cached.get(int(val_idx))
-            if lists is None:
-                lists = cached[int(val_idx)] = pixel_lists(self.ref_imgs_info['masks'][val_idx, 0].cpu().numpy() > 0)
             que = _take(self._resident('ref'), [val_idx])
-            coords = sample_train_coords(None, self.cfg['train_ray_num'], self.cfg['foreground_ratio'], lists).reshape(1, -1, 2)
+            if coords is None:
+                coords = _train_coords(self, val_idx, np.random)
         else:
             que = _take(self._resident('val'), [val_idx])
             hn, wn = que['imgs'].shape[-2:]
@@ -399,15 +497,21 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
         return outputs
 
     def train_step(self):
-        """renderer.py:521-543: a random view as the query, 8 of its 16 nearest other views (itself with 1 % probability)."""
-        que_i = np.random.randint(0, len(self.ref_ids))
-        ref_idx = self.ref_dist_idx[que_i]
-        if np.random.random() > self.cfg['include_self_prob']:
-            ref_idx = ref_idx[1:]
-        ref_idx = ref_idx[:self.cfg['neighbor_view_num'] * self.cfg['neighbor_pool_ratio']].copy()
-        np.random.shuffle(ref_idx)
-        ref_idx = ref_idx[:self.cfg['neighbor_view_num']]
-        ref_imgs_info, que_imgs_info = self.slice_imgs_info(ref_idx, que_i, True)
+        """renderer.py:521-543: a random view as the query, 8 of its 16 nearest other views (itself with 1 % probability).
+
+        The step's np.random draws (view, neighbours, the ray sampler's two shuffles over the 640 000 pixels of the query image: 8 ms
+        of the host's 22 ms per step) are the reference's, in its order.  With cfg['hip_prefetch_ray_sampling'] (default
+        on) the NEXT step's draws are made speculatively on a worker thread, on a private copy of the global generator, while this
+        step's kernels are being queued; the next call adopts them - and moves the global generator to where those draws left the copy -
+        only if the global generator is still exactly where the speculation started (nobody else drew from np.random or re-seeded it in
+        between) and the sampling cfg is unchanged; otherwise it draws afresh.  Either way the stream and the rays are the reference's."""
+        drawn = _prefetch_take(self)
+        if drawn is None:
+            drawn = _draw_train_step(self, np.random)
+        que_i, ref_idx, coords = drawn
+        if self.cfg.get('hip_prefetch_ray_sampling', True):
+            _prefetch_start(self)
+        ref_imgs_info, que_imgs_info = self.slice_imgs_info(ref_idx, que_i, True, coords=coords)
         self.touched_views = sorted(set(int(i) for i in ref_idx) | ({int(que_i)} if self.cfg['use_self_hit_prob'] else set()))
         outputs = self.render(que_imgs_info.copy(), ref_imgs_info.copy(), True)
         for k in ('ray_feats', 'img_feats', '_neuray_qconst', '_neuray_qconst_entry'):

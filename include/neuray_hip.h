@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 7
+#define NEURAY_ABI_VERSION 8
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -349,15 +349,33 @@ int neuray_direct_render_rays(const float* alpha_dev, const float* colors_dev, i
  * forward:  out_padded [n][c][h + 2 pad][w + 2 pad] = reflect_pad(act(gamma (x - mean) / sqrt(var + eps) + beta [+ res])), act 0 = none,
  *           1 = ReLU, 2 = ELU; res (NULL = none) is addressed with element strides (a view of another padded buffer);
  *           raw_zeroed [n*c][2] is scratch that must be zero on entry; stats [n*c][2] receives (mean, 1 / std) for the backward.
+ *           out_stride_n: floats between consecutive images of out_padded (0 = c (h + 2 pad) (w + 2 pad), contiguous) - the output may
+ *           be the leading channels of a wider buffer, e.g. the first half of a channel concatenation.
  * backward: d_out_padded is the gradient of the padded output (everything that consumed the padded tensor or its interior view);
  *           -> dx [n][c][h][w], d_res [n][c][h][w] (NULL = no residual).  raw_zeroed [n*c][2] (zero on entry) returns per plane
- *           (sum g, sum g xhat): d beta[c] = sum over images of the first, d gamma[c] of the second. */
+ *           (sum g, sum g xhat); d_gamma_zeroed / d_beta_zeroed [c] (zero on entry, NULL = not wanted) receive their sums over the
+ *           images: the gradients of the affine parameters.  out_padded / d_out_padded take image strides as the forward's output. */
 int neuray_inorm_forward(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, long long res_stride_n,
                          long long res_stride_c, long long res_stride_h, int n, int c, int h, int w, int pad, int act, float eps,
-                         float* raw_zeroed_dev, float* stats_dev, float* out_padded_dev, void* stream);
-int neuray_inorm_backward(const float* x_dev, const float* out_padded_dev, const float* d_out_padded_dev, const float* stats_dev,
-                          const float* gamma_dev, int n, int c, int h, int w, int pad, int act, float* raw_zeroed_dev, float* dx_dev,
-                          float* d_res_dev, void* stream);
+                         float* raw_zeroed_dev, float* stats_dev, float* out_padded_dev, long long out_stride_n, void* stream);
+int neuray_inorm_backward(const float* x_dev, const float* out_padded_dev, long long out_stride_n, const float* d_out_padded_dev,
+                          long long d_out_stride_n, const float* stats_dev, const float* gamma_dev, int n, int c, int h, int w, int pad,
+                          int act, float* raw_zeroed_dev, float* dx_dev, float* d_res_dev, float* d_gamma_zeroed_dev,
+                          float* d_beta_zeroed_dev, void* stream);
+
+/* ---- f-1: bilinear x2 up-sampling + reflection padding of the image encoder's decoder half ------------------------------------
+ * Replaces: F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) followed by the reflection padding of the next 3 x 3
+ * convolution (network/ops.py:150-230, ResUNetLight.upconv3 / upconv2) and, in the backward, PyTorch's four float atomics per
+ * output-gradient element.  x [planes][h][w] -> out [planes][2h + 2 pad][2w + 2 pad], pad 0 or 1; scale_y = fp32((h - 1) / (2h - 1)),
+ * scale_x likewise (PyTorch's area_pixel_compute_scale): source index = scale * output index, truncated.
+ * backward: a gather per input element over per-axis tables the caller builds with the same fp32 arithmetic - for input row y the
+ * cnt_y[y] <= 8 padded output rows idx_y[y][k] that read it with weight wgt_y[y][k] (mirrored padding rows included), columns alike;
+ * w <= 2047 (the combined rows of a workgroup are staged in LDS). */
+int neuray_upsample2x_pad_forward(const float* x_dev, int planes, int h, int w, int pad, float scale_y, float scale_x,
+                                  float* out_padded_dev, void* stream);
+int neuray_upsample2x_pad_backward(const float* d_out_padded_dev, int planes, int h, int w, int pad, const int* cnt_y_dev,
+                                   const int* idx_y_dev /*[h][8]*/, const float* wgt_y_dev /*[h][8]*/, const int* cnt_x_dev,
+                                   const int* idx_x_dev /*[w][8]*/, const float* wgt_x_dev /*[w][8]*/, float* dx_dev, void* stream);
 
 /* ---- a9 stand-alone: MixtureLogisticsDistDecoder.forward / predict_mean on arbitrary rows (dist_decoder.py:99-107,147-149).
  * feats [n][32] -> mean [n][2], var [n][2] (bias_val included), aw [n], vis [n] (vis only with a vis head, else NULL). */

@@ -111,8 +111,11 @@ SYMBOLS = {
     'neuray_project_points': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_alpha2hit_prob': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    'neuray_inorm_forward': (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] * 3 + [C.c_int] * 6 + [C.c_float] + [C.c_void_p] * 4),
-    'neuray_inorm_backward': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p] * 4),
+    'neuray_inorm_forward': (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] * 3 + [C.c_int] * 6 + [C.c_float] + [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
+    'neuray_inorm_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 6),
+    'neuray_upsample2x_pad_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'neuray_upsample2x_pad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_direct_render_points': (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_direct_render_rays': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_dist_decoder_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -361,32 +361,63 @@ int norm_chunks(int planes, int hw) {          // workgroups per plane: ~4096 wo
 
 int neuray_inorm_forward(const float* x, const float* gamma, const float* beta, const float* res, long long res_stride_n,
                          long long res_stride_c, long long res_stride_h, int n, int c, int h, int w, int pad, int act, float eps,
-                         float* raw_zeroed, float* stats, float* out_padded, void* stream) {
+                         float* raw_zeroed, float* stats, float* out_padded, long long out_stride_n, void* stream) {
     if (!x || !gamma || !beta || !raw_zeroed || !stats || !out_padded) return fail("neuray_inorm_forward: null pointer");
     if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2 || (long long)(h + 2 * pad) * (w + 2 * pad) >= (1 << 23))
         return fail("neuray_inorm_forward: bad arguments n=%d c=%d h=%d w=%d pad=%d act=%d", n, c, h, w, pad, act);
+    const long long img = (long long)c * (h + 2 * pad) * (w + 2 * pad);
+    if (out_stride_n != 0 && out_stride_n < img) return fail("neuray_inorm_forward: out_stride_n %lld < %lld", out_stride_n, img);
     const int planes = n * c, hw = h * w;
     NR_LAUNCH(nr::inorm_stats_kernel, dim3(norm_chunks(planes, hw), planes), dim3(256), 0, stream, x, hw, raw_zeroed);
     nr::NormApplyParams p;
     p.x = x; p.raw = raw_zeroed; p.gamma = gamma; p.beta = beta; p.res = res; p.out = out_padded; p.stats = stats;
-    p.rs_n = res_stride_n; p.rs_c = res_stride_c; p.rs_h = res_stride_h;
+    p.rs_n = res_stride_n; p.rs_c = res_stride_c; p.rs_h = res_stride_h; p.out_stride_n = out_stride_n ? out_stride_n : img;
     p.n = n; p.c = c; p.h = h; p.w = w; p.pad = pad; p.act = act; p.eps = eps;
     NR_LAUNCH(nr::inorm_apply_kernel, dim3(norm_chunks(planes, (h + 2 * pad) * (w + 2 * pad)), planes), dim3(256), 0, stream, p);
     return check_launch("neuray_inorm_forward");
 }
 
-int neuray_inorm_backward(const float* x, const float* out_padded, const float* d_out_padded, const float* stats, const float* gamma,
-                          int n, int c, int h, int w, int pad, int act, float* raw_zeroed, float* dx, float* d_res, void* stream) {
+int neuray_inorm_backward(const float* x, const float* out_padded, long long out_stride_n, const float* d_out_padded, long long d_out_stride_n,
+                          const float* stats, const float* gamma, int n, int c, int h, int w, int pad, int act, float* raw_zeroed, float* dx,
+                          float* d_res, float* d_gamma_zeroed, float* d_beta_zeroed, void* stream) {
     if (!x || !out_padded || !d_out_padded || !stats || !gamma || !raw_zeroed || !dx) return fail("neuray_inorm_backward: null pointer");
     if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2 || (long long)(h + 2 * pad) * (w + 2 * pad) >= (1 << 23))
         return fail("neuray_inorm_backward: bad arguments n=%d c=%d h=%d w=%d pad=%d act=%d", n, c, h, w, pad, act);
+    const long long img = (long long)c * (h + 2 * pad) * (w + 2 * pad);
+    if ((out_stride_n != 0 && out_stride_n < img) || (d_out_stride_n != 0 && d_out_stride_n < img))
+        return fail("neuray_inorm_backward: image strides %lld / %lld < %lld", out_stride_n, d_out_stride_n, img);
     nr::NormBwdParams p;
     p.x = x; p.out = out_padded; p.d_out = d_out_padded; p.stats = stats; p.gamma = gamma; p.raw = raw_zeroed; p.dx = dx; p.d_res = d_res;
+    p.d_gamma = d_gamma_zeroed; p.d_beta = d_beta_zeroed;
+    p.out_stride_n = out_stride_n ? out_stride_n : img; p.d_out_stride_n = d_out_stride_n ? d_out_stride_n : img;
     p.n = n; p.c = c; p.h = h; p.w = w; p.pad = pad; p.act = act;
     const int planes = n * c, hw = h * w;
     NR_LAUNCH(nr::inorm_backward_reduce_kernel, dim3(norm_chunks(planes, hw), planes), dim3(256), 0, stream, p);
     NR_LAUNCH(nr::inorm_backward_apply_kernel, dim3(norm_chunks(planes, hw), planes), dim3(256), 0, stream, p);
     return check_launch("neuray_inorm_backward");
+}
+
+int neuray_upsample2x_pad_forward(const float* x, int planes, int h, int w, int pad, float scale_y, float scale_x, float* out_padded, void* stream) {
+    if (!x || !out_padded) return fail("neuray_upsample2x_pad_forward: null pointer");
+    if (planes < 1 || h < 2 || w < 2 || pad < 0 || pad > 1 || (long long)(2 * h + 2 * pad) * (2 * w + 2 * pad) >= (1 << 23))
+        return fail("neuray_upsample2x_pad_forward: bad arguments planes=%d h=%d w=%d pad=%d", planes, h, w, pad);
+    nr::UpsampleParams p;
+    p.x = x; p.out = out_padded; p.planes = planes; p.h = h; p.w = w; p.pad = pad; p.sy = scale_y; p.sx = scale_x;
+    NR_LAUNCH(nr::upsample2x_pad_kernel, dim3(norm_chunks(planes, (2 * h + 2 * pad) * (2 * w + 2 * pad)), planes), dim3(256), 0, stream, p);
+    return check_launch("neuray_upsample2x_pad_forward");
+}
+
+int neuray_upsample2x_pad_backward(const float* d_out_padded, int planes, int h, int w, int pad, const int* cnt_y, const int* idx_y,
+                                   const float* wgt_y, const int* cnt_x, const int* idx_x, const float* wgt_x, float* dx, void* stream) {
+    if (!d_out_padded || !cnt_y || !idx_y || !wgt_y || !cnt_x || !idx_x || !wgt_x || !dx) return fail("neuray_upsample2x_pad_backward: null pointer");
+    if (planes < 1 || h < 2 || w < 2 || w > 2047 || pad < 0 || pad > 1 || (long long)h * w >= (1 << 23))
+        return fail("neuray_upsample2x_pad_backward: bad arguments planes=%d h=%d w=%d (<= 2047) pad=%d", planes, h, w, pad);
+    nr::UpsampleBwdParams p;
+    p.d_out = d_out_padded; p.dx = dx; p.cnt_y = cnt_y; p.idx_y = idx_y; p.wgt_y = wgt_y; p.cnt_x = cnt_x; p.idx_x = idx_x; p.wgt_x = wgt_x;
+    p.planes = planes; p.h = h; p.w = w; p.hp = 2 * h + 2 * pad; p.wp = 2 * w + 2 * pad;
+    NR_LAUNCH(nr::upsample2x_pad_backward_kernel, dim3((h + nr::kUpRows - 1) / nr::kUpRows, planes), dim3(256),
+              sizeof(float) * nr::kUpRows * (size_t)p.wp, stream, p);
+    return check_launch("neuray_upsample2x_pad_backward");
 }
 
 int neuray_rays_points(const float* query_const, const float* coords, const float* depth, int rn, int dn, float* centers,

@@ -66,9 +66,9 @@ struct NormApplyParams {
     const float* gamma;    // [c]
     const float* beta;     // [c]
     const float* res;      // residual, or null; element (n_, c_, y, x) at res[n_ * rs_n + c_ * rs_c + y * rs_h + x]
-    float* out;            // [n][c][h + 2 pad][w + 2 pad]
+    float* out;            // [n][c][h + 2 pad][w + 2 pad]; image i at out + i * out_stride_n (the leading channels of a wider buffer)
     float* stats;          // [n*c][2]: mean, rstd (kept for the backward)
-    long long rs_n, rs_c, rs_h;
+    long long rs_n, rs_c, rs_h, out_stride_n;
     int n, c, h, w, pad, act;
     float eps;
 };
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) inorm_apply_kernel(NormApplyParams p) {
     const float rstd = 1.0f / sqrtf(fmaxf(m2 - m1 * m1, 0.0f) + p.eps);
     const float sc = rstd * p.gamma[ch], sh = p.beta[ch] - mean * sc;            // gamma (x - mean) rstd + beta = x sc + sh
     const float* pr = p.res ? p.res + img * p.rs_n + ch * p.rs_c : nullptr;
-    float* po = p.out + (size_t)plane * hp * wp;
+    float* po = p.out + (size_t)img * p.out_stride_n + (size_t)ch * hp * wp;
     if (blockIdx.x == 0 && threadIdx.x == 0) { p.stats[2 * plane] = mean; p.stats[2 * plane + 1] = rstd; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hp * wp; i += gridDim.x * blockDim.x) {
         int yp, xp;
@@ -119,13 +119,16 @@ __global__ void __launch_bounds__(256) inorm_apply_kernel(NormApplyParams p) {
 
 struct NormBwdParams {
     const float* x;        // [n][c][h][w] forward input
-    const float* out;      // [n][c][hp][wp] forward output (padded)
-    const float* d_out;    // [n][c][hp][wp] gradient of the padded output
+    const float* out;      // [n][c][hp][wp] forward output (padded); image i at out + i * out_stride_n
+    const float* d_out;    // [n][c][hp][wp] gradient of the padded output; image i at d_out + i * d_out_stride_n
     const float* stats;    // [n*c][2] mean, rstd
     const float* gamma;    // [c]
     float* raw;            // [n*c][2]: sum g, sum g xhat (zeroed; reduce kernel adds, apply kernel reads)
+    float* d_gamma;        // [c] (zeroed; the reduce kernel adds every plane's sum g xhat) or null
+    float* d_beta;         // [c] (zeroed; sum g) or null
     float* dx;             // [n][c][h][w]
     float* d_res;          // [n][c][h][w] or null
+    long long out_stride_n, d_out_stride_n;
     int n, c, h, w, pad, act;
 };
 
@@ -152,9 +155,10 @@ __device__ __forceinline__ float norm_bwd_g(const NormBwdParams& p, const float*
 // grid = (chunks, planes)
 __global__ void __launch_bounds__(256) inorm_backward_reduce_kernel(NormBwdParams p) {
     const int plane = blockIdx.y, hw = p.h * p.w, hpwp = (p.h + 2 * p.pad) * (p.w + 2 * p.pad);
+    const int img = plane / p.c, ch = plane - img * p.c;
     const float* px = p.x + (size_t)plane * hw;
-    const float* dpl = p.d_out + (size_t)plane * hpwp;
-    const float* opl = p.out + (size_t)plane * hpwp;
+    const float* dpl = p.d_out + (size_t)img * p.d_out_stride_n + (size_t)ch * hpwp;
+    const float* opl = p.out + (size_t)img * p.out_stride_n + (size_t)ch * hpwp;
     const float mean = p.stats[2 * plane], rstd = p.stats[2 * plane + 1];
     float s1 = 0.0f, s2 = 0.0f;
     const float inv_w = 1.0f / (float)p.w;
@@ -175,6 +179,9 @@ __global__ void __launch_bounds__(256) inorm_backward_reduce_kernel(NormBwdParam
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += sh[0][w]; b += sh[1][w]; }
         atomicAdd(p.raw + 2 * plane, a);
         atomicAdd(p.raw + 2 * plane + 1, b);
+        // the affine parameters' gradients: the same sums over the images of a channel (PyTorch: one more reduction kernel per call)
+        if (p.d_beta) atomicAdd(p.d_beta + ch, a);
+        if (p.d_gamma) atomicAdd(p.d_gamma + ch, b);
     }
 }
 
@@ -182,12 +189,13 @@ __global__ void __launch_bounds__(256) inorm_backward_reduce_kernel(NormBwdParam
 __global__ void __launch_bounds__(256) inorm_backward_apply_kernel(NormBwdParams p) {
     const int plane = blockIdx.y, hw = p.h * p.w, hpwp = (p.h + 2 * p.pad) * (p.w + 2 * p.pad);
     const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.w;
+    const int img = plane / p.c, ch = plane - img * p.c;
     const float* px = p.x + (size_t)plane * hw;
-    const float* dpl = p.d_out + (size_t)plane * hpwp;
-    const float* opl = p.out + (size_t)plane * hpwp;
+    const float* dpl = p.d_out + (size_t)img * p.d_out_stride_n + (size_t)ch * hpwp;
+    const float* opl = p.out + (size_t)img * p.out_stride_n + (size_t)ch * hpwp;
     const float mean = p.stats[2 * plane], rstd = p.stats[2 * plane + 1];
     const float mg = p.raw[2 * plane] * inv_hw, mgx = p.raw[2 * plane + 1] * inv_hw;
-    const float gr = p.gamma[plane % p.c] * rstd;
+    const float gr = p.gamma[ch] * rstd;
     float* pdx = p.dx + (size_t)plane * hw;
     float* pdr = p.d_res ? p.d_res + (size_t)plane * hw : nullptr;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
@@ -197,6 +205,90 @@ __global__ void __launch_bounds__(256) inorm_backward_apply_kernel(NormBwdParams
         const float xhat = (px[i] - mean) * rstd;
         pdx[i] = gr * (g - mg - xhat * mgx);
         if (pdr) pdr[i] = g;
+    }
+}
+
+// ---- bilinear x2 up-sampling (align_corners) + reflection padding of the decoder half of the image encoder ------------------------
+// network/ops.py:150-230 (ResUNetLight.upconv3 / upconv2: F.interpolate(scale_factor=2, mode='bilinear', align_corners=True), then a
+// reflect-padded 3 x 3 convolution).  PyTorch: the up-sampling kernel (0.4 TB/s), reflection_pad2d, and in the backward one thread
+// per OUTPUT-gradient element with four float atomics each.  Here: one kernel writes the up-sampled plane already padded for the
+// convolution, and the backward is a gather - one thread per INPUT element sums the (<= 8 x 8, typically 4 x 4) padded output
+// gradients that touch it, from per-axis tables the host builds with the forward's own fp32 arithmetic (source index = scale *
+// output index, truncated) - no atomics, deterministic.
+struct UpsampleParams {
+    const float* x;      // [planes][h][w]
+    float* out;          // [planes][2h + 2 pad][2w + 2 pad]
+    int planes, h, w, pad;
+    float sy, sx;        // (h - 1) / (2h - 1), (w - 1) / (2w - 1) in fp32, computed by the host
+};
+
+// grid = (chunks, planes)
+__global__ void __launch_bounds__(256) upsample2x_pad_kernel(UpsampleParams p) {
+    const int plane = blockIdx.y, H = 2 * p.h, W = 2 * p.w, hp = H + 2 * p.pad, wp = W + 2 * p.pad;
+    const float* px = p.x + (size_t)plane * p.h * p.w;
+    float* po = p.out + (size_t)plane * hp * wp;
+    const float inv_wp = 1.0f / (float)wp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hp * wp; i += gridDim.x * blockDim.x) {
+        int yp, xp;
+        fast_divmod(i, wp, inv_wp, yp, xp);
+        const int oy = reflect_index(yp - p.pad, H), ox = reflect_index(xp - p.pad, W);
+        const float fy = p.sy * (float)oy, fx = p.sx * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        const float* r0 = px + y0 * p.w;
+        const float* r1 = px + y1 * p.w;
+        po[i] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+    }
+}
+
+constexpr int kUpTaps = 8;       // padded output rows (columns) that read one input row (column): at most 3 + 3 + 2 mirrored
+struct UpsampleBwdParams {
+    const float* d_out;  // [planes][hp][wp]
+    float* dx;           // [planes][h][w]
+    const int* cnt_y;    // [h]
+    const int* idx_y;    // [h][kUpTaps] padded output rows
+    const float* wgt_y;  // [h][kUpTaps]
+    const int* cnt_x;    // [w]
+    const int* idx_x;    // [w][kUpTaps]
+    const float* wgt_x;  // [w][kUpTaps]
+    int planes, h, w, hp, wp;
+};
+
+constexpr int kUpRows = 4;       // input rows per workgroup of the backward
+// grid = (ceil(h / kUpRows), planes), dynamic LDS kUpRows * wp floats.  Separable: for each of the workgroup's input rows the padded
+// output-gradient rows that read it are combined first (threads along the padded width: coalesced reads, the row's table entries are
+// uniform), the result goes to LDS, and the columns are gathered from there.
+__global__ void __launch_bounds__(256) upsample2x_pad_backward_kernel(UpsampleBwdParams p) {
+    NR_DYNAMIC_SMEM(float, vs);
+    const int plane = blockIdx.y, y0 = blockIdx.x * kUpRows;
+    const float* dpl = p.d_out + (size_t)plane * p.hp * p.wp;
+    float* pdx = p.dx + (size_t)plane * p.h * p.w;
+    for (int r = 0; r < kUpRows && y0 + r < p.h; ++r) {
+        const int y = y0 + r, ny = p.cnt_y[y];
+        const int* iy = p.idx_y + y * kUpTaps;
+        const float* wy = p.wgt_y + y * kUpTaps;
+        for (int ox = threadIdx.x; ox < p.wp; ox += blockDim.x) {
+            float v = 0.0f;
+            for (int a = 0; a < ny; ++a) v = fmaf(wy[a], dpl[iy[a] * p.wp + ox], v);
+            vs[r * p.wp + ox] = v;
+        }
+    }
+    __syncthreads();
+    for (int xx = threadIdx.x; xx < p.w; xx += blockDim.x) {
+        const int nx = p.cnt_x[xx];
+        int ix[kUpTaps];
+        float wx[kUpTaps];
+        NR_PRAGMA_UNROLL
+        for (int b = 0; b < kUpTaps; ++b) { ix[b] = p.idx_x[xx * kUpTaps + b]; wx[b] = p.wgt_x[xx * kUpTaps + b]; }
+        for (int r = 0; r < kUpRows && y0 + r < p.h; ++r) {
+            const float* row = vs + r * p.wp;
+            float acc = 0.0f;
+            NR_PRAGMA_UNROLL
+            for (int b = 0; b < kUpTaps; ++b)
+                if (b < nx) acc = fmaf(wx[b], row[ix[b]], acc);
+            pdx[(y0 + r) * p.w + xx] = acc;
+        }
     }
 }
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import fused_norm
-from .fused_norm import conv_prepadded, interior, norm_act
+from .fused_norm import conv_prepadded, interior, norm_act, upsample2x_pad
 
 
 # memory format the convolution stacks run in.  True: channels-last end to end (the NHWC storage the HIP gathers read, no relayout
@@ -73,8 +73,10 @@ class _ConvNormElu(nn.Module):
         super().__init__()
         self.conv, self.bn = _conv(cin, cout, 3, bias=True), _inorm(cout)
 
-    def forward(self, x):
-        return norm_act(self.bn, self.conv(x), 'elu', 0)
+    def forward(self, x, prepadded=False, pad_out=0, tail=None):
+        """x (with `prepadded`: already carrying the convolution's reflection padding) -> ELU(IN(conv(x))) padded by `pad_out`
+        (with `tail`: followed by it on the channel axis)"""
+        return norm_act(self.bn, conv_prepadded(self.conv, x) if prepadded else self.conv(x), 'elu', pad_out, tail=tail)
 
 
 class _Up(nn.Module):
@@ -82,8 +84,9 @@ class _Up(nn.Module):
         super().__init__()
         self.conv = _ConvNormElu(cin, cout)
 
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True))
+    def forward(self, x, pad_out=0, tail=None):
+        # bilinear x2 (align_corners) written already padded for the 3x3 convolution: one kernel instead of up-sampling + reflection pad
+        return self.conv(upsample2x_pad(x, 1), prepadded=True, pad_out=pad_out, tail=tail)
 
 
 def _stage(cin, cout, n):
@@ -105,6 +108,16 @@ def _join(skip, x):
     return torch.cat([x, skip], 1)
 
 
+def _up_join_padded(up, x, skip_p):
+    """[up(x), skip] on the channel axis, carrying 1 pixel of reflection padding for the 3x3 convolution that follows; skip_p is the
+    skip tensor with that padding already.  Reflection padding is per channel, so when the sizes agree the padded halves are
+    concatenated as they are (no interior view of the skip, no padding pass over the concatenation, and none in the backward); odd
+    sizes (the skip is one pixel larger than twice x) take the zero-padded join of the reference and pad afterwards."""
+    if 2 * x.shape[2] == skip_p.shape[2] - 2 and 2 * x.shape[3] == skip_p.shape[3] - 2:
+        return up(x, pad_out=1, tail=skip_p)        # (the up branch's norm kernel writes its half of the concatenation in place)
+    return F.pad(_join(interior(skip_p, 1), up(x)), (1, 1, 1, 1), mode='reflect')
+
+
 class ImageEncoder(nn.Module):
     """state_dict-compatible with the reference's `image_encoder` (ResUNetLight(3, [1,2,6,4], 32, inplanes=16))."""
 
@@ -124,8 +137,8 @@ class ImageEncoder(nn.Module):
         s1p = _run_stage(self.layer1, xp, 1)
         s2p = _run_stage(self.layer2, s1p, 1)
         s3 = _run_stage(self.layer3, s2p, 0)
-        x = self.iconv3(_join(interior(s2p, 1), self.upconv3(s3)))
-        x = self.iconv2(_join(interior(s1p, 1), self.upconv2(x)))
+        x = self.iconv3(_up_join_padded(self.upconv3, s3, s2p), prepadded=True)
+        x = self.iconv2(_up_join_padded(self.upconv2, x, s1p), prepadded=True)
         return self.out_conv(x).contiguous(memory_format=torch.channels_last)     # (no-op when the convs kept the format)
 
 

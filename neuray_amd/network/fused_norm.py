@@ -8,6 +8,7 @@ reflection_pad2d), with a two-pass backward.  The result is handed to the next c
 (`conv_prepadded`); the un-padded activation is the interior view of the same buffer (`interior`).  On a device without the
 kernels (plain CPU) the same function composes the PyTorch ops, so the modules have one forward."""
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -24,11 +25,18 @@ def _engine(device):
 
 class _NormActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, pad, act, eps):
+    def forward(ctx, x, gamma, beta, res, pad, act, eps, tail):
         eng = _engine(x.device)
         x = x.contiguous().float()
         n, c, h, w = x.shape
-        out = torch.empty(n, c, h + 2 * pad, w + 2 * pad, dtype=torch.float32, device=x.device)
+        hp, wp = h + 2 * pad, w + 2 * pad
+        ct = 0
+        if tail is not None:                  # the result becomes the leading channels of [result, tail] (a channel concatenation)
+            assert tail.dtype == torch.float32 and tuple(tail.shape[0:1] + tail.shape[2:]) == (n, hp, wp), (tuple(tail.shape), (n, hp, wp))
+            ct = tail.shape[1]
+        out = torch.empty(n, c + ct, hp, wp, dtype=torch.float32, device=x.device)
+        if ct:
+            out[:, c:].copy_(tail)
         stats = torch.empty(n * c, 2, dtype=torch.float32, device=x.device)
         raw = eng.zero_scratch(2 * n * c)
         g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
@@ -40,40 +48,45 @@ class _NormActFn(torch.autograd.Function):
             rs = res.stride()[:3]
         eng._check(eng.lib.neuray_inorm_forward(
             x.data_ptr(), g.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, rs[0], rs[1], rs[2],
-            n, c, h, w, int(pad), int(act), float(eps), raw.data_ptr(), stats.data_ptr(), out.data_ptr(), eng._stream()))
+            n, c, h, w, int(pad), int(act), float(eps), raw.data_ptr(), stats.data_ptr(), out.data_ptr(), (c + ct) * hp * wp, eng._stream()))
         ctx.save_for_backward(x, out, stats, g)
-        ctx.meta = (int(pad), int(act), res is not None)
+        ctx.meta = (int(pad), int(act), res is not None, ct)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         x, out, stats, g = ctx.saved_tensors
-        pad, act, has_res = ctx.meta
+        pad, act, has_res, ct = ctx.meta
         eng = _engine(x.device)
         n, c, h, w = x.shape
         d_out = d_out.contiguous().float()
-        raw = eng.zero_scratch(2 * n * c)[:2 * n * c]
+        img = (c + ct) * (h + 2 * pad) * (w + 2 * pad)
+        zz = eng.zero_scratch(2 * n * c + 2 * c)
+        raw, d_gamma, d_beta = zz[:2 * n * c], zz[2 * n * c:2 * n * c + c], zz[2 * n * c + c:2 * n * c + 2 * c]
         dx = torch.empty_like(x)
         d_res = torch.empty_like(x) if has_res else None
+        # (the affine parameters' gradients come out of the reduction kernel itself - channel sums by atomics - instead of one more
+        # PyTorch reduction per call: 30 launches of ~15 us per encoder pass)
         eng._check(eng.lib.neuray_inorm_backward(
-            x.data_ptr(), out.data_ptr(), d_out.data_ptr(), stats.data_ptr(), g.data_ptr(), n, c, h, w, pad, act, raw.data_ptr(),
-            dx.data_ptr(), d_res.data_ptr() if has_res else None, eng._stream()))
-        sums = raw.view(n, c, 2).permute(2, 0, 1).sum(1)          # [2, c] straight out of the reduction: rows are the two gradients, no copies
-        return dx, sums[1], sums[0], d_res, None, None, None
+            x.data_ptr(), out.data_ptr(), img, d_out.data_ptr(), img, stats.data_ptr(), g.data_ptr(), n, c, h, w, pad, act, raw.data_ptr(),
+            dx.data_ptr(), d_res.data_ptr() if has_res else None, d_gamma.data_ptr(), d_beta.data_ptr(), eng._stream()))
+        return dx, d_gamma, d_beta, d_res, None, None, None, (d_out[:, c:] if ct else None)
 
 
-def norm_act(bn, y, act=None, pad=0, res=None):
-    """-> reflect_pad(act(bn(y) [+ res]), pad) as one [n, c, h + 2 pad, w + 2 pad] tensor"""
+def norm_act(bn, y, act=None, pad=0, res=None, tail=None):
+    """-> reflect_pad(act(bn(y) [+ res]), pad) as one [n, c, h + 2 pad, w + 2 pad] tensor; with `tail` (a tensor of that padded size):
+    torch.cat([that, tail], 1), the normalised half written into the concatenation in place"""
     # (a padded plane of >= 2^23 elements - 2896 x 2896 - is beyond the kernels' fast division: such a map takes the composed PyTorch
     # ops below.  A missing library on a GPU still raises: the package never silently swaps its kernels for something else.)
     if (FUSED_NORM and bn.affine and not bn.track_running_stats and (y.shape[2] + 2 * pad) * (y.shape[3] + 2 * pad) < (1 << 23)
             and _engine(y.device) is not None):
-        return _NormActFn.apply(y, bn.weight, bn.bias, res, pad, ACTS[act], bn.eps)
+        return _NormActFn.apply(y, bn.weight, bn.bias, res, pad, ACTS[act], bn.eps, tail)
     z = bn(y)
     if res is not None:
         z = z + res
     z = F.relu(z) if act == 'relu' else (F.elu(z) if act == 'elu' else z)
-    return F.pad(z, (pad, pad, pad, pad), mode='reflect') if pad else z
+    z = F.pad(z, (pad, pad, pad, pad), mode='reflect') if pad else z
+    return z if tail is None else torch.cat([z, tail], 1)
 
 
 class _InteriorFn(torch.autograd.Function):
@@ -102,3 +115,75 @@ def interior(zp, pad):
 def conv_prepadded(conv, xp):
     """`conv` (an nn.Conv2d with padding_mode='reflect') on an input that already carries its reflection padding"""
     return F.conv2d(xp, conv.weight, conv.bias, conv.stride, 0, conv.dilation, conv.groups)
+
+
+# ---- bilinear x2 up-sampling (align_corners) + reflection padding in one kernel, gather backward (csrc/nr_kernels_norm.h) ----------
+_UP_TAPS = 8
+_UP_TABLES = {}
+
+
+def _up_axis(n_in, pad):
+    """fp32 scale of PyTorch's align_corners up-sampling and, per input index, the padded output indices that read it with their
+    weights (the transpose of the forward's `source = scale * output, truncated` in the same fp32 arithmetic; mirrored padding rows
+    included) -> scale, cnt [n_in], idx [n_in, 8], wgt [n_in, 8]"""
+    n_out = 2 * n_in
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1)
+    op = np.arange(n_out + 2 * pad)
+    o = np.abs(op - pad)
+    o = np.where(o >= n_out, 2 * n_out - 2 - o, o)
+    src = scale * o.astype(np.float32)
+    i0 = src.astype(np.int32)
+    l1 = src - i0.astype(np.float32)
+    l0 = np.float32(1.0) - l1
+    i1 = i0 + (i0 < n_in - 1)
+    cnt, idx, wgt = np.zeros(n_in, np.int32), np.zeros((n_in, _UP_TAPS), np.int32), np.zeros((n_in, _UP_TAPS), np.float32)
+    for k in range(op.shape[0]):
+        for i, l in ((i0[k], l0[k]), (i1[k], l1[k])):
+            if l != 0.0:
+                assert cnt[i] < _UP_TAPS
+                idx[i, cnt[i]], wgt[i, cnt[i]] = k, l
+                cnt[i] += 1
+    return float(scale), cnt, idx, wgt
+
+
+def _up_tables(n_in, pad, device):
+    key = (n_in, pad, str(device))
+    hit = _UP_TABLES.get(key)
+    if hit is None:
+        scale, cnt, idx, wgt = _up_axis(n_in, pad)
+        hit = _UP_TABLES[key] = (scale,) + tuple(torch.from_numpy(a).to(device) for a in (cnt, idx, wgt))
+    return hit
+
+
+class _Upsample2xPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad):
+        eng = _engine(x.device)
+        x = x.contiguous().float()
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, 2 * h + 2 * pad, 2 * w + 2 * pad, dtype=torch.float32, device=x.device)
+        sy, sx = _up_tables(h, pad, x.device)[0], _up_tables(w, pad, x.device)[0]
+        eng._check(eng.lib.neuray_upsample2x_pad_forward(x.data_ptr(), n * c, h, w, int(pad), sy, sx, out.data_ptr(), eng._stream()))
+        ctx.meta = (n, c, h, w, int(pad))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n, c, h, w, pad = ctx.meta
+        eng = _engine(d_out.device)
+        d_out = d_out.contiguous().float()
+        ty, tx = _up_tables(h, pad, d_out.device), _up_tables(w, pad, d_out.device)
+        dx = torch.empty(n, c, h, w, dtype=torch.float32, device=d_out.device)
+        eng._check(eng.lib.neuray_upsample2x_pad_backward(d_out.data_ptr(), n * c, h, w, pad, ty[1].data_ptr(), ty[2].data_ptr(), ty[3].data_ptr(),
+                                                          tx[1].data_ptr(), tx[2].data_ptr(), tx[3].data_ptr(), dx.data_ptr(), eng._stream()))
+        return dx, None
+
+
+def upsample2x_pad(x, pad=0):
+    """-> reflect_pad(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), pad) as one [n, c, 2h + 2 pad, 2w + 2 pad]
+    tensor (network/ops.py:150-230: the up-sampling in front of upconv3 / upconv2 and the padding of their 3 x 3 convolutions)"""
+    h, w = x.shape[2:]
+    if (FUSED_NORM and h >= 2 and 2 <= w <= 2047 and pad in (0, 1) and (2 * h + 2 * pad) * (2 * w + 2 * pad) < (1 << 23) and _engine(x.device) is not None):
+        return _Upsample2xPadFn.apply(x, pad)
+    z = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    return F.pad(z, (pad, pad, pad, pad), mode='reflect') if pad else z

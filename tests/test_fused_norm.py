@@ -106,3 +106,86 @@ def test_encoders_with_and_without_the_fused_kernels(device):
     top = max(float(b.abs().max()) for b in g0)
     worst = max(float((a - b).abs().max()) / max(1e-3 * top, float(b.abs().max())) for a, b in zip(g1, g0))
     assert worst <= 2e-3, worst
+
+
+@pytest.mark.parametrize('device', BACKENDS, indirect=True)
+@pytest.mark.parametrize('pad', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 3, 2, 2), (1, 4, 5, 7), (2, 2, 25, 38), (1, 3, 50, 50), (1, 2, 100, 75)])
+def test_upsample2x_pad_equals_interpolate_then_reflection_pad(device, pad, shape):
+    """network/ops.py:150-230 (upconv3 / upconv2): F.interpolate(scale_factor=2, bilinear, align_corners=True) + the reflection padding
+    of the next convolution, forward and gradient (PyTorch's backward sums with atomics: compared to summation-order tolerance)"""
+    g = torch.Generator().manual_seed(sum(shape) + pad)
+    n, c, h, w = shape
+    x0 = torch.randn(n, c, h, w, generator=g).to(device)
+    dz = torch.randn(n, c, 2 * h + 2 * pad, 2 * w + 2 * pad, generator=g).to(device)
+    outs = []
+    for fused in (True, False):
+        fused_norm.FUSED_NORM = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            out = fused_norm.upsample2x_pad(x, pad)
+            assert (type(out.grad_fn).__name__ == '_Upsample2xPadFnBackward') == fused
+            (out * dz).sum().backward()
+            outs.append((out.detach().cpu(), x.grad.cpu()))
+        finally:
+            fused_norm.FUSED_NORM = True
+    (o1, g1), (o0, g0) = outs
+    assert o1.shape == (n, c, 2 * h + 2 * pad, 2 * w + 2 * pad)
+    assert float((o1 - o0).abs().max()) <= 2e-6 * max(1.0, float(o0.abs().max()))
+    assert float((g1 - g0).abs().max()) <= 1e-5 * max(1.0, float(g0.abs().max()))
+
+
+def test_upsample_gather_tables_are_the_transpose_of_the_forward():
+    """every (padded output, input) pair of the forward appears exactly once in the backward tables, with the forward's weight, for
+    every size the encoders can meet"""
+    for n_in in list(range(2, 70)) + [100, 101, 200, 203, 400, 511]:
+        for pad in (0, 1):
+            scale, cnt, idx, wgt = fused_norm._up_axis(n_in, pad)
+            n_out = 2 * n_in
+            dense = np.zeros((n_out + 2 * pad, n_in), np.float64)
+            for op in range(n_out + 2 * pad):
+                o = abs(op - pad)
+                o = 2 * n_out - 2 - o if o >= n_out else o
+                src = np.float32(scale) * np.float32(o)
+                i0 = int(src)
+                l1 = np.float32(src - np.float32(i0))
+                dense[op, i0] += float(np.float32(1.0) - l1)
+                dense[op, min(i0 + 1, n_in - 1)] += float(l1)
+            back = np.zeros_like(dense)
+            for i in range(n_in):
+                assert 1 <= cnt[i] <= 8
+                for k in range(cnt[i]):
+                    back[idx[i, k], i] += float(wgt[i, k])
+            assert np.array_equal(back, dense), (n_in, pad)
+            assert np.allclose(dense.sum(1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize('device', BACKENDS, indirect=True)
+@pytest.mark.parametrize('act,pad,shape,ct', [('elu', 1, (2, 3, 8, 10), 5), ('relu', 0, (1, 4, 6, 7), 2), ('elu', 1, (3, 6, 12, 9), 6)])
+def test_norm_act_writes_its_half_of_a_channel_concatenation(device, act, pad, shape, ct):
+    """norm_act(..., tail=t) = torch.cat([norm_act(...), t], 1): the decoder joins of the image encoder (network/ops.py:150-230,
+    iconv3 / iconv2 inputs), outputs and every gradient (y, gamma, beta, tail)"""
+    g = torch.Generator().manual_seed(sum(shape) + ct)
+    n, c, h, w = shape
+    bn = nn.InstanceNorm2d(c, affine=True, track_running_stats=False)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    bn = bn.to(device)
+    y0 = torch.randn(n, c, h, w, generator=g).to(device)
+    t0 = torch.randn(n, ct, h + 2 * pad, w + 2 * pad, generator=g).to(device)
+    dz = torch.randn(n, c + ct, h + 2 * pad, w + 2 * pad, generator=g).to(device)
+    outs = []
+    for fused in (True, False):
+        fused_norm.FUSED_NORM = fused
+        try:
+            y, t = y0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+            for p_ in bn.parameters():
+                p_.grad = None
+            out = fused_norm.norm_act(bn, y, act, pad, None, tail=t * 1.0)
+            (out * dz).sum().backward()
+            outs.append([v.detach().cpu() for v in (out, y.grad, t.grad, bn.weight.grad.clone(), bn.bias.grad.clone())])
+        finally:
+            fused_norm.FUSED_NORM = True
+    for a, b, tol in zip(outs[0], outs[1], (2e-5, 2e-4, 0.0, 2e-4, 2e-4)):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))

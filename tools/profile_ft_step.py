@@ -65,6 +65,10 @@ def classify(path, steps):
         cls = 'other'
         if 'inorm' in name:
             cls = 'fused norm (nr::inorm)'
+        elif 'nr::upsample2x' in name:
+            cls = 'up-sampling'
+        elif 'nr::costreg' in name or 'nr::warp_variance' in name or 'nr::diff_feats' in name:
+            cls = 'init net (nr:: cost volume / consistency kernels)'
         else:
             for c, keys in classes:
                 if any(k in name for k in keys):

@@ -353,15 +353,15 @@ int neuray_direct_render_rays(const float* alpha_dev, const float* colors_dev, i
  *           be the leading channels of a wider buffer, e.g. the first half of a channel concatenation.
  * backward: d_out_padded is the gradient of the padded output (everything that consumed the padded tensor or its interior view);
  *           -> dx [n][c][h][w], d_res [n][c][h][w] (NULL = no residual).  raw_zeroed [n*c][2] (zero on entry) returns per plane
- *           (sum g, sum g xhat); d_gamma_zeroed / d_beta_zeroed [c] (zero on entry, NULL = not wanted) receive their sums over the
- *           images: the gradients of the affine parameters.  out_padded / d_out_padded take image strides as the forward's output. */
+ *           (sum g, sum g xhat); d_gamma / d_beta [c] (both or neither; NULL = not wanted) receive their sums over the images: the
+ *           gradients of the affine parameters.  out_padded / d_out_padded take image strides as the forward's output. */
 int neuray_inorm_forward(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, long long res_stride_n,
                          long long res_stride_c, long long res_stride_h, int n, int c, int h, int w, int pad, int act, float eps,
                          float* raw_zeroed_dev, float* stats_dev, float* out_padded_dev, long long out_stride_n, void* stream);
 int neuray_inorm_backward(const float* x_dev, const float* out_padded_dev, long long out_stride_n, const float* d_out_padded_dev,
                           long long d_out_stride_n, const float* stats_dev, const float* gamma_dev, int n, int c, int h, int w, int pad,
-                          int act, float* raw_zeroed_dev, float* dx_dev, float* d_res_dev, float* d_gamma_zeroed_dev,
-                          float* d_beta_zeroed_dev, void* stream);
+                          int act, float* raw_zeroed_dev, float* dx_dev, float* d_res_dev, float* d_gamma_dev,
+                          float* d_beta_dev, void* stream);
 
 /* ---- f-1: bilinear x2 up-sampling + reflection padding of the image encoder's decoder half ------------------------------------
  * Replaces: F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) followed by the reflection padding of the next 3 x 3

@@ -124,8 +124,8 @@ struct NormBwdParams {
     const float* stats;    // [n*c][2] mean, rstd
     const float* gamma;    // [c]
     float* raw;            // [n*c][2]: sum g, sum g xhat (zeroed; reduce kernel adds, apply kernel reads)
-    float* d_gamma;        // [c] (zeroed; the reduce kernel adds every plane's sum g xhat) or null
-    float* d_beta;         // [c] (zeroed; sum g) or null
+    float* d_gamma;        // [c] or null: sum over the images of the planes' sum g xhat (written by the apply kernel)
+    float* d_beta;         // [c] or null: ... of sum g
     float* dx;             // [n][c][h][w]
     float* d_res;          // [n][c][h][w] or null
     long long out_stride_n, d_out_stride_n;
@@ -179,9 +179,6 @@ __global__ void __launch_bounds__(256) inorm_backward_reduce_kernel(NormBwdParam
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += sh[0][w]; b += sh[1][w]; }
         atomicAdd(p.raw + 2 * plane, a);
         atomicAdd(p.raw + 2 * plane + 1, b);
-        // the affine parameters' gradients: the same sums over the images of a channel (PyTorch: one more reduction kernel per call)
-        if (p.d_beta) atomicAdd(p.d_beta + ch, a);
-        if (p.d_gamma) atomicAdd(p.d_gamma + ch, b);
     }
 }
 
@@ -196,6 +193,14 @@ __global__ void __launch_bounds__(256) inorm_backward_apply_kernel(NormBwdParams
     const float mean = p.stats[2 * plane], rstd = p.stats[2 * plane + 1];
     const float mg = p.raw[2 * plane] * inv_hw, mgx = p.raw[2 * plane + 1] * inv_hw;
     const float gr = p.gamma[ch] * rstd;
+    // the affine parameters' gradients: the planes' sums added over the images, in image order, by the first workgroup of image 0's
+    // plane (PyTorch: one more reduction kernel per call; same-address atomics from every plane of a channel cost more than that)
+    if (img == 0 && blockIdx.x == 0 && threadIdx.x == 0 && p.d_gamma && p.d_beta) {
+        float sb = 0.0f, sg = 0.0f;
+        for (int i = 0; i < p.n; ++i) { sb += p.raw[2 * (i * p.c + ch)]; sg += p.raw[2 * (i * p.c + ch) + 1]; }
+        p.d_beta[ch] = sb;
+        p.d_gamma[ch] = sg;
+    }
     float* pdx = p.dx + (size_t)plane * hw;
     float* pdr = p.d_res ? p.d_res + (size_t)plane * hw : nullptr;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {

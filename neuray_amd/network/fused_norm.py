@@ -61,11 +61,12 @@ class _NormActFn(torch.autograd.Function):
         n, c, h, w = x.shape
         d_out = d_out.contiguous().float()
         img = (c + ct) * (h + 2 * pad) * (w + 2 * pad)
-        zz = eng.zero_scratch(2 * n * c + 2 * c)
-        raw, d_gamma, d_beta = zz[:2 * n * c], zz[2 * n * c:2 * n * c + c], zz[2 * n * c + c:2 * n * c + 2 * c]
+        raw = eng.zero_scratch(2 * n * c)[:2 * n * c]
+        d_affine = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        d_gamma, d_beta = d_affine[0], d_affine[1]
         dx = torch.empty_like(x)
         d_res = torch.empty_like(x) if has_res else None
-        # (the affine parameters' gradients come out of the reduction kernel itself - channel sums by atomics - instead of one more
+        # (the affine parameters' gradients come out of the apply kernel - the planes' sums added over the images - instead of one more
         # PyTorch reduction per call: 30 launches of ~15 us per encoder pass)
         eng._check(eng.lib.neuray_inorm_backward(
             x.data_ptr(), out.data_ptr(), img, d_out.data_ptr(), img, stats.data_ptr(), g.data_ptr(), n, c, h, w, pad, act, raw.data_ptr(),

@@ -100,8 +100,11 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
                 # (convolutions + InstanceNorm), so this is the reference's two encoder passes (renderer.py:229-235) in half the
                 # launches, forward and backward - a training step is host-bound on exactly those
                 n = ref_imgs_info['imgs'].shape[0]
-                feats, rays = self.encode_views(torch.cat([ref_imgs_info['imgs'], que_imgs_info['imgs']], 0),
-                                                torch.cat([ref_imgs_info['ray_feats'], que_imgs_info['ray_feats']], 0))
+                joint = ref_imgs_info.get('_neuray_joint')
+                if joint is None or que_imgs_info.get('_neuray_joint') is not joint:      # (slice_imgs_info hands the parts over as views of one tensor)
+                    joint = (torch.cat([ref_imgs_info['imgs'], que_imgs_info['imgs']], 0),
+                             torch.cat([ref_imgs_info['ray_feats'], que_imgs_info['ray_feats']], 0))
+                feats, rays = self.encode_views(*joint)
                 # (split, not three slices: one concatenation per tensor in the backward instead of a zero-fill + copy per slice)
                 ref_imgs_info['img_feats'] = feats.split([n, feats.shape[0] - n])[0]
                 ref_imgs_info['ray_feats'], que_imgs_info['ray_feats'] = rays.split([n, rays.shape[0] - n])
@@ -471,18 +474,28 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
 
     def slice_imgs_info(self, ref_idx, val_idx, is_train, coords=None):
         """renderer.py:484-507.  coords: the training rays of `val_idx` when they have been drawn already (train_step's prefetch)."""
-        ref_imgs_info = self._ref_views(ref_idx, is_train)
+        if is_train and self.cfg['use_self_hit_prob']:
+            # the query view rides along with the reference views through the encoders (render()): gather the nine views and their nine
+            # ray_feats maps ONCE and hand out the two parts as views - one 69 MB stack and one 46 MB concatenation per step instead of
+            # two of each (the second pair was render()'s torch.cat of the parts)
+            n = len(ref_idx)
+            joint = _take(self._resident('ref'), list(ref_idx) + [val_idx])
+            maps = torch.cat([self.ray_feats[int(i)] for i in list(ref_idx) + [val_idx]], 0)
+            ref_imgs_info, que = {k: v[:n] for k, v in joint.items()}, {k: v[n:] for k, v in joint.items()}
+            ref_imgs_info['ray_feats'] = maps[:n]
+            ref_imgs_info['_neuray_joint'] = que['_neuray_joint'] = (joint['imgs'], maps)
+        else:
+            ref_imgs_info = self._ref_views(ref_idx, is_train)
+            que = _take(self._resident('ref' if is_train else 'val'), [val_idx])
         if is_train:
-            que = _take(self._resident('ref'), [val_idx])
             if coords is None:
                 coords = _train_coords(self, val_idx, np.random)
         else:
-            que = _take(self._resident('val'), [val_idx])
             hn, wn = que['imgs'].shape[-2:]
             coords = np.stack(np.meshgrid(np.arange(wn), np.arange(hn)), -1).reshape(1, -1, 2).astype(np.float32)
         que['coords'] = _upload(coords, self._device())
         if is_train and self.cfg['use_self_hit_prob']:
-            que['ray_feats'] = self.ray_feats[int(val_idx)]
+            que['ray_feats'] = maps[n:]
         return ref_imgs_info, que
 
     def validate_step(self, val_idx):
@@ -514,7 +527,7 @@ class NeuralRayFtRenderer(NeuralRayBaseRenderer):
         ref_imgs_info, que_imgs_info = self.slice_imgs_info(ref_idx, que_i, True, coords=coords)
         self.touched_views = sorted(set(int(i) for i in ref_idx) | ({int(que_i)} if self.cfg['use_self_hit_prob'] else set()))
         outputs = self.render(que_imgs_info.copy(), ref_imgs_info.copy(), True)
-        for k in ('ray_feats', 'img_feats', '_neuray_qconst', '_neuray_qconst_entry'):
+        for k in ('ray_feats', 'img_feats', '_neuray_qconst', '_neuray_qconst_entry', '_neuray_joint'):
             que_imgs_info.pop(k, None)
         outputs['que_imgs_info'] = que_imgs_info
         return outputs

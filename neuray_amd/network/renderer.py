@@ -164,7 +164,10 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         """renderer.py:272-278 (quirk kept: the pairs are (row, col) although the gather reads them as (x, y))."""
         num = self.cfg['depth_loss_coords_num']
         pick = torch.randperm(h * w)[:num]
-        return torch.stack([pick // w, pick % w], -1).to(device)
+        pairs = torch.stack([pick // w, pick % w], -1)
+        # (a copy from pageable memory blocks the host until everything queued so far has run - 5 ms of a training step behind the per-ray
+        # kernels; pinned staging + an asynchronous copy does not)
+        return pairs.pin_memory().to(device, non_blocking=True) if torch.device(device).type == 'cuda' else pairs.to(device)
 
     def predict_mean_for_depth_loss(self, ref_imgs_info):
         """renderer.py:280-316: decoded mixture means of every reference view at random pixels of that view."""

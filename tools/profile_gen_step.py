@@ -41,6 +41,7 @@ def main():
     pr.disable()
     torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats('cumulative').print_stats(24)
+    pstats.Stats(pr).sort_stats('tottime').print_stats(30)
 
 
 if __name__ == '__main__':

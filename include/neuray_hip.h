@@ -297,9 +297,11 @@ int neuray_warp_variance_layout(const float* ref_feats_dev, const float* src_fea
 /* ---- f-3, MVSNet cost regularisation (network/mvsnet/mvsnet.py:29-69 CostRegNet, frozen / evaluation-only inside the cost-volume init
  * net, network/init_net.py:121-160): its first and last layer.
  * neuray_conv3d_c32_c8: `conv0` = leaky_relu(batch_norm(Conv3d(32, 8, 3, padding=1, bias=False)(x)), slope) with the frozen batch norm folded:
- *   x_ndhwc_dev [n][d][h][w][32] (channels-last), wpack_dev [27][2][64][4] = the folded weights as per-lane MFMA A fragments - tap
- *   t = (kz * 3 + ky) * 3 + kx, quad q, lane l (m = l & 15, g = l >> 4), component i: W'[m][8 g + 4 q + i][kz][ky][kx] for m < 8, else 0,
- *   W' = W * gamma / sqrt(var + eps) per output channel -, bias_dev [8] = beta - mean * gamma / sqrt(var + eps); out_dev [n][8][d][h][w].
+ *   x_ndhwc_dev [n][d][h][w][32] (channels-last), wpack_dev [3 kz][4 r][3 kx][2 q][64 lanes][4] = the folded weights as per-lane MFMA
+ *   A fragments for TWO output rows per wave - row slot r = input row - first output row + 1, lane l (m = l & 15, g = l >> 4),
+ *   component i: W'[m][8 g + 4 q + i][kz][r][kx] for m < 8 and r <= 2, W'[m - 8][8 g + 4 q + i][kz][r - 1][kx] for m >= 8 and r >= 1,
+ *   else 0; W' = W * gamma / sqrt(var + eps) per output channel -, bias_dev [8] = beta - mean * gamma / sqrt(var + eps);
+ *   out_dev [n][8][d][h][w].
  * neuray_conv3d_c8_c1: `prob` = Conv3d(8, 1, 3, padding=1): x_dev [n][8][d][h][w], w27_dev [8][27], out_dev [n][d][h][w]. */
 int neuray_conv3d_c32_c8(const float* x_ndhwc_dev, const float* wpack_dev, const float* bias_dev, float slope, int n, int d, int h, int w,
                          float* out_dev, void* stream);

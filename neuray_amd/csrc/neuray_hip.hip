@@ -321,9 +321,14 @@ int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* 
         return fail("neuray_conv3d_c32_c8: bad shape n=%d d=%d h=%d w=%d (one image's volume must stay below 2^31 bytes)", n, d, h, w);
     nr::Conv0Params p;
     p.x = x_ndhwc; p.wpack = wpack; p.bias = bias; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
-    const long long strips = (long long)n * d * h * ((w + 15) / 16);
+    const long long strips = (long long)n * d * ((h + 1) / 2) * ((w + 15) / 16);       // a wave takes two output rows of a 16-voxel strip
     const int grid = grid_for(strips, nr::kConv0Waves, 256 * 8);
-    NR_LAUNCH(nr::costreg_conv0_kernel, dim3(grid), dim3(64 * nr::kConv0Waves), 0, stream, p);
+    const size_t smem = sizeof(float) * nr::kConv0PackFloats;                            // 72 KB: two workgroups per CU
+    auto k = nr::costreg_conv0_kernel;
+#ifndef NEURAY_EMU
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+    NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kConv0Waves), smem, stream, p);
     return check_launch("neuray_conv3d_c32_c8");
 }
 

@@ -6,13 +6,21 @@
 //           the frozen batch norm folded into weights and bias, leaky ReLU in the epilogue.
 //   prob    Conv3d(8 -> 1, 3 x 3 x 3, pad 1): 216 MACs per voxel over a 420 MB input - memory bound; MIOpen: 6.2 ms (0.9 TFLOP/s).
 //
-// conv0 mapping (v_mfma_f32_16x16x4_f32, the layout conventions of nr_layout.h): the weights are the A operand - M = output channel
-// (8 real rows, 8 zero rows) -, 16 consecutive voxels along x are the N columns, K = 27 taps x 32 channels.  The input is channels-last
-// ([n][D][H][W][32], written that way by warp_variance_kernel): a voxel's channels are one 128-byte line, lane group g loads channels
-// 8 g .. 8 g + 7 of its column's voxel as two 16-byte loads per tap and supplies channel 8 g + j in K-step j - the point kernel's
-// "gathered order".  The packed weights (27 taps x 2 quads x 64 lanes x float4 = 55 KB) live in LDS for the whole launch.  Out-of-volume
-// taps are buffer loads beyond the descriptor's range: they return 0, which is the zero padding.  (Two strips per wave sharing every A
-// fragment - two accumulator chains - measured the same: 13.3 vs 13.1 ms for the U-Net; not kept.)
+// conv0 mapping (v_mfma_f32_16x16x4_f32, the layout conventions of nr_layout.h): the weights are the A operand, 16 consecutive voxels
+// along x are the N columns, K = taps x 32 channels.  M = 16 rows = 8 output channels x TWO output rows (y, y + 1) of the same
+// x-strip: an input row yy at depth zz feeds output row y through tap ky = yy - y + 1 and output row y + 1 through tap ky - 1, so the A
+// fragment of "row slot" r = yy - y + 1 in 0 .. 3 carries W[kz][r] in its rows 0 .. 7 and W[kz][r - 1] in its rows 8 .. 15 (zero where
+// that tap does not exist): 36 (kz, r, kx) slots for two output rows instead of 2 x 27 half-empty ones - 1.5 x fewer MFMAs - and four
+// input rows loaded per kz for two output rows instead of six.  The three kx taps of a row slot are ONE load: the input is
+// channels-last ([n][D][H][W][32], written that way by warp_variance_kernel), lane (column c, group g) loads channels 8 g .. 8 g + 7 of
+// voxel x0 + c as two 16-byte loads and supplies channel 8 g + j in K-step j (the point kernel's "gathered order"); the kx = 0 / 2
+// operands are the same registers moved one lane inside the 16-lane group (DPP row shift), and the two voxels just outside the strip
+// come with one more load pair that only lanes c = 0 and c = 15 aim at memory.  12 load pairs + 12 edge pairs per two output rows where
+// the first version issued 108.  The packed weights (36 slots x 2 quads x 64 lanes x float4 = 72 KB) live in LDS for the whole launch
+// (two workgroups per CU).  Out-of-volume rows / voxels are buffer loads beyond the descriptor's range: they return 0, the zero padding;
+// a row slot that lies outside the volume is skipped (wave-uniform).
+// (First version, one output row per wave and a load per tap: 5.0 ms for 8 x 64 x 160 x 160, 0.46 of its own MFMA bound; two strips per
+// wave sharing every A fragment measured the same and was not kept.)
 #pragma once
 #include "nr_device.h"
 
@@ -20,7 +28,8 @@ namespace nr {
 
 struct Conv0Params {
     const float* x;        // [n][D][H][W][32]
-    const float* wpack;    // [27][2][64] float4: tap (kz, ky, kx), quad q, lane (m = l & 15, g = l >> 4), component i -> W'[m][8 g + 4 q + i][tap] (0 for m >= 8)
+    const float* wpack;    // [3 kz][4 r][3 kx][2 q][64 lanes] float4: lane (m = l & 15, g = l >> 4), component i -> channel 8 g + 4 q + i of
+                           // W'[m][.][kz][r][kx] (m < 8, r <= 2) / W'[m - 8][.][kz][r - 1][kx] (m >= 8, r >= 1), else 0
     const float* bias;     // [8] (batch norm folded)
     float* out;            // [n][8][D][H][W]
     int n, d, h, w;
@@ -28,10 +37,11 @@ struct Conv0Params {
 };
 
 constexpr int kConv0Waves = 8;
-constexpr int kConv0PackFloats = 27 * 2 * 64 * 4;
+constexpr int kConv0Slots = 3 * 4 * 3;
+constexpr int kConv0PackFloats = kConv0Slots * 2 * 64 * 4;
 
 __global__ void __launch_bounds__(64 * kConv0Waves) costreg_conv0_kernel(Conv0Params p) {
-    __shared__ __attribute__((aligned(16))) float wl[kConv0PackFloats];
+    NR_DYNAMIC_SMEM(float, wl);
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
     for (int i = threadIdx.x; i < kConv0PackFloats / 4; i += blockDim.x)
@@ -39,50 +49,62 @@ __global__ void __launch_bounds__(64 * kConv0Waves) costreg_conv0_kernel(Conv0Pa
     __syncthreads();
     const int c = lane & 15, g = lane >> 4;
     const long long vol = (long long)p.d * p.h * p.w;
-    const int sx = (p.w + 15) / 16;                                  // strips of 16 voxels per row
-    const long long strips = (long long)p.n * p.d * p.h * sx;
+    const int sx = (p.w + 15) / 16, hy = (p.h + 1) / 2;              // strips of 16 voxels per row, pairs of rows
+    const long long strips = (long long)p.n * p.d * hy * sx;
     const float4* wq = reinterpret_cast<const float4*>(wl) + lane + nr_opaque_zero();
     const float b0 = p.bias[(4 * g + 0) & 7], b1 = p.bias[(4 * g + 1) & 7], b2 = p.bias[(4 * g + 2) & 7], b3 = p.bias[(4 * g + 3) & 7];
     for (long long s = (long long)blockIdx.x * kConv0Waves + wave; s < strips; s += (long long)gridDim.x * kConv0Waves) {
         const int xs = (int)(s % sx);
         long long t = s / sx;
-        const int y = (int)(t % p.h);
-        t /= p.h;
+        const int y = 2 * (int)(t % hy);
+        t /= hy;
         const int z = (int)(t % p.d), img = (int)(t / p.d);
         const int x = xs * 16 + c;
+        const int xe = c == 0 ? x - 1 : (c == 15 ? x + 1 : -1);       // the voxel just outside the strip (lanes 0 / 15 only)
         const nr_mbuf X = nr_make_mbuf(p.x + (size_t)img * vol * 32, sizeof(float) * 32 * (size_t)vol);      // this image's volume (< 2^31 bytes)
         v4f acc;
         acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
+        // row slot `slot` = kz * 4 + r: its four loads (centre pair, edge pair) are issued one slot ahead of the MFMAs that consume them
+        auto slot_ok = [&](int slot) {
+            const int zz = z + slot / 4 - 1, yy = y + slot % 4 - 1;
+            return zz >= 0 && zz < p.d && yy >= 0 && yy < p.h;          // wave-uniform; false: the slot lies in the zero padding
+        };
+        auto issue = [&](int slot, float4 (&q)[4]) {
+            const int zz = z + slot / 4 - 1, yy = y + slot % 4 - 1;
+            const long long row = ((long long)zz * p.h + yy) * p.w;
+            const bool ok = slot_ok(slot);
+            // (a byte offset past the buffer's range reads as 0: the zero padding)
+            const int voc = (ok && x < p.w) ? (int)((row + x) * 128 + 32 * g) : 0x7ffffff0;
+            const int voe = (ok && xe >= 0 && xe < p.w) ? (int)((row + xe) * 128 + 32 * g) : 0x7ffffff0;
+            q[0] = mld4(X, voc, 0); q[1] = mld4(X, voc, 16); q[2] = mld4(X, voe, 0); q[3] = mld4(X, voe, 16);
+        };
+        float4 cur[4], nxt[4];
+        issue(0, cur);
         NR_PRAGMA_UNROLL
-        for (int kz = 0; kz < 3; ++kz) {
-            const int zz = z + kz - 1;
-            NR_PRAGMA_UNROLL
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = y + ky - 1;
-                const bool row_ok = zz >= 0 && zz < p.d && yy >= 0 && yy < p.h;          // wave-uniform
-                const long long row = ((long long)zz * p.h + yy) * p.w;
-                float4 q0[3], q1[3];
+        for (int slot = 0; slot < 12; ++slot) {
+            if (slot + 1 < 12) issue(slot + 1, nxt);
+            if (slot_ok(slot)) {
+                const float bc[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+                const float be[8] = {cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w};
+                float bl[8], br[8];
+                NR_PRAGMA_UNROLL
+                for (int j = 0; j < 8; ++j) { bl[j] = nr_row_from_left(bc[j], be[j]); br[j] = nr_row_from_right(bc[j], be[j]); }
                 NR_PRAGMA_UNROLL
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = x + kx - 1;
-                    // (a byte offset past the buffer's range reads as 0: the zero padding)
-                    const int voff = (row_ok && xx >= 0 && xx < p.w) ? (int)((row + xx) * 128 + 32 * g) : 0x7ffffff0;
-                    q0[kx] = mld4(X, voff, 0);
-                    q1[kx] = mld4(X, voff, 16);
-                }
-                NR_PRAGMA_UNROLL
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int tap = (kz * 3 + ky) * 3 + kx;
-                    const float4 a0 = wq[(tap * 2 + 0) * 64], a1 = wq[(tap * 2 + 1) * 64];
-                    acc = nr_mfma16(a0.x, q0[kx].x, acc); acc = nr_mfma16(a0.y, q0[kx].y, acc);
-                    acc = nr_mfma16(a0.z, q0[kx].z, acc); acc = nr_mfma16(a0.w, q0[kx].w, acc);
-                    acc = nr_mfma16(a1.x, q1[kx].x, acc); acc = nr_mfma16(a1.y, q1[kx].y, acc);
-                    acc = nr_mfma16(a1.z, q1[kx].z, acc); acc = nr_mfma16(a1.w, q1[kx].w, acc);
+                    const float4 a0 = wq[((slot * 3 + kx) * 2 + 0) * 64], a1 = wq[((slot * 3 + kx) * 2 + 1) * 64];
+                    const float* b = kx == 0 ? bl : (kx == 1 ? bc : br);
+                    acc = nr_mfma16(a0.x, b[0], acc); acc = nr_mfma16(a0.y, b[1], acc);
+                    acc = nr_mfma16(a0.z, b[2], acc); acc = nr_mfma16(a0.w, b[3], acc);
+                    acc = nr_mfma16(a1.x, b[4], acc); acc = nr_mfma16(a1.y, b[5], acc);
+                    acc = nr_mfma16(a1.z, b[6], acc); acc = nr_mfma16(a1.w, b[7], acc);
                 }
             }
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
         }
-        if (g < 2 && x < p.w) {                                     // D layout: lane (column c, group g), register r = output channel 4 g + r
-            float* o = p.out + ((long long)img * 8 + 4 * g) * vol + ((long long)z * p.h + y) * p.w + x;
+        const int yo = y + (g >> 1);                                  // D layout: lane (column c, group g), register r = row 4 g + r: output row y + g / 2, channel 4 (g & 1) + r
+        if (x < p.w && yo < p.h) {
+            float* o = p.out + ((long long)img * 8 + 4 * (g & 1)) * vol + ((long long)z * p.h + yo) * p.w + x;
             const float v0 = acc[0] + b0, v1 = acc[1] + b1, v2 = acc[2] + b2, v3 = acc[3] + b3;
             o[0] = v0 > 0.0f ? v0 : v0 * p.slope;
             o[vol] = v1 > 0.0f ? v1 : v1 * p.slope;

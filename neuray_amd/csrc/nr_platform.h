@@ -249,6 +249,20 @@ __device__ __forceinline__ float nr_group_sum(float t) {
 }
 #endif
 
+// the value held by the lane one column to the left / right inside a 16-lane group (DPP row shift); the group's first / last lane,
+// which has no such neighbour, receives its own `edge`
+#ifdef NEURAY_EMU
+static inline float nr_row_from_left(float v, float edge) { const int l = emu::my_lane(); const float t = emu_shfl_f(v, (l & 15) ? l - 1 : l); return (l & 15) ? t : edge; }
+static inline float nr_row_from_right(float v, float edge) { const int l = emu::my_lane(); const float t = emu_shfl_f(v, (l & 15) != 15 ? l + 1 : l); return (l & 15) != 15 ? t : edge; }
+#else
+__device__ __forceinline__ float nr_row_from_left(float v, float edge) {          // row_shr:1, lanes without a source keep `edge`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float nr_row_from_right(float v, float edge) {         // row_shl:1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false));
+}
+#endif
+
 // ---- exactly rounded single operations (the "rounding contract") --------------------------------------
 // HIP's __fadd_rn/__fmul_rn are plain `a + b` / `a * b` compiled with fp-contract=fast, so a product feeding a
 // sum is still fused into an FMA after inlining.  These helpers are compiled with contraction off (the fmul and

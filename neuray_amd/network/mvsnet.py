@@ -112,15 +112,24 @@ class CostRegNet(nn.Module):
         if hit is None or hit[0] != stamp:
             with torch.no_grad():
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-                w = (conv.weight * scale[:, None, None, None, None]).reshape(8, 32, 27).float()
+                w = (conv.weight * scale[:, None, None, None, None]).float()                      # [8, 32, kz, ky, kx]
                 shift = (bn.bias - bn.running_mean * scale).float().contiguous()
                 lane = torch.arange(64, device=w.device)
                 m, g = lane & 15, lane >> 4
-                pack = torch.zeros(27, 2, 64, 4, device=w.device)
-                for q in range(2):
-                    for i in range(4):
-                        vals = w[m.clamp(max=7), 8 * g + 4 * q + i, :] * (m < 8)[:, None]          # [64 lanes, 27 taps]
-                        pack[:, q, :, i] = vals.t()
+                top, bottom = (m < 8)[:, None, None].float(), (m >= 8)[:, None, None].float()
+                # A fragments of the kernel's row slots r = 0 .. 3: MFMA rows 0 .. 7 = tap ky = r of the wave's first output row,
+                # rows 8 .. 15 = tap ky = r - 1 of its second one
+                pack = torch.zeros(3, 4, 3, 2, 64, 4, device=w.device)
+                for r in range(4):
+                    for q in range(2):
+                        for i in range(4):
+                            ch = 8 * g + 4 * q + i
+                            vals = torch.zeros(64, 3, 3, device=w.device)                                  # [lane, kz, kx]
+                            if r <= 2:
+                                vals = vals + w[m.clamp(max=7), ch, :, r, :] * top
+                            if r >= 1:
+                                vals = vals + w[(m - 8).clamp(min=0), ch, :, r - 1, :] * bottom
+                            pack[:, r, :, q, :, i] = vals.permute(1, 2, 0)
                 hit = (stamp, pack.contiguous().to(device), shift.to(device), float(bn.slope),
                        self.prob.weight.detach().reshape(8, 27).float().contiguous().to(device), float(self.prob.bias.detach()[0]))
             self.__dict__['_fast_packs'] = hit

@@ -361,7 +361,7 @@ def ft_step_timing(device, steps=20):
             'ms_per_step': 1e3 * (time.perf_counter() - t0) / steps}
 
 
-def gen_train_case(device, h=416, w=608, rfn=8, extra_src=4, rays=512):
+def gen_train_case(device, h=416, w=608, rfn=8, extra_src=4, rays=512, host_ks_inv=False):
     """One generalisation-training step at the shape of BASELINE.json configs[4] (configs/train/gen/neuray_gen_cost_volume_train.yaml;
     dataset/train_dataset.py:78-102,304-378): NeuralRayGenRenderer with the cost-volume init net (`init_net_type: cost_volume`, frozen
     MVSNet + trained heads), image / visibility encoders, 8 working views of a 400 x 600 crop padded to the ref_pad_interval of 32
@@ -384,6 +384,12 @@ def gen_train_case(device, h=416, w=608, rfn=8, extra_src=4, rays=512):
                                                    for v in range(rfn)])[:, None].astype(np.float32)).to(device)
     tq = {k: torch.from_numpy(v).to(device) for k, v in que.items() if k != 'ray_feats'}
     tq['coords'] = torch.from_numpy((np.random.RandomState(0).rand(1, rays, 2) * np.array([w - 1, h - 1])).astype(np.float32)).to(device)
+    if host_ks_inv:
+        # what a host data pipeline can hand over with the batch: K^-1 of the query view, evaluated where engine.prepare_query would
+        # evaluate it (torch.inverse on the host, the same call on the same bytes) BEFORE the upload - the step then has no device ->
+        # host copy, i.e. no wait for the previous step's queue (INTEGRATION.md "Training")
+        from neuray_amd.engine import host_inverse
+        tq['Ks_inv'] = host_inverse(torch.from_numpy(que['Ks'])).to(device)
     opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=4e-4)
     near, far = -1 / ref['depth_range'][:, 0:1], -1 / ref['depth_range'][:, 1:2]
 
@@ -414,10 +420,24 @@ def gen_train_step_timing(device, steps=10):
         loss = step()
     torch.cuda.synchronize(device)
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    del model, opt, step
+    _, _, step2 = gen_train_case(device, host_ks_inv=True)
+    for _ in range(6):
+        step2()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step2()
+    torch.cuda.synchronize(device)
+    ms_kinv = 1e3 * (time.perf_counter() - t0) / steps
     # the init net alone, forward only (what an evaluation pays per image at this size)
     return {'what': 'NeuralRayGenRenderer(cost_volume init net + encoders) forward + render/depth loss + backward + Adam: 512 rays, 8 views of '
                     '416 x 608 (+ 4 source views), 64+64 samples, fp32',
-            'ms_per_step': ms, 'loss_is_finite': bool(torch.isfinite(loss).item()),
+            'ms_per_step': ms, 'ms_per_step_with_host_Ks_inv': ms_kinv,
+            'note': "ms_per_step: the batch as the reference's loader hands it over (K^-1 of the query view = torch.inverse on the host "
+                    "inside the step: a 36-byte device -> host copy that waits for the previous step's queue); with_host_Ks_inv: the batch "
+                    "carries que_imgs_info['Ks_inv'] computed by the host pipeline before the upload",
+            'loss_is_finite': bool(torch.isfinite(loss).item()),
             'kernel_classes': 'profiles/r04_*_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
 
 

@@ -306,6 +306,12 @@ int neuray_warp_variance_layout(const float* ref_feats_dev, const float* src_fea
 int neuray_conv3d_c32_c8(const float* x_ndhwc_dev, const float* wpack_dev, const float* bias_dev, float slope, int n, int d, int h, int w,
                          float* out_dev, void* stream);
 int neuray_conv3d_c8_c1(const float* x_dev, const float* w27_dev, float bias, int n, int d, int h, int w, float* out_dev, void* stream);
+/* neuray_convtranspose3d_c16_c8: the last decoder step, `c0 + conv11(x)` = skip + leaky_relu(batch_norm(ConvTranspose3d(16, 8, 3, stride=2,
+ *   padding=1, output_padding=1, bias=False)(x)), slope) with the frozen batch norm folded (mvsnet.py:57-69): x_dev [n][16][d][h][w],
+ *   wpack_dev [3 kz][3 ky][16 ci][8 co][3 kx] = W[ci][co][kz][ky][kx] * gamma[co] / sqrt(var[co] + eps), bias_dev [8], skip_dev
+ *   [n][8][2d][2h][2w] or NULL, out_dev [n][8][2d][2h][2w]. */
+int neuray_convtranspose3d_c16_c8(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, const float* skip_dev,
+                                  int n, int d, int h, int w, float* out_dev, void* stream);
 
 /* ---- a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
  * render_ops.py:54-70): bilinear, padding_mode='border'.  feats [b][c][fh][fw], points [b][n][2] pixel (x,y) in

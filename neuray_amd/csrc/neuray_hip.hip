@@ -332,6 +332,18 @@ int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* 
     return check_launch("neuray_conv3d_c32_c8");
 }
 
+int neuray_convtranspose3d_c16_c8(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int d, int h, int w,
+                                  float* out, void* stream) {
+    if (!x || !wpack || !bias || !out) return fail("neuray_convtranspose3d_c16_c8: null pointer");
+    const long long groups = (long long)((w + 127) / 128) * 2 * h * 2 * d * n;
+    if (n < 1 || d < 1 || h < 1 || w < 1 || groups > 0x7fffffffLL)
+        return fail("neuray_convtranspose3d_c16_c8: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
+    nr::Up11Params p;
+    p.x = x; p.wpack = wpack; p.bias = bias; p.skip = skip; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
+    NR_LAUNCH(nr::costreg_up11_kernel, dim3((unsigned)groups), dim3(128), 0, stream, p);
+    return check_launch("neuray_convtranspose3d_c16_c8");
+}
+
 int neuray_conv3d_c8_c1(const float* x, const float* w27, float bias, int n, int d, int h, int w, float* out, void* stream) {
     if (!x || !w27 || !out) return fail("neuray_conv3d_c8_c1: null pointer");
     if (n < 1 || d < 1 || h < 1 || w < 1) return fail("neuray_conv3d_c8_c1: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);

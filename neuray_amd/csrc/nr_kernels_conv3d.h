@@ -156,4 +156,78 @@ __global__ void __launch_bounds__(256) costreg_prob_kernel(ProbParams p) {
     }
 }
 
+// up11: the last decoder step of the cost regularisation, c0 + ConvTranspose3d(16 -> 8, 3, stride 2, padding 1, output_padding 1) + frozen
+// batch norm + leaky ReLU (network/mvsnet/mvsnet.py:57-69 conv11 and the skip add; MIOpen: 2.9 ms for the transposed convolution to
+// 8 x 8 x 64 x 160 x 160 plus three element-wise passes over that 420 MB tensor).  11 GFLOP against 0.95 GB of compulsory traffic: memory
+// bound; one kernel that reads x and c0 once and writes the sum once.  Output o reads input i through tap k where o = 2 i - 1 + k: an even
+// o has one tap (k = 1, i = o / 2), an odd o two (k = 2 at i = (o - 1) / 2, k = 0 at i = (o + 1) / 2 if that exists).  A thread owns the
+// output pair (2 j, 2 j + 1) of one (z, y) row - uniform work: x[j] feeds both, x[j + 1] the odd one - and all 8 output channels; (z, y)
+// are uniform per workgroup, so which z / y taps exist and their weights are too (LDS broadcast reads).
+struct Up11Params {
+    const float* x;        // [n][16][d][h][w]
+    const float* wpack;    // [3 kz][3 ky][16 ci][8 co][3 kx], batch norm folded
+    const float* bias;     // [8]
+    const float* skip;     // [n][8][2d][2h][2w] or null
+    float* out;            // [n][8][2d][2h][2w]
+    int n, d, h, w;
+    float slope;
+};
+
+constexpr int kUp11PackFloats = 3 * 3 * 16 * 8 * 3;
+
+// grid = ceil(w / 128) * 2h * 2d * n workgroups of 128 threads (x fastest, then output row, plane, image)
+__global__ void __launch_bounds__(128) costreg_up11_kernel(Up11Params p) {
+    __shared__ __attribute__((aligned(16))) float wl[kUp11PackFloats];
+    for (int i = threadIdx.x; i < kUp11PackFloats; i += blockDim.x) wl[i] = p.wpack[i];
+    __syncthreads();
+    const int chunks = (p.w + (int)blockDim.x - 1) / (int)blockDim.x;
+    long long row = (long long)blockIdx.x / chunks;
+    const int j = ((int)(blockIdx.x % chunks)) * (int)blockDim.x + (int)threadIdx.x;
+    const int oy = (int)(row % (2 * p.h));
+    row /= 2 * p.h;
+    const int oz = (int)(row % (2 * p.d)), img = (int)(row / (2 * p.d));
+    if (j >= p.w) return;
+    const long long plane = (long long)p.h * p.w, vol = plane * p.d;
+    // taps of this (z, y) row: index 0 = the tap every output has, index 1 = the second tap of an odd output
+    const int nz = (oz & 1) ? ((oz + 1) / 2 < p.d ? 2 : 1) : 1, ny = (oy & 1) ? ((oy + 1) / 2 < p.h ? 2 : 1) : 1;
+    const int iz0 = (oz & 1) ? (oz - 1) / 2 : oz / 2, kz0 = (oz & 1) ? 2 : 1;
+    const int iy0 = (oy & 1) ? (oy - 1) / 2 : oy / 2, ky0 = (oy & 1) ? 2 : 1;
+    const bool has_next = j + 1 < p.w;
+    float a0[8], a1[8];
+    NR_PRAGMA_UNROLL
+    for (int co = 0; co < 8; ++co) { a0[co] = 0.0f; a1[co] = 0.0f; }
+    const float* xi = p.x + (long long)img * 16 * vol + j;
+    for (int tz = 0; tz < nz; ++tz) {
+        const int iz = tz ? iz0 + 1 : iz0, kz = tz ? 0 : kz0;
+        for (int ty = 0; ty < ny; ++ty) {
+            const int iy = ty ? iy0 + 1 : iy0, ky = ty ? 0 : ky0;
+            const float* src = xi + (long long)iz * plane + (long long)iy * p.w;
+            const float* wk = wl + (kz * 3 + ky) * (16 * 8 * 3);
+            NR_PRAGMA_UNROLL
+            for (int ci = 0; ci < 16; ++ci) {
+                const float xa = src[ci * vol], xb = has_next ? src[ci * vol + 1] : 0.0f;
+                const float4* w4 = reinterpret_cast<const float4*>(wk + ci * 24);      // [8 co][3 kx]: 6 float4
+                float wv[24];
+                NR_PRAGMA_UNROLL
+                for (int q = 0; q < 6; ++q) { const float4 t = w4[q]; wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w; }
+                NR_PRAGMA_UNROLL
+                for (int co = 0; co < 8; ++co) {
+                    a0[co] = fmaf(xa, wv[3 * co + 1], a0[co]);                                 // even output: kx = 1 at j
+                    a1[co] = fmaf(xa, wv[3 * co + 2], fmaf(xb, wv[3 * co + 0], a1[co]));       // odd output: kx = 2 at j, kx = 0 at j + 1
+                }
+            }
+        }
+    }
+    const long long oplane = 4 * plane, ovol = 8 * vol;
+    const long long o = (long long)img * 8 * ovol + (long long)oz * oplane + (long long)oy * (2 * p.w) + 2 * j;
+    NR_PRAGMA_UNROLL
+    for (int co = 0; co < 8; ++co) {
+        float v0 = a0[co] + p.bias[co], v1 = a1[co] + p.bias[co];
+        v0 = v0 > 0.0f ? v0 : v0 * p.slope;
+        v1 = v1 > 0.0f ? v1 : v1 * p.slope;
+        if (p.skip) { const float2 sk = *reinterpret_cast<const float2*>(p.skip + o + co * ovol); v0 += sk.x; v1 += sk.y; }
+        *reinterpret_cast<float2*>(p.out + o + co * ovol) = make_float2(v0, v1);
+    }
+}
+
 }  // namespace nr

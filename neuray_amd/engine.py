@@ -229,6 +229,16 @@ class RenderEngine:
                                                   out.data_ptr(), self._stream()))
         return out
 
+    def costreg_up11(self, x, wpack, bias, slope, skip):
+        """MVSNet CostRegNet: skip + conv11(x) with the frozen batch norm folded (neuray_convtranspose3d_c16_c8): x [n,16,d,h,w] -> [n,8,2d,2h,2w]"""
+        n, c, d, h, w = x.shape
+        assert c == 16 and x.is_contiguous() and x.dtype == torch.float32
+        assert skip is None or (tuple(skip.shape) == (n, 8, 2 * d, 2 * h, 2 * w) and skip.is_contiguous() and skip.dtype == torch.float32)
+        out = self.empty(n, 8, 2 * d, 2 * h, 2 * w)
+        self._check(self.lib.neuray_convtranspose3d_c16_c8(x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), float(slope),
+                                                           skip.data_ptr() if skip is not None else None, n, d, h, w, out.data_ptr(), self._stream()))
+        return out
+
     def costreg_prob(self, x, w27, bias):
         """MVSNet CostRegNet.prob (neuray_conv3d_c8_c1): x [n,8,d,h,w] contiguous -> [n,1,d,h,w]"""
         n, c, d, h, w = x.shape

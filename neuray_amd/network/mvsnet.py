@@ -82,11 +82,14 @@ class CostRegNet(nn.Module):
         self.conv7, self.conv9, self.conv11 = _up3(64, 32), _up3(32, 16), _up3(16, 8)
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
 
-    def _tail(self, c0):
+    def _tail(self, c0, fast=False):
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))
         x = c4 + self.conv7(self.conv6(self.conv5(c4)))
         x = c2 + self.conv9(x)
+        if fast:        # c0 + conv11(x): transposed convolution, frozen batch norm, leaky ReLU and the skip add in one kernel
+            pack, shift, slope = self._packs(c0.device)[5:8]
+            return self._engine(c0).costreg_up11(x.contiguous(), pack, shift, slope, c0.contiguous())
         return c0 + self.conv11(x)
 
     def forward_modules(self, x):
@@ -106,7 +109,9 @@ class CostRegNet(nn.Module):
         """conv0's weights with the frozen batch norm folded in, as per-lane MFMA A fragments (csrc/nr_kernels_conv3d.h Conv0Params.wpack),
         and prob's 8 x 27 taps; rebuilt when a parameter or buffer changes"""
         conv, bn = self.conv0.conv, self.conv0.bn
-        src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.prob.weight, self.prob.bias)
+        up, ubn = self.conv11[0], self.conv11[1]
+        src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.prob.weight, self.prob.bias,
+               up.weight, ubn.weight, ubn.bias, ubn.running_mean, ubn.running_var)
         stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(device),)
         hit = self.__dict__.get('_fast_packs')
         if hit is None or hit[0] != stamp:
@@ -130,27 +135,32 @@ class CostRegNet(nn.Module):
                             if r >= 1:
                                 vals = vals + w[(m - 8).clamp(min=0), ch, :, r - 1, :] * bottom
                             pack[:, r, :, q, :, i] = vals.permute(1, 2, 0)
+                # conv11 (ConvTranspose3d weight [16 in, 8 out, kz, ky, kx]) with its batch norm folded -> [kz][ky][ci][co][kx]
+                uscale = ubn.weight / torch.sqrt(ubn.running_var + ubn.eps)
+                upack = (up.weight * uscale[None, :, None, None, None]).float().permute(2, 3, 0, 1, 4).contiguous()
+                ushift = (ubn.bias - ubn.running_mean * uscale).float().contiguous()
                 hit = (stamp, pack.contiguous().to(device), shift.to(device), float(bn.slope),
-                       self.prob.weight.detach().reshape(8, 27).float().contiguous().to(device), float(self.prob.bias.detach()[0]))
+                       self.prob.weight.detach().reshape(8, 27).float().contiguous().to(device), float(self.prob.bias.detach()[0]),
+                       upack.to(device), ushift.to(device), float(ubn.slope))
             self.__dict__['_fast_packs'] = hit
         return hit[1:]
 
     def conv0_fast(self, x):
         """leaky_relu(batch_norm(conv0(x))) on a [n, 32, D, H, W] volume (any strides; channels-last-3d storage is taken as it is)"""
-        pack, shift, slope, _, _ = self._packs(x.device)
+        pack, shift, slope = self._packs(x.device)[:3]
         xl = x.permute(0, 2, 3, 4, 1)
         if not xl.is_contiguous():
             xl = xl.contiguous()
         return self._engine(x).costreg_conv0(xl, pack, shift, slope)
 
     def prob_fast(self, x):
-        _, _, _, w, b = self._packs(x.device)
+        w, b = self._packs(x.device)[3:5]
         return self._engine(x).costreg_prob(x.contiguous(), w, b)
 
     def forward(self, x):
         if not self._fast_ok(x):
             return self.forward_modules(x)
-        return self.prob_fast(self._tail(self.conv0_fast(x)))
+        return self.prob_fast(self._tail(self.conv0_fast(x), fast=True))
 
 
 class MVSNet(nn.Module):

@@ -84,3 +84,21 @@ def test_costregnet_fast_path_equals_the_module_path(dev):
     xg = x.clone().requires_grad_(True)
     out = net(xg)
     assert out.requires_grad
+
+
+@pytest.mark.parametrize('shape', [(1, 2, 3, 5), (2, 3, 4, 17), (1, 1, 2, 130)])
+@pytest.mark.parametrize('with_skip', [True, False])
+def test_up11_kernel_matches_convtranspose_bn_leaky_plus_skip(dev, shape, with_skip):
+    """c0 + conv11(x) (mvsnet.py:57-69: ConvTranspose3d(16, 8, 3, stride 2, padding 1, output_padding 1) + frozen batch norm + leaky
+    ReLU + the skip add) as one kernel: every parity of the output coordinates, the last odd plane / row / column that has a single tap,
+    rows wider than one workgroup"""
+    n, d, h, w = shape
+    net = make_net(dev, seed=4)
+    x = torch.randn(n, 16, d, h, w, generator=torch.Generator().manual_seed(5)).to(dev)
+    c0 = torch.randn(n, 8, 2 * d, 2 * h, 2 * w, generator=torch.Generator().manual_seed(6)).to(dev)
+    with torch.no_grad():
+        want = net.conv11(x) + (c0 if with_skip else 0.0)
+        pack, shift, slope = net._packs(x.device)[5:8]
+        got = net._engine(x).costreg_up11(x, pack, shift, slope, c0 if with_skip else None)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))

@@ -335,12 +335,12 @@ int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* 
 int neuray_convtranspose3d_c16_c8(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int d, int h, int w,
                                   float* out, void* stream) {
     if (!x || !wpack || !bias || !out) return fail("neuray_convtranspose3d_c16_c8: null pointer");
-    const long long groups = (long long)((w + 127) / 128) * 2 * h * 2 * d * n;
+    const long long groups = (long long)((nr::kUp11Rows * w + 255) / 256) * 2 * ((h + nr::kUp11Rows - 1) / nr::kUp11Rows) * 2 * d * n;
     if (n < 1 || d < 1 || h < 1 || w < 1 || groups > 0x7fffffffLL)
         return fail("neuray_convtranspose3d_c16_c8: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
     nr::Up11Params p;
     p.x = x; p.wpack = wpack; p.bias = bias; p.skip = skip; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
-    NR_LAUNCH(nr::costreg_up11_kernel, dim3((unsigned)groups), dim3(128), 0, stream, p);
+    NR_LAUNCH(nr::costreg_up11_kernel, dim3((unsigned)groups), dim3(256), 0, stream, p);
     return check_launch("neuray_convtranspose3d_c16_c8");
 }
 

@@ -161,8 +161,10 @@ __global__ void __launch_bounds__(256) costreg_prob_kernel(ProbParams p) {
 // 8 x 8 x 64 x 160 x 160 plus three element-wise passes over that 420 MB tensor).  11 GFLOP against 0.95 GB of compulsory traffic: memory
 // bound; one kernel that reads x and c0 once and writes the sum once.  Output o reads input i through tap k where o = 2 i - 1 + k: an even
 // o has one tap (k = 1, i = o / 2), an odd o two (k = 2 at i = (o - 1) / 2, k = 0 at i = (o + 1) / 2 if that exists).  A thread owns the
-// output pair (2 j, 2 j + 1) of one (z, y) row - uniform work: x[j] feeds both, x[j + 1] the odd one - and all 8 output channels; (z, y)
-// are uniform per workgroup, so which z / y taps exist and their weights are too (LDS broadcast reads).
+// output pair (2 j, 2 j + 1) of one (z, y) row - uniform work: x[j] feeds both, x[j + 1] the odd one - and all 8 output channels.  A
+// workgroup takes kUp11Rows output rows of one plane that share their y parity (oy, oy + 2, ...), laid end to end over its threads: which
+// z / y taps exist, and their weights, are then uniform per workgroup - the weights are scalar loads, no LDS - and every lane has work
+// whatever the row length.  (First version, one row per workgroup with the 14 KB of weights copied into LDS by each: 2.1 ms.)
 struct Up11Params {
     const float* x;        // [n][16][d][h][w]
     const float* wpack;    // [3 kz][3 ky][16 ci][8 co][3 kx], batch norm folded
@@ -173,25 +175,29 @@ struct Up11Params {
     float slope;
 };
 
-constexpr int kUp11PackFloats = 3 * 3 * 16 * 8 * 3;
+constexpr int kUp11Rows = 4;
 
-// grid = ceil(w / 128) * 2h * 2d * n workgroups of 128 threads (x fastest, then output row, plane, image)
-__global__ void __launch_bounds__(128) costreg_up11_kernel(Up11Params p) {
-    __shared__ __attribute__((aligned(16))) float wl[kUp11PackFloats];
-    for (int i = threadIdx.x; i < kUp11PackFloats; i += blockDim.x) wl[i] = p.wpack[i];
-    __syncthreads();
-    const int chunks = (p.w + (int)blockDim.x - 1) / (int)blockDim.x;
-    long long row = (long long)blockIdx.x / chunks;
-    const int j = ((int)(blockIdx.x % chunks)) * (int)blockDim.x + (int)threadIdx.x;
-    const int oy = (int)(row % (2 * p.h));
-    row /= 2 * p.h;
-    const int oz = (int)(row % (2 * p.d)), img = (int)(row / (2 * p.d));
-    if (j >= p.w) return;
+// grid = (chunks of 256 threads over kUp11Rows * w) * (row groups per plane = 2 parities * ceil(h / kUp11Rows)) * 2d * n
+__global__ void __launch_bounds__(256) costreg_up11_kernel(Up11Params p) {
+    const int per_group = kUp11Rows * p.w, chunks = (per_group + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int groups_y = (p.h + kUp11Rows - 1) / kUp11Rows;                   // row groups of one parity
+    long long g = (long long)blockIdx.x / chunks;
+    const int t = ((int)(blockIdx.x % chunks)) * (int)blockDim.x + (int)threadIdx.x;
+    const int gy = (int)(g % groups_y);
+    g /= groups_y;
+    const int par = (int)(g & 1);                                             // y parity of the group's rows
+    g >>= 1;
+    const int oz = (int)(g % (2 * p.d)), img = (int)(g / (2 * p.d));
+    const int r = t / p.w, j = t - r * p.w;
+    const int hy = gy * kUp11Rows + r;                                        // the row's input row index (oy = 2 hy + par)
+    if (r >= kUp11Rows || hy >= p.h) return;
+    const int oy = 2 * hy + par;
     const long long plane = (long long)p.h * p.w, vol = plane * p.d;
-    // taps of this (z, y) row: index 0 = the tap every output has, index 1 = the second tap of an odd output
-    const int nz = (oz & 1) ? ((oz + 1) / 2 < p.d ? 2 : 1) : 1, ny = (oy & 1) ? ((oy + 1) / 2 < p.h ? 2 : 1) : 1;
+    // taps: index 0 = the tap every output has, index 1 = the second tap of an odd output (uniform per workgroup; the last odd row /
+    // plane has no second tap: its loads are redirected to a valid address and multiplied by 0)
+    const int nz = (oz & 1) ? 2 : 1, ny = par ? 2 : 1;
     const int iz0 = (oz & 1) ? (oz - 1) / 2 : oz / 2, kz0 = (oz & 1) ? 2 : 1;
-    const int iy0 = (oy & 1) ? (oy - 1) / 2 : oy / 2, ky0 = (oy & 1) ? 2 : 1;
+    const int ky0 = par ? 2 : 1;
     const bool has_next = j + 1 < p.w;
     float a0[8], a1[8];
     NR_PRAGMA_UNROLL
@@ -199,21 +205,21 @@ __global__ void __launch_bounds__(128) costreg_up11_kernel(Up11Params p) {
     const float* xi = p.x + (long long)img * 16 * vol + j;
     for (int tz = 0; tz < nz; ++tz) {
         const int iz = tz ? iz0 + 1 : iz0, kz = tz ? 0 : kz0;
+        if (iz >= p.d) continue;                                              // uniform
         for (int ty = 0; ty < ny; ++ty) {
-            const int iy = ty ? iy0 + 1 : iy0, ky = ty ? 0 : ky0;
-            const float* src = xi + (long long)iz * plane + (long long)iy * p.w;
-            const float* wk = wl + (kz * 3 + ky) * (16 * 8 * 3);
+            const int iy = ty ? hy + 1 : hy, ky = ty ? 0 : ky0;
+            const bool row_ok = iy < p.h;
+            const float* src = xi + (long long)iz * plane + (long long)(row_ok ? iy : hy) * p.w;
+            const float live = row_ok ? 1.0f : 0.0f;
+            const float* __restrict__ wk = p.wpack + (kz * 3 + ky) * (16 * 8 * 3);   // uniform: scalar loads
             NR_PRAGMA_UNROLL
             for (int ci = 0; ci < 16; ++ci) {
-                const float xa = src[ci * vol], xb = has_next ? src[ci * vol + 1] : 0.0f;
-                const float4* w4 = reinterpret_cast<const float4*>(wk + ci * 24);      // [8 co][3 kx]: 6 float4
-                float wv[24];
-                NR_PRAGMA_UNROLL
-                for (int q = 0; q < 6; ++q) { const float4 t = w4[q]; wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w; }
+                const float xa = src[ci * vol] * live, xb = has_next ? src[ci * vol + 1] * live : 0.0f;
                 NR_PRAGMA_UNROLL
                 for (int co = 0; co < 8; ++co) {
-                    a0[co] = fmaf(xa, wv[3 * co + 1], a0[co]);                                 // even output: kx = 1 at j
-                    a1[co] = fmaf(xa, wv[3 * co + 2], fmaf(xb, wv[3 * co + 0], a1[co]));       // odd output: kx = 2 at j, kx = 0 at j + 1
+                    const float w0 = wk[ci * 24 + 3 * co], w1 = wk[ci * 24 + 3 * co + 1], w2 = wk[ci * 24 + 3 * co + 2];
+                    a0[co] = fmaf(xa, w1, a0[co]);                            // even output: kx = 1 at j
+                    a1[co] = fmaf(xa, w2, fmaf(xb, w0, a1[co]));              // odd output: kx = 2 at j, kx = 0 at j + 1
                 }
             }
         }

@@ -984,6 +984,12 @@ def main(argv=None):
                 put(k_, v_)
 
     if rank == 0:
+        if world == 1 and emu is None and not args.no_eager_baseline and not args.no_cpu_baseline:
+            # the whole-step training legs first: they are host-sensitive (host time ~ device time), and after the CPU baselines' minute
+            # of all-core work below the host's single-thread speed stays depressed for a while - measured after them the generalisation
+            # step read 39-47 ms where a quiet machine gives 33-34 (fresh_process_leg)
+            put('ft_step', side(fresh_process_leg, 'ft_step', device))
+            put('gen_train_step', side(fresh_process_leg, 'gen_train_step', device))
         if world == 1 and emu is None and not args.no_cpu_baseline:   # baselines: rank 0 at N = 1 only
             put('cpu_baseline', side(cpu_baseline, cfg, weights, que, ref))
             if args.cpu_sample_rays > 0:
@@ -1006,8 +1012,6 @@ def main(argv=None):
             put('direct_rendering', side(direct_rendering_timing, device, tq, tr))
             put('training_step', side(training_step_timing, device))
             put('encoders', side(encoder_timing, device))
-            put('ft_step', side(fresh_process_leg, 'ft_step', device))
-            put('gen_train_step', side(fresh_process_leg, 'gen_train_step', device))
             put('init_net', side(init_net_timing, device))
             put('pipeline_pcie_inclusive', side(pipeline_timing, device, args.fine_samples))
             put('bf16_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy()))

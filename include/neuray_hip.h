@@ -214,7 +214,13 @@ typedef struct NeurayPointsBwdArgs {
     const float* packed_weights_dev;   /* [neuray_packed_pass_floats()] or NULL */
     const float* packed_t_weights_dev; /* [neuray_packed_t_floats()] or NULL */
     const float* saved_dev;            /* resident kernel: what neuray_render_points left in NeurayPointsArgs.saved_dev for the same inputs */
+    float* handover_dev;               /* resident kernel: NULL = one launch; neuray_points_backward_handover_floats(rn * dn) floats of scratch =
+                                        * two launches (the network's tail, then its front: each half keeps only its own weight-gradient
+                                        * accumulators and chain state in registers - 80 + 0 spilled VGPRs instead of 290 - and the tail hands
+                                        * 20 floats per (point, view) lane over: 0.63 instead of 0.92 ms per 512 x 64 x 8 pass).  Same gradients
+                                        * up to the summation order of the atomics. */
 } NeurayPointsBwdArgs;
+size_t neuray_points_backward_handover_floats(int npoints);
 size_t neuray_packed_t_floats(void);
 /* index[neuray_packed_t_floats()] (host, int32): packed_t[i] = index[i] >= 0 ? flat[index[i]] : 0 */
 int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
@@ -224,8 +230,9 @@ int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
  * packer gathers fp32 values with the index maps above and converts exactly these ranges. */
 int neuray_packed_quad_ranges(int transposed, int* ranges_host, int max_pairs);
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
-/* Kept for ABI stability: variant 0 / 2 = the resident kernel (csrc/nr_kernels_bwd2.h).  Variant 3 - round 3's 4-wave x 2-view decomposition,
- * measured slower on the MI355X - was retired in round 4 and is refused. */
+/* Variant 0 / 2 = the resident kernel (csrc/nr_kernels_bwd2.h), as two launches whenever handover_dev is given; 1 = always as ONE launch
+ * (A/B timing, cross-check of the two forms).  Variant 3 - round 3's 4-wave x 2-view decomposition, measured slower - was retired in
+ * round 4 and is refused. */
 int neuray_select_points_backward(int variant);
 
 /* ---- backward of the a19 path (renderer.py:137-155): hit_prob_self [rn][dn] as a function of the gathered query-view

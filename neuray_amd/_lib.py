@@ -65,7 +65,8 @@ class NeurayPointsBwdArgs(C.Structure):
         'rgba_dev', 'flat_weights_dev', 'd_point_rec_dev', 'd_flat_weights_dev', 'd_ray_feats_nhwc_dev',
         'd_img_feats_nhwc_dev', 'workspace_dev')] + \
         [(n, C.c_int) for n in ('rfn', 'rn', 'dn', 'h', 'w', 'fh', 'fw', 'has_vis_head', 'use_vis')] + \
-        [('var_bias', C.c_float), ('packed_weights_dev', C.c_void_p), ('packed_t_weights_dev', C.c_void_p), ('saved_dev', C.c_void_p)]
+        [('var_bias', C.c_float), ('packed_weights_dev', C.c_void_p), ('packed_t_weights_dev', C.c_void_p), ('saved_dev', C.c_void_p),
+         ('handover_dev', C.c_void_p)]
 
 
 PACKED_RAY_FLOATS = 1348
@@ -130,6 +131,7 @@ SYMBOLS = {
     'neuray_packed_t_floats': (C.c_size_t, []),
     'neuray_pack_pass_t_index_map': (C.c_int, [C.c_int, C.c_void_p]),
     'neuray_select_points_backward': (C.c_int, [C.c_int]),
+    'neuray_points_backward_handover_floats': (C.c_size_t, [C.c_int]),
     'neuray_packed_quad_ranges': (C.c_int, [C.c_int, C.c_void_p, C.c_int]),
     'neuray_render_points_backward': (C.c_int, [C.POINTER(NeurayPointsBwdArgs), C.c_void_p]),
     'neuray_self_hit_backward_workspace_floats': (C.c_size_t, [C.c_int]),

@@ -571,13 +571,27 @@ size_t neuray_points_backward_workspace_floats(int npoints, int rfn) {
     return (size_t)points_bwd_grid(npoints, pow2_at_least(rfn)) * nr::kBwdRows * 64;
 }
 
-// The resident point backward is nr_kernels_bwd2.h (8 waves x 1 view at two waves per SIMD: 0.88 ms per 512 x 64 x 8 pass on the MI355X).
+// The resident point backward is nr_kernels_bwd2.h (8 waves x 1 view at two waves per SIMD: 0.88-0.93 ms per 512 x 64 x 8 pass on the MI355X as
+// one launch, 0.63 ms as its two halves - tail, then front - with a hand-over buffer in between: NeurayPointsBwdArgs.handover_dev).
 // Round 3's second decomposition (4 waves x 2 views per wave at one wave per SIMD, accumulators in AGPRs: 1.06 ms) was
 // retired in round 4 - it lost on the hardware and three parity-tested implementations of one gradient were one too many; the
 // first-version kernel (nr_kernels_bwd.h) remains as the rfn > 8 fallback and the cross-check.  The selector stays for ABI stability.
+static int g_bwd_one_launch = 0;
 int neuray_select_points_backward(int variant) {
-    if (variant != 0 && variant != 2) return fail("neuray_select_points_backward: variant %d is not built (0 / 2 = the resident kernel; 3 was retired in round 4)", variant);
+    if (variant != 0 && variant != 2 && variant != 1)
+        return fail("neuray_select_points_backward: variant %d is not built (0 / 2 = the resident kernel, as two launches when handover_dev is given; "
+                    "1 = always as one launch; 3 was retired in round 4)", variant);
+    g_bwd_one_launch = variant == 1;
     return 0;
+}
+
+size_t neuray_points_backward_handover_floats(int npoints) {
+#ifdef NR_INFERENCE_ONLY
+    (void)npoints;
+    return 0;
+#else
+    return npoints < 1 ? 0 : nr::point_bwd2_handover_floats(npoints);
+#endif
 }
 
 int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
@@ -600,22 +614,24 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
         q.d_img_feats = a->d_img_feats_nhwc_dev; q.saved = a->saved_dev;
         q.rfn = a->rfn; q.rn = a->rn; q.dn = a->dn; q.h = a->h; q.w = a->w; q.fh = a->fh; q.fw = a->fw;
         q.use_vis = a->use_vis; q.var_bias = a->var_bias;
+        q.handover = a->handover_dev;
         const int grid2 = grid_for((long long)a->rn * a->dn, 16, 256);            // persistent: one workgroup per CU
         const size_t smem = nr::point_bwd2_smem_bytes();
+        auto launch = [&](auto k) {
+#ifndef NEURAY_EMU
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+            NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
+        };
         // (a vis head that compute_prob does not consume - the fine decoder's when the coarse decoder has use_vis = False, quirk A.9.2 -
         // has an identically zero gradient on this path: the kernel without the head is the same computation)
-        if (a->has_vis_head && a->use_vis) {
-            auto k = nr::points_backward2_kernel<true>;
-#ifndef NEURAY_EMU
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
-            NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
+        const bool vis = a->has_vis_head && a->use_vis;
+        if (a->handover_dev && g_bwd_one_launch == 0) {        // two launches: tail, then front (nr_kernels_bwd2.h B2Part)
+            if (vis) { launch(nr::points_backward2_kernel<true, nr::B2_TAIL>); launch(nr::points_backward2_kernel<true, nr::B2_FRONT>); }
+            else { launch(nr::points_backward2_kernel<false, nr::B2_TAIL>); launch(nr::points_backward2_kernel<false, nr::B2_FRONT>); }
         } else {
-            auto k = nr::points_backward2_kernel<false>;
-#ifndef NEURAY_EMU
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-#endif
-            NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
+            if (vis) launch(nr::points_backward2_kernel<true, nr::B2_WHOLE>);
+            else launch(nr::points_backward2_kernel<false, nr::B2_WHOLE>);
         }
         return check_launch("neuray_render_points_backward (resident)");
     }

@@ -40,6 +40,7 @@ struct PointBwd2Params {
     const float* weights_t;    // packed transposed layers (kPackedTFloats)
     const float* d_point_rec;  // [rn*dn][kPointRec]: [0..15] d geometry feature, [16..18] d colour
     const float* saved;        // [ceil(rn*dn / 16)][kSavedTileFloats]: what the training forward (points_kernel<SAVE>) left (nr_kernels.h)
+    float* handover;           // [ceil(rn*dn / 16)][8 waves][kB2Handover][64 lanes]: tail kernel -> front kernel (the two-kernel form), else null
     float* d_flat;             // [kFlatPassFloats], accumulated
     float* d_ray_feats;        // [rfn][fh][fw][32], accumulated
     float* d_img_feats;        // [rfn][fh][fw][32], accumulated
@@ -53,6 +54,15 @@ constexpr int kB2Stride = 132;           // floats per staged row: 128 columns (
 constexpr int kB2StageRows = 176;
 constexpr int kB2PStride = 20;           // per-point staging: 16 columns + 4
 constexpr int kB2Rmax = 12;              // rows of the widest all-reduce
+// The kernel as ONE launch (B2_WHOLE) or as TWO (round 4): B2_TAIL = geometry_fc -> blend -> rgb_fc -> vis_fc2 -> vis_fc -> base_fc -> the
+// cross-view statistics, leaving per (point, view) column the gradients of what the front of the network produced (d gi: 8 per lane,
+// d e: 8, d gr: 3, d sn: 1 = kB2Handover floats per lane); B2_FRONT = neuray_fc / ray_dir_fc / prob_embed -> probabilities -> dist decoder
+// heads -> map gradients from those.  Each half holds only its own weight-gradient accumulators (109 / 57 of the 166 jobs) and its own
+// part of the chain state: 80 + 0 spilled VGPRs instead of 290, at the price of the geometry, the gathers and part of the recomputed
+// forward twice and 84 MB of hand-over per pass: 0.63 ms instead of 0.92.
+enum B2Part { B2_TAIL = 0, B2_FRONT = 1, B2_WHOLE = 2 };
+constexpr int kB2Handover = 20;
+inline size_t point_bwd2_handover_floats(int npts) { return (size_t)((npts + 15) / 16) * kB2Waves * kB2Handover * 64; }
 // LDS (floats): all-reduce scratch | xch (base_fc.0 per-point part: 64 features x 16 points, kept from the forward to its
 // backward) | stash (the four cross-view statistics, lane layout: 44 values per lane) | hx (hand-off of per-point
 // gradients from their owner waves to every wave: <= 44 values per lane) | staging (also: per-point staging, geometry
@@ -337,8 +347,9 @@ __device__ __forceinline__ void dw_flush_all(const v4f (&acc)[kDwAcc], const flo
     (dw_flush<IDS>(acc, bacc, d_flat, wave, lane), ...);
 }
 
-template <bool HAS_VIS>
+template <bool HAS_VIS, int PART = B2_WHOLE>
 __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Params p) {
+    constexpr bool DO_TAIL = PART != B2_FRONT, DO_FRONT = PART != B2_TAIL;
     NR_DYNAMIC_SMEM(float, smem);
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
@@ -386,7 +397,8 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         // base_fc.0's per-point part and the four statistics of this tile, as the forward kernel left them: global -> xch | stash by
         // LDS-DMA (15 KB, two 1 KB pieces per wave); visible after the barriers of the first all-reduce below
         const float* svt = p.saved + (size_t)(base / 16) * kSavedTileFloats;
-        {
+        float* ho = p.handover ? p.handover + ((size_t)(base / 16) * kB2Waves + wave) * (kB2Handover * 64) + lane : nullptr;
+        if constexpr (DO_TAIL) {
             const nr_wbuf SV = nr_make_wbuf(svt, sizeof(float) * kSavedTileFloats);
             for (int i = wave; i < (kB2Xch + kB2Stash) / 256; i += kB2Waves) nr_dma16(SV, xch + i * 256, lane, lane * 16, i * 1024);
             // rows kSavedGeoRow .. kSavedSvisRow (39 rows; 40 copied) -> the geometry exchange area xg: hidden layer of geometry_fc (16
@@ -552,6 +564,8 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         // ================= backward =================
         const float* up = p.d_point_rec + (size_t)pi * kPointRec;
         const float gsc = pvalid ? 1.0f : 0.0f;
+        float dgi[8], dgr[3], de[1][8], dsn;
+        if constexpr (DO_TAIL) {
         // ---- geometry_fc (per point; ibrnet.py:353-354).  Hidden layer h and output G are the forward's (xg rows 0..15, 32..35).
         // Waves 0..3 each redo the small transposed geometry_fc.2 and take output tile `wave` of geometry_fc.0^T.
         float dgm[8], dgv[8], dmeanw;                          // d mean, d var (natural D layout), d mean weight
@@ -721,7 +735,6 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
         }
         B2_MARK(23);
         // ---- base_fc backward (ibrnet.py:342) -> d gi, d gr, d e, d (statistics)
-        float dgi[8], dgr[3], de[1][8];
         {
             float h64[1][16], dxp[1][8], dh64[1][16], dcat[1][16], drgb[1][3];
             base_hidden(h64);
@@ -810,7 +823,6 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             }
         }
         // ---- cross-view statistics backward: d statistics (per point, in hx rows 0..43) -> d gi / d gr +=, d sn
-        float dsn;
         {
             float dw0 = 0.0f, dw0r = 0.0f;
             NR_PRAGMA_UNROLL
@@ -827,6 +839,18 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             }
             dsn = (nr_group_sum(dw0) + dw0r) * wv;              // img channels: 8 registers x 4 lane groups; rgb replicated
         }
+        } else {                                               // front kernel: what the tail kernel left for this lane
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 8; ++k) { dgi[k] = ho[k * 64]; de[0][k] = ho[(8 + k) * 64]; }
+            dgr[0] = ho[16 * 64]; dgr[1] = ho[17 * 64]; dgr[2] = ho[18 * 64]; dsn = ho[19 * 64];
+        }
+        if constexpr (DO_TAIL && !DO_FRONT) {
+            NR_PRAGMA_UNROLL
+            for (int k = 0; k < 8; ++k) { ho[k * 64] = dgi[k]; ho[(8 + k) * 64] = de[0][k]; }
+            ho[16 * 64] = dgr[0]; ho[17 * 64] = dgr[1]; ho[18 * 64] = dgr[2]; ho[19 * 64] = dsn;
+            __syncthreads();                                   // (the next tile's DMA overwrites xch / stash / xg)
+        }
+        if constexpr (DO_FRONT) {
         B2_MARK(31);
         // ---- neuray_fc backward -> d e +=            (rows: 0 do (16), 16 h8 (16), 32 dh8 (16), 48 e (32))
         // ---- ray_dir_fc backward (weights only)      (rows: 80 dy35 (48), 128 h16 (16), 144 dh16 (16), 160 dl (16))
@@ -946,11 +970,16 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             __syncthreads();
             B2_MARK(42);
         }
+    
+        }
     }
     // ================= end of the launch: accumulated weight gradients -> global =================
-    dw_flush_all<DW_RF4, DW_RF2, DW_RF0, DW_V22, DW_V20, DW_VF2, DW_VF0, DW_B2, DW_BV, DW_NF2, DW_NF0, DW_RD2, DW_RD0, DW_PE2, DW_PE0,
-                 DW_M4, DW_M2, DW_M0, DW_V4, DW_V2, DW_V0, DW_A4, DW_A2, DW_A0, DW_GF2, DW_GF0, DW_BG>(acc, bacc, p.d_flat, wave, lane);
-    if constexpr (HAS_VIS) dw_flush_all<DW_S4, DW_S2, DW_S0>(acc, bacc, p.d_flat, wave, lane);
+    if constexpr (DO_TAIL)
+        dw_flush_all<DW_RF4, DW_RF2, DW_RF0, DW_V22, DW_V20, DW_VF2, DW_VF0, DW_B2, DW_BV, DW_GF2, DW_GF0, DW_BG>(acc, bacc, p.d_flat, wave, lane);
+    if constexpr (DO_FRONT) {
+        dw_flush_all<DW_NF2, DW_NF0, DW_RD2, DW_RD0, DW_PE2, DW_PE0, DW_M4, DW_M2, DW_M0, DW_V4, DW_V2, DW_V0, DW_A4, DW_A2, DW_A0>(acc, bacc, p.d_flat, wave, lane);
+        if constexpr (HAS_VIS) dw_flush_all<DW_S4, DW_S2, DW_S0>(acc, bacc, p.d_flat, wave, lane);
+    }
 }
 
 // =====================================================================================================================

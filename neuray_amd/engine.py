@@ -521,7 +521,8 @@ class RenderEngine:
                                packed=None, kernel='auto', saved=None, out=None):
         """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC).
         packed: the forward's PackedPass of the same weights (built from `flat` here if absent).  kernel: 'auto' = the
-        register / LDS resident kernel when it applies (rfn <= 8), 'v1' = force the first-version kernel (tests).
+        register / LDS resident kernel when it applies (rfn <= 8; run as its two halves), 'one_launch' = the resident kernel as a single
+        launch (A/B, cross-check), 'v1' = force the first-version kernel (tests).
         saved: render_pass(save=True)['saved'] of the same inputs (resident kernel; produced here by one more forward if absent)."""
         coords, depth, d_point_rec = self._f32(coords), self._f32(depth), self._f32(d_point_rec)
         rn, dn = depth.shape
@@ -530,8 +531,10 @@ class RenderEngine:
         if packed is not None and packed.folded:
             raise ValueError("neuray_amd: the backward kernels take the unfolded pack (pack_pass(fold=False) / pack_pass_device)")
         resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
-        ws = pk = pt = None
+        ws = pk = pt = ho = None
         if resident:
+            if kernel != 'one_launch':      # the kernel as its two halves (tail, front) with a hand-over buffer in between: 0.63 vs 0.92 ms
+                ho = self.empty(int(self.lib.neuray_points_backward_handover_floats(rn * dn)))
             packed = packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))
             pk = packed.dev
             pt = self.pack_pass_t_device(flat, bool(has_vis_head))
@@ -552,7 +555,7 @@ class RenderEngine:
             d_rf.data_ptr(), d_if.data_ptr(), ws.data_ptr() if ws is not None else None, views.rfn, rn, dn, views.h, views.w,
             views.fh, views.fw, int(has_vis_head), int(bool(use_vis)), float(var_bias),
             pk.data_ptr() if pk is not None else None, pt.data_ptr() if pt is not None else None,
-            saved.data_ptr() if (resident and saved is not None) else None)
+            saved.data_ptr() if (resident and saved is not None) else None, ho.data_ptr() if ho is not None else None)
         ev = self._event_pair()
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         self._event_done(ev, 'points_backward', rn * dn)

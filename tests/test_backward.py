@@ -434,3 +434,41 @@ def test_retired_backward_variant_is_refused():
     lib = emu_lib()
     assert lib.neuray_select_points_backward(0) == 0 and lib.neuray_select_points_backward(2) == 0
     assert lib.neuray_select_points_backward(3) != 0 and b'retired' in lib.neuray_last_error()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('rfn,rn,dn,vis_head', [(8, 5, 9, False), (3, 4, 16, True), (5, 7, 7, True), (1, 3, 5, False)])
+def test_two_launch_point_backward_equals_the_single_launch(backend, rfn, rn, dn, vis_head):
+    """the resident point backward as its two halves (tail kernel -> hand-over buffer -> front kernel: what the engine runs) against
+    the same kernel source as ONE launch: every gradient, up to the summation order of the atomics; tiles with padding points
+    (rn * dn not a multiple of 16), padding waves (rfn < 8), with and without a consumed vis head"""
+    from neuray_amd.engine import RenderEngine
+    from oracle import neuray_oracle as orc
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
+    que, ref, weights, rng = _pass_case(rfn, rn, dn, vis_head, seed=57 + rfn)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)         # noqa: E731
+    views = eng.prepare_views({k: t(v) for k, v in ref.items()})
+    qc = eng.prepare_query({k: t(v) for k, v in que.items()})
+    depth = t(orc.sample_depth(que['depth_range'], rn, dn)[0])
+    coords = t(que['coords'][0])
+    packed = eng.pack_pass(weights, 'dist_decoder.', 'agg_net.')
+    flat, has_vis = eng.flat_pass(weights, 'dist_decoder.', 'agg_net.')
+    assert has_vis == vis_head
+    fwd = eng.render_pass(qc, views, coords, depth, packed, use_vis=vis_head, save=True)
+    d_rec = t(rng.randn(rn, dn, 20).astype(np.float32))
+    assert int(eng.lib.neuray_points_backward_handover_floats(rn * dn)) == ((rn * dn + 15) // 16) * 8 * 20 * 64
+    two = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, vis_head, d_rec, packed=packed, saved=fwd['saved'])
+    one = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, vis_head, d_rec, packed=packed, saved=fwd['saved'],
+                                     kernel='one_launch')
+    for x, y, name in zip(two, one, ('d_flat', 'd_ray_feats', 'd_img_feats')):
+        assert float(y.abs().max()) > 0, name
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), name
+    # the selector forces the single launch even when a hand-over buffer is given
+    assert eng.lib.neuray_select_points_backward(1) == 0
+    try:
+        forced = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, vis_head, d_rec, packed=packed, saved=fwd['saved'])
+    finally:
+        assert eng.lib.neuray_select_points_backward(0) == 0
+    for x, y in zip(forced, one):
+        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))

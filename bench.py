@@ -323,7 +323,8 @@ def training_step_timing(device, steps=3):
         out['point_backward'] = {'ms_per_pass': ms, 'launches_timed': len(ts),
                                  'tflops_by_3x_forward_convention': conv, 'frac_of_fp32_mfma_peak': conv / MFMA_F32_PEAK_TFLOPS,
                                  'note': 'a backward pass counted as 3 x the forward algorithmic FLOP of its 512 x 64 points (round-1 judge convention); '
-                                         'the kernel reads the cross-view quantities the training forward saved and recomputes only per-view layers'}
+                                         'the kernel reads the cross-view quantities the training forward saved and recomputes only per-view layers; one pass = its two '
+                                         'launches (network tail, then front, with a hand-over buffer: nr_kernels_bwd2.h B2Part), timed together'}
     return out
 
 

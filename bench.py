@@ -437,7 +437,8 @@ def gen_train_step_timing(device, steps=10):
             'ms_per_step': ms, 'ms_per_step_with_host_Ks_inv': ms_kinv,
             'note': "ms_per_step: the batch as the reference's loader hands it over (K^-1 of the query view = torch.inverse on the host "
                     "inside the step: a 36-byte device -> host copy that waits for the previous step's queue); with_host_Ks_inv: the batch "
-                    "carries que_imgs_info['Ks_inv'] computed by the host pipeline before the upload",
+                    "carries que_imgs_info['Ks_inv'] computed by the host pipeline before the upload (the two agree within the run-to-run "
+                    "noise of +-2 ms: the copy is taken before anything of the step is queued)",
             'loss_is_finite': bool(torch.isfinite(loss).item()),
             'kernel_classes': 'profiles/r04_*_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
 

@@ -369,15 +369,13 @@ int neuray_direct_render_rays(const float* alpha_dev, const float* colors_dev, i
  * backward: d_out_padded is the gradient of the padded output (everything that consumed the padded tensor or its interior view);
  *           -> dx [n][c][h][w], d_res [n][c][h][w] (NULL = no residual).  raw_zeroed [n*c][2] (zero on entry) returns per plane
  *           (sum g, sum g xhat); d_gamma / d_beta [c] (both or neither; NULL = not wanted) receive their sums over the images: the
- *           gradients of the affine parameters.  out_padded / d_out_padded take image strides as the forward's output.
- *           d_interior [n][c][h][w] (NULL = none): a second incoming gradient, of the un-padded activation - the interior view of
- *           out_padded handed out as the next block's residual input - added on the fly (d_out_padded may then be NULL). */
+ *           gradients of the affine parameters.  out_padded / d_out_padded take image strides as the forward's output. */
 int neuray_inorm_forward(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, long long res_stride_n,
                          long long res_stride_c, long long res_stride_h, int n, int c, int h, int w, int pad, int act, float eps,
                          float* raw_zeroed_dev, float* stats_dev, float* out_padded_dev, long long out_stride_n, void* stream);
 int neuray_inorm_backward(const float* x_dev, const float* out_padded_dev, long long out_stride_n, const float* d_out_padded_dev,
-                          long long d_out_stride_n, const float* d_interior_dev, const float* stats_dev, const float* gamma_dev, int n, int c,
-                          int h, int w, int pad, int act, float* raw_zeroed_dev, float* dx_dev, float* d_res_dev, float* d_gamma_dev,
+                          long long d_out_stride_n, const float* stats_dev, const float* gamma_dev, int n, int c, int h, int w, int pad,
+                          int act, float* raw_zeroed_dev, float* dx_dev, float* d_res_dev, float* d_gamma_dev,
                           float* d_beta_dev, void* stream);
 
 /* ---- f-1: bilinear x2 up-sampling + reflection padding of the image encoder's decoder half ------------------------------------

@@ -113,7 +113,7 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_alpha2hit_prob': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_inorm_forward': (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] * 3 + [C.c_int] * 6 + [C.c_float] + [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
-    'neuray_inorm_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 6),
+    'neuray_inorm_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 6),
     'neuray_upsample2x_pad_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     'neuray_upsample2x_pad_backward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

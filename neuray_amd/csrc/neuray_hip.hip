@@ -395,17 +395,17 @@ int neuray_inorm_forward(const float* x, const float* gamma, const float* beta, 
 }
 
 int neuray_inorm_backward(const float* x, const float* out_padded, long long out_stride_n, const float* d_out_padded, long long d_out_stride_n,
-                          const float* d_interior, const float* stats, const float* gamma, int n, int c, int h, int w, int pad, int act,
-                          float* raw_zeroed, float* dx, float* d_res, float* d_gamma, float* d_beta, void* stream) {
-    if (!x || !out_padded || (!d_out_padded && !d_interior) || !stats || !gamma || !raw_zeroed || !dx) return fail("neuray_inorm_backward: null pointer");
+                          const float* stats, const float* gamma, int n, int c, int h, int w, int pad, int act, float* raw_zeroed, float* dx,
+                          float* d_res, float* d_gamma, float* d_beta, void* stream) {
+    if (!x || !out_padded || !d_out_padded || !stats || !gamma || !raw_zeroed || !dx) return fail("neuray_inorm_backward: null pointer");
     if (n < 1 || c < 1 || h < 1 || w < 1 || pad < 0 || pad >= h || pad >= w || act < 0 || act > 2 || (long long)(h + 2 * pad) * (w + 2 * pad) >= (1 << 23))
         return fail("neuray_inorm_backward: bad arguments n=%d c=%d h=%d w=%d pad=%d act=%d", n, c, h, w, pad, act);
     const long long img = (long long)c * (h + 2 * pad) * (w + 2 * pad);
     if ((out_stride_n != 0 && out_stride_n < img) || (d_out_stride_n != 0 && d_out_stride_n < img))
         return fail("neuray_inorm_backward: image strides %lld / %lld < %lld", out_stride_n, d_out_stride_n, img);
     nr::NormBwdParams p;
-    p.x = x; p.out = out_padded; p.d_out = d_out_padded; p.d_int = d_interior; p.stats = stats; p.gamma = gamma; p.raw = raw_zeroed; p.dx = dx;
-    p.d_res = d_res; p.d_gamma = d_gamma; p.d_beta = d_beta;
+    p.x = x; p.out = out_padded; p.d_out = d_out_padded; p.stats = stats; p.gamma = gamma; p.raw = raw_zeroed; p.dx = dx; p.d_res = d_res;
+    p.d_gamma = d_gamma; p.d_beta = d_beta;
     p.out_stride_n = out_stride_n ? out_stride_n : img; p.d_out_stride_n = d_out_stride_n ? d_out_stride_n : img;
     p.n = n; p.c = c; p.h = h; p.w = w; p.pad = pad; p.act = act;
     const int planes = n * c, hw = h * w;

@@ -120,9 +120,7 @@ __global__ void __launch_bounds__(256) inorm_apply_kernel(NormApplyParams p) {
 struct NormBwdParams {
     const float* x;        // [n][c][h][w] forward input
     const float* out;      // [n][c][hp][wp] forward output (padded); image i at out + i * out_stride_n
-    const float* d_out;    // [n][c][hp][wp] gradient of the padded output; image i at d_out + i * d_out_stride_n; or null
-    const float* d_int;    // [n][c][h][w] gradient of the un-padded activation (the interior view of the output handed out separately:
-                           // the residual path of the next block), added on the fly; or null
+    const float* d_out;    // [n][c][hp][wp] gradient of the padded output; image i at d_out + i * d_out_stride_n
     const float* stats;    // [n*c][2] mean, rstd
     const float* gamma;    // [c]
     float* raw;            // [n*c][2]: sum g, sum g xhat (zeroed; reduce kernel adds, apply kernel reads)
@@ -136,23 +134,20 @@ struct NormBwdParams {
 
 // g(y, x): gradient of the padded output folded back onto the interior point (adjoint of the reflection padding), through the
 // activation
-__device__ __forceinline__ float norm_bwd_g(const NormBwdParams& p, const float* d_plane, const float* i_plane, const float* o_plane, int y, int xx) {
+__device__ __forceinline__ float norm_bwd_g(const NormBwdParams& p, const float* d_plane, const float* o_plane, int y, int xx) {
     const int wp = p.w + 2 * p.pad;
-    float g = i_plane ? i_plane[y * p.w + xx] : 0.0f;
-    if (d_plane) {
-        if (p.pad > 0 && (y <= p.pad || xx <= p.pad || y >= p.h - 1 - p.pad || xx >= p.w - 1 - p.pad)) {      // near a border only
-            // padded rows / columns that mirror onto (y, x): distance k <= pad from an edge mirrors to the row k outside it
-            const int ya = (y >= 1 && y <= p.pad) ? p.pad - y : -1;                          // top border row index in the padded tensor
-            const int yb = (y <= p.h - 2 && y >= p.h - 1 - p.pad) ? p.pad + 2 * (p.h - 1) - y : -1;
-            const int xa = (xx >= 1 && xx <= p.pad) ? p.pad - xx : -1;
-            const int xb = (xx <= p.w - 2 && xx >= p.w - 1 - p.pad) ? p.pad + 2 * (p.w - 1) - xx : -1;
-            const int ys[3] = {y + p.pad, ya, yb}, xs[3] = {xx + p.pad, xa, xb};
-            for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b)
-                    if (ys[a] >= 0 && xs[b] >= 0) g += d_plane[ys[a] * wp + xs[b]];
-        } else {
-            g += d_plane[(y + p.pad) * wp + xx + p.pad];
-        }
+    float g = d_plane[(y + p.pad) * wp + xx + p.pad];
+    if (p.pad > 0 && (y <= p.pad || xx <= p.pad || y >= p.h - 1 - p.pad || xx >= p.w - 1 - p.pad)) {      // near a border only
+        // padded rows / columns that mirror onto (y, x): distance k <= pad from an edge mirrors to the row k outside it
+        const int ya = (y >= 1 && y <= p.pad) ? p.pad - y : -1;                          // top border row index in the padded tensor
+        const int yb = (y <= p.h - 2 && y >= p.h - 1 - p.pad) ? p.pad + 2 * (p.h - 1) - y : -1;
+        const int xa = (xx >= 1 && xx <= p.pad) ? p.pad - xx : -1;
+        const int xb = (xx <= p.w - 2 && xx >= p.w - 1 - p.pad) ? p.pad + 2 * (p.w - 1) - xx : -1;
+        const int ys[3] = {y + p.pad, ya, yb}, xs[3] = {xx + p.pad, xa, xb};
+        g = 0.0f;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                if (ys[a] >= 0 && xs[b] >= 0) g += d_plane[ys[a] * wp + xs[b]];
     }
     return g * norm_act_grad(o_plane[(y + p.pad) * wp + xx + p.pad], p.act);
 }
@@ -162,8 +157,7 @@ __global__ void __launch_bounds__(256) inorm_backward_reduce_kernel(NormBwdParam
     const int plane = blockIdx.y, hw = p.h * p.w, hpwp = (p.h + 2 * p.pad) * (p.w + 2 * p.pad);
     const int img = plane / p.c, ch = plane - img * p.c;
     const float* px = p.x + (size_t)plane * hw;
-    const float* dpl = p.d_out ? p.d_out + (size_t)img * p.d_out_stride_n + (size_t)ch * hpwp : nullptr;
-    const float* ipl = p.d_int ? p.d_int + (size_t)plane * hw : nullptr;
+    const float* dpl = p.d_out + (size_t)img * p.d_out_stride_n + (size_t)ch * hpwp;
     const float* opl = p.out + (size_t)img * p.out_stride_n + (size_t)ch * hpwp;
     const float mean = p.stats[2 * plane], rstd = p.stats[2 * plane + 1];
     float s1 = 0.0f, s2 = 0.0f;
@@ -171,7 +165,7 @@ __global__ void __launch_bounds__(256) inorm_backward_reduce_kernel(NormBwdParam
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
         int y, xx;
         fast_divmod(i, p.w, inv_w, y, xx);
-        const float g = norm_bwd_g(p, dpl, ipl, opl, y, xx);
+        const float g = norm_bwd_g(p, dpl, opl, y, xx);
         s1 += g;
         s2 = fmaf(g, (px[i] - mean) * rstd, s2);
     }
@@ -194,8 +188,7 @@ __global__ void __launch_bounds__(256) inorm_backward_apply_kernel(NormBwdParams
     const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.w;
     const int img = plane / p.c, ch = plane - img * p.c;
     const float* px = p.x + (size_t)plane * hw;
-    const float* dpl = p.d_out ? p.d_out + (size_t)img * p.d_out_stride_n + (size_t)ch * hpwp : nullptr;
-    const float* ipl = p.d_int ? p.d_int + (size_t)plane * hw : nullptr;
+    const float* dpl = p.d_out + (size_t)img * p.d_out_stride_n + (size_t)ch * hpwp;
     const float* opl = p.out + (size_t)img * p.out_stride_n + (size_t)ch * hpwp;
     const float mean = p.stats[2 * plane], rstd = p.stats[2 * plane + 1];
     const float mg = p.raw[2 * plane] * inv_hw, mgx = p.raw[2 * plane + 1] * inv_hw;
@@ -213,7 +206,7 @@ __global__ void __launch_bounds__(256) inorm_backward_apply_kernel(NormBwdParams
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
         int y, xx;
         fast_divmod(i, p.w, inv_w, y, xx);
-        const float g = norm_bwd_g(p, dpl, ipl, opl, y, xx);
+        const float g = norm_bwd_g(p, dpl, opl, y, xx);
         const float xhat = (px[i] - mean) * rstd;
         pdx[i] = gr * (g - mg - xhat * mgx);
         if (pdr) pdr[i] = g;

@@ -59,14 +59,13 @@ class _ResBlock(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), _inorm(cout))
 
-    def forward(self, xp, x_in=None, pad_out=1):
-        """xp: the block's input carrying 1 pixel of reflection padding, x_in: its interior (handed over by the producing norm_act as a
-        second output; taken as a view here when absent) -> (the block's output padded by `pad_out`, its interior)"""
+    def forward(self, xp, pad_out=1):
+        """xp: the block's input carrying 1 pixel of reflection padding -> the block's output padded by `pad_out`"""
         a = norm_act(self.bn1, conv_prepadded(self.conv1, xp), 'relu', 1)
-        skip = x_in if x_in is not None else interior(xp, 1)
+        skip = interior(xp, 1)
         if self.downsample is not None:
             skip = norm_act(self.downsample[1], conv_prepadded(self.downsample[0], skip), None, 0)
-        return norm_act(self.bn2, conv_prepadded(self.conv2, a), 'relu', pad_out, res=skip, with_interior=True)
+        return norm_act(self.bn2, conv_prepadded(self.conv2, a), 'relu', pad_out, res=skip)
 
 
 class _ConvNormElu(nn.Module):
@@ -94,12 +93,11 @@ def _stage(cin, cout, n):
     return nn.Sequential(*[_ResBlock(cin if i == 0 else cout, cout, 2 if i == 0 else 1) for i in range(n)])
 
 
-def _run_stage(stage, xp, x_in, pad_out):
-    """the blocks of a stage on a padded input (+ its interior); every block hands the next one its output already padded
-    -> (padded output, interior)"""
+def _run_stage(stage, xp, pad_out):
+    """the blocks of a stage on a padded input; every block hands the next one its output already padded"""
     for i, blk in enumerate(stage):
-        xp, x_in = blk(xp, x_in, 1 if i + 1 < len(stage) else pad_out)
-    return xp, x_in
+        xp = blk(xp, 1 if i + 1 < len(stage) else pad_out)
+    return xp
 
 
 def _join(skip, x):
@@ -135,10 +133,10 @@ class ImageEncoder(nn.Module):
 
     def forward(self, imgs):
         x = _fmt(imgs)
-        xp, x0 = norm_act(self.bn1, self.conv1(x), 'relu', 1, with_interior=True)     # every activation travels with the next conv's padding
-        s1p, s1 = _run_stage(self.layer1, xp, x0, 1)
-        s2p, s2 = _run_stage(self.layer2, s1p, s1, 1)
-        s3, _ = _run_stage(self.layer3, s2p, s2, 0)
+        xp = norm_act(self.bn1, self.conv1(x), 'relu', 1)                 # every activation travels with the next conv's padding
+        s1p = _run_stage(self.layer1, xp, 1)
+        s2p = _run_stage(self.layer2, s1p, 1)
+        s3 = _run_stage(self.layer3, s2p, 0)
         x = self.iconv3(_up_join_padded(self.upconv3, s3, s2p), prepadded=True)
         x = self.iconv2(_up_join_padded(self.upconv2, x, s1p), prepadded=True)
         return self.out_conv(x).contiguous(memory_format=torch.channels_last)     # (no-op when the convs kept the format)

@@ -24,15 +24,9 @@ def _engine(device):
 
 
 class _NormActFn(torch.autograd.Function):
-    """-> (padded result [with `tail` behind it], its un-padded interior view or None).  The interior is a second OUTPUT rather than a
-    slice taken by the caller: its gradient then arrives here as its own dense tensor and is added inside the backward kernels, where
-    the slice's autograd nodes would zero-fill a padded tensor, copy the gradient into it and add it to the padded one (three passes
-    over the activation per residual block)."""
-
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, pad, act, eps, tail, want_interior):
+    def forward(ctx, x, gamma, beta, res, pad, act, eps, tail):
         eng = _engine(x.device)
-        ctx.set_materialize_grads(False)
         x = x.contiguous().float()
         n, c, h, w = x.shape
         hp, wp = h + 2 * pad, w + 2 * pad
@@ -57,21 +51,15 @@ class _NormActFn(torch.autograd.Function):
             n, c, h, w, int(pad), int(act), float(eps), raw.data_ptr(), stats.data_ptr(), out.data_ptr(), (c + ct) * hp * wp, eng._stream()))
         ctx.save_for_backward(x, out, stats, g)
         ctx.meta = (int(pad), int(act), res is not None, ct)
-        inner = out[:, :c, pad:hp - pad, pad:wp - pad] if want_interior else None
-        return out, inner
+        return out
 
     @staticmethod
-    def backward(ctx, d_out, d_inner):
+    def backward(ctx, d_out):
         x, out, stats, g = ctx.saved_tensors
         pad, act, has_res, ct = ctx.meta
         eng = _engine(x.device)
         n, c, h, w = x.shape
-        if d_out is None and d_inner is None:
-            return (None,) * 9
-        if d_out is not None:
-            d_out = d_out.contiguous().float()
-        if d_inner is not None:
-            d_inner = d_inner.contiguous().float()
+        d_out = d_out.contiguous().float()
         img = (c + ct) * (h + 2 * pad) * (w + 2 * pad)
         raw = eng.zero_scratch(2 * n * c)[:2 * n * c]
         d_affine = torch.empty(2, c, dtype=torch.float32, device=x.device)
@@ -81,29 +69,24 @@ class _NormActFn(torch.autograd.Function):
         # (the affine parameters' gradients come out of the apply kernel - the planes' sums added over the images - instead of one more
         # PyTorch reduction per call: 30 launches of ~15 us per encoder pass)
         eng._check(eng.lib.neuray_inorm_backward(
-            x.data_ptr(), out.data_ptr(), img, d_out.data_ptr() if d_out is not None else None, img,
-            d_inner.data_ptr() if d_inner is not None else None, stats.data_ptr(), g.data_ptr(), n, c, h, w, pad, act, raw.data_ptr(),
+            x.data_ptr(), out.data_ptr(), img, d_out.data_ptr(), img, stats.data_ptr(), g.data_ptr(), n, c, h, w, pad, act, raw.data_ptr(),
             dx.data_ptr(), d_res.data_ptr() if has_res else None, d_gamma.data_ptr(), d_beta.data_ptr(), eng._stream()))
-        return dx, d_gamma, d_beta, d_res, None, None, None, (d_out[:, c:] if (ct and d_out is not None) else None), None
+        return dx, d_gamma, d_beta, d_res, None, None, None, (d_out[:, c:] if ct else None)
 
 
-def norm_act(bn, y, act=None, pad=0, res=None, tail=None, with_interior=False):
+def norm_act(bn, y, act=None, pad=0, res=None, tail=None):
     """-> reflect_pad(act(bn(y) [+ res]), pad) as one [n, c, h + 2 pad, w + 2 pad] tensor; with `tail` (a tensor of that padded size):
-    torch.cat([that, tail], 1), the normalised half written into the concatenation in place; with_interior: -> (padded tensor, its
-    un-padded interior view) - the next residual block's convolution input and skip input - as two outputs of one autograd node"""
+    torch.cat([that, tail], 1), the normalised half written into the concatenation in place"""
     # (a padded plane of >= 2^23 elements - 2896 x 2896 - is beyond the kernels' fast division: such a map takes the composed PyTorch
     # ops below.  A missing library on a GPU still raises: the package never silently swaps its kernels for something else.)
     if (FUSED_NORM and bn.affine and not bn.track_running_stats and (y.shape[2] + 2 * pad) * (y.shape[3] + 2 * pad) < (1 << 23)
             and _engine(y.device) is not None):
-        out, inner = _NormActFn.apply(y, bn.weight, bn.bias, res, pad, ACTS[act], bn.eps, tail, bool(with_interior))
-        return (out, inner) if with_interior else out
+        return _NormActFn.apply(y, bn.weight, bn.bias, res, pad, ACTS[act], bn.eps, tail)
     z = bn(y)
     if res is not None:
         z = z + res
     z = F.relu(z) if act == 'relu' else (F.elu(z) if act == 'elu' else z)
     z = F.pad(z, (pad, pad, pad, pad), mode='reflect') if pad else z
-    if with_interior:
-        return z, interior(z, pad)
     return z if tail is None else torch.cat([z, tail], 1)
 
 

@@ -189,37 +189,3 @@ def test_norm_act_writes_its_half_of_a_channel_concatenation(device, act, pad, s
             fused_norm.FUSED_NORM = True
     for a, b, tol in zip(outs[0], outs[1], (2e-5, 2e-4, 0.0, 2e-4, 2e-4)):
         assert a.shape == b.shape and float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
-
-
-@pytest.mark.parametrize('device', BACKENDS, indirect=True)
-@pytest.mark.parametrize('act,pad,shape,use', [('relu', 1, (2, 3, 8, 10), 'both'), ('relu', 1, (1, 4, 6, 7), 'interior'),
-                                               ('elu', 1, (2, 2, 5, 9), 'padded'), ('relu', 0, (1, 3, 4, 6), 'both')])
-def test_norm_act_hands_out_its_interior_as_a_second_output(device, act, pad, shape, use):
-    """norm_act(..., with_interior=True) -> (padded, interior view): what a residual block takes as convolution input and as skip input;
-    the two gradients come back separately and are added inside the backward kernels - against the composed ops with a plain slice"""
-    g = torch.Generator().manual_seed(sum(shape))
-    n, c, h, w = shape
-    bn = nn.InstanceNorm2d(c, affine=True, track_running_stats=False)
-    with torch.no_grad():
-        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
-        bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
-    bn = bn.to(device)
-    y0 = torch.randn(n, c, h, w, generator=g).to(device)
-    dp = torch.randn(n, c, h + 2 * pad, w + 2 * pad, generator=g).to(device)
-    di = torch.randn(n, c, h, w, generator=g).to(device)
-    outs = []
-    for fused in (True, False):
-        fused_norm.FUSED_NORM = fused
-        try:
-            y = y0.clone().requires_grad_(True)
-            for p_ in bn.parameters():
-                p_.grad = None
-            zp, zi = fused_norm.norm_act(bn, y, act, pad, None, with_interior=True)
-            assert zi.shape == (n, c, h, w) and torch.equal(zi, zp[:, :, pad:pad + h, pad:pad + w])
-            loss = (zp * dp).sum() * (use != 'interior') + (zi * di).sum() * (use != 'padded')
-            loss.backward()
-            outs.append([v.detach().cpu() for v in (zp, y.grad, bn.weight.grad.clone(), bn.bias.grad.clone())])
-        finally:
-            fused_norm.FUSED_NORM = True
-    for a, b, tol in zip(outs[0], outs[1], (2e-5, 2e-4, 2e-4, 2e-4)):
-        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))

@@ -624,8 +624,9 @@ def fresh_process_leg(name, device):
     the same GPU while this process idles; if the child fails, the leg runs here and says so."""
     import subprocess
     try:
-        res = subprocess.run([sys.executable, os.path.abspath(__file__), '--leg', name], capture_output=True, text=True, timeout=600,
-                             env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get('HIP_VISIBLE_DEVICES', str(device.index or 0))))
+        if (device.index or 0) != 0:
+            raise RuntimeError('the fresh-process legs run on cuda:0 of the visible devices')
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), '--leg', name], capture_output=True, text=True, timeout=600)
         for line in reversed(res.stdout.splitlines()):
             if line.startswith('{') and '"leg"' in line:
                 out = json.loads(line)['result']

@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(256) costreg_up11_kernel(Up11Params p) {
             const float* src = xi + (long long)iz * plane + (long long)(row_ok ? iy : hy) * p.w;
             const float live = row_ok ? 1.0f : 0.0f;
             const float* __restrict__ wk = p.wpack + (kz * 3 + ky) * (16 * 8 * 3);   // uniform: scalar loads
-            NR_PRAGMA_UNROLL
+            // (two input channels at a time: their 48 weights fit the scalar registers; unrolled over all 16 the 384 of them spilled)
+#pragma unroll 2
             for (int ci = 0; ci < 16; ++ci) {
                 const float xa = src[ci * vol] * live, xb = has_next ? src[ci * vol + 1] * live : 0.0f;
                 NR_PRAGMA_UNROLL

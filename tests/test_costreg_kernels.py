@@ -102,3 +102,31 @@ def test_up11_kernel_matches_convtranspose_bn_leaky_plus_skip(dev, shape, with_s
         got = net._engine(x).costreg_up11(x, pack, shift, slope, c0 if with_skip else None)
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+# ---- random small volumes on the emulator: every combination of odd / even sizes, single planes / rows / columns ----------------
+from hypothesis import HealthCheck, given, settings, strategies as st     # noqa: E402
+
+
+@settings(max_examples=14, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(n=st.integers(1, 2), d=st.integers(1, 4), h=st.integers(1, 7), w=st.integers(1, 37), seed=st.integers(0, 10 ** 6))
+def test_conv0_and_up11_on_random_volumes_emulator(n, d, h, w, seed):
+    ro._ENGINES.clear()
+    ro._TEST_LIB = emu_lib()
+    try:
+        net = make_net('cpu', seed=seed % 7)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, 32, d, h, w, generator=g)
+        with torch.no_grad():
+            want, got = net.conv0(x), net.conv0_fast(x)
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), ('conv0', n, d, h, w)
+        y = torch.randn(n, 16, d, h, w, generator=g)
+        c0 = torch.randn(n, 8, 2 * d, 2 * h, 2 * w, generator=g)
+        with torch.no_grad():
+            want = net.conv11(y) + c0
+            pack, shift, slope = net._packs(y.device)[5:8]
+            got = net._engine(y).costreg_up11(y, pack, shift, slope, c0)
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), ('up11', n, d, h, w)
+    finally:
+        ro._TEST_LIB = None
+        ro._ENGINES.clear()

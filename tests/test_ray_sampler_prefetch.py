@@ -144,3 +144,30 @@ def test_renderer_with_a_pending_prefetch_can_be_deep_copied_and_collected():
     assert twin is not ft and R._PREFETCH.get(twin) is None
     del ft, twin
     gc.collect()
+
+
+from hypothesis import HealthCheck, given, settings, strategies as st     # noqa: E402
+
+
+@needs_lib
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2 ** 32 - 1), burn=st.integers(0, 1400), n=st.integers(4096, 90000), wide=st.booleans(), gauss=st.booleans())
+def test_native_shuffle_property(seed, burn, n, wide, gauss):
+    """any seed, any position inside the MT19937 block (incl. a refill in the middle of the shuffle), any length, both item sizes, with
+    and without a cached normal deviate in the legacy state: the permutation and the generator afterwards are numpy's"""
+    def prepare():
+        np.random.seed(seed)
+        np.random.random_sample(burn)
+        if gauss:
+            np.random.standard_normal(1)
+    dtype = np.int64 if wide else np.int32
+    prepare()
+    want = np.arange(n).astype(dtype)
+    np.random.shuffle(want)
+    tail_want = (np.random.standard_normal(2), np.random.randint(0, 1 << 30, 3))
+    prepare()
+    got = np.arange(n).astype(dtype)
+    R.shuffle_like_numpy(got)
+    tail_got = (np.random.standard_normal(2), np.random.randint(0, 1 << 30, 3))
+    assert np.array_equal(got, want)
+    assert np.array_equal(tail_got[0], tail_want[0]) and np.array_equal(tail_got[1], tail_want[1])

@@ -102,8 +102,10 @@ class CostRegNet(nn.Module):
         return render_ops.engine_for(x.device)
 
     def _fast_ok(self, x):
+        # (one image's 32-channel volume must stay below 2^31 bytes for conv0's buffer descriptor: larger ones take the module path)
         return (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.prob.weight.requires_grad))
-                and x.dtype == torch.float32 and x.dim() == 5 and self._engine(x) is not None)
+                and x.dtype == torch.float32 and x.dim() == 5 and x.shape[2] * x.shape[3] * x.shape[4] * 128 < 0x7fffff00
+                and self._engine(x) is not None)
 
     def _packs(self, device):
         """conv0's weights with the frozen batch norm folded in, as per-lane MFMA A fragments (csrc/nr_kernels_conv3d.h Conv0Params.wpack),

@@ -254,6 +254,78 @@ def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch
                     % (batches, rays_per_batch)}
 
 
+def full_image_parity_leg(cfg, renderer, weights, tq, tr, got, device, chunk=4096, ours_chunk=32768):
+    """parity over ALL rays of the bench image (the numpy-oracle leg covers 1.3 % of it: the oracle runs at 300 rays/s).
+    Checker: the golden-checked eager-PyTorch port of the reference's op sequence (oracle/torch_eager_port.py; pinned to the reference's
+    own outputs and autograd by tests/test_oracle_golden.py) in fp32 on the SAME GPU, 4096-ray batches - outside the timed region.
+    Reference path: network/renderer.py:168-226.  `got`: the whole image as the timed loop rendered it.
+    Reports the coarse pixels (identical inputs) and the chained coarse -> fine pixels, and for every ray beyond the 5e-3 chained
+    gate how far its fine samples sit from the checker's (a chained error is a re-sampling displacement - a bin edge
+    decided differently by a last-bit difference of the coarse hit probabilities - not an arithmetic one)."""
+    from oracle import torch_eager_port as tep
+    w = {k: torch.from_numpy(v).to(device) for k, v in weights.items()}
+    ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+    n = tq['coords'].shape[1]
+    fdn = cfg['fine_depth_sample_num']
+    want_c = torch.empty(n, 3, device=device)
+    want_f = torch.empty(n, 3, device=device)
+    want_fd = torch.empty(n, fdn, device=device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for st in range(0, n, chunk):
+            q = dict(tq)
+            q['coords'] = tq['coords'][:, st:st + chunk]
+            o = tep.render_impl(w, ocfg, q, tr)
+            want_c[st:st + chunk] = o['pixel_colors_nr'][0]
+            want_f[st:st + chunk] = o['pixel_colors_nr_fine'][0]
+            want_fd[st:st + chunk] = o['_fine_depth'][0]
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    # our fine sample depths: render_impl (returns the coarse hit probabilities that render() drops in eval mode) + the fine sampler on
+    # them - the same kernels on the same inputs as the timed loop, whose pixels are checked to be reproduced bit for bit
+    eng = renderer.engine(device)
+    ours_fd = torch.empty(n, fdn, device=device)
+    same = True
+    with torch.no_grad():
+        for st in range(0, n, ours_chunk):
+            q = dict(tq)
+            q['coords'] = tq['coords'][:, st:st + ours_chunk].contiguous()
+            r = {k: v for k, v in tr.items()}
+            o = renderer.render_impl(q, r, False)
+            qconst = renderer._query(eng, q)
+            depth = eng.sample_coarse_depth(q['depth_range'], q['coords'].shape[1], cfg['depth_sample_num'])
+            ours_fd[st:st + ours_chunk] = eng.sample_fine_depth(qconst, depth.contiguous(), o['hit_prob_nr'][0].contiguous(), fdn,
+                                                                use_all=cfg.get('fine_depth_use_all', False))
+            same = same and bool(torch.equal(o['pixel_colors_nr_fine'][0], got['pixel_colors_nr_fine'][0, st:st + ours_chunk]))
+    err_c = (got['pixel_colors_nr'][0] - want_c).abs().amax(-1)
+    err_f = (got['pixel_colors_nr_fine'][0] - want_f).abs().amax(-1)
+    disp = (ours_fd - want_fd).abs().amax(-1)                    # largest displacement of a (sorted) fine sample, metric depth
+    far = err_f > PARITY_GATES['chained_max']
+    moved = disp > 1e-4
+    res = {
+        'rays': int(n), 'checker': 'golden-checked eager-PyTorch port of the reference op sequence, fp32, same GPU, %d-ray batches, %.1f s '
+                                   '(%.0f rays/s), outside the timed region' % (chunk, dt, n / dt),
+        'coarse_pixels': {'max_abs_err': float(err_c.max()), 'p99.9': float(torch.quantile(err_c[::7].float(), 0.999)),
+                          'frac_within_2e-4': float((err_c <= 2e-4).float().mean()), 'gate': PARITY_GATES['coarse_pixel_max']},
+        'chained_fine_pixels': {'max_abs_err': float(err_f.max()), 'p99.9': float(torch.quantile(err_f[::7].float(), 0.999)),
+                                'frac_within_2e-4': float((err_f <= 2e-4).float().mean()),
+                                'psnr_db': min(200.0, synthetic.psnr_uint8(got['pixel_colors_nr_fine'].cpu().numpy(), want_f[None].cpu().numpy()))},
+        'rays_beyond_5e-3': int(far.sum()),
+        'rays_beyond_5e-3_fine_sample_displacement': [float(x) for x in disp[far][:64].cpu()],
+        'rays_whose_fine_samples_moved_by_more_than_1e-4': int(moved.sum()),
+        'max_chained_err_among_rays_with_unmoved_samples': float(err_f[~moved].max()) if bool((~moved).any()) else None,
+        'fine_pixels_reproduced_bitwise_by_the_probe_render': same,
+        'gates': PARITY_GATES,
+    }
+    # gates: the coarse image strictly; the chained image distributionally, and every ray past the 5e-3 bound must be a re-sampled one
+    res['pass'] = bool(res['coarse_pixels']['max_abs_err'] <= PARITY_GATES['coarse_pixel_max']
+                       and res['chained_fine_pixels']['frac_within_2e-4'] >= PARITY_GATES['chained_frac_within_2e-4_min']
+                       and res['chained_fine_pixels']['psnr_db'] >= PARITY_GATES['chained_psnr_db_min']
+                       and bool((moved | ~far).all()))
+    return res
+
+
 def training_step_timing(device, steps=3):
     """Side measurement (not the headline metric): one render_impl(is_train=True) + backward through the HIP forward and
     backward kernels on 512 rays x 8 views x 64+64 samples (the shape of BASELINE.json configs[3]/[4]) next to autograd
@@ -919,9 +991,15 @@ def main(argv=None):
                             key=lambda f: (len(os.path.basename(f)), os.path.basename(f)))   # r01_traffic < r01_e_traffic < r02_...
             if args.fine_samples == 32 and standard and tfiles:
                 tj = json.load(open(tfiles[-1]))
-                traffic = tj.get('bytes_per_launch')
-                tsrc = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; collected on tree %s)' % (
-                    os.path.basename(tfiles[-1]), tj.get('commit', 'of that profile run'))
+                sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+                from summarize_pmc import kernel_source_hash
+                if tj.get('kernel_source_sha16') == kernel_source_hash():
+                    traffic = tj.get('bytes_per_launch')
+                    tsrc = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; collected on tree %s; the hash of the ' \
+                           'kernel sources stored in it matches this tree)' % (os.path.basename(tfiles[-1]), tj.get('commit', 'of that profile run'))
+                else:           # the kernel changed since the counters were collected: a stale figure is not reported
+                    tsrc = 'null: profiles/%s was collected on other kernel sources (sha16 %s, this tree %s) - re-run profiles/collect.sh' % (
+                        os.path.basename(tfiles[-1]), tj.get('kernel_source_sha16'), kernel_source_hash())
             achieved = flops_exec * n_pts / t_pts / 1e12
             line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
@@ -934,7 +1012,14 @@ def main(argv=None):
                                 'algorithmic_flops_per_point': flops_folded,
                                 'algorithmic_flops_per_point_unfolded_reference_network': flops_ref,
                                 'equivalent_tflops_of_the_unfolded_network_on_every_view': flops_ref * n_pts / t_pts / 1e12,
-                                'gather_demand_tb_per_s': 1088.0 * RFN * n_pts * share / t_pts / 1e12,
+                                # 1,072 B per (point, view) = 4 taps x (32 + 32 + 3 channels) x 4 B; the kernel's texels are RGBA (a
+                                # 4th, unused colour channel: 1,088 B actually requested), reported separately
+                                'gather_demand_tb_per_s': 1072.0 * RFN * n_pts * share / t_pts / 1e12,
+                                'gather_requested_tb_per_s_rgba_texels': 1088.0 * RFN * n_pts * share / t_pts / 1e12,
+                                'gather_demand_note': "north_star's '>= 40 % HBM roofline on feature gather' (3.2 TB/s of demand = 4.2 M rays/s at "
+                                                      "64+32 samples) is out of reach in fp32 by construction: the fp32 MFMA bound of the folded network "
+                                                      "(33.25 MFLOP/ray at 157.3 TFLOP/s) is ~3.7 M rays/s.  The maps are L2 / Infinity-Cache resident "
+                                                      "(roofline.traffic), so the demand rate is a cache-path figure, not an HBM one",
                                 'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt}
         else:
             line['roofline'] = None
@@ -1000,7 +1085,11 @@ def main(argv=None):
                            {k: out[k].cpu().numpy() for k in ('pixel_colors_nr', 'pixel_colors_nr_fine')}, args.cpu_sample_rays, 1024)
                 if isinstance(res, tuple):
                     put('numpy_oracle', res[0])
-                    put('parity', res[1])
+                    parity = res[1]
+                    if not args.no_eager_baseline:
+                        # all 640 000 rays against the eager port on this GPU (the numpy oracle above: 1.3 % of them)
+                        parity['full_image'] = side(full_image_parity_leg, cfg, renderer, weights, tq, tr, out, device)
+                    put('parity', parity)
                 else:
                     put('numpy_oracle', res)
         if world == 1 and emu is None and not args.no_eager_baseline and not args.no_cpu_baseline:

@@ -1165,6 +1165,9 @@ __global__ void __launch_bounds__(256) fine_kernel(FineParams p) {
         // then the n % 8 tail added one by one - so that the cdf, and with it every searchsorted bin, is the oracle's bit for bit on
         // identical inputs (tests/test_fine_index.py; a wave butterfly differed in the total's last bit on ~40 % of the rays, which
         // moved a bin only where u sat within an ulp of a cdf entry - shown there as well).  Every lane computes the same value.
+        // Scope of the claim: the ORACLE's order (numpy), not torch.sum's, and only while numpy sums one block, i.e. dn <= 128 - which
+        // is every dn this entry point accepts (neuray_sample_fine_depth rejects dn > NEURAY_MAX_SAMPLES):
+        static_assert(kMaxSamples <= 128, "above 128 entries np.sum splits recursively: implement the split or drop the bit-exact claim");
         float tot = 0.0f;
         if (dn < 8) {
             for (int i = 0; i < dn; ++i) tot += pdf[i];

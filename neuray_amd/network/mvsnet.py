@@ -103,7 +103,10 @@ class CostRegNet(nn.Module):
 
     def _fast_ok(self, x):
         # (one image's 32-channel volume must stay below 2^31 bytes for conv0's buffer descriptor: larger ones take the module path)
-        return (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or self.prob.weight.requires_grad))
+        # under autograd the kernels (no backward) run only when nothing they replace wants a gradient: the input and every parameter of
+        # conv0 / conv11 / prob (the reference freezes MVSNet; a user who unfreezes any of them gets the module path and its gradients)
+        fused = (*self.conv0.parameters(), *self.conv11.parameters(), *self.prob.parameters())
+        return (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in fused)))
                 and x.dtype == torch.float32 and x.dim() == 5 and x.shape[2] * x.shape[3] * x.shape[4] * 128 < 0x7fffff00
                 and self._engine(x) is not None)
 

@@ -104,6 +104,11 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
                 if joint is None or que_imgs_info.get('_neuray_joint') is not joint:      # (slice_imgs_info hands the parts over as views of one tensor)
                     joint = (torch.cat([ref_imgs_info['imgs'], que_imgs_info['imgs']], 0),
                              torch.cat([ref_imgs_info['ray_feats'], que_imgs_info['ray_feats']], 0))
+                # consumed: the private entry must not outlive this call - a host class that only pops the reference's keys (the reference's
+                # own train_step, renderer.py:521-543, under patch_ft_host) would otherwise return it inside render_outputs['que_imgs_info']
+                # and keep ~115 MB alive per step
+                ref_imgs_info.pop('_neuray_joint', None)
+                que_imgs_info.pop('_neuray_joint', None)
                 feats, rays = self.encode_views(*joint)
                 # (split, not three slices: one concatenation per tensor in the backward instead of a zero-fill + copy per slice)
                 ref_imgs_info['img_feats'] = feats.split([n, feats.shape[0] - n])[0]
@@ -119,7 +124,13 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
             # `ray_batch_num` bounds the reference's activation memory (1.7 GB per 4096 rays); here a batch costs 80 B per
             # sample point, results do not depend on the batching bit for bit, and a 4096-ray launch leaves a third of the
             # machine idle in its tail (2.56 vs 2.79 M rays/s): inference uses at least cfg['hip_min_ray_batch'] rays per launch
-            ray_batch_num = max(ray_batch_num, int(self.cfg.get('hip_min_ray_batch', 32768)))
+            # Direct rendering (use_dr_prediction) adds the per-(point, view) record: rn * dn * rfn * 16 floats per pass (1.1 GB at 32768
+            # rays x 64 samples x 8 views), so there the merged batch is bounded to ~1 GiB of record and never below the configured size.
+            merged = int(self.cfg.get('hip_min_ray_batch', 32768))
+            if self.cfg.get('use_dr_prediction', False):
+                dn_max = max(self.cfg['depth_sample_num'], self.cfg['fine_depth_sample_num'] if self.cfg['use_hierarchical_sampling'] else 0)
+                merged = min(merged, max(1, (1 << 30) // (dn_max * ref_imgs_info['imgs'].shape[0] * 16 * 4)))
+            ray_batch_num = max(ray_batch_num, merged)
         coords = que_imgs_info['coords']
         ray_num = coords.shape[1]
         render_info_all = {}
@@ -237,6 +248,9 @@ def shuffle_like_numpy(arr, rs=np.random):
         rs.shuffle(arr)
         return
     st = rs.get_state()
+    if not _is_mt19937_state(st):
+        rs.shuffle(arr)           # another bit generator behind the legacy interface (np.random.set_bit_generator): numpy's own shuffle
+        return
     key = np.array(st[1], dtype=np.uint32)
     pos = ctypes.c_int(int(st[2]))
     _lib.check(lib, lib.neuray_mt19937_shuffle(key.ctypes.data, ctypes.byref(pos), arr.ctypes.data, arr.shape[0], arr.itemsize))
@@ -270,7 +284,7 @@ def sample_train_coords(fg_mask, ray_num, foreground_ratio, lists=None, rs=np.ra
 
 
 def _same_generator_state(a, b):
-    return a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1])
+    return _is_mt19937_state(a) and _is_mt19937_state(b) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1])
 
 
 # speculative draws of the NEXT training step, per renderer (kept outside the module so that it stays picklable / deep-copyable)
@@ -303,14 +317,20 @@ def _draw_train_step(ft, rs):
     return que_i, ref_idx, _train_coords(ft, que_i, rs)
 
 
+def _is_mt19937_state(st):
+    return isinstance(st, tuple) and len(st) == 5 and st[0] == 'MT19937' and len(st[1]) == 624
+
+
 def _prefetch_start(ft):
     start, cfg = np.random.get_state(), _sampling_cfg(ft)
+    if not _is_mt19937_state(start):       # another bit generator behind np.random (np.random.set_bit_generator): no speculation, the
+        return                             # step draws from the global generator as the reference does
     slot = {'start': start, 'cfg': cfg}
 
     def work():
-        rs = np.random.RandomState()
-        rs.set_state(start)
         try:
+            rs = np.random.RandomState()
+            rs.set_state(start)
             slot['drawn'] = _draw_train_step(ft_ref(), rs)
             slot['end'] = rs.get_state()
         except Exception:                                    # (a vanished renderer, a changed scene: the next step draws afresh)

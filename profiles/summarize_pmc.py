@@ -12,8 +12,20 @@ import csv
 import glob
 import json
 import os
+import hashlib
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources the point kernel is compiled from: bench.py quotes a traffic file only while their hash matches the tree it runs on
+KERNEL_SOURCES = ('nr_kernels.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h')
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, 'neuray_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def main(out):
@@ -38,6 +50,7 @@ def main(out):
                    'correction': 'FETCH_SIZE x2 (gfx950 wide-load under-count, MI355X_MICROARCH.md HBM section); '
                                  'WRITE_SIZE as reported (uncalibrated)'}
         traffic['bytes_per_launch'] = (2.0 * r['FETCH_SIZE'] + r.get('WRITE_SIZE', 0.0)) * 1024.0 / r['dispatches']
+        traffic['kernel_source_sha16'] = kernel_source_hash()     # (of KERNEL_SOURCES, on the tree the counters were collected on)
         if 'TCC_HIT_sum' in r:
             traffic['l2_hit_rate'] = r['TCC_HIT_sum'] / max(r['TCC_HIT_sum'] + r['TCC_MISS_sum'], 1.0)
         json.dump(traffic, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)

@@ -324,6 +324,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             // Measured: +5% whole-job; holding two slots' taps (160 registers) or staggering slot s+1's loads into slot s's
             // blends spills and is slower than this.
             float fray[NA1][8], fimg[NA1][8], rgb[NA1][3];
+#ifdef NR_PROBE_PRE
+            float fm1[NA1][8], fv1[NA1][8], fa1[NA1][8];
+#endif
             if constexpr (NA > 0) {
                 Taps tfs[NA], tcs[NA];
                 NR_PRAGMA_UNROLL
@@ -352,6 +355,21 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     NR_PRAGMA_UNROLL
                     for (int j = 0; j < 3; ++j) NR_KEEP(rgb[s][j]);
                     NR_PIN();
+#ifdef NR_PROBE_PRE            // timing probe (wrong results): the gathers of a map that carries the first layers of the dist heads per texel
+                    {
+                        float4 q1[8], q2[8], q3[8];
+                        issue8(rf_map, goff, soff_f[s] + 4096, tfs[s], q1);
+                        issue8(rf_map, goff, soff_f[s] + 8192, tfs[s], q2);
+                        issue8(rf_map, goff, soff_f[s] + 12288, tfs[s], q3);
+                        NR_PIN();
+                        blend8(q1, tfs[s], mask[s], fm1[s]);
+                        blend8(q2, tfs[s], mask[s], fv1[s]);
+                        blend8(q3, tfs[s], mask[s], fa1[s]);
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) { NR_KEEP(fm1[s][k]); NR_KEEP(fv1[s][k]); NR_KEEP(fa1[s][k]); }
+                        NR_PIN();
+                    }
+#endif
                 }
             }
             float none[NA1][1];
@@ -368,12 +386,27 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 const LdsW W1 = phase_enter<PH_DIST_M, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                 if constexpr (NA > 0) {
                     LayerPre<L_DM1> p_dm1; LayerPre<L_DM2> p_dm2; LayerPre<L_DV1> p_dv1; VecPre<L_DFIN_M> p_fm;
+#ifdef NR_PROBE_PRE
+                    layer_prefetch<L_DM2>(W1, lane, p_dm2);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) h1[s][k] = elu_s(fm1[s][k]);
+#else
                     layer_prefetch<L_DM1>(W1, lane, p_dm1);
                     layer_fwd<L_DM1, NA, ACT_ELU>(W1, lane, p_dm1, fray, none, h1, p_dm2);
+#endif
                     layer_fwd<L_DM2, NA, ACT_ELU>(W1, lane, p_dm2, h1, none, h2, p_fm);
                     layer_prefetch<L_DV1>(W1, lane, p_dv1);
                     layer_vec<L_DFIN_M, NA>(p_fm, h2, fm);
+#ifdef NR_PROBE_PRE
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) h1[s][k] = elu_s(fv1[s][k]);
+#else
                     layer_fwd<L_DV1, NA, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, last);
+#endif
                 }
                 const LdsW W2 = phase_enter<PH_DIST_VA, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                 if constexpr (NA > 0) {
@@ -387,7 +420,15 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         mu0[s] = softplus(fm[s][0]); mu1[s] = softplus(fm[s][1]);
                         s0[s] = softplus(fv[s][0]) + p.var_bias; s1[s] = softplus(fv[s][1]) + p.var_bias;
                     }
+#ifdef NR_PROBE_PRE
+                    layer_prefetch<L_DA2>(W2, lane, p_da2);
+                    NR_PRAGMA_UNROLL
+                    for (int s = 0; s < NA; ++s)
+                        NR_PRAGMA_UNROLL
+                        for (int k = 0; k < 8; ++k) h1[s][k] = elu_s(fa1[s][k]);
+#else
                     layer_fwd<L_DA1, NA, ACT_ELU>(W2, lane, p_da1, fray, none, h1, p_da2);
+#endif
                     layer_fwd<L_DA2, NA, ACT_ELU>(W2, lane, p_da2, h1, none, h2, p_fa);
                     layer_vec<L_DFIN_A, NA>(p_fa, h2, fa);
                 }
@@ -441,7 +482,15 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         x1[s][0] = sel4(g, (hit[s] - 0.5f) * 2.0f, (vis[s] - 0.5f) * 2.0f, 0.0f, 0.0f);
                     if (folded) {
                         // prob_embed.2 lives inside neuray_fc.0 / base_fc.0 of this pack: their input is the ReLU output itself
+#ifdef NR_PROBE_PRE
+                        layer_prefetch<L_RD1>(W3, lane, p_rd1);
+                        NR_PRAGMA_UNROLL
+                        for (int s = 0; s < NA; ++s)
+                            NR_PRAGMA_UNROLL
+                            for (int k = 0; k < 8; ++k) e[s][k] = fmaxf(fray[s][k] + x1[s][0], 0.0f);
+#else
                         layer_fwd<L_PE1, NA, ACT_RELU>(W3, lane, p_pe1, fray, x1, e, p_rd1);
+#endif
                     } else {
                         float h[NA][8];
                         LayerPre<L_PE2> p_pe2;

@@ -211,6 +211,11 @@ class HipRenderPath:
         # the fine-sampling uniforms (render_ops.py:205: torch.rand on the CPU generator, the only draw of render_impl) are taken
         # BEFORE the coarse pass is launched and uploaded asynchronously, so the host never waits for the coarse pass
         u = eng.draw_uniforms([1, rn, self.cfg['fine_depth_sample_num']]) if (is_train and self.cfg['use_hierarchical_sampling']) else None
+        # (the pass's only draw from the CPU generator is done: a host class whose NEXT draw can be made ahead of time - the generalisation
+        # renderer's depth-loss pixel permutation, renderer.py:272-278 - starts it now, in the reference's order, while the kernels are queued)
+        hook = self.__dict__.pop('_neuray_after_fine_draw', None)
+        if hook is not None:
+            hook()
         que_depth = eng.sample_coarse_depth(que_imgs_info['depth_range'], rn, self.cfg['depth_sample_num'])[None]
         outputs = self.render_by_depth(que_depth, que_imgs_info, ref_imgs_info, is_train, False)
         if self.cfg['use_hierarchical_sampling']:

@@ -82,7 +82,7 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         are queued it waits for next to nothing; taken where the per-ray path first needs it, it drained 25 ms of queued convolutions per
         training step and left the GPU idle behind them (profiles/r04_n_gen_host_profile.txt: 8.6 ms per step).  Cached in the dict."""
         coords = que_imgs_info.get('coords')
-        if coords is not None and coords.is_cuda and coords.shape[0] == 1 and 'Ks' in que_imgs_info:
+        if coords is not None and coords.shape[0] == 1 and 'Ks' in que_imgs_info:
             self._query(self.engine(coords.device), que_imgs_info)
 
     def render(self, que_imgs_info, ref_imgs_info, is_train):
@@ -174,11 +174,30 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
     def gen_depth_loss_coords(self, h, w, device):
         """renderer.py:272-278 (quirk kept: the pairs are (row, col) although the gather reads them as (x, y))."""
         num = self.cfg['depth_loss_coords_num']
-        pick = torch.randperm(h * w)[:num]
+        slot = self.__dict__.pop('_depth_coords_slot', None)
+        if slot is not None:
+            slot['thread'].join()
+        if slot is not None and slot.get('n') == h * w and 'perm' in slot:
+            pick = slot['perm'][:num]                 # drawn ahead of time by _prefetch_depth_coords, at this draw's place in the stream
+        else:
+            pick = torch.randperm(h * w)[:num]
         pairs = torch.stack([pick // w, pick % w], -1)
         # (a copy from pageable memory blocks the host until everything queued so far has run - 5 ms of a training step behind the per-ray
         # kernels; pinned staging + an asynchronous copy does not)
         return pairs.pin_memory().to(device, non_blocking=True) if torch.device(device).type == 'cuda' else pairs.to(device)
+
+    def _prefetch_depth_coords(self, n):
+        """torch.randperm(h * w) over the pixels of a reference view costs 5 ms of host time per generalisation step (a quarter of a
+        million draws; the step is host-bound) and releases the interpreter lock: it runs on a worker thread, started by
+        render_impl right after the step's only other draw from the CPU generator (the fine-sampling uniforms, render_ops.py:205) - the
+        reference's order, so a seeded run consumes the generator identically - while the main thread queues the per-ray kernels."""
+        slot = {'n': n}
+
+        def work():
+            slot['perm'] = torch.randperm(n)
+        slot['thread'] = threading.Thread(target=work, name='neuray-depth-coords', daemon=True)
+        self.__dict__['_depth_coords_slot'] = slot
+        slot['thread'].start()
 
     def predict_mean_for_depth_loss(self, ref_imgs_info):
         """renderer.py:280-316: decoded mixture means of every reference view at random pixels of that view."""
@@ -199,9 +218,22 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         ref_imgs_info, que_imgs_info = data['ref_imgs_info'].copy(), data['que_imgs_info'].copy()
         is_train = 'eval' not in data
         src_imgs_info = data['src_imgs_info'].copy() if 'src_imgs_info' in data else None
-        outputs = self.render_call(que_imgs_info, ref_imgs_info, is_train, src_imgs_info)
-        if (self.cfg['use_depth_loss'] and 'true_depth' in ref_imgs_info) or not is_train:
+        depth_readout = (self.cfg['use_depth_loss'] and 'true_depth' in ref_imgs_info) or not is_train
+        coords = que_imgs_info['coords']
+        if (depth_readout and is_train and self.cfg.get('hip_prefetch_depth_coords', True) and coords.shape[0] == 1
+                and coords.shape[1] <= self.cfg['ray_batch_num']):          # (one render_impl call: one place in the stream to start at)
+            _, _, h, w = ref_imgs_info['imgs'].shape
+            self.__dict__['_neuray_after_fine_draw'] = lambda: self._prefetch_depth_coords(h * w)
+        try:
+            outputs = self.render_call(que_imgs_info, ref_imgs_info, is_train, src_imgs_info)
+        finally:
+            self.__dict__.pop('_neuray_after_fine_draw', None)
+        if depth_readout:
             outputs.update(self.predict_mean_for_depth_loss(ref_imgs_info))
+        else:
+            slot = self.__dict__.pop('_depth_coords_slot', None)
+            if slot is not None:
+                slot['thread'].join()
         return outputs
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 8
+#define NEURAY_ABI_VERSION 9
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -309,7 +309,8 @@ int neuray_warp_variance_layout(const float* ref_feats_dev, const float* src_fea
  *   component i: W'[m][8 g + 4 q + i][kz][r][kx] for m < 8 and r <= 2, W'[m - 8][8 g + 4 q + i][kz][r - 1][kx] for m >= 8 and r >= 1,
  *   else 0; W' = W * gamma / sqrt(var + eps) per output channel -, bias_dev [8] = beta - mean * gamma / sqrt(var + eps);
  *   out_dev [n][8][d][h][w].
- * neuray_conv3d_c8_c1: `prob` = Conv3d(8, 1, 3, padding=1): x_dev [n][8][d][h][w], w27_dev [8][27], out_dev [n][d][h][w]. */
+ * neuray_conv3d_c8_c1: `prob` = Conv3d(8, 1, 3, padding=1): x_dev [n][8][d][h][w], w27_dev [3 ky][8 c][3 kz][3 kx] = W[0][c][kz][ky][kx] (the order
+ *   the kernel walks them in; ABI 9 - [8][27] before), out_dev [n][d][h][w]. */
 int neuray_conv3d_c32_c8(const float* x_ndhwc_dev, const float* wpack_dev, const float* bias_dev, float slope, int n, int d, int h, int w,
                          float* out_dev, void* stream);
 int neuray_conv3d_c8_c1(const float* x_dev, const float* w27_dev, float bias, int n, int d, int h, int w, float* out_dev, void* stream);
@@ -319,6 +320,12 @@ int neuray_conv3d_c8_c1(const float* x_dev, const float* w27_dev, float bias, in
  *   [n][8][2d][2h][2w] or NULL, out_dev [n][8][2d][2h][2w]. */
 int neuray_convtranspose3d_c16_c8(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, const float* skip_dev,
                                   int n, int d, int h, int w, float* out_dev, void* stream);
+
+/* neuray_scale_shift_leaky: MVSNet's frozen activated batch norm behind every convolution of the feature net and the cost regularisation
+ *   (inplace_abn.ABN in evaluation mode; network/mvsnet/modules.py:7-23 `self.bn(self.conv(x))`, network/mvsnet/mvsnet.py:7-69) as ONE pass, in
+ *   place on the convolution's output: x_dev [n][c][inner] (inner = h w or d h w) <- leaky_relu(x * scale_dev[c] + shift_dev[c], slope),
+ *   scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (the caller folds them). */
+int neuray_scale_shift_leaky(float* x_dev, const float* scale_dev, const float* shift_dev, int n, int c, long long inner, float slope, void* stream);
 
 /* ---- a7 standalone: interpolate_feats / interpolate_feature_map on NCHW maps (network/ops.py:14-34,
  * render_ops.py:54-70): bilinear, padding_mode='border'.  feats [b][c][fh][fw], points [b][n][2] pixel (x,y) in

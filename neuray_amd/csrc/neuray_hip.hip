@@ -335,12 +335,12 @@ int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* 
 int neuray_convtranspose3d_c16_c8(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int d, int h, int w,
                                   float* out, void* stream) {
     if (!x || !wpack || !bias || !out) return fail("neuray_convtranspose3d_c16_c8: null pointer");
-    const long long groups = (long long)((nr::kUp11Rows * w + 255) / 256) * 2 * ((h + nr::kUp11Rows - 1) / nr::kUp11Rows) * 2 * d * n;
+    const long long groups = (long long)(((long long)h * w + 255) / 256) * d * n;      // one thread per input voxel = 2 x 2 x 2 output block
     if (n < 1 || d < 1 || h < 1 || w < 1 || groups > 0x7fffffffLL)
         return fail("neuray_convtranspose3d_c16_c8: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
     nr::Up11Params p;
     p.x = x; p.wpack = wpack; p.bias = bias; p.skip = skip; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
-    NR_LAUNCH(nr::costreg_up11_kernel, dim3((unsigned)groups), dim3(256), 0, stream, p);
+    NR_LAUNCH(nr::costreg_up11_kernel, dim3((unsigned)groups, 8 / nr::kUp11Co), dim3(256), 0, stream, p);
     return check_launch("neuray_convtranspose3d_c16_c8");
 }
 
@@ -349,9 +349,24 @@ int neuray_conv3d_c8_c1(const float* x, const float* w27, float bias, int n, int
     if (n < 1 || d < 1 || h < 1 || w < 1) return fail("neuray_conv3d_c8_c1: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
     nr::ProbParams p;
     p.x = x; p.w = w27; p.out = out; p.n = n; p.d = d; p.h = h; p.w_ = w; p.bias = bias;
-    const int grid = grid_for((long long)n * d * h * w, 256, 256 * 32);
-    NR_LAUNCH(nr::costreg_prob_kernel, dim3(grid), dim3(256), 0, stream, p);
+    const long long grid = (long long)((h * w + 255) / 256) * ((d + nr::kProbSeg - 1) / nr::kProbSeg) * n;
+    if (grid > 0x7fffffffLL) return fail("neuray_conv3d_c8_c1: volume too large");
+    NR_LAUNCH(nr::costreg_prob_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     return check_launch("neuray_conv3d_c8_c1");
+}
+
+int neuray_scale_shift_leaky(float* x, const float* scale, const float* shift, int n, int c, long long inner, float slope, void* stream) {
+    if (!x || !scale || !shift) return fail("neuray_scale_shift_leaky: null pointer");
+    if (n < 1 || c < 1 || inner < 1 || (long long)n * c > 0x7fffffffLL) return fail("neuray_scale_shift_leaky: bad shape n=%d c=%d inner=%lld", n, c, inner);
+    nr::ScaleShiftLeakyParams p;
+    p.x = x; p.scale = scale; p.shift = shift; p.inner = inner; p.n = n; p.c = c; p.slope = slope;
+    const long long planes = (long long)n * c;
+    if (planes > 65535) return fail("neuray_scale_shift_leaky: %lld planes exceed the grid's y range", planes);
+    long long chunks = (4096 + planes - 1) / planes, most = (inner / 4 + 255) / 256;     // ~4096 workgroups, each thread >= one 16-byte piece
+    if (chunks > most) chunks = most;
+    if (chunks < 1) chunks = 1;
+    NR_LAUNCH(nr::scale_shift_leaky_kernel, dim3((unsigned)chunks, (unsigned)planes), dim3(256), 0, stream, p);
+    return check_launch("neuray_scale_shift_leaky");
 }
 
 int neuray_warp_variance_layout(const float* ref_feats, const float* src_feats, const int* nn_ids, const float* transforms, const float* depth_vals,

@@ -26,6 +26,7 @@
 
 namespace nr {
 
+
 struct Conv0Params {
     const float* x;        // [n][D][H][W][32]
     const float* wpack;    // [3 kz][4 r][3 kx][2 q][64 lanes] float4: lane (m = l & 15, g = l >> 4), component i -> channel 8 g + 4 q + i of
@@ -114,45 +115,78 @@ __global__ void __launch_bounds__(64 * kConv0Waves) costreg_conv0_kernel(Conv0Pa
     }
 }
 
-// prob: out[n][z][y][x] = bias + sum_{c < 8, taps} w[c][tap] x[n][c][z + dz][y + dy][x + dx], zero padding.  One thread per voxel, x fastest:
-// every load of a warp is 64 consecutive floats of one row.
+// prob: out[n][z][y][x] = bias + sum_{c < 8, taps} w[c][tap] x[n][c][z + dz][y + dy][x + dx], zero padding.  A thread owns one (y, x) column
+// and WALKS ALONG z over a segment of kProbSeg planes: every input plane it reads (8 channels x 3 rows x 3 columns = 72 loads, a wave's
+// load = 64 consecutive floats of one row) feeds the three outputs z - 1, z, z + 1 through three rotating accumulators, so an output costs 72
+// (+ the segment's two halo planes: 81) L1 reads instead of the 216 of one thread per voxel - that version sat on the L1 bandwidth
+// (27 x 420 MB per call: 0.57 ms = 0.82 TB/s of compulsory traffic, round 4).  The 216 weights sit in LDS in the order they are used
+// ([ky][c][kz][kx]) and are read as 16-byte broadcasts.  Missing neighbours (image borders) are loaded from a clamped address and
+// replaced by 0 with a select: no divergent control flow inside the walk.
 struct ProbParams {
     const float* x;     // [n][8][D][H][W]
-    const float* w;     // [8][27]
+    const float* w;     // [3 ky][8 c][3 kz][3 kx]
     float* out;         // [n][D][H][W]
     int n, d, h, w_;
     float bias;
 };
 
-__global__ void __launch_bounds__(256) costreg_prob_kernel(ProbParams p) {
-    __shared__ float ws[8 * 27];
-    for (int i = threadIdx.x; i < 8 * 27; i += blockDim.x) ws[i] = p.w[i];
-    __syncthreads();
-    const long long vol = (long long)p.d * p.h * p.w_, total = vol * p.n;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % p.w_);
-        long long t = i / p.w_;
-        const int y = (int)(t % p.h);
-        t /= p.h;
-        const int z = (int)(t % p.d), img = (int)(t / p.d);
-        float acc = p.bias;
-        for (int c = 0; c < 8; ++c) {
-            const float* base = p.x + ((long long)img * 8 + c) * vol;
-            NR_PRAGMA_UNROLL
-            for (int kz = 0; kz < 3; ++kz) {
-                const int zz = z + kz - 1;
-                NR_PRAGMA_UNROLL
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = y + ky - 1;
-                    const bool ok = zz >= 0 && zz < p.d && yy >= 0 && yy < p.h;
-                    const float* row = base + ((long long)(ok ? zz : z) * p.h + (ok ? yy : y)) * p.w_;
-                    const float l = (ok && x > 0) ? row[x - 1] : 0.0f, m = ok ? row[x] : 0.0f, r = (ok && x + 1 < p.w_) ? row[x + 1] : 0.0f;
-                    const float* wk = ws + c * 27 + (kz * 3 + ky) * 3;
-                    acc = fmaf(wk[0], l, acc); acc = fmaf(wk[1], m, acc); acc = fmaf(wk[2], r, acc);
-                }
-            }
+constexpr int kProbSeg = 16;        // output planes per thread
+
+// one row slot of one input plane: tap kz = 2 of output z - 1, kz = 1 of output z, kz = 0 of output z + 1.  ws: the row slot's 72 weights
+__device__ __forceinline__ void prob_row(const float* ws, const float* __restrict__ row, long long vol, int dl, int dr, bool okl, bool okm, bool okr,
+                                         float& acc_m, float& acc_c, float& acc_p) {
+    NR_PRAGMA_UNROLL
+    for (int c = 0; c < 8; ++c) {
+        const float* q = row + c * vol;
+        const float lv = q[dl], mv = q[0], rv = q[dr];
+        const float l = okl ? lv : 0.0f, m = okm ? mv : 0.0f, r = okr ? rv : 0.0f;
+        float w[12];                                           // [kz][kx] + 3 unused (three 16-byte broadcast reads)
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < 3; ++i) {
+            const float4 t = ld4(ws + 12 * c + 4 * i);
+            w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
         }
-        p.out[i] = acc;
+        acc_p = fmaf(w[0], l, acc_p); acc_p = fmaf(w[1], m, acc_p); acc_p = fmaf(w[2], r, acc_p);
+        acc_c = fmaf(w[3], l, acc_c); acc_c = fmaf(w[4], m, acc_c); acc_c = fmaf(w[5], r, acc_c);
+        acc_m = fmaf(w[6], l, acc_m); acc_m = fmaf(w[7], m, acc_m); acc_m = fmaf(w[8], r, acc_m);
+    }
+}
+
+// grid = ceil(h * w / 256) * ceil(d / kProbSeg) * n
+__global__ void __launch_bounds__(256) costreg_prob_kernel(ProbParams p) {
+    __shared__ __attribute__((aligned(16))) float ws[3 * 8 * 12];             // [ky][c][9 weights + 3 pad]
+    for (int i = threadIdx.x; i < 3 * 8 * 12; i += blockDim.x) ws[i] = (i % 12) < 9 ? p.w[(i / 12) * 9 + i % 12] : 0.0f;
+    __syncthreads();
+    const int plane = p.h * p.w_, chunks = (plane + (int)blockDim.x - 1) / (int)blockDim.x, segs = (p.d + kProbSeg - 1) / kProbSeg;
+    int b = (int)blockIdx.x;
+    const int chunk = b % chunks;
+    b /= chunks;
+    const int seg = b % segs, img = b / segs;
+    const int pix0 = chunk * (int)blockDim.x + (int)threadIdx.x;
+    const bool pvalid = pix0 < plane;
+    const int pix = pvalid ? pix0 : plane - 1;                 // (no early exit: every lane runs the same walk)
+    const int y = pix / p.w_, x = pix - y * p.w_;
+    const int z0 = seg * kProbSeg, z1 = (z0 + kProbSeg < p.d) ? z0 + kProbSeg : p.d;      // outputs [z0, z1)
+    const long long vol = (long long)p.d * plane;
+    const float* base = p.x + (long long)img * 8 * vol + pix;
+    const bool xl = x > 0, xr = x + 1 < p.w_, yu = y > 0, yd = y + 1 < p.h;
+    const int dl = xl ? -1 : 0, dr = xr ? 1 : 0, dy0 = yu ? -p.w_ : 0, dy2 = yd ? p.w_ : 0;
+    // acc_m: output zi - 1 (complete after this plane), acc_c: output zi, acc_p: output zi + 1
+    float acc_m = p.bias, acc_c = p.bias, acc_p = p.bias;
+    float* o = p.out + (long long)img * vol + pix;
+#pragma unroll 1
+    for (int zi = z0 - 1; zi <= z1; ++zi) {
+        if (zi >= 0 && zi < p.d) {                             // uniform
+            const float* pl = base + (long long)zi * plane;
+            // (an address the compiler cannot see through, re-made per plane: the weight reads are loop invariant and would otherwise be
+            // hoisted out of the walk - 216 registers; the sched barriers keep one row slot's reads from being issued ahead of another's)
+            const float* wz = ws + nr_opaque_zero();
+            prob_row(wz, pl + dy0, vol, dl, dr, xl && yu, yu, xr && yu, acc_m, acc_c, acc_p); NR_PIN();
+            prob_row(wz + 96, pl, vol, dl, dr, xl, true, xr, acc_m, acc_c, acc_p); NR_PIN();
+            prob_row(wz + 192, pl + dy2, vol, dl, dr, xl && yd, yd, xr && yd, acc_m, acc_c, acc_p); NR_PIN();
+        }
+        if (zi - 1 >= z0 && pvalid) o[(long long)(zi - 1) * plane] = acc_m;
+        acc_m = acc_c; acc_c = acc_p; acc_p = p.bias;
     }
 }
 
@@ -160,11 +194,14 @@ __global__ void __launch_bounds__(256) costreg_prob_kernel(ProbParams p) {
 // batch norm + leaky ReLU (network/mvsnet/mvsnet.py:57-69 conv11 and the skip add; MIOpen: 2.9 ms for the transposed convolution to
 // 8 x 8 x 64 x 160 x 160 plus three element-wise passes over that 420 MB tensor).  11 GFLOP against 0.95 GB of compulsory traffic: memory
 // bound; one kernel that reads x and c0 once and writes the sum once.  Output o reads input i through tap k where o = 2 i - 1 + k: an even
-// o has one tap (k = 1, i = o / 2), an odd o two (k = 2 at i = (o - 1) / 2, k = 0 at i = (o + 1) / 2 if that exists).  A thread owns the
-// output pair (2 j, 2 j + 1) of one (z, y) row - uniform work: x[j] feeds both, x[j + 1] the odd one - and all 8 output channels.  A
-// workgroup takes kUp11Rows output rows of one plane that share their y parity (oy, oy + 2, ...), laid end to end over its threads: which
-// z / y taps exist, and their weights, are then uniform per workgroup - the weights are scalar loads, no LDS - and every lane has work
-// whatever the row length.  (First version, one row per workgroup with the 14 KB of weights copied into LDS by each: 2.1 ms.)
+// o has one tap (k = 1, i = o / 2), an odd o two (k = 2 at i = (o - 1) / 2, k = 0 at i = (o + 1) / 2 if that exists).
+// Round 5: a thread owns the 2 x 2 x 2 OUTPUT BLOCK of input voxel (iz, iy, j) - outputs (2 iz + a, 2 iy + b, 2 j + c) - and all 8 output
+// channels: it reads the 8 input voxels (iz .. iz + 1, iy .. iy + 1, j .. j + 1) of each of the 16 input channels once and spends each of the
+// 27 taps exactly once per output channel (216 FMAs per input channel: the work is the same for every thread, where the round-4 mapping -
+// a thread per output pair of one (z, y) row, row groups of one parity per workgroup - ran workgroups of 1, 2 and 4 tap pairs side by
+// side and read every input row up to four times).  Threads are laid end to end over a plane's (iy, j), so a wave's loads are 64
+// consecutive floats of each of the 2 x 2 (z, y) neighbours; the weights are uniform per instruction: 16-byte LDS broadcasts (as
+// scalar operands, 216 per input channel against ~100 scalar registers, hipcc spilled them to VGPR lanes inside the loop).
 struct Up11Params {
     const float* x;        // [n][16][d][h][w]
     const float* wpack;    // [3 kz][3 ky][16 ci][8 co][3 kx], batch norm folded
@@ -175,65 +212,144 @@ struct Up11Params {
     float slope;
 };
 
-constexpr int kUp11Rows = 4;
-
-// grid = (chunks of 256 threads over kUp11Rows * w) * (row groups per plane = 2 parities * ceil(h / kUp11Rows)) * 2d * n
-__global__ void __launch_bounds__(256) costreg_up11_kernel(Up11Params p) {
-    const int per_group = kUp11Rows * p.w, chunks = (per_group + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int groups_y = (p.h + kUp11Rows - 1) / kUp11Rows;                   // row groups of one parity
-    long long g = (long long)blockIdx.x / chunks;
-    const int t = ((int)(blockIdx.x % chunks)) * (int)blockDim.x + (int)threadIdx.x;
-    const int gy = (int)(g % groups_y);
-    g /= groups_y;
-    const int par = (int)(g & 1);                                             // y parity of the group's rows
-    g >>= 1;
-    const int oz = (int)(g % (2 * p.d)), img = (int)(g / (2 * p.d));
-    const int r = t / p.w, j = t - r * p.w;
-    const int hy = gy * kUp11Rows + r;                                        // the row's input row index (oy = 2 hy + par)
-    if (r >= kUp11Rows || hy >= p.h) return;
-    const int oy = 2 * hy + par;
-    const long long plane = (long long)p.h * p.w, vol = plane * p.d;
-    // taps: index 0 = the tap every output has, index 1 = the second tap of an odd output (uniform per workgroup; the last odd row /
-    // plane has no second tap: its loads are redirected to a valid address and multiplied by 0)
-    const int nz = (oz & 1) ? 2 : 1, ny = par ? 2 : 1;
-    const int iz0 = (oz & 1) ? (oz - 1) / 2 : oz / 2, kz0 = (oz & 1) ? 2 : 1;
-    const int ky0 = par ? 2 : 1;
-    const bool has_next = j + 1 < p.w;
-    float a0[8], a1[8];
+#ifndef NR_UP11_CO
+#define NR_UP11_CO 4               // output channels per thread: 4 = two threads per input voxel (blockIdx.y = the channel half), 32 accumulators, 121 VGPRs,
+                                   // 4 waves per SIMD: 0.42 ms on 8 x 64 x 160 x 160; 8 = one thread per voxel, 230 VGPRs, 2 waves per SIMD: 0.55 ms
+#endif
+constexpr int kUp11Co = NR_UP11_CO;
+// one (kz, ky) tap pair of one input channel: output parity a = (KZ != 1), read from input plane iz + (KZ == 0); the same along y.
+// w: the pair's weights [co][kx] of this thread's channels in LDS (16-byte broadcast reads)
+template <int KZ, int KY>
+__device__ __forceinline__ void up11_tap(const float* w, const float (&v)[2][2][2], float (&acc)[2][2][2][kUp11Co]) {
+    constexpr int A = KZ != 1, DA = KZ == 0, B = KY != 1, DB = KY == 0;
+    const float x0 = v[DA][DB][0], x1 = v[DA][DB][1];
+    float wr[3 * kUp11Co];
     NR_PRAGMA_UNROLL
-    for (int co = 0; co < 8; ++co) { a0[co] = 0.0f; a1[co] = 0.0f; }
-    const float* xi = p.x + (long long)img * 16 * vol + j;
-    for (int tz = 0; tz < nz; ++tz) {
-        const int iz = tz ? iz0 + 1 : iz0, kz = tz ? 0 : kz0;
-        if (iz >= p.d) continue;                                              // uniform
-        for (int ty = 0; ty < ny; ++ty) {
-            const int iy = ty ? hy + 1 : hy, ky = ty ? 0 : ky0;
-            const bool row_ok = iy < p.h;
-            const float* src = xi + (long long)iz * plane + (long long)(row_ok ? iy : hy) * p.w;
-            const float live = row_ok ? 1.0f : 0.0f;
-            const float* __restrict__ wk = p.wpack + (kz * 3 + ky) * (16 * 8 * 3);   // uniform: scalar loads
-            // (two input channels at a time: their 48 weights fit the scalar registers; unrolled over all 16 the 384 of them spilled)
-#pragma unroll 2
-            for (int ci = 0; ci < 16; ++ci) {
-                const float xa = src[ci * vol] * live, xb = has_next ? src[ci * vol + 1] * live : 0.0f;
-                NR_PRAGMA_UNROLL
-                for (int co = 0; co < 8; ++co) {
-                    const float w0 = wk[ci * 24 + 3 * co], w1 = wk[ci * 24 + 3 * co + 1], w2 = wk[ci * 24 + 3 * co + 2];
-                    a0[co] = fmaf(xa, w1, a0[co]);                            // even output: kx = 1 at j
-                    a1[co] = fmaf(xa, w2, fmaf(xb, w0, a1[co]));              // odd output: kx = 2 at j, kx = 0 at j + 1
-                }
-            }
-        }
+    for (int i = 0; i < 3 * kUp11Co / 4; ++i) {
+        const float4 t = ld4(w + 4 * i);
+        wr[4 * i] = t.x; wr[4 * i + 1] = t.y; wr[4 * i + 2] = t.z; wr[4 * i + 3] = t.w;
     }
-    const long long oplane = 4 * plane, ovol = 8 * vol;
-    const long long o = (long long)img * 8 * ovol + (long long)oz * oplane + (long long)oy * (2 * p.w) + 2 * j;
     NR_PRAGMA_UNROLL
-    for (int co = 0; co < 8; ++co) {
-        float v0 = a0[co] + p.bias[co], v1 = a1[co] + p.bias[co];
-        v0 = v0 > 0.0f ? v0 : v0 * p.slope;
-        v1 = v1 > 0.0f ? v1 : v1 * p.slope;
-        if (p.skip) { const float2 sk = *reinterpret_cast<const float2*>(p.skip + o + co * ovol); v0 += sk.x; v1 += sk.y; }
-        *reinterpret_cast<float2*>(p.out + o + co * ovol) = make_float2(v0, v1);
+    for (int co = 0; co < kUp11Co; ++co) {
+        const float w0 = wr[3 * co], w1 = wr[3 * co + 1], w2 = wr[3 * co + 2];
+        acc[A][B][0][co] = fmaf(x0, w1, acc[A][B][0][co]);                          // even output: kx = 1 at j
+        acc[A][B][1][co] = fmaf(x0, w2, fmaf(x1, w0, acc[A][B][1][co]));            // odd output: kx = 2 at j, kx = 0 at j + 1
+    }
+}
+
+// grid = ceil(h w / 256) * d * n
+#ifndef NR_UP11_MINW
+#define NR_UP11_MINW 4
+#endif
+__global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Params p) {
+    __shared__ __attribute__((aligned(16))) float wl[9 * 16 * 24];            // the folded weights, 13.5 KB: 54 B per thread of a workgroup whose
+    for (int i = threadIdx.x; i < 9 * 16 * 24 / 4; i += blockDim.x)           // threads each spend them on 3456 multiply-adds
+        reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(p.wpack)[i];
+    __syncthreads();
+    const int plane = p.h * p.w, chunks = (plane + (int)blockDim.x - 1) / (int)blockDim.x;
+    int b = (int)blockIdx.x;
+    const int chunk = b % chunks;
+    b /= chunks;
+    const int iz = b % p.d, img = b / p.d;
+    const int pix = chunk * (int)blockDim.x + (int)threadIdx.x;
+    if (pix >= plane) return;
+    const int iy = pix / p.w, j = pix - iy * p.w;
+    const long long vol = (long long)plane * p.d;
+    // neighbours that do not exist (last plane / row / column) are read at the voxel itself and multiplied by 0
+    const bool zn = iz + 1 < p.d, yn = iy + 1 < p.h, xn = j + 1 < p.w;
+    const long long dz = zn ? plane : 0;
+    const int dy = yn ? p.w : 0, dx = xn ? 1 : 0;
+    const float fz = zn ? 1.0f : 0.0f, fy = yn ? 1.0f : 0.0f, fx = xn ? 1.0f : 0.0f;
+    const int cog = (int)blockIdx.y * kUp11Co;                 // first output channel of this thread
+    float acc[2][2][2][kUp11Co];
+    NR_PRAGMA_UNROLL
+    for (int a = 0; a < 2; ++a)
+        NR_PRAGMA_UNROLL
+        for (int b_ = 0; b_ < 2; ++b_)
+            NR_PRAGMA_UNROLL
+            for (int c = 0; c < 2; ++c)
+                NR_PRAGMA_UNROLL
+                for (int co = 0; co < kUp11Co; ++co) acc[a][b_][c][co] = 0.0f;
+    const float* xi = p.x + (long long)img * 16 * vol + (long long)iz * plane + pix;
+    const float f01 = fx, f10 = fy, f11 = fy * fx, g00 = fz, g01 = fz * fx, g10 = fz * fy, g11 = fz * fy * fx;
+    // the 8 inputs of channel ci + 1 are loaded while channel ci is being spent (one memory round trip ahead): with the loads at the top
+    // of their own iteration hipcc holds a tap's weights in registers until the value they multiply arrives - 230 VGPRs
+    float raw[8];
+    auto issue = [&](int ci) {
+        const float* s_ = xi + ci * vol;
+        raw[0] = s_[0]; raw[1] = s_[dx]; raw[2] = s_[dy]; raw[3] = s_[dy + dx];
+        raw[4] = s_[dz]; raw[5] = s_[dz + dx]; raw[6] = s_[dz + dy]; raw[7] = s_[dz + dy + dx];
+    };
+    issue(0);
+#pragma unroll 1
+    for (int ci = 0; ci < 16; ++ci) {
+        float v[2][2][2];
+        v[0][0][0] = raw[0];        v[0][0][1] = raw[1] * f01;
+        v[0][1][0] = raw[2] * f10;  v[0][1][1] = raw[3] * f11;
+        v[1][0][0] = raw[4] * g00;  v[1][0][1] = raw[5] * g01;
+        v[1][1][0] = raw[6] * g10;  v[1][1][1] = raw[7] * g11;
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < 8; ++i) NR_KEEP(v[i >> 2][(i >> 1) & 1][i & 1]);
+        issue(ci + 1 < 16 ? ci + 1 : 15);
+        const float* wk = wl + ci * 24 + 3 * cog;                                   // + (kz * 3 + ky) * 384
+        // (sched barriers: left alone the scheduler issues all 54 weight reads of the channel up front - 216 registers)
+        up11_tap<0, 0>(wk + 0 * 384, v, acc); NR_PIN(); up11_tap<0, 1>(wk + 1 * 384, v, acc); NR_PIN(); up11_tap<0, 2>(wk + 2 * 384, v, acc); NR_PIN();
+        up11_tap<1, 0>(wk + 3 * 384, v, acc); NR_PIN(); up11_tap<1, 1>(wk + 4 * 384, v, acc); NR_PIN(); up11_tap<1, 2>(wk + 5 * 384, v, acc); NR_PIN();
+        up11_tap<2, 0>(wk + 6 * 384, v, acc); NR_PIN(); up11_tap<2, 1>(wk + 7 * 384, v, acc); NR_PIN(); up11_tap<2, 2>(wk + 8 * 384, v, acc); NR_PIN();
+    }
+    const long long orow = 2 * p.w, oplane = 4 * (long long)plane, ovol = 8 * vol;
+    const long long o000 = (long long)img * 8 * ovol + (long long)(2 * iz) * oplane + (long long)(2 * iy) * orow + 2 * j;
+    NR_PRAGMA_UNROLL
+    for (int co_ = 0; co_ < kUp11Co; ++co_) {
+        const int co = cog + co_;
+        const float bc = p.bias[co];
+        NR_PRAGMA_UNROLL
+        for (int a = 0; a < 2; ++a)
+            NR_PRAGMA_UNROLL
+            for (int b_ = 0; b_ < 2; ++b_) {
+                const long long o = o000 + co * ovol + a * oplane + b_ * orow;
+                float v0 = acc[a][b_][0][co_] + bc, v1 = acc[a][b_][1][co_] + bc;
+                v0 = v0 > 0.0f ? v0 : v0 * p.slope;
+                v1 = v1 > 0.0f ? v1 : v1 * p.slope;
+                if (p.skip) { const float2 sk = *reinterpret_cast<const float2*>(p.skip + o); v0 += sk.x; v1 += sk.y; }
+                *reinterpret_cast<float2*>(p.out + o) = make_float2(v0, v1);
+            }
+    }
+}
+
+// Frozen activated batch norm of MVSNet (inplace_abn.ABN in evaluation mode: network/mvsnet/modules.py:7-23 `self.bn(self.conv(x))`,
+// mvsnet.py:7-69): y = leaky_relu(x * scale[c] + shift[c]) with scale = gamma / sqrt(var + eps), shift = beta - mean * scale, IN PLACE on the
+// convolution's output [n][c][inner] (inner = h w or d h w) - one read and one write per element where batch_norm + leaky_relu are two of
+// each (the 2-D feature net runs its first layers on 8 x 800 x 800 x 12 views: 0.9 of its 2.7 ms were these passes).  HBM bound.
+struct ScaleShiftLeakyParams {
+    float* x;              // [n][c][inner], in place
+    const float* scale;    // [c]
+    const float* shift;    // [c]
+    long long inner;
+    int n, c;
+    float slope;
+};
+
+// grid = (chunks, n * c): a workgroup stays inside one (image, channel) plane, so scale / shift are scalar loads
+__global__ void __launch_bounds__(256) scale_shift_leaky_kernel(ScaleShiftLeakyParams p) {
+    const int plane = blockIdx.y, ch = plane % p.c;
+    const float a = p.scale[ch], b = p.shift[ch], sl = p.slope;
+    float* px = p.x + (size_t)plane * p.inner;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if ((p.inner & 3) == 0) {
+        float4* p4 = reinterpret_cast<float4*>(px);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.inner / 4; i += stride) {
+            float4 v = p4[i];
+            v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
+            v.x = v.x > 0.0f ? v.x : v.x * sl; v.y = v.y > 0.0f ? v.y : v.y * sl;
+            v.z = v.z > 0.0f ? v.z : v.z * sl; v.w = v.w > 0.0f ? v.w : v.w * sl;
+            p4[i] = v;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.inner; i += stride) {
+            const float v = fmaf(px[i], a, b);
+            px[i] = v > 0.0f ? v : v * sl;
+        }
     }
 }
 

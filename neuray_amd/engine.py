@@ -239,6 +239,15 @@ class RenderEngine:
                                                            skip.data_ptr() if skip is not None else None, n, d, h, w, out.data_ptr(), self._stream()))
         return out
 
+    def scale_shift_leaky_(self, x, scale, shift, slope):
+        """x [n,c,...] contiguous fp32 <- leaky_relu(x * scale[c] + shift[c], slope), in place (neuray_scale_shift_leaky: MVSNet's frozen
+        activated batch norm as one pass)"""
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() >= 3
+        n, c = x.shape[:2]
+        inner = x.numel() // (n * c)
+        self._check(self.lib.neuray_scale_shift_leaky(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), n, c, inner, float(slope), self._stream()))
+        return x
+
     def costreg_prob(self, x, w27, bias):
         """MVSNet CostRegNet.prob (neuray_conv3d_c8_c1): x [n,8,d,h,w] contiguous -> [n,1,d,h,w]"""
         n, c, d, h, w = x.shape

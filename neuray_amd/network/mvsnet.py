@@ -16,6 +16,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+FUSED_ABN = True          # False: always compose the PyTorch ops (A/B timing, tests)
+
+
 class ActivatedBatchNorm(nn.Module):
     def __init__(self, num_features, eps=1e-5, slope=0.01):
         super().__init__()
@@ -25,7 +28,28 @@ class ActivatedBatchNorm(nn.Module):
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
 
+    def _folded(self, device):
+        """scale = gamma / sqrt(var + eps), shift = beta - mean * scale of the frozen module; rebuilt when a parameter or buffer changes"""
+        src = (self.weight, self.bias, self.running_mean, self.running_var)
+        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(device),)
+        hit = self.__dict__.get('_fold')
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                scale = (self.weight / torch.sqrt(self.running_var + self.eps)).float().contiguous()
+                shift = (self.bias - self.running_mean * scale).float().contiguous()
+            hit = self.__dict__['_fold'] = (stamp, scale, shift)
+        return hit[1], hit[2]
+
     def forward(self, x):
+        # Evaluation mode with nothing to differentiate (how the cost-volume init net runs MVSNet: frozen, under no_grad,
+        # init_net.py:121-160): batch norm on the running statistics + leaky ReLU as ONE in-place pass over the convolution's output
+        # (neuray_scale_shift_leaky) instead of two kernels and two round trips.  Everything else takes the PyTorch ops.
+        if (FUSED_ABN and not self.training and not torch.is_grad_enabled() and x.dtype == torch.float32 and x.dim() >= 3
+                and x.is_contiguous() and x.shape[0] * x.shape[1] <= 65535):
+            from . import render_ops
+            if x.device.type == 'cuda' or render_ops._TEST_LIB is not None:
+                scale, shift = self._folded(x.device)
+                return render_ops.engine_for(x.device).scale_shift_leaky_(x, scale, shift, self.slope)
         x = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training, 0.1, self.eps)
         return F.leaky_relu(x, self.slope)
 
@@ -112,7 +136,7 @@ class CostRegNet(nn.Module):
 
     def _packs(self, device):
         """conv0's weights with the frozen batch norm folded in, as per-lane MFMA A fragments (csrc/nr_kernels_conv3d.h Conv0Params.wpack),
-        and prob's 8 x 27 taps; rebuilt when a parameter or buffer changes"""
+        and prob's 216 taps ([ky][c][kz][kx]); rebuilt when a parameter or buffer changes"""
         conv, bn = self.conv0.conv, self.conv0.bn
         up, ubn = self.conv11[0], self.conv11[1]
         src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.prob.weight, self.prob.bias,
@@ -145,7 +169,8 @@ class CostRegNet(nn.Module):
                 upack = (up.weight * uscale[None, :, None, None, None]).float().permute(2, 3, 0, 1, 4).contiguous()
                 ushift = (ubn.bias - ubn.running_mean * uscale).float().contiguous()
                 hit = (stamp, pack.contiguous().to(device), shift.to(device), float(bn.slope),
-                       self.prob.weight.detach().reshape(8, 27).float().contiguous().to(device), float(self.prob.bias.detach()[0]),
+                       self.prob.weight.detach()[0].permute(2, 0, 1, 3).reshape(216).float().contiguous().to(device),      # [ky][c][kz][kx]: the order the kernel spends them in
+                       float(self.prob.bias.detach()[0]),
                        upack.to(device), ushift.to(device), float(ubn.slope))
             self.__dict__['_fast_packs'] = hit
         return hit[1:]

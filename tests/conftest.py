@@ -14,6 +14,7 @@ GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fused_abn: tests/test_costreg_kernels.py - the test drives mvsnet.FUSED_ABN itself")
 
 
 def load_case(name):

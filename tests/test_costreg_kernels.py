@@ -27,6 +27,17 @@ def dev(request):
         yield 'cuda:0'
 
 
+@pytest.fixture(autouse=True)
+def pure_pytorch_module_path(request):
+    """the `want` side of every comparison here is PyTorch's own batch_norm + leaky_relu; the fused pass has its own test"""
+    if 'fused_abn' in request.keywords:
+        yield
+        return
+    mvsnet.FUSED_ABN = False
+    yield
+    mvsnet.FUSED_ABN = True
+
+
 def make_net(dev, seed=0):
     torch.manual_seed(seed)
     net = mvsnet.CostRegNet().eval()
@@ -130,3 +141,35 @@ def test_conv0_and_up11_on_random_volumes_emulator(n, d, h, w, seed):
     finally:
         ro._TEST_LIB = None
         ro._ENGINES.clear()
+
+
+@pytest.mark.fused_abn
+@pytest.mark.parametrize('shape', [(2, 8, 5, 23), (3, 16, 7, 12, 20), (1, 32, 1, 3), (12, 8, 40, 52)])
+def test_fused_activated_batch_norm_matches_batch_norm_plus_leaky_relu(dev, shape):
+    """neuray_scale_shift_leaky (MVSNet's frozen InPlaceABN, modules.py:7-23) against F.batch_norm on the running statistics +
+    F.leaky_relu: 2-D and 3-D outputs, plane sizes that are and are not multiples of four, in place"""
+    torch.manual_seed(3)
+    c = shape[1]
+    abn = mvsnet.ActivatedBatchNorm(c).eval()
+    with torch.no_grad():
+        abn.weight.copy_(torch.rand(c) * 0.5 + 0.75); abn.bias.copy_(torch.randn(c) * 0.1)
+        abn.running_mean.copy_(torch.randn(c) * 0.1); abn.running_var.copy_(torch.rand(c) * 0.5 + 0.75)
+    abn = abn.to(dev)
+    x = torch.randn(*shape).to(dev)
+    with torch.no_grad():
+        mvsnet.FUSED_ABN = False
+        want = abn(x.clone())
+        mvsnet.FUSED_ABN = True
+        xin = x.clone()
+        got = abn(xin)
+    assert got.data_ptr() == xin.data_ptr()                    # in place, as the reference's InPlaceABN
+    assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    # with gradients enabled (or in training mode) the module takes the PyTorch ops: differentiable, running statistics untouched in eval
+    y = abn(x.clone().requires_grad_(True))
+    assert y.requires_grad and torch.allclose(y.detach(), want, atol=1e-6)
+    with torch.no_grad():                                      # a changed buffer is picked up (the folded scale / shift are rebuilt)
+        abn.running_mean.add_(0.25)
+        mvsnet.FUSED_ABN = False
+        want2 = abn(x.clone())
+        mvsnet.FUSED_ABN = True
+        assert float((abn(x.clone()) - want2).abs().max()) <= 2e-6 * max(1.0, float(want2.abs().max()))

@@ -35,9 +35,43 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float (&a)[16]) 
 
 __device__ __forceinline__ constexpr int sym(int i, int j) { return i <= j ? i * 16 - i * (i - 1) / 2 + (j - i) : j * 16 - j * (j - 1) / 2 + (i - j); }
 
+template <int K>
+__device__ __forceinline__ void dr_eliminate(float (&M)[136], float (&R)[16][3]) {
+    if constexpr (K < 16) {
+        const float inv = 1.0f / M[sym(K, K)];
+        NR_PRAGMA_UNROLL
+        for (int i = K + 1; i < 16; ++i) {
+            const float f = M[sym(K, i)] * inv;
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 16; ++j)
+                if (j >= i) M[sym(i, j)] = fmaf(-f, M[sym(K, j)], M[sym(i, j)]);
+            NR_PRAGMA_UNROLL
+            for (int c = 0; c < 3; ++c) R[i][c] = fmaf(-f, R[K][c], R[i][c]);
+        }
+        dr_eliminate<K + 1>(M, R);
+    }
+}
+template <int K>
+__device__ __forceinline__ void dr_back_substitute(const float (&M)[136], float (&R)[16][3]) {          // on the upper triangle left in M
+    if constexpr (K >= 0) {
+        const float inv = 1.0f / M[sym(K, K)];
+        NR_PRAGMA_UNROLL
+        for (int c = 0; c < 3; ++c) {
+            float s = R[K][c];
+            NR_PRAGMA_UNROLL
+            for (int j = K + 1; j < 16; ++j) s = fmaf(-M[sym(K, j)], R[j][c], s);
+            R[K][c] = s * inv;
+        }
+        dr_back_substitute<K - 1>(M, R);
+    }
+}
+
 // per (point): alpha logit + SH colour.  view_rec [npts][rfn][kDbgFields] (the point kernel's per-view record),
 // regs [16] (SphericalHarmonicsSolver.regs), alpha_out [npts], color_out [npts][3] (null: use_nr_color_for_dr).
-__global__ void __launch_bounds__(128) dr_points_kernel(const float* __restrict__ qc, const float* __restrict__ view_const,
+#ifndef NR_DR_MINW
+#define NR_DR_MINW 1
+#endif
+__global__ void __launch_bounds__(128, NR_DR_MINW) dr_points_kernel(const float* __restrict__ qc, const float* __restrict__ view_const,
                                                         const float* __restrict__ coords, const float* __restrict__ depth,
                                                         const float* __restrict__ rgba, const float* __restrict__ view_rec,
                                                         const float* __restrict__ regs, int rfn, int rn, int dn, int h, int w,
@@ -97,37 +131,19 @@ __global__ void __launch_bounds__(128) dr_points_kernel(const float* __restrict_
             NR_PRAGMA_UNROLL
             for (int i = 0; i < 16; ++i) {
                 NR_PRAGMA_UNROLL
-                for (int j = i; j < 16; ++j) M[sym(i, j)] = fmaf(aw[i], a[j], M[sym(i, j)]);
+                for (int j = 0; j < 16; ++j)          // (constant trip count + a predicate that folds: a bound that depends on i keeps the
+                    if (j >= i) M[sym(i, j)] = fmaf(aw[i], a[j], M[sym(i, j)]);      //  inner loop from being unrolled before the outer one is)
                 NR_PRAGMA_UNROLL
                 for (int c = 0; c < 3; ++c) R[i][c] = fmaf(aw[i], rgb[c], R[i][c]);
             }
         }
         NR_PRAGMA_UNROLL
         for (int i = 0; i < 16; ++i) M[sym(i, i)] += regs[i];
-        // LDL^T elimination of the SPD system (no pivoting needed), three right-hand sides
-        NR_PRAGMA_UNROLL
-        for (int k = 0; k < 16; ++k) {
-            const float inv = 1.0f / M[sym(k, k)];
-            NR_PRAGMA_UNROLL
-            for (int i = k + 1; i < 16; ++i) {
-                const float f = M[sym(k, i)] * inv;
-                NR_PRAGMA_UNROLL
-                for (int j = i; j < 16; ++j) M[sym(i, j)] = fmaf(-f, M[sym(k, j)], M[sym(i, j)]);
-                NR_PRAGMA_UNROLL
-                for (int c = 0; c < 3; ++c) R[i][c] = fmaf(-f, R[k][c], R[i][c]);
-            }
-        }
-        NR_PRAGMA_UNROLL
-        for (int k = 15; k >= 0; --k) {          // back substitution on the upper triangle left in M
-            const float inv = 1.0f / M[sym(k, k)];
-            NR_PRAGMA_UNROLL
-            for (int c = 0; c < 3; ++c) {
-                float s = R[k][c];
-                NR_PRAGMA_UNROLL
-                for (int j = k + 1; j < 16; ++j) s = fmaf(-M[sym(k, j)], R[j][c], s);
-                R[k][c] = s * inv;
-            }
-        }
+        // LDL^T elimination of the SPD system (no pivoting needed), three right-hand sides.  One function instantiation per pivot: with the
+        // pivot a run-time loop variable hipcc stopped unrolling part-way, indexed M / R dynamically and put both arrays into scratch
+        // memory (752 B per lane, every access a memory round trip at one wave per SIMD: 2.99 ms per launch of 1.6 M points, round 4)
+        dr_eliminate<0>(M, R);
+        dr_back_substitute<15>(M, R);
         float q[16];
         sh16(r.qx, r.qy, r.qz, q);
         NR_PRAGMA_UNROLL

@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--ft', action='store_true', help='a NeuralRayFtRenderer.train_step on a 24-view 800 x 800 in-memory scene '
                                                       '(per-view learnable ray_feats, encoders trained) instead of the bare render_impl step')
     ap.add_argument('--kernel', default='auto', help="'v1': the first-version point backward (A/B)")
+    ap.add_argument('--use-all', action='store_true', help="cfg fine_depth_use_all: the fine pass runs on 64 + 64 = 128 samples per ray (rays_backward_kernel<2>)")
     ap.add_argument('--variant', default='fp32', help="'bf16x3': the split library (hi + lo bf16 MFMA operands, fp32 accumulate)")
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
@@ -58,6 +59,8 @@ def main():
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': 64,
            'fine_depth_sample_num': 64, 'agg_net_cfg': {'sample_num': 64}, 'fine_agg_net_cfg': {'sample_num': 64},
            'use_self_hit_prob': True, 'hip_variant': args.variant}
+    if args.use_all:
+        cfg.update(fine_depth_use_all=True, fine_agg_net_cfg={'sample_num': 128})
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).train().to(dev)
     r.engine(dev).points_backward_kernel = args.kernel

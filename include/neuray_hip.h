@@ -257,9 +257,23 @@ int neuray_self_hit_prob_backward_resident(const float* query_const_dev, const f
 int neuray_dist_decoder_rows_backward(const float* feats_dev, const float* flat_weights_dev, int n, int has_vis_head, float var_bias,
                                       const float* d_mean_dev, const float* d_var_dev, const float* d_aw_dev, const float* d_vis_dev,
                                       float* d_feats_dev, float* d_flat_weights_dev, float* workspace_dev, void* stream);
+/* The same on the resident scheme of neuray_self_hit_prob_backward_resident (one wave per 16 rows, the heads in registers on the packed /
+ * transposed packs of neuray_pack_pass_weights / neuray_pack_pass_t_index_map, weight gradients on the MFMA): no workspace; a head whose
+ * gradient pointer is NULL is skipped (predict_mean, renderer.py:280-316: the mean head only).  ABI 9. */
+int neuray_dist_decoder_rows_backward_resident(const float* feats_dev, const float* packed_weights_dev, const float* packed_t_dev, int n,
+                                               int has_vis_head, float var_bias, const float* d_mean_dev, const float* d_var_dev,
+                                               const float* d_aw_dev, const float* d_vis_dev, float* d_feats_dev, float* d_flat_dev,
+                                               void* stream);
 /* ---- backward of neuray_interpolate_feats: d_feats [b][c][fh][fw] += bilinear weights * d_out [b][n][c] (accumulated). */
 int neuray_interpolate_feats_backward(const float* d_out_dev, const float* points_dev, const float* mask_dev, int b, int n, int c,
                                       int fh, int fw, int h_full, int w_full, int align_corners, float* d_feats_dev, void* stream);
+/* The same through a channels-last staging map: the scatter adds a point's c channels to c CONSECUTIVE floats of a texel of
+ * tmp_nhwc_zeroed_dev [b][fh][fw][c] (zeroed by the caller; one cache line per tap and wave instead of one per lane), then that map is
+ * transposed and ADDED to d_feats_dev [b][c][fh][fw].  For many points per map (the generalisation renderer's 8192 depth-loss pixels per
+ * view, renderer.py:280-316).  ABI 9. */
+int neuray_interpolate_feats_backward_staged(const float* d_out_dev, const float* points_dev, const float* mask_dev, int b, int n, int c,
+                                             int fh, int fw, int h_full, int w_full, int align_corners, float* tmp_nhwc_zeroed_dev,
+                                             float* d_feats_dev, void* stream);
 
 /* ---- a17: sample_fine_depth + torch.sort (render_ops.py:172-229, renderer.py:210-213) ------------------------
  * u_dev: externally drawn uniforms [rn][fdn] (training: the reference draws torch.rand on the CPU,

@@ -139,8 +139,12 @@ SYMBOLS = {
                                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_self_hit_prob_backward_resident': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                          C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_dist_decoder_rows_backward_resident': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_dist_decoder_rows_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_interpolate_feats_backward_staged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_interpolate_feats_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_group_sum_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

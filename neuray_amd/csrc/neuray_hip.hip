@@ -713,6 +713,25 @@ int neuray_dist_decoder_rows_backward(const float* feats, const float* flat, int
     return check_launch("neuray_dist_decoder_rows_backward");
 }
 
+int neuray_dist_decoder_rows_backward_resident(const float* feats, const float* packed, const float* packed_t, int n, int has_vis_head,
+                                               float var_bias, const float* d_mean, const float* d_var, const float* d_aw, const float* d_vis,
+                                               float* d_feats, float* d_flat, void* stream) {
+#ifdef NR_INFERENCE_ONLY
+    return fail("neuray_dist_decoder_rows_backward_resident: the bf16-operand variant is inference only");
+#else
+    if (!feats || !packed || !packed_t || !d_feats || !d_flat) return fail("neuray_dist_decoder_rows_backward_resident: null argument");
+    if (n < 1) return fail("neuray_dist_decoder_rows_backward_resident: n=%d", n);
+    nr::RowsBwd2Params p;
+    p.feats = feats; p.weights = packed; p.weights_t = packed_t; p.d_mean = d_mean; p.d_var = d_var; p.d_aw = d_aw; p.d_vis = d_vis;
+    p.d_feats = d_feats; p.d_flat = d_flat; p.n = n; p.var_bias = var_bias;
+    // (a persistent grid: every workgroup ends with one atomicAdd per weight of the heads it ran - 2048 of them cost more in the flush than in the rows)
+    const dim3 grid(grid_for(n, 16, 512));
+    if (has_vis_head && d_vis) NR_LAUNCH(nr::decoder_rows_backward2_kernel<true>, grid, dim3(64), 0, stream, p);      // (no gradient into the vis head: not run)
+    else NR_LAUNCH(nr::decoder_rows_backward2_kernel<false>, grid, dim3(64), 0, stream, p);
+    return check_launch("neuray_dist_decoder_rows_backward_resident");
+#endif
+}
+
 int neuray_interpolate_feats_backward(const float* d_out, const float* points, const float* mask, int b, int n, int c, int fh,
                                       int fw, int h_full, int w_full, int align_corners, float* d_feats, void* stream) {
     if (!d_out || !points || !d_feats) return fail("neuray_interpolate_feats_backward: null argument");
@@ -720,6 +739,17 @@ int neuray_interpolate_feats_backward(const float* d_out, const float* points, c
     NR_LAUNCH(nr::interpolate_backward_kernel, dim3(grid_for((long long)b * n * c, 256, 4096)), dim3(256), 0, stream, d_out, points,
               mask, b, n, c, fh, fw, h_full, w_full, align_corners, d_feats);
     return check_launch("neuray_interpolate_feats_backward");
+}
+
+int neuray_interpolate_feats_backward_staged(const float* d_out, const float* points, const float* mask, int b, int n, int c, int fh,
+                                             int fw, int h_full, int w_full, int align_corners, float* tmp_nhwc_zeroed, float* d_feats, void* stream) {
+    if (!d_out || !points || !d_feats || !tmp_nhwc_zeroed) return fail("neuray_interpolate_feats_backward_staged: null argument");
+    if (b < 1 || n < 1 || c < 1 || fh < 1 || fw < 1 || (long long)b * ((c + 31) / 32) > 65535) return fail("neuray_interpolate_feats_backward_staged: bad shape");
+    NR_LAUNCH(nr::interpolate_backward_nhwc_kernel, dim3(grid_for((long long)b * n * c, 256, 4096)), dim3(256), 0, stream, d_out, points,
+              mask, b, n, c, fh, fw, h_full, w_full, align_corners, tmp_nhwc_zeroed);
+    if (int rc = check_launch("neuray_interpolate_feats_backward_staged")) return rc;
+    NR_LAUNCH(nr::nhwc_add_to_nchw_kernel, dim3((fh * fw + 31) / 32, ((c + 31) / 32) * b), dim3(256), 0, stream, tmp_nhwc_zeroed, fh * fw, c, d_feats);
+    return check_launch("neuray_interpolate_feats_backward_staged");
 }
 
 int neuray_group_sum_selftest(const float* x, float* y, void* stream) {

@@ -594,21 +594,30 @@ class RenderEngine:
                                                            rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), ws.data_ptr(), self._stream()))
         return d_feats, d_flat
 
-    def dist_decoder_rows_backward(self, feats, flat, has_vis_head, var_bias, d_mean=None, d_var=None, d_aw=None, d_vis=None):
-        """Backward of dist_decoder_rows: -> (d_feats [n,32], d_flat)"""
+    def dist_decoder_rows_backward(self, feats, flat, has_vis_head, var_bias, d_mean=None, d_var=None, d_aw=None, d_vis=None, packed=None,
+                                   kernel='auto'):
+        """Backward of dist_decoder_rows: -> (d_feats [n,32], d_flat).  The resident kernel (one wave per 16 rows, the heads in registers on the
+        packed / transposed packs; heads without an incoming gradient are skipped) unless kernel == 'v1' (first version: lane = row, global arena)."""
         feats = self._f32(feats).reshape(-1, 32)
         n = feats.shape[0]
         g = [self._f32(t).reshape(-1) if t is not None else None for t in (d_mean, d_var, d_aw, d_vis)]
         d_feats = self.empty(n, 32)
         d_flat = torch.zeros_like(flat)
+        ptr = lambda t: t.data_ptr() if t is not None else None       # noqa: E731
+        if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant in ('fp32', 'bf16x3'):
+            pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
+            pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+            self._check(self.lib.neuray_dist_decoder_rows_backward_resident(
+                feats.data_ptr(), pk.data_ptr(), pt.data_ptr(), n, int(has_vis_head), float(var_bias), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]),
+                d_feats.data_ptr(), d_flat.data_ptr(), self._stream()))
+            return d_feats, d_flat
         ws = self.empty(int(self.lib.neuray_self_hit_backward_workspace_floats(n)))
-        ptr = lambda t: t.data_ptr() if t is not None else None
         self._check(self.lib.neuray_dist_decoder_rows_backward(feats.data_ptr(), flat.data_ptr(), n, int(has_vis_head), float(var_bias),
                                                                ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), d_feats.data_ptr(),
                                                                d_flat.data_ptr(), ws.data_ptr(), self._stream()))
         return d_feats, d_flat
 
-    def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None, out=None):
+    def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None, out=None, staged=None):
         """Backward of interpolate_feats w.r.t. the feature maps: -> d_feats [b,c,fh,fw] (out: a zeroed buffer to add into)"""
         d_out, points = self._f32(d_out), self._f32(points)
         b, c, fh, fw = feats_shape
@@ -617,6 +626,14 @@ class RenderEngine:
             h, w = fh, fw
         d_feats = out if out is not None else torch.zeros(b, c, fh, fw, dtype=torch.float32, device=self.device)
         m = self._f32(mask) if mask is not None else None
+        if staged is None:            # many points per map: scatter into a channels-last staging map (coalesced atomics), then transpose-add
+            staged = n >= 1024 and b * fh * fw * c <= (1 << 28)
+        if staged:
+            tmp = torch.zeros(b, fh, fw, c, dtype=torch.float32, device=self.device)
+            self._check(self.lib.neuray_interpolate_feats_backward_staged(
+                d_out.data_ptr(), points.data_ptr(), m.data_ptr() if m is not None else None, b, n, c, fh, fw, int(h), int(w),
+                int(bool(align_corners)), tmp.data_ptr(), d_feats.data_ptr(), self._stream()))
+            return d_feats
         self._check(self.lib.neuray_interpolate_feats_backward(d_out.data_ptr(), points.data_ptr(), m.data_ptr() if m is not None else None,
                                                                b, n, c, fh, fw, int(h), int(w), int(bool(align_corners)),
                                                                d_feats.data_ptr(), self._stream()))

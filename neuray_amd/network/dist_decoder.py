@@ -32,7 +32,8 @@ class _RowsFn(torch.autograd.Function):
         flat, has_vis = eng.flat_pass_device(named, 'd.', 'a.', allow_missing_agg=True)
         packed = eng.pack_pass_device(flat, has_vis)
         mean, var, vis, aw = eng.dist_decoder_rows(feats, packed, dec.cfg['bias_val'])
-        ctx.dec, ctx.flat, ctx.has_vis = dec, flat, has_vis
+        ctx.dec, ctx.flat, ctx.has_vis, ctx.packed = dec, flat, has_vis, packed
+        ctx.set_materialize_grads(False)          # an output the loss does not use arrives as None: its head's backward is skipped
         ctx.save_for_backward(feats.detach())
         if vis is None:
             vis = torch.zeros_like(aw)
@@ -44,7 +45,7 @@ class _RowsFn(torch.autograd.Function):
         feats, = ctx.saved_tensors
         eng = dec._engine(feats.device)
         d_feats, d_flat = eng.dist_decoder_rows_backward(feats, ctx.flat, ctx.has_vis, dec.cfg['bias_val'], d_mean, d_var, d_aw,
-                                                         d_vis if ctx.has_vis else None)
+                                                         d_vis if ctx.has_vis else None, packed=ctx.packed)
         sd = {'d.' + k: v.detach() for k, v in dec.named_parameters()}
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
         return (None, d_feats.view_as(feats)) + tuple(grads['d.' + k].clone() for k, _ in dec.named_parameters())

@@ -258,6 +258,62 @@ def test_dist_decoder_module_forward_backward(use_vis, backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('use_vis', [False, True])
+def test_resident_rows_backward_equals_the_first_version(use_vis, backend):
+    """neuray_dist_decoder_rows_backward_resident (one wave per 16 rows, heads in registers) against the first-version kernel (global
+    arena) on the same rows: all heads, and with heads left out (a null gradient pointer = no contribution, as predict_mean's backward)"""
+    from neuray_amd.network.dist_decoder import MixtureLogisticsDistDecoder
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    torch.manual_seed(6)
+    dec = MixtureLogisticsDistDecoder({'use_vis': use_vis})
+    if backend == 'emu':
+        dec._engine_test_lib = emu_lib()
+    dec = dec.to(dev)
+    eng = dec._engine(torch.device(dev))
+    flat, has_vis = eng.flat_pass_device({'d.' + k: v for k, v in dec.named_parameters()}, 'd.', 'a.', allow_missing_agg=True)
+    n = 53                                                       # not a multiple of 16: a partly filled tile
+    feats = torch.randn(n, 32, device=dev)
+    gm, gv, ga, gs = torch.randn(n, 2, device=dev), torch.randn(n, 2, device=dev), torch.randn(n, 1, device=dev), torch.randn(n, 1, device=dev)
+    for heads in ((gm, gv, ga, gs if use_vis else None), (gm, None, None, None), (None, gv, ga, None)):
+        f1, w1 = eng.dist_decoder_rows_backward(feats, flat, has_vis, 0.05, *heads, kernel='v1')
+        f2, w2 = eng.dist_decoder_rows_backward(feats, flat, has_vis, 0.05, *heads)
+        assert float((f1 - f2).abs().max()) <= 1e-5 * max(1.0, float(f1.abs().max()))
+        assert float((w1 - w2).abs().max()) <= 2e-5 * max(1.0, float(w1.abs().max()))
+        assert float(w1.abs().max()) > 0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('shape', [(2, 32, 13, 17, 300), (3, 5, 8, 40, 77)])
+def test_staged_interpolate_backward_equals_the_direct_scatter_and_autograd(shape, backend):
+    """neuray_interpolate_feats_backward_staged (scatter into a channels-last map, transpose-add) against the direct channel-major scatter
+    and against autograd of F.grid_sample as interpolate_feats calls it (network/ops.py:14-34), incl. masked points, border taps, a
+    channel count that is not a multiple of 32 and accumulation into a non-zero buffer"""
+    import torch.nn.functional as F
+    from neuray_amd.engine import RenderEngine
+    b, c, fh, fw, n = shape
+    dev = 'cpu' if backend == 'emu' else 'cuda:0'
+    eng = RenderEngine(torch.device(dev), _test_lib=emu_lib() if backend == 'emu' else None)
+    g = torch.Generator().manual_seed(4)
+    h, w = 4 * fh, 4 * fw
+    pts = (torch.rand(b, n, 2, generator=g) * torch.tensor([w + 3.0, h + 3.0]) - 1.5)          # some outside: border padding
+    mask = (torch.rand(b, n, generator=g) > 0.2).float()
+    d_out = torch.randn(b, n, c, generator=g)
+    base = torch.randn(b, c, fh, fw, generator=g)
+    feats = torch.zeros(b, c, fh, fw, requires_grad=True)
+    norm = torch.stack([pts[..., 0] / (w - 1), pts[..., 1] / (h - 1)], -1) * 2 - 1
+    out = F.grid_sample(feats, norm[:, :, None], mode='bilinear', padding_mode='border', align_corners=False)[..., 0].permute(0, 2, 1)
+    (out * mask[..., None] * d_out).sum().backward()
+    got = {}
+    for staged in (True, False):
+        buf = base.clone().to(dev)
+        got[staged] = eng.interpolate_feats_backward(d_out.to(dev), (b, c, fh, fw), pts.to(dev), h, w, align_corners=False, mask=mask.to(dev),
+                                                     out=buf, staged=staged).cpu() - base
+    scale = float(feats.grad.abs().max())
+    assert float((got[True] - got[False]).abs().max()) <= 1e-5 * scale
+    assert float((got[True] - feats.grad).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_adam_steps_reduce_the_render_loss(backend):
     """A few optimiser steps through the HIP forward + backward kernels (weights AND the per-view ray_feats, as the
     reference's fine-tuning does, renderer.py:404-437) must reduce a fixed render loss."""

@@ -1024,8 +1024,12 @@ def main(argv=None):
             # inside this process); the committed summary of the same command is reported here (profiles/README.md)
             traffic, tsrc = None, None
             import glob
-            tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')),
-                            key=lambda f: (len(os.path.basename(f)), os.path.basename(f)))   # r01_traffic < r01_e_traffic < r02_...
+            import re
+
+            def tkey(f):         # r01_traffic < r01_e_traffic < r01_zz_traffic < r02_a_traffic: by round, then by tag (length first)
+                m = re.match(r'r(\d+)_?(.*?)_?traffic\.json$', os.path.basename(f))
+                return (int(m.group(1)), len(m.group(2)), m.group(2)) if m else (-1, 0, os.path.basename(f))
+            tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), key=tkey)
             if args.fine_samples == 32 and standard and tfiles:
                 tj = json.load(open(tfiles[-1]))
                 sys.path.insert(0, os.path.join(ROOT, 'profiles'))

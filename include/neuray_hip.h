@@ -335,6 +335,14 @@ int neuray_conv3d_c8_c1(const float* x_dev, const float* w27_dev, float bias, in
 int neuray_convtranspose3d_c16_c8(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, const float* skip_dev,
                                   int n, int d, int h, int w, float* out_dev, void* stream);
 
+/* neuray_conv3d_bn_leaky: the interior layers of the cost regularisation's encoder half, leaky_relu(batch_norm(Conv3d(C_in, C_out, 3, stride,
+ *   padding=1, bias=False)(x)), slope) with the frozen batch norm folded - conv1 (8 -> 16, stride 2), conv2 (16 -> 16), conv3 (16 -> 32, stride 2),
+ *   conv4 (32 -> 32) of network/mvsnet/mvsnet.py:29-69 (ConvBnReLU3D, modules.py:16-23); other shapes return an error.  x_dev [n][C_in][d][h][w],
+ *   wpack_dev [3 dz][C_in / 4 q][3 dy][3 dx][C_out / 16 mt][64 lanes] = per-lane MFMA A operands: lane l (m = l & 15, g = l >> 4) holds
+ *   W[16 mt + m][4 q + g][dz][dy][dx] * gamma / sqrt(var + eps) of output channel 16 mt + m; bias_dev [C_out] = beta - mean * gamma / sqrt(var + eps);
+ *   out_dev [n][C_out][(d - 1) / stride + 1][(h - 1) / stride + 1][(w - 1) / stride + 1].  ABI 9. */
+int neuray_conv3d_bn_leaky(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, int n, int cin, int cout, int stride,
+                           int d, int h, int w, float* out_dev, void* stream);
 /* neuray_scale_shift_leaky: MVSNet's frozen activated batch norm behind every convolution of the feature net and the cost regularisation
  *   (inplace_abn.ABN in evaluation mode; network/mvsnet/modules.py:7-23 `self.bn(self.conv(x))`, network/mvsnet/mvsnet.py:7-69) as ONE pass, in
  *   place on the convolution's output: x_dev [n][c][inner] (inner = h w or d h w) <- leaky_relu(x * scale_dev[c] + shift_dev[c], slope),

@@ -355,6 +355,26 @@ int neuray_conv3d_c8_c1(const float* x, const float* w27, float bias, int n, int
     return check_launch("neuray_conv3d_c8_c1");
 }
 
+int neuray_conv3d_bn_leaky(const float* x, const float* wpack, const float* bias, float slope, int n, int cin, int cout, int stride, int d,
+                           int h, int w, float* out, void* stream) {
+    if (!x || !wpack || !bias || !out) return fail("neuray_conv3d_bn_leaky: null pointer");
+    if (n < 1 || d < 1 || h < 1 || w < 1) return fail("neuray_conv3d_bn_leaky: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
+    if ((long long)cin * d * h * w * 4 >= 0x7fffff00LL) return fail("neuray_conv3d_bn_leaky: one image's input volume must stay below 2^31 bytes");
+    if (stride != 1 && stride != 2) return fail("neuray_conv3d_bn_leaky: stride %d", stride);
+    nr::Conv3dParams p;
+    p.x = x; p.wpack = wpack; p.bias = bias; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
+    const int od = (d - 1) / stride + 1, oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+    const long long tasks = (long long)n * od * ((oh + nr::kC3Rows - 1) / nr::kC3Rows) * ((ow + 15) / 16);
+    const dim3 grid(grid_for(tasks, nr::kC3Waves, 256 * 16)), block(64 * nr::kC3Waves);
+    if (cin == 16 && cout == 16 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<16, 16, 1>), grid, block, 0, stream, p);
+    else if (cin == 32 && cout == 32 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<32, 32, 1>), grid, block, 0, stream, p);
+    else if (cin == 8 && cout == 16 && stride == 2) NR_LAUNCH((nr::conv3d_kernel<8, 16, 2>), grid, block, 0, stream, p);
+    else if (cin == 16 && cout == 32 && stride == 2) NR_LAUNCH((nr::conv3d_kernel<16, 32, 2>), grid, block, 0, stream, p);
+    else return fail("neuray_conv3d_bn_leaky: (C_in, C_out, stride) = (%d, %d, %d) is not built (8 -> 16 / 16 -> 32 at stride 2, 16 -> 16 / 32 -> 32 at stride 1)",
+                     cin, cout, stride);
+    return check_launch("neuray_conv3d_bn_leaky");
+}
+
 int neuray_scale_shift_leaky(float* x, const float* scale, const float* shift, int n, int c, long long inner, float slope, void* stream) {
     if (!x || !scale || !shift) return fail("neuray_scale_shift_leaky: null pointer");
     if (n < 1 || c < 1 || inner < 1 || (long long)n * c > 0x7fffffffLL) return fail("neuray_scale_shift_leaky: bad shape n=%d c=%d inner=%lld", n, c, inner);

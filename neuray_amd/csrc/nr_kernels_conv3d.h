@@ -317,6 +317,125 @@ __global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Par
     }
 }
 
+// The interior layers of the U-Net's encoder half - conv1 (8 -> 16, stride 2), conv2 (16 -> 16), conv3 (16 -> 32, stride 2), conv4 (32 -> 32):
+// ConvBnReLU3D(C_in, C_out, 3, stride, pad 1), network/mvsnet/mvsnet.py:29-69, modules.py:16-23 - as an implicit GEMM on the fp32 MFMA with
+// the frozen batch norm folded into weights and bias and the leaky ReLU in the epilogue (MIOpen / CK: 0.95 + 1.54 + 0.30 + 0.51 ms per
+// 8 x 800 x 800 at 20-35 TFLOP/s, plus two element-wise passes each).  NCDHW in and out (the neighbouring layers are MIOpen's).
+//   A = weights (M = 16 output channels per tile, MT = C_out / 16 tiles), N = 16 consecutive OUTPUT voxels along x, K = 4 input channels
+//   of one tap per MFMA: lane (column c, group g) supplies channel 4 q + g at input voxel S (x0 + c) + dx - 1.  A wave owns kC3Rows = 4
+//   output rows of one x-strip: per (dz, channel quad q) it loads the S * 3 + 3 input rows it needs ONCE -
+//     stride 1: one dword per lane (+ the voxel just outside the strip on lanes 0 / 15), the dx = 0 / 2 operands by DPP row shifts;
+//     stride 2: the even and the odd voxel of the lane's pair (dx = 1 / 2), the dx = 0 operand = the odd voxel of the lane to the left -
+//   and spends them on 3 dy x 3 dx x 4 rows x MT MFMAs.  Out-of-volume rows / voxels are buffer loads beyond the descriptor's range
+//   (0 = the zero padding).
+//   wpack [3 dz][C_in / 4 q][3 dy][3 dx][MT][64 lanes]: lane (m = l & 15, g = l >> 4) -> W[16 mt + m][4 q + g][dz][dy][dx] * scale[16 mt + m].
+// Measured (tools/time_costreg.py, two views per call): conv2 0.452 -> 0.062 ms = 92 TFLOP/s = 0.58 of the fp32 MFMA peak, conv4 0.166 ->
+// 0.042 ms; conv6 (64 -> 64 on 8 x 25 x 25: 224 wave tasks) is slower than the library's kernel and stays with it.
+struct Conv3dParams {
+    const float* x;        // [n][C_in][D][H][W]
+    const float* wpack;
+    const float* bias;     // [C_out] (batch norm folded)
+    float* out;            // [n][C_out][OD][OH][OW], O* = (* - 1) / S + 1
+    int n, d, h, w;        // input volume
+    float slope;
+};
+
+constexpr int kC3Rows = 4, kC3Waves = 4;
+
+template <int CIN, int COUT, int S>
+__global__ void __launch_bounds__(64 * kC3Waves) conv3d_kernel(Conv3dParams p) {
+    constexpr int MT = COUT / 16, NQ = CIN / 4, NY = kC3Rows, NR = S * (NY - 1) + 3;
+    static_assert(CIN % 4 == 0 && COUT % 16 == 0 && (S == 1 || S == 2), "shape");
+    const int lane = threadIdx.x & 63;
+    const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
+    const int c = lane & 15, g = lane >> 4;
+    const int od = (p.d - 1) / S + 1, oh = (p.h - 1) / S + 1, ow = (p.w - 1) / S + 1;
+    const long long plane = (long long)p.h * p.w, vol = plane * p.d, oplane = (long long)oh * ow, ovol = oplane * od;
+    const int sx = (ow + 15) / 16, gy = (oh + NY - 1) / NY;
+    const long long tasks = (long long)p.n * od * gy * sx;
+    const nr_wbuf WP = nr_make_wbuf(p.wpack, sizeof(float) * 27 * NQ * MT * 64);
+    for (long long s = (long long)blockIdx.x * kC3Waves + wave; s < tasks; s += (long long)gridDim.x * kC3Waves) {
+        const int xs = (int)(s % sx);
+        long long t = s / sx;
+        const int y0 = NY * (int)(t % gy);
+        t /= gy;
+        const int z = (int)(t % od), img = (int)(t / od);
+        const int x = xs * 16 + c;                                        // output column
+        // input columns: S = 1: centre xi, edge = the voxel just outside the strip (lanes 0 / 15); S = 2: the pair (xi, xi + 1), edge = xi - 1 (lane 0)
+        const int xi = S * x;
+        const int xe = S == 1 ? (c == 0 ? xi - 1 : (c == 15 ? xi + 1 : -1)) : (c == 0 ? xi - 1 : -1);
+        const nr_mbuf X = nr_make_mbuf(p.x + (size_t)img * CIN * vol, sizeof(float) * CIN * (size_t)vol);
+        v4f acc[NY][MT];
+        NR_PRAGMA_UNROLL
+        for (int oy = 0; oy < NY; ++oy)
+            NR_PRAGMA_UNROLL
+            for (int mt = 0; mt < MT; ++mt) { acc[oy][mt][0] = 0.0f; acc[oy][mt][1] = 0.0f; acc[oy][mt][2] = 0.0f; acc[oy][mt][3] = 0.0f; }
+        for (int dz = 0; dz < 3; ++dz) {
+            const int zz = S * z + dz - 1;
+            if (zz < 0 || zz >= p.d) continue;                           // wave-uniform: the plane lies in the zero padding
+#pragma unroll 1
+            for (int q = 0; q < NQ; ++q) {
+                const long long chan = ((long long)(4 * q + g) * p.d + zz) * plane;
+                float b0[NR], b1[NR], b2[NR];                            // the dx = 0 / 1 / 2 operands of input row r
+                NR_PRAGMA_UNROLL
+                for (int r = 0; r < NR; ++r) {
+                    const int yy = S * y0 + r - 1;
+                    const bool ok = yy >= 0 && yy < p.h;                 // uniform
+                    const long long row = chan + (long long)yy * p.w;
+                    const int voc = (ok && xi < p.w) ? (int)((row + xi) * 4) : 0x7ffffff0;          // (past the buffer's range: reads 0)
+                    const int voe = (ok && xe >= 0 && xe < p.w) ? (int)((row + xe) * 4) : 0x7ffffff0;
+                    const float ctr = nr_buf_ld1(X, voc, 0), be = nr_buf_ld1(X, voe, 0);
+                    if constexpr (S == 1) {
+                        b1[r] = ctr;
+                        b0[r] = nr_row_from_left(ctr, be);
+                        b2[r] = nr_row_from_right(ctr, be);
+                    } else {
+                        const int voo = (ok && xi + 1 < p.w) ? (int)((row + xi + 1) * 4) : 0x7ffffff0;
+                        const float odd = nr_buf_ld1(X, voo, 0);
+                        b1[r] = ctr;
+                        b2[r] = odd;
+                        b0[r] = nr_row_from_left(odd, be);
+                    }
+                }
+                const int wbase = ((dz * NQ + q) * 9) * MT * 64 + lane;
+                NR_PRAGMA_UNROLL
+                for (int dy = 0; dy < 3; ++dy)
+                    NR_PRAGMA_UNROLL
+                    for (int dx = 0; dx < 3; ++dx) {
+                        float a[MT];
+                        NR_PRAGMA_UNROLL
+                        for (int mt = 0; mt < MT; ++mt) a[mt] = nr_buf_ld1(WP, (wbase + ((dy * 3 + dx) * MT + mt) * 64) * 4, 0);
+                        NR_PRAGMA_UNROLL
+                        for (int oy = 0; oy < NY; ++oy) {
+                            const float b = dx == 0 ? b0[S * oy + dy] : (dx == 1 ? b1[S * oy + dy] : b2[S * oy + dy]);
+                            NR_PRAGMA_UNROLL
+                            for (int mt = 0; mt < MT; ++mt) acc[oy][mt] = nr_mfma16(a[mt], b, acc[oy][mt]);
+                        }
+                    }
+            }
+        }
+        // D layout: lane (column c, group g), register r of tile mt = output channel 16 mt + 4 g + r of output voxel x0 + c
+        if (x < ow) {
+            NR_PRAGMA_UNROLL
+            for (int mt = 0; mt < MT; ++mt) {
+                const float4 b4 = ld4(p.bias + 16 * mt + 4 * g);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                NR_PRAGMA_UNROLL
+                for (int oy = 0; oy < NY; ++oy) {
+                    const int y = y0 + oy;
+                    if (y >= oh) continue;
+                    float* o = p.out + ((long long)img * COUT + 16 * mt + 4 * g) * ovol + (long long)z * oplane + (long long)y * ow + x;
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[oy][mt][r] + bb[r];
+                        o[r * ovol] = v > 0.0f ? v : v * p.slope;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Frozen activated batch norm of MVSNet (inplace_abn.ABN in evaluation mode: network/mvsnet/modules.py:7-23 `self.bn(self.conv(x))`,
 // mvsnet.py:7-69): y = leaky_relu(x * scale[c] + shift[c]) with scale = gamma / sqrt(var + eps), shift = beta - mean * scale, IN PLACE on the
 // convolution's output [n][c][inner] (inner = h w or d h w) - one read and one write per element where batch_norm + leaky_relu are two of

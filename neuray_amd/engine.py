@@ -239,6 +239,16 @@ class RenderEngine:
                                                            skip.data_ptr() if skip is not None else None, n, d, h, w, out.data_ptr(), self._stream()))
         return out
 
+    def conv3d_bn_leaky(self, x, wpack, bias, slope, cout, stride):
+        """leaky_relu(batch_norm(Conv3d(C_in, cout, 3, stride, padding=1)(x))) with the frozen batch norm folded (neuray_conv3d_bn_leaky):
+        x [n,C_in,d,h,w] -> [n,cout,(d-1)//stride+1,(h-1)//stride+1,(w-1)//stride+1]"""
+        n, c, d, h, w = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32 and bias.numel() == cout
+        out = self.empty(n, cout, (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1)
+        self._check(self.lib.neuray_conv3d_bn_leaky(x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), float(slope), n, c, cout, int(stride), d, h, w,
+                                                    out.data_ptr(), self._stream()))
+        return out
+
     def scale_shift_leaky_(self, x, scale, shift, slope):
         """x [n,c,...] contiguous fp32 <- leaky_relu(x * scale[c] + shift[c], slope), in place (neuray_scale_shift_leaky: MVSNet's frozen
         activated batch norm as one pass)"""

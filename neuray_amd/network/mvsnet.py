@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 
 FUSED_ABN = True          # False: always compose the PyTorch ops (A/B timing, tests)
+FAST_CONV3D = True        # False: conv1 ... conv4 of the cost regularisation through their modules (A/B timing)
 
 
 class ActivatedBatchNorm(nn.Module):
@@ -92,7 +93,8 @@ class FeatureNet(nn.Module):
 
 class CostRegNet(nn.Module):
     """mvsnet.py:29-69.  Inside CostVolumeInitNet the network is frozen and evaluated under no_grad (init_net.py:121-160), so its two
-    layers that MIOpen runs far off any roofline go through hand-written kernels (csrc/nr_kernels_conv3d.h): `conv0` (32 -> 8 channels
+    layers that MIOpen runs far off any roofline go through hand-written kernels (csrc/nr_kernels_conv3d.h; round 5: also the encoder half's
+    interior layers conv1 ... conv4 and the last decoder step conv11): `conv0` (32 -> 8 channels
     on the full-resolution variance volume: 68 % of the U-Net's MACs, 23 of its 37 ms through MIOpen on 8 x 64 x 160 x 160) as an
     implicit GEMM on the fp32 MFMA with the frozen batch norm folded into weights and bias, and `prob` (8 -> 1, memory bound: 6.2 ms
     through MIOpen).  Everything else, and every call that needs gradients or runs in training mode, takes the module path."""
@@ -106,9 +108,34 @@ class CostRegNet(nn.Module):
         self.conv7, self.conv9, self.conv11 = _up3(64, 32), _up3(32, 16), _up3(16, 8)
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
 
+    _MFMA_LAYERS = {(8, 16, 2), (16, 16, 1), (16, 32, 2), (32, 32, 1)}          # (C_in, C_out, stride) built in csrc/nr_kernels_conv3d.h conv3d_kernel
+
+    def _mfma(self, layer, x, fast):
+        """an interior layer of the encoder half (conv1 ... conv4): the MFMA kernel with the frozen batch norm folded when `fast`, else the module.
+        (conv5 / conv6 work on 8 x 25 x 25 volumes - a couple of hundred wave tasks - where the library's kernel is the faster one.)"""
+        conv, bn = layer.conv, layer.bn
+        key = (conv.in_channels, conv.out_channels, conv.stride[0])
+        if not (fast and FAST_CONV3D and key in self._MFMA_LAYERS and x.shape[1] * x.shape[2] * x.shape[3] * x.shape[4] * 4 < 0x7fffff00):
+            return layer(x)
+        src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(x.device),)
+        hit = layer.__dict__.get('_mfma_pack')
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                w = (conv.weight * scale[:, None, None, None, None]).float()                      # [C_out, C_in, dz, dy, dx]
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                lane = torch.arange(64, device=w.device)
+                co = 16 * torch.arange(w.shape[0] // 16, device=w.device)[:, None] + (lane & 15)[None]     # [MT, 64]
+                ci = 4 * torch.arange(w.shape[1] // 4, device=w.device)[:, None] + (lane >> 4)[None]       # [NQ, 64]
+                # per-lane MFMA A operands (csrc/nr_kernels_conv3d.h Conv3dParams.wpack): [dz][q][dy][dx][mt][lane]
+                pack = w[co[None], ci[:, None]].permute(3, 0, 4, 5, 1, 2).contiguous()
+            hit = layer.__dict__['_mfma_pack'] = (stamp, pack.to(x.device), shift.to(x.device))
+        return self._engine(x).conv3d_bn_leaky(x.contiguous(), hit[1], hit[2], bn.slope, key[1], key[2])
+
     def _tail(self, c0, fast=False):
-        c2 = self.conv2(self.conv1(c0))
-        c4 = self.conv4(self.conv3(c2))
+        c2 = self._mfma(self.conv2, self._mfma(self.conv1, c0, fast), fast)
+        c4 = self._mfma(self.conv4, self._mfma(self.conv3, c2, fast), fast)
         x = c4 + self.conv7(self.conv6(self.conv5(c4)))
         x = c2 + self.conv9(x)
         if fast:        # c0 + conv11(x): transposed convolution, frozen batch norm, leaky ReLU and the skip add in one kernel
@@ -129,7 +156,8 @@ class CostRegNet(nn.Module):
         # (one image's 32-channel volume must stay below 2^31 bytes for conv0's buffer descriptor: larger ones take the module path)
         # under autograd the kernels (no backward) run only when nothing they replace wants a gradient: the input and every parameter of
         # conv0 / conv11 / prob (the reference freezes MVSNet; a user who unfreezes any of them gets the module path and its gradients)
-        fused = (*self.conv0.parameters(), *self.conv11.parameters(), *self.prob.parameters())
+        fused = (*self.conv0.parameters(), *self.conv11.parameters(), *self.prob.parameters(), *self.conv1.parameters(), *self.conv2.parameters(),
+                 *self.conv3.parameters(), *self.conv4.parameters())
         return (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in fused)))
                 and x.dtype == torch.float32 and x.dim() == 5 and x.shape[2] * x.shape[3] * x.shape[4] * 128 < 0x7fffff00
                 and self._engine(x) is not None)

@@ -173,3 +173,20 @@ def test_fused_activated_batch_norm_matches_batch_norm_plus_leaky_relu(dev, shap
         want2 = abn(x.clone())
         mvsnet.FUSED_ABN = True
         assert float((abn(x.clone()) - want2).abs().max()) <= 2e-6 * max(1.0, float(want2.abs().max()))
+
+
+@pytest.mark.parametrize('layer,shape', [('conv2', (2, 5, 9, 21)), ('conv4', (1, 3, 6, 16)), ('conv1', (2, 6, 11, 37)), ('conv1', (1, 5, 8, 32)),
+                                         ('conv3', (1, 4, 7, 19)), ('conv3', (2, 3, 10, 34))])
+def test_interior_layers_match_conv3d_bn_leaky(dev, layer, shape):
+    """neuray_conv3d_bn_leaky (conv1 ... conv4: stride 1 and 2, frozen batch norm folded, leaky ReLU) against the module: odd and even
+    sizes, sizes that are not multiples of the 16-voxel strip / the 4-row group, every face of the zero padding"""
+    n, d, h, w = shape
+    net = make_net(dev)
+    mod = getattr(net, layer)
+    x = torch.randn(n, mod.conv.in_channels, d, h, w, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        want = mod(x)
+        got = net._mfma(mod, x, True)
+    assert got.shape == want.shape and got.data_ptr() != want.data_ptr()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert net._mfma(net.conv6, torch.zeros(1, 64, 2, 3, 3, device=dev), True).shape == (1, 64, 2, 3, 3)      # (not built: the module)

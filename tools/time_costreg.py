@@ -75,6 +75,19 @@ def main():
                 mvsnet.FUSED_ABN = False
                 res['abn_pytorch_ms'] = timeit(lambda: bn(y))
                 mvsnet.FUSED_ABN = True
+            if getattr(eng.lib, 'neuray_conv3d_bn_leaky', None) is not None and getattr(eng.lib.neuray_conv3d_bn_leaky, 'argtypes', None):
+                # the stride-1 interior layers at their shapes inside the U-Net of this volume, two reference views per call as the init net runs them
+                for name, (c, dd, hh, ww) in (('conv1', (8, d, h, w)), ('conv2', (16, d // 2, h // 2, w // 2)), ('conv3', (16, d // 2, h // 2, w // 2)), ('conv4', (32, d // 4, h // 4, w // 4))):
+                    mod = getattr(net, name)
+                    xin = torch.randn(2, c, dd, hh, ww, device=dev)
+                    mvsnet.FUSED_ABN = False
+                    want = mod(xin)
+                    mvsnet.FUSED_ABN = True
+                    got = net._mfma(mod, xin, True)
+                    res[name + '_err'] = float((got - want).abs().max())
+                    res[name + '_kernel_ms'] = timeit(lambda: net._mfma(mod, xin, True))
+                    res[name + '_module_ms'] = timeit(lambda: mod(xin))
+                    res[name + '_kernel_tflops'] = 2 * got.numel() * c * 27 / res[name + '_kernel_ms'] / 1e9
         print(json.dumps(res), flush=True)
 
 

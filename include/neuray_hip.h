@@ -334,6 +334,11 @@ int neuray_conv3d_c8_c1(const float* x_dev, const float* w27_dev, float bias, in
  *   [n][8][2d][2h][2w] or NULL, out_dev [n][8][2d][2h][2w]. */
 int neuray_convtranspose3d_c16_c8(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, const float* skip_dev,
                                   int n, int d, int h, int w, float* out_dev, void* stream);
+/* neuray_convtranspose3d_bn_leaky: the same kernel for (C_in, C_out) = (16, 8) (conv11, as above) and (32, 16) (conv9: `c2 + conv9(x)`, one level
+ *   down the decoder; mvsnet.py:57-69); other shapes return an error.  x_dev [n][C_in][d][h][w], wpack_dev [3 kz][3 ky][C_in][C_out][3 kx] (batch
+ *   norm folded), bias_dev [C_out], skip_dev / out_dev [n][C_out][2d][2h][2w].  ABI 9. */
+int neuray_convtranspose3d_bn_leaky(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, const float* skip_dev,
+                                    int n, int cin, int cout, int d, int h, int w, float* out_dev, void* stream);
 
 /* neuray_conv3d_bn_leaky: the interior layers of the cost regularisation's encoder half, leaky_relu(batch_norm(Conv3d(C_in, C_out, 3, stride,
  *   padding=1, bias=False)(x)), slope) with the frozen batch norm folded - conv1 (8 -> 16, stride 2), conv2 (16 -> 16), conv3 (16 -> 32, stride 2),

@@ -332,16 +332,23 @@ int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* 
     return check_launch("neuray_conv3d_c32_c8");
 }
 
-int neuray_convtranspose3d_c16_c8(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int d, int h, int w,
-                                  float* out, void* stream) {
-    if (!x || !wpack || !bias || !out) return fail("neuray_convtranspose3d_c16_c8: null pointer");
+int neuray_convtranspose3d_bn_leaky(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int cin, int cout,
+                                    int d, int h, int w, float* out, void* stream) {
+    if (!x || !wpack || !bias || !out) return fail("neuray_convtranspose3d_bn_leaky: null pointer");
     const long long groups = (long long)(((long long)h * w + 255) / 256) * d * n;      // one thread per input voxel = 2 x 2 x 2 output block
     if (n < 1 || d < 1 || h < 1 || w < 1 || groups > 0x7fffffffLL)
-        return fail("neuray_convtranspose3d_c16_c8: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
+        return fail("neuray_convtranspose3d_bn_leaky: bad shape n=%d d=%d h=%d w=%d", n, d, h, w);
     nr::Up11Params p;
     p.x = x; p.wpack = wpack; p.bias = bias; p.skip = skip; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
-    NR_LAUNCH(nr::costreg_up11_kernel, dim3((unsigned)groups, 8 / nr::kUp11Co), dim3(256), 0, stream, p);
-    return check_launch("neuray_convtranspose3d_c16_c8");
+    if (cin == 16 && cout == 8) NR_LAUNCH((nr::costreg_up11_kernel<16, 8>), dim3((unsigned)groups, 8 / nr::kUp11Co), dim3(256), 0, stream, p);
+    else if (cin == 32 && cout == 16) NR_LAUNCH((nr::costreg_up11_kernel<32, 16>), dim3((unsigned)groups, 16 / nr::kUp11Co), dim3(256), 0, stream, p);
+    else return fail("neuray_convtranspose3d_bn_leaky: (C_in, C_out) = (%d, %d) is not built (16 -> 8, 32 -> 16)", cin, cout);
+    return check_launch("neuray_convtranspose3d_bn_leaky");
+}
+
+int neuray_convtranspose3d_c16_c8(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int d, int h, int w,
+                                  float* out, void* stream) {
+    return neuray_convtranspose3d_bn_leaky(x, wpack, bias, slope, skip, n, 16, 8, d, h, w, out, stream);
 }
 
 int neuray_conv3d_c8_c1(const float* x, const float* w27, float bias, int n, int d, int h, int w, float* out, void* stream) {

@@ -202,12 +202,12 @@ __global__ void __launch_bounds__(256) costreg_prob_kernel(ProbParams p) {
 // side and read every input row up to four times).  Threads are laid end to end over a plane's (iy, j), so a wave's loads are 64
 // consecutive floats of each of the 2 x 2 (z, y) neighbours; the weights are uniform per instruction: 16-byte LDS broadcasts (as
 // scalar operands, 216 per input channel against ~100 scalar registers, hipcc spilled them to VGPR lanes inside the loop).
-struct Up11Params {
-    const float* x;        // [n][16][d][h][w]
-    const float* wpack;    // [3 kz][3 ky][16 ci][8 co][3 kx], batch norm folded
-    const float* bias;     // [8]
-    const float* skip;     // [n][8][2d][2h][2w] or null
-    float* out;            // [n][8][2d][2h][2w]
+struct Up11Params {         // (C_in, C_out) = (16, 8): conv11, or (32, 16): conv9 (the same kernel one level down, round 5)
+    const float* x;        // [n][C_in][d][h][w]
+    const float* wpack;    // [3 kz][3 ky][C_in ci][C_out co][3 kx], batch norm folded
+    const float* bias;     // [C_out]
+    const float* skip;     // [n][C_out][2d][2h][2w] or null
+    float* out;            // [n][C_out][2d][2h][2w]
     int n, d, h, w;
     float slope;
 };
@@ -241,9 +241,11 @@ __device__ __forceinline__ void up11_tap(const float* w, const float (&v)[2][2][
 #ifndef NR_UP11_MINW
 #define NR_UP11_MINW 4
 #endif
+template <int CIN, int COUT>
 __global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Params p) {
-    __shared__ __attribute__((aligned(16))) float wl[9 * 16 * 24];            // the folded weights, 13.5 KB: 54 B per thread of a workgroup whose
-    for (int i = threadIdx.x; i < 9 * 16 * 24 / 4; i += blockDim.x)           // threads each spend them on 3456 multiply-adds
+    constexpr int WB = COUT * 3;           // weights of one (tap pair, input channel): [co][kx]
+    __shared__ __attribute__((aligned(16))) float wl[9 * CIN * WB];           // the folded weights (13.5 KB at 16 -> 8, 54 KB at 32 -> 16): 54 B per
+    for (int i = threadIdx.x; i < 9 * CIN * WB / 4; i += blockDim.x)          // thread of a workgroup whose threads each spend them on 1728 multiply-adds
         reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(p.wpack)[i];
     __syncthreads();
     const int plane = p.h * p.w, chunks = (plane + (int)blockDim.x - 1) / (int)blockDim.x;
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Par
             for (int c = 0; c < 2; ++c)
                 NR_PRAGMA_UNROLL
                 for (int co = 0; co < kUp11Co; ++co) acc[a][b_][c][co] = 0.0f;
-    const float* xi = p.x + (long long)img * 16 * vol + (long long)iz * plane + pix;
+    const float* xi = p.x + (long long)img * CIN * vol + (long long)iz * plane + pix;
     const float f01 = fx, f10 = fy, f11 = fy * fx, g00 = fz, g01 = fz * fx, g10 = fz * fy, g11 = fz * fy * fx;
     // the 8 inputs of channel ci + 1 are loaded while channel ci is being spent (one memory round trip ahead): with the loads at the top
     // of their own iteration hipcc holds a tap's weights in registers until the value they multiply arrives - 230 VGPRs
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Par
     };
     issue(0);
 #pragma unroll 1
-    for (int ci = 0; ci < 16; ++ci) {
+    for (int ci = 0; ci < CIN; ++ci) {
         float v[2][2][2];
         v[0][0][0] = raw[0];        v[0][0][1] = raw[1] * f01;
         v[0][1][0] = raw[2] * f10;  v[0][1][1] = raw[3] * f11;
@@ -290,15 +292,16 @@ __global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Par
         v[1][1][0] = raw[6] * g10;  v[1][1][1] = raw[7] * g11;
         NR_PRAGMA_UNROLL
         for (int i = 0; i < 8; ++i) NR_KEEP(v[i >> 2][(i >> 1) & 1][i & 1]);
-        issue(ci + 1 < 16 ? ci + 1 : 15);
-        const float* wk = wl + ci * 24 + 3 * cog;                                   // + (kz * 3 + ky) * 384
+        issue(ci + 1 < CIN ? ci + 1 : CIN - 1);
+        const float* wk = wl + ci * WB + 3 * cog;                                   // + (kz * 3 + ky) * CIN * WB
+        constexpr int TS = CIN * WB;
         // (sched barriers: left alone the scheduler issues all 54 weight reads of the channel up front - 216 registers)
-        up11_tap<0, 0>(wk + 0 * 384, v, acc); NR_PIN(); up11_tap<0, 1>(wk + 1 * 384, v, acc); NR_PIN(); up11_tap<0, 2>(wk + 2 * 384, v, acc); NR_PIN();
-        up11_tap<1, 0>(wk + 3 * 384, v, acc); NR_PIN(); up11_tap<1, 1>(wk + 4 * 384, v, acc); NR_PIN(); up11_tap<1, 2>(wk + 5 * 384, v, acc); NR_PIN();
-        up11_tap<2, 0>(wk + 6 * 384, v, acc); NR_PIN(); up11_tap<2, 1>(wk + 7 * 384, v, acc); NR_PIN(); up11_tap<2, 2>(wk + 8 * 384, v, acc); NR_PIN();
+        up11_tap<0, 0>(wk + 0 * TS, v, acc); NR_PIN(); up11_tap<0, 1>(wk + 1 * TS, v, acc); NR_PIN(); up11_tap<0, 2>(wk + 2 * TS, v, acc); NR_PIN();
+        up11_tap<1, 0>(wk + 3 * TS, v, acc); NR_PIN(); up11_tap<1, 1>(wk + 4 * TS, v, acc); NR_PIN(); up11_tap<1, 2>(wk + 5 * TS, v, acc); NR_PIN();
+        up11_tap<2, 0>(wk + 6 * TS, v, acc); NR_PIN(); up11_tap<2, 1>(wk + 7 * TS, v, acc); NR_PIN(); up11_tap<2, 2>(wk + 8 * TS, v, acc); NR_PIN();
     }
     const long long orow = 2 * p.w, oplane = 4 * (long long)plane, ovol = 8 * vol;
-    const long long o000 = (long long)img * 8 * ovol + (long long)(2 * iz) * oplane + (long long)(2 * iy) * orow + 2 * j;
+    const long long o000 = (long long)img * COUT * ovol + (long long)(2 * iz) * oplane + (long long)(2 * iy) * orow + 2 * j;
     NR_PRAGMA_UNROLL
     for (int co_ = 0; co_ < kUp11Co; ++co_) {
         const int co = cog + co_;

@@ -229,6 +229,19 @@ class RenderEngine:
                                                   out.data_ptr(), self._stream()))
         return out
 
+    def convtranspose3d_bn_leaky(self, x, wpack, bias, slope, skip):
+        """skip + leaky_relu(batch_norm(ConvTranspose3d(C_in, C_out, 3, stride 2, padding 1, output_padding 1)(x))) with the frozen batch norm
+        folded (neuray_convtranspose3d_bn_leaky: conv11 16 -> 8, conv9 32 -> 16): x [n,C_in,d,h,w] -> [n,C_out,2d,2h,2w]"""
+        n, c, d, h, w = x.shape
+        cout = bias.numel()
+        assert x.is_contiguous() and x.dtype == torch.float32
+        assert skip is None or (tuple(skip.shape) == (n, cout, 2 * d, 2 * h, 2 * w) and skip.is_contiguous() and skip.dtype == torch.float32)
+        out = self.empty(n, cout, 2 * d, 2 * h, 2 * w)
+        self._check(self.lib.neuray_convtranspose3d_bn_leaky(x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), float(slope),
+                                                             skip.data_ptr() if skip is not None else None, n, c, cout, d, h, w, out.data_ptr(),
+                                                             self._stream()))
+        return out
+
     def costreg_up11(self, x, wpack, bias, slope, skip):
         """MVSNet CostRegNet: skip + conv11(x) with the frozen batch norm folded (neuray_convtranspose3d_c16_c8): x [n,16,d,h,w] -> [n,8,2d,2h,2w]"""
         n, c, d, h, w = x.shape

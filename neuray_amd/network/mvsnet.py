@@ -133,11 +133,28 @@ class CostRegNet(nn.Module):
             hit = layer.__dict__['_mfma_pack'] = (stamp, pack.to(x.device), shift.to(x.device))
         return self._engine(x).conv3d_bn_leaky(x.contiguous(), hit[1], hit[2], bn.slope, key[1], key[2])
 
+    def _up(self, layer, x, skip, fast):
+        """skip + a decoder step (conv9: 32 -> 16; conv11 goes through _packs / costreg_up11): transposed convolution + frozen batch norm + leaky
+        ReLU + the skip add in one kernel when `fast`, else the modules"""
+        up, bn = layer[0], layer[1]
+        if not (fast and FAST_CONV3D and (up.in_channels, up.out_channels) == (32, 16)):
+            return skip + layer(x)
+        src = (up.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(x.device),)
+        hit = layer.__dict__.get('_up_pack')
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():       # ConvTranspose3d weight [C_in, C_out, kz, ky, kx] with the batch norm folded -> [kz][ky][ci][co][kx]
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                pack = (up.weight * scale[None, :, None, None, None]).float().permute(2, 3, 0, 1, 4).contiguous()
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+            hit = layer.__dict__['_up_pack'] = (stamp, pack.to(x.device), shift.to(x.device))
+        return self._engine(x).convtranspose3d_bn_leaky(x.contiguous(), hit[1], hit[2], bn.slope, skip.contiguous())
+
     def _tail(self, c0, fast=False):
         c2 = self._mfma(self.conv2, self._mfma(self.conv1, c0, fast), fast)
         c4 = self._mfma(self.conv4, self._mfma(self.conv3, c2, fast), fast)
         x = c4 + self.conv7(self.conv6(self.conv5(c4)))
-        x = c2 + self.conv9(x)
+        x = self._up(self.conv9, x, c2, fast)
         if fast:        # c0 + conv11(x): transposed convolution, frozen batch norm, leaky ReLU and the skip add in one kernel
             pack, shift, slope = self._packs(c0.device)[5:8]
             return self._engine(c0).costreg_up11(x.contiguous(), pack, shift, slope, c0.contiguous())
@@ -157,7 +174,7 @@ class CostRegNet(nn.Module):
         # under autograd the kernels (no backward) run only when nothing they replace wants a gradient: the input and every parameter of
         # conv0 / conv11 / prob (the reference freezes MVSNet; a user who unfreezes any of them gets the module path and its gradients)
         fused = (*self.conv0.parameters(), *self.conv11.parameters(), *self.prob.parameters(), *self.conv1.parameters(), *self.conv2.parameters(),
-                 *self.conv3.parameters(), *self.conv4.parameters())
+                 *self.conv3.parameters(), *self.conv4.parameters(), *self.conv9.parameters())
         return (not self.training and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in fused)))
                 and x.dtype == torch.float32 and x.dim() == 5 and x.shape[2] * x.shape[3] * x.shape[4] * 128 < 0x7fffff00
                 and self._engine(x) is not None)

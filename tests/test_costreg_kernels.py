@@ -190,3 +190,18 @@ def test_interior_layers_match_conv3d_bn_leaky(dev, layer, shape):
     assert got.shape == want.shape and got.data_ptr() != want.data_ptr()
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
     assert net._mfma(net.conv6, torch.zeros(1, 64, 2, 3, 3, device=dev), True).shape == (1, 64, 2, 3, 3)      # (not built: the module)
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 5, 9), (2, 2, 6, 20)])
+def test_conv9_decoder_step_matches_the_modules(dev, shape):
+    """neuray_convtranspose3d_bn_leaky at (32 -> 16): c2 + conv9(x) (transposed convolution + frozen batch norm + leaky ReLU + skip) against
+    the modules, odd and even sizes"""
+    n, d, h, w = shape
+    net = make_net(dev)
+    x = torch.randn(n, 32, d, h, w, generator=torch.Generator().manual_seed(3)).to(dev)
+    c2 = torch.randn(n, 16, 2 * d, 2 * h, 2 * w, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        want = c2 + net.conv9(x)
+        got = net._up(net.conv9, x, c2, True)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))

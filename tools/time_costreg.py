@@ -88,6 +88,15 @@ def main():
                     res[name + '_kernel_ms'] = timeit(lambda: net._mfma(mod, xin, True))
                     res[name + '_module_ms'] = timeit(lambda: mod(xin))
                     res[name + '_kernel_tflops'] = 2 * got.numel() * c * 27 / res[name + '_kernel_ms'] / 1e9
+            if getattr(eng.lib, 'neuray_convtranspose3d_bn_leaky', None) is not None and getattr(eng.lib.neuray_convtranspose3d_bn_leaky, 'argtypes', None):
+                x9 = torch.randn(2, 32, d // 4, h // 4, w // 4, device=dev)
+                c2 = torch.randn(2, 16, d // 2, h // 2, w // 2, device=dev)
+                mvsnet.FUSED_ABN = False
+                want = c2 + net.conv9(x9)
+                mvsnet.FUSED_ABN = True
+                res['conv9_err'] = float((net._up(net.conv9, x9, c2, True) - want).abs().max())
+                res['conv9_kernel_ms'] = timeit(lambda: net._up(net.conv9, x9, c2, True))
+                res['conv9_module_ms'] = timeit(lambda: c2 + net.conv9(x9))
         print(json.dumps(res), flush=True)
 
 

@@ -85,10 +85,48 @@ class FeatureNet(nn.Module):
         self.conv5, self.conv6 = _c2(16, 32, 5, 2, 2), _c2(32, 32)
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
 
+    def _mfma2d(self, conv, bn, x):
+        """a 3 x 3, stride-1 layer with 16 or 32 channels in and out (conv3 / conv4 / conv6 with their frozen batch norm + leaky ReLU; `feature`:
+        bias only) through the 3-D implicit-GEMM kernel on a one-plane volume: with D = 1 the kernel's dz = 0 / 2 taps lie in the zero padding
+        and are skipped, so the [dz = 1] slice of its weight pack IS the 2-D convolution (neuray_conv3d_bn_leaky, csrc/nr_kernels_conv3d.h)."""
+        src = (conv.weight,) + ((conv.bias,) if bn is None else (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(x.device),)
+        hit = conv.__dict__.get('_mfma_pack')
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                if bn is None:
+                    w, shift = conv.weight.float(), conv.bias.float().contiguous()
+                else:
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    w = (conv.weight * scale[:, None, None, None]).float()                        # [C_out, C_in, dy, dx]
+                    shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                lane = torch.arange(64, device=w.device)
+                co = 16 * torch.arange(w.shape[0] // 16, device=w.device)[:, None] + (lane & 15)[None]     # [MT, 64]
+                ci = 4 * torch.arange(w.shape[1] // 4, device=w.device)[:, None] + (lane >> 4)[None]       # [NQ, 64]
+                plane = w[co[None], ci[:, None]].permute(0, 3, 4, 1, 2)                             # [q][dy][dx][mt][lane]
+                pack = torch.zeros((3,) + tuple(plane.shape), device=w.device)
+                pack[1] = plane
+            hit = conv.__dict__['_mfma_pack'] = (stamp, pack.contiguous().to(x.device), shift.to(x.device))
+        from . import render_ops
+        y = render_ops.engine_for(x.device).conv3d_bn_leaky(x.contiguous()[:, :, None], hit[1], hit[2], 1.0 if bn is None else bn.slope,
+                                                            conv.out_channels, 1)
+        return y[:, :, 0]
+
+    def _fast(self, x):
+        from . import render_ops
+        return (FAST_CONV3D and not self.training and not torch.is_grad_enabled() and x.dtype == torch.float32
+                and (x.device.type == 'cuda' or render_ops._TEST_LIB is not None))
+
     def forward(self, x):
         x = self.conv1(self.conv0(x))
-        x = self.conv4(self.conv3(self.conv2(x)))
-        return self.feature(self.conv6(self.conv5(x)))
+        if not self._fast(x):
+            x = self.conv4(self.conv3(self.conv2(x)))
+            return self.feature(self.conv6(self.conv5(x)))
+        # frozen, no gradients (how the cost-volume init net runs it): the stride-1 layers with 16 / 32 channels on the MFMA kernel
+        x = self.conv2(x)
+        x = self._mfma2d(self.conv4.conv, self.conv4.bn, self._mfma2d(self.conv3.conv, self.conv3.bn, x))
+        x = self._mfma2d(self.conv6.conv, self.conv6.bn, self.conv5(x))
+        return self._mfma2d(self.feature, None, x)
 
 
 class CostRegNet(nn.Module):

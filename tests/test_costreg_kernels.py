@@ -205,3 +205,31 @@ def test_conv9_decoder_step_matches_the_modules(dev, shape):
         got = net._up(net.conv9, x, c2, True)
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_feature_net_mfma_layers_match_the_modules(dev):
+    """FeatureNet (mvsnet.py:7-30) with its 16 / 32-channel 3 x 3 layers on the implicit-GEMM kernel (a one-plane volume through
+    neuray_conv3d_bn_leaky) against the module path: odd sizes, batch of 3"""
+    torch.manual_seed(5)
+    net = mvsnet.FeatureNet().eval()
+    with torch.no_grad():
+        for name, buf in net.named_buffers():
+            if name.endswith('running_mean'):
+                buf.copy_(torch.randn(buf.shape) * 0.1)
+            elif name.endswith('running_var'):
+                buf.copy_(torch.rand(buf.shape) * 0.5 + 0.75)
+        for name, prm in net.named_parameters():
+            if name.endswith('bn.weight'):
+                prm.copy_(torch.rand(prm.shape) * 0.5 + 0.75)
+            elif name.endswith('bn.bias'):
+                prm.copy_(torch.randn(prm.shape) * 0.1)
+    net = net.to(dev)
+    x = torch.randn(3, 3, 44, 68, generator=torch.Generator().manual_seed(6)).to(dev)
+    with torch.no_grad():
+        mvsnet.FAST_CONV3D = False
+        want = net(x)
+        mvsnet.FAST_CONV3D = True
+        got = net(x)
+        assert net._fast(x)
+    assert got.shape == want.shape == (3, 32, 11, 17)
+    assert float((got - want).abs().max()) <= 3e-5 * max(1.0, float(want.abs().max()))

@@ -82,7 +82,7 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         are queued it waits for next to nothing; taken where the per-ray path first needs it, it drained 25 ms of queued convolutions per
         training step and left the GPU idle behind them (profiles/r04_n_gen_host_profile.txt: 8.6 ms per step).  Cached in the dict."""
         coords = que_imgs_info.get('coords')
-        if coords is not None and coords.shape[0] == 1 and 'Ks' in que_imgs_info:
+        if coords is not None and coords.is_cuda and coords.shape[0] == 1 and 'Ks' in que_imgs_info:
             self._query(self.engine(coords.device), que_imgs_info)
 
     def render(self, que_imgs_info, ref_imgs_info, is_train):
@@ -226,6 +226,11 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
             self.__dict__['_neuray_after_fine_draw'] = lambda: self._prefetch_depth_coords(h * w)
         try:
             outputs = self.render_call(que_imgs_info, ref_imgs_info, is_train, src_imgs_info)
+        except BaseException:
+            slot = self.__dict__.pop('_depth_coords_slot', None)       # a permutation drawn for a step that failed is not kept for the next one
+            if slot is not None:
+                slot['thread'].join()
+            raise
         finally:
             self.__dict__.pop('_neuray_after_fine_draw', None)
         if depth_readout:

@@ -21,6 +21,10 @@ FAST_CONV3D = True        # False: conv1 ... conv4 of the cost regularisation th
 
 
 class ActivatedBatchNorm(nn.Module):
+    """inplace_abn.InPlaceABN as the reference instantiates it (network/mvsnet/modules.py:7-23, norm_act = InPlaceABN): batch norm + leaky
+    ReLU(0.01), same parameter / buffer names.  Like that class it may work IN PLACE on its input (the fused evaluation path below does; the
+    composed PyTorch path returns a new tensor): hand it a tensor you do not need afterwards, as `self.bn(self.conv(x))` does."""
+
     def __init__(self, num_features, eps=1e-5, slope=0.01):
         super().__init__()
         self.eps, self.slope = eps, slope

@@ -23,7 +23,8 @@ the reference tree itself does not exist on the GPU box; where it exists, the po
 itself - 0.83 ... 1.02 x on a shared host - with identical pixels: tools/port_vs_reference_cpu.py) on the host - with torch.set_num_threads(physical cores) and,
 on a many-core host, with 16 threads; the faster one is `value` - on a bounded sample of the same workload.  At N = 1 side measurements ride along (reported baselines, not the metric):
 `eager_torch_baseline` (the same port on the same GPU - the stand-in for "the reference on stock PyTorch-ROCm"),
-`numpy_oracle` (parity of the rendered image against the numpy oracle + its speed), `extra` (64+64 samples, the
+`numpy_oracle` (parity of the rendered image against the numpy oracle + its speed; `parity.full_image`, round 5: ALL rays of the image
+against that port on the GPU, the rays it disputes re-rendered by the numpy oracle), `extra` (64+64 samples, the
 reference CLI's 4096-ray batches), `training_step`, `init_net`, `pipeline_pcie_inclusive` (host buffers in, uint8 image
 out), `bf16_variant`.  These legs are the only places this
 file touches oracle/.

@@ -342,7 +342,10 @@ int neuray_convtranspose3d_bn_leaky(const float* x_dev, const float* wpack_dev, 
 
 /* neuray_conv3d_bn_leaky: the interior layers of the cost regularisation's encoder half, leaky_relu(batch_norm(Conv3d(C_in, C_out, 3, stride,
  *   padding=1, bias=False)(x)), slope) with the frozen batch norm folded - conv1 (8 -> 16, stride 2), conv2 (16 -> 16), conv3 (16 -> 32, stride 2),
- *   conv4 (32 -> 32) of network/mvsnet/mvsnet.py:29-69 (ConvBnReLU3D, modules.py:16-23); other shapes return an error.  x_dev [n][C_in][d][h][w],
+ *   conv4 (32 -> 32) of network/mvsnet/mvsnet.py:29-69 (ConvBnReLU3D, modules.py:16-23) - and, on one-plane volumes (d = 1: the dz = 0 / 2 taps lie in
+ *   the zero padding), the 3 x 3 stride-1 layers of the 2-D feature net (mvsnet.py:7-30: 3 -> 8, 8 -> 8, 16 -> 16, 32 -> 32).  Built for C_in rounded up
+ *   to a multiple of 4 and C_out to a multiple of 16 in {(4 | 8 | 16, 16, s1), (32, 32, s1), (8, 16, s2), (16, 32, s2)}; wpack_dev / bias_dev are padded
+ *   with zeros to those counts, x_dev / out_dev carry the true ones; other shapes return an error.  x_dev [n][C_in][d][h][w],
  *   wpack_dev [3 dz][C_in / 4 q][3 dy][3 dx][C_out / 16 mt][64 lanes] = per-lane MFMA A operands: lane l (m = l & 15, g = l >> 4) holds
  *   W[16 mt + m][4 q + g][dz][dy][dx] * gamma / sqrt(var + eps) of output channel 16 mt + m; bias_dev [C_out] = beta - mean * gamma / sqrt(var + eps);
  *   out_dev [n][C_out][(d - 1) / stride + 1][(h - 1) / stride + 1][(w - 1) / stride + 1].  ABI 9. */

@@ -369,16 +369,20 @@ int neuray_conv3d_bn_leaky(const float* x, const float* wpack, const float* bias
     if ((long long)cin * d * h * w * 4 >= 0x7fffff00LL) return fail("neuray_conv3d_bn_leaky: one image's input volume must stay below 2^31 bytes");
     if (stride != 1 && stride != 2) return fail("neuray_conv3d_bn_leaky: stride %d", stride);
     nr::Conv3dParams p;
-    p.x = x; p.wpack = wpack; p.bias = bias; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope;
+    p.x = x; p.wpack = wpack; p.bias = bias; p.out = out; p.n = n; p.d = d; p.h = h; p.w = w; p.slope = slope; p.cin = cin; p.cout = cout;
     const int od = (d - 1) / stride + 1, oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
     const long long tasks = (long long)n * od * ((oh + nr::kC3Rows - 1) / nr::kC3Rows) * ((ow + 15) / 16);
     const dim3 grid(grid_for(tasks, nr::kC3Waves, 256 * 16)), block(64 * nr::kC3Waves);
-    if (cin == 16 && cout == 16 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<16, 16, 1>), grid, block, 0, stream, p);
-    else if (cin == 32 && cout == 32 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<32, 32, 1>), grid, block, 0, stream, p);
-    else if (cin == 8 && cout == 16 && stride == 2) NR_LAUNCH((nr::conv3d_kernel<8, 16, 2>), grid, block, 0, stream, p);
-    else if (cin == 16 && cout == 32 && stride == 2) NR_LAUNCH((nr::conv3d_kernel<16, 32, 2>), grid, block, 0, stream, p);
-    else return fail("neuray_conv3d_bn_leaky: (C_in, C_out, stride) = (%d, %d, %d) is not built (8 -> 16 / 16 -> 32 at stride 2, 16 -> 16 / 32 -> 32 at stride 1)",
-                     cin, cout, stride);
+    // the kernel's channel counts: C_in rounded up to a multiple of 4, C_out to a multiple of 16 (wpack / bias are padded with zeros to them)
+    const int ci = (cin + 3) / 4 * 4, co = (cout + 15) / 16 * 16;
+    if (ci == 16 && co == 16 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<16, 16, 1>), grid, block, 0, stream, p);
+    else if (ci == 32 && co == 32 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<32, 32, 1>), grid, block, 0, stream, p);
+    else if (ci == 8 && co == 16 && stride == 2) NR_LAUNCH((nr::conv3d_kernel<8, 16, 2>), grid, block, 0, stream, p);
+    else if (ci == 16 && co == 32 && stride == 2) NR_LAUNCH((nr::conv3d_kernel<16, 32, 2>), grid, block, 0, stream, p);
+    else if (ci == 4 && co == 16 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<4, 16, 1>), grid, block, 0, stream, p);
+    else if (ci == 8 && co == 16 && stride == 1) NR_LAUNCH((nr::conv3d_kernel<8, 16, 1>), grid, block, 0, stream, p);
+    else return fail("neuray_conv3d_bn_leaky: (C_in, C_out, stride) = (%d, %d, %d) is not built (padded to multiples of 4 / 16: 4 | 8 | 16 -> 16 and 32 -> 32 at "
+                     "stride 1, 8 -> 16 and 16 -> 32 at stride 2)", cin, cout, stride);
     return check_launch("neuray_conv3d_bn_leaky");
 }
 

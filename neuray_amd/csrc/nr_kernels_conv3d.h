@@ -337,10 +337,11 @@ __global__ void __launch_bounds__(256, NR_UP11_MINW) costreg_up11_kernel(Up11Par
 struct Conv3dParams {
     const float* x;        // [n][C_in][D][H][W]
     const float* wpack;
-    const float* bias;     // [C_out] (batch norm folded)
+    const float* bias;     // [COUT] (batch norm folded; padded to the kernel's COUT)
     float* out;            // [n][C_out][OD][OH][OW], O* = (* - 1) / S + 1
     int n, d, h, w;        // input volume
     float slope;
+    int cin, cout;         // the tensors' channel counts: <= the kernel's CIN / COUT (a multiple of 4 / 16); the pack carries zeros for the rest
 };
 
 constexpr int kC3Rows = 4, kC3Waves = 4;
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(64 * kC3Waves) conv3d_kernel(Conv3dParams p) {
         // input columns: S = 1: centre xi, edge = the voxel just outside the strip (lanes 0 / 15); S = 2: the pair (xi, xi + 1), edge = xi - 1 (lane 0)
         const int xi = S * x;
         const int xe = S == 1 ? (c == 0 ? xi - 1 : (c == 15 ? xi + 1 : -1)) : (c == 0 ? xi - 1 : -1);
-        const nr_mbuf X = nr_make_mbuf(p.x + (size_t)img * CIN * vol, sizeof(float) * CIN * (size_t)vol);
+        const nr_mbuf X = nr_make_mbuf(p.x + (size_t)img * p.cin * vol, sizeof(float) * p.cin * (size_t)vol);
         v4f acc[NY][MT];
         NR_PRAGMA_UNROLL
         for (int oy = 0; oy < NY; ++oy)
@@ -379,11 +380,12 @@ __global__ void __launch_bounds__(64 * kC3Waves) conv3d_kernel(Conv3dParams p) {
 #pragma unroll 1
             for (int q = 0; q < NQ; ++q) {
                 const long long chan = ((long long)(4 * q + g) * p.d + zz) * plane;
+                const bool chok = 4 * q + g < p.cin;                      // (a padded input channel: reads 0, its weights are 0 as well)
                 float b0[NR], b1[NR], b2[NR];                            // the dx = 0 / 1 / 2 operands of input row r
                 NR_PRAGMA_UNROLL
                 for (int r = 0; r < NR; ++r) {
                     const int yy = S * y0 + r - 1;
-                    const bool ok = yy >= 0 && yy < p.h;                 // uniform
+                    const bool ok = chok && yy >= 0 && yy < p.h;          // (row test: uniform)
                     const long long row = chan + (long long)yy * p.w;
                     const int voc = (ok && xi < p.w) ? (int)((row + xi) * 4) : 0x7ffffff0;          // (past the buffer's range: reads 0)
                     const int voe = (ok && xe >= 0 && xe < p.w) ? (int)((row + xe) * 4) : 0x7ffffff0;
@@ -427,11 +429,11 @@ __global__ void __launch_bounds__(64 * kC3Waves) conv3d_kernel(Conv3dParams p) {
                 for (int oy = 0; oy < NY; ++oy) {
                     const int y = y0 + oy;
                     if (y >= oh) continue;
-                    float* o = p.out + ((long long)img * COUT + 16 * mt + 4 * g) * ovol + (long long)z * oplane + (long long)y * ow + x;
+                    float* o = p.out + ((long long)img * p.cout + 16 * mt + 4 * g) * ovol + (long long)z * oplane + (long long)y * ow + x;
                     NR_PRAGMA_UNROLL
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[oy][mt][r] + bb[r];
-                        o[r * ovol] = v > 0.0f ? v : v * p.slope;
+                        if (16 * mt + 4 * g + r < p.cout) o[r * ovol] = v > 0.0f ? v : v * p.slope;
                     }
                 }
             }

@@ -256,7 +256,7 @@ class RenderEngine:
         """leaky_relu(batch_norm(Conv3d(C_in, cout, 3, stride, padding=1)(x))) with the frozen batch norm folded (neuray_conv3d_bn_leaky):
         x [n,C_in,d,h,w] -> [n,cout,(d-1)//stride+1,(h-1)//stride+1,(w-1)//stride+1]"""
         n, c, d, h, w = x.shape
-        assert x.is_contiguous() and x.dtype == torch.float32 and bias.numel() == cout
+        assert x.is_contiguous() and x.dtype == torch.float32 and bias.numel() == (cout + 15) // 16 * 16        # (pack / bias padded to the kernel's counts)
         out = self.empty(n, cout, (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1)
         self._check(self.lib.neuray_conv3d_bn_leaky(x.data_ptr(), wpack.data_ptr(), bias.data_ptr(), float(slope), n, c, cout, int(stride), d, h, w,
                                                     out.data_ptr(), self._stream()))

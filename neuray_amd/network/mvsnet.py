@@ -81,6 +81,24 @@ def _up3(cin, cout):
                          ActivatedBatchNorm(cout))
 
 
+def _mfma_conv_pack(w, shift):
+    """folded weights w [C_out, C_in, (dz,) dy, dx] + shift [C_out] -> the per-lane MFMA A operands of csrc/nr_kernels_conv3d.h conv3d_kernel
+    ([dz][q][dy][dx][mt][lane], a 2-D kernel in the dz = 1 slice) and the bias, both padded with zeros to C_in % 4 == 0 / C_out % 16 == 0"""
+    if w.dim() == 4:
+        w3 = torch.zeros(w.shape[0], w.shape[1], 3, 3, 3, device=w.device, dtype=w.dtype)
+        w3[:, :, 1] = w
+        w = w3
+    co_p, ci_p = (w.shape[0] + 15) // 16 * 16, (w.shape[1] + 3) // 4 * 4
+    wp = torch.zeros(co_p, ci_p, 3, 3, 3, device=w.device, dtype=torch.float32)
+    wp[:w.shape[0], :w.shape[1]] = w
+    sp = torch.zeros(co_p, device=w.device, dtype=torch.float32)
+    sp[:shift.numel()] = shift
+    lane = torch.arange(64, device=w.device)
+    co = 16 * torch.arange(co_p // 16, device=w.device)[:, None] + (lane & 15)[None]          # [MT, 64]
+    ci = 4 * torch.arange(ci_p // 4, device=w.device)[:, None] + (lane >> 4)[None]            # [NQ, 64]
+    return wp[co[None], ci[:, None]].permute(3, 0, 4, 5, 1, 2).contiguous(), sp
+
+
 class FeatureNet(nn.Module):
     def __init__(self):
         super().__init__()
@@ -90,9 +108,8 @@ class FeatureNet(nn.Module):
         self.feature = nn.Conv2d(32, 32, 3, 1, 1)
 
     def _mfma2d(self, conv, bn, x):
-        """a 3 x 3, stride-1 layer with 16 or 32 channels in and out (conv3 / conv4 / conv6 with their frozen batch norm + leaky ReLU; `feature`:
-        bias only) through the 3-D implicit-GEMM kernel on a one-plane volume: with D = 1 the kernel's dz = 0 / 2 taps lie in the zero padding
-        and are skipped, so the [dz = 1] slice of its weight pack IS the 2-D convolution (neuray_conv3d_bn_leaky, csrc/nr_kernels_conv3d.h)."""
+        """a 3 x 3, stride-1 layer (conv0 / conv1 / conv3 / conv4 / conv6 with their frozen batch norm + leaky ReLU; `feature`: bias only)
+        through the 3-D implicit-GEMM kernel on a one-plane volume: with D = 1 the kernel's dz = 0 / 2 taps lie in the zero padding and are skipped, so the [dz = 1] slice of its weight pack IS the 2-D convolution (neuray_conv3d_bn_leaky, csrc/nr_kernels_conv3d.h)."""
         src = (conv.weight,) + ((conv.bias,) if bn is None else (bn.weight, bn.bias, bn.running_mean, bn.running_var))
         stamp = tuple((t.data_ptr(), t._version) for t in src) + (str(x.device),)
         hit = conv.__dict__.get('_mfma_pack')
@@ -104,13 +121,8 @@ class FeatureNet(nn.Module):
                     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
                     w = (conv.weight * scale[:, None, None, None]).float()                        # [C_out, C_in, dy, dx]
                     shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-                lane = torch.arange(64, device=w.device)
-                co = 16 * torch.arange(w.shape[0] // 16, device=w.device)[:, None] + (lane & 15)[None]     # [MT, 64]
-                ci = 4 * torch.arange(w.shape[1] // 4, device=w.device)[:, None] + (lane >> 4)[None]       # [NQ, 64]
-                plane = w[co[None], ci[:, None]].permute(0, 3, 4, 1, 2)                             # [q][dy][dx][mt][lane]
-                pack = torch.zeros((3,) + tuple(plane.shape), device=w.device)
-                pack[1] = plane
-            hit = conv.__dict__['_mfma_pack'] = (stamp, pack.contiguous().to(x.device), shift.to(x.device))
+                pack, shift = _mfma_conv_pack(w, shift)
+            hit = conv.__dict__['_mfma_pack'] = (stamp, pack.to(x.device), shift.to(x.device))
         from . import render_ops
         y = render_ops.engine_for(x.device).conv3d_bn_leaky(x.contiguous()[:, :, None], hit[1], hit[2], 1.0 if bn is None else bn.slope,
                                                             conv.out_channels, 1)
@@ -122,11 +134,13 @@ class FeatureNet(nn.Module):
                 and (x.device.type == 'cuda' or render_ops._TEST_LIB is not None))
 
     def forward(self, x):
-        x = self.conv1(self.conv0(x))
         if not self._fast(x):
+            x = self.conv1(self.conv0(x))
             x = self.conv4(self.conv3(self.conv2(x)))
             return self.feature(self.conv6(self.conv5(x)))
-        # frozen, no gradients (how the cost-volume init net runs it): the stride-1 layers with 16 / 32 channels on the MFMA kernel
+        # frozen, no gradients (how the cost-volume init net runs it): the 3 x 3 stride-1 layers on the MFMA kernel (the two full-resolution
+        # ones, 3 -> 8 -> 8, were 1.74 of the net's 3.1 ms per 16 x 800 x 800 through the library); the 5 x 5 stride-2 layers stay the library's
+        x = self._mfma2d(self.conv1.conv, self.conv1.bn, self._mfma2d(self.conv0.conv, self.conv0.bn, x))
         x = self.conv2(x)
         x = self._mfma2d(self.conv4.conv, self.conv4.bn, self._mfma2d(self.conv3.conv, self.conv3.bn, x))
         x = self._mfma2d(self.conv6.conv, self.conv6.bn, self.conv5(x))
@@ -167,11 +181,7 @@ class CostRegNet(nn.Module):
                 scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
                 w = (conv.weight * scale[:, None, None, None, None]).float()                      # [C_out, C_in, dz, dy, dx]
                 shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-                lane = torch.arange(64, device=w.device)
-                co = 16 * torch.arange(w.shape[0] // 16, device=w.device)[:, None] + (lane & 15)[None]     # [MT, 64]
-                ci = 4 * torch.arange(w.shape[1] // 4, device=w.device)[:, None] + (lane >> 4)[None]       # [NQ, 64]
-                # per-lane MFMA A operands (csrc/nr_kernels_conv3d.h Conv3dParams.wpack): [dz][q][dy][dx][mt][lane]
-                pack = w[co[None], ci[:, None]].permute(3, 0, 4, 5, 1, 2).contiguous()
+                pack, shift = _mfma_conv_pack(w, shift)
             hit = layer.__dict__['_mfma_pack'] = (stamp, pack.to(x.device), shift.to(x.device))
         return self._engine(x).conv3d_bn_leaky(x.contiguous(), hit[1], hit[2], bn.slope, key[1], key[2])
 

@@ -39,6 +39,8 @@ def composed(bn, y, act, pad, res):
 @pytest.mark.parametrize('act,pad,with_res,shape', [
     ('relu', 1, False, (2, 5, 9, 11)), ('relu', 1, True, (3, 4, 8, 6)), (None, 0, False, (2, 3, 7, 5)), ('elu', 0, False, (1, 6, 10, 13)),
     ('relu', 0, True, (2, 4, 6, 6)), ('elu', 1, True, (2, 2, 2, 3)), ('relu', 1, False, (1, 16, 40, 50)),
+    # planes at the encoders' training resolutions: several chunks per plane, atomically added partial sums
+    ('relu', 1, True, (3, 2, 104, 152)), ('elu', 1, True, (2, 2, 180, 181)), ('relu', 0, False, (1, 3, 182, 181)),
 ])
 def test_fused_norm_act_equals_the_pytorch_composition(device, act, pad, with_res, shape):
     g = torch.Generator().manual_seed(sum(shape) + pad)
@@ -55,15 +57,19 @@ def test_fused_norm_act_equals_the_pytorch_composition(device, act, pad, with_re
     for fused in (True, False):
         fused_norm.FUSED_NORM = fused
         try:
-            y = y0.clone().requires_grad_(True)
-            b = base.clone().requires_grad_(True)
+            # the composition is evaluated in float64: on a one-image batch with planes far from zero mean MIOpen's own fp32 instance
+            # norm is 4e-4 off the float64 value (tools/diag_norm_error.py, profiles/r05_s_norm_error.log; the kernels here: 2e-7)
+            dt = torch.float32 if fused else torch.float64
+            mod = bn if fused else bn.double()
+            y = y0.detach().to(dt).clone().requires_grad_(True)
+            b = base.detach().to(dt).clone().requires_grad_(True)
             res = b[:, :, 1:-1, 1:-1] if with_res else None             # a strided view, as the interior of a padded buffer is
-            for p_ in bn.parameters():
+            for p_ in mod.parameters():
                 p_.grad = None
-            out = fused_norm.norm_act(bn, y, act, pad, res) if fused else composed(bn, y, act, pad, res)
-            (out * dz).sum().backward()
-            outs.append((out.detach().cpu(), y.grad.cpu(), bn.weight.grad.cpu().clone(), bn.bias.grad.cpu().clone(),
-                         b.grad.cpu() if with_res else None))
+            out = fused_norm.norm_act(mod, y, act, pad, res) if fused else composed(mod, y, act, pad, res)
+            (out * dz.to(dt)).sum().backward()
+            outs.append((out.detach().float().cpu(), y.grad.float().cpu(), mod.weight.grad.float().cpu().clone(),
+                         mod.bias.grad.float().cpu().clone(), b.grad.float().cpu() if with_res else None))
         finally:
             fused_norm.FUSED_NORM = True
     (o1, gy1, gw1, gb1, gr1), (o0, gy0, gw0, gb0, gr0) = outs

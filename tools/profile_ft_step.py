@@ -67,7 +67,7 @@ def classify(path, steps):
             cls = 'fused norm (nr::inorm)'
         elif 'nr::upsample2x' in name:
             cls = 'up-sampling'
-        elif 'nr::costreg' in name or 'nr::warp_variance' in name or 'nr::diff_feats' in name:
+        elif any(k in name for k in ('nr::costreg', 'nr::warp_variance', 'nr::diff_feats', 'nr::conv3d_kernel', 'nr::scale_shift_leaky')):
             cls = 'init net (nr:: cost volume / consistency kernels)'
         else:
             for c, keys in classes:

@@ -21,7 +21,7 @@ from neuray_amd.network import fused_norm               # noqa: E402
 from neuray_amd.network import render_ops as ro         # noqa: E402
 
 SHAPES = [(9, 32, 104, 152, True), (9, 64, 52, 76, True), (9, 128, 26, 38, False), (9, 32, 150, 200, True), (2, 32, 104, 152, False),
-          (9, 32, 400, 400, True)]
+          (9, 32, 400, 400, True), (9, 64, 200, 200, True), (9, 128, 100, 100, True), (9, 64, 400, 400, False)]
 
 
 def main():

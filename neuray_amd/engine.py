@@ -418,8 +418,17 @@ class RenderEngine:
                 if not (('.vis_decoder.' in k and not has_vis) or (allow_missing_agg and k.startswith(agg_prefix))):
                     raise KeyError("neuray_amd: missing weight %s" % k)
                 off = self._flat_offsets()
-                parts.append(torch.zeros(off[i + 1] - off[i], dtype=torch.float32, device=self.device))
+                parts.append(self._zero_const(off[i + 1] - off[i]))
         return torch.cat(parts), has_vis
+
+    def _zero_const(self, n):
+        """n zero floats as a view of one cached, never written buffer (a decoder-only pack asks for ~26 absent tensors on every call: one
+        fill launch each as torch.zeros - 112 launches per generalisation step, tools/count_step_ops.py)"""
+        z = self.__dict__.get('_zero_const_buf')
+        if z is None or z.numel() < n:
+            z = torch.zeros(max(int(n), 1 << 16), dtype=torch.float32, device=self.device)
+            self.__dict__['_zero_const_buf'] = z
+        return z[:n]
 
     def pack_pass_device(self, flat, has_vis):
         """PackedPass from the flat natural layout, on the device: packed = flat[index] * scale (neuray_pack_pass_index_map)."""

@@ -48,7 +48,8 @@ class _RowsFn(torch.autograd.Function):
                                                          d_vis if ctx.has_vis else None, packed=ctx.packed)
         sd = {'d.' + k: v.detach() for k, v in dec.named_parameters()}
         grads = eng.unflatten_pass_grads(d_flat, sd, 'd.', 'a.')
-        return (None, d_feats.view_as(feats)) + tuple(grads['d.' + k].clone() for k, _ in dec.named_parameters())
+        # (views of the freshly allocated d_flat, as RenderPassFn returns them: no per-parameter copy)
+        return (None, d_feats.view_as(feats)) + tuple(grads['d.' + k] for k, _ in dec.named_parameters())
 
 
 class MixtureLogisticsDistDecoder(nn.Module):

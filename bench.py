@@ -686,7 +686,12 @@ def init_net_timing(device, reps=10):
         dv = init_net.get_depth_vals(info['depth_range'], 64)
         ids = info['nn_ids'][:1]
         got, want = eng.warp_variance(f[:1], f, ids, prj[:1], prj, dv[:1]), tep.variance_volume(f[:1], f, ids, prj[:1], prj, dv[:1])
+        got_cl = eng.warp_variance(f[:1], f, ids, prj[:1], prj, dv[:1], channels_last=True)
         res.update({'hip_warp_variance_ms_per_ref_view': timeit(lambda: eng.warp_variance(f[:1], f, ids, prj[:1], prj, dv[:1]), reps),
+                    # the layout the init net's conv0 kernel reads (warp_variance_cl_kernel: eight lanes per voxel), the same bits
+                    'hip_warp_variance_channels_last_ms_per_ref_view': timeit(
+                        lambda: eng.warp_variance(f[:1], f, ids, prj[:1], prj, dv[:1], channels_last=True), reps),
+                    'warp_variance_channels_last_equals_ncdhw_bitwise': bool(torch.equal(got_cl, got)),
                     'eager_torch_warp_variance_ms_per_ref_view': timeit(lambda: tep.variance_volume(f[:1], f, ids, prj[:1], prj, dv[:1]), 3),
                     'warp_variance_frac_within_1e-3_of_eager': float(((got - want).abs() <= 1e-3).float().mean()),
                     'cost_volume_init_net_ms': timeit(lambda: cv(info, info, False), 3)})

@@ -408,6 +408,10 @@ int neuray_warp_variance_layout(const float* ref_feats, const float* src_feats, 
     nr::WarpVarParams p;
     p.ref_feats = ref_feats; p.src_feats = src_feats; p.nn_ids = nn_ids; p.transforms = transforms; p.depth_vals = depth_vals; p.out = out;
     p.rfn = rfn; p.n_num = n_num; p.dn = dn; p.fh = fh; p.fw = fw; p.channels_last = channels_last;
+    if (channels_last && (long long)rfn * dn <= 65535) {        // eight lanes per voxel, a tap = one 128-byte line per instruction
+        NR_LAUNCH(nr::warp_variance_cl_kernel, dim3((fh * fw + 31) / 32, rfn * dn), dim3(256), 0, stream, p);
+        return check_launch("neuray_warp_variance (channels last)");
+    }
     const int grid = grid_for((long long)rfn * dn * fh * fw, 256, 256 * 64);
     NR_LAUNCH(nr::warp_variance_kernel, dim3(grid), dim3(256), 0, stream, p);
     return check_launch("neuray_warp_variance");

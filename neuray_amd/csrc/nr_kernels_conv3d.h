@@ -477,4 +477,86 @@ __global__ void __launch_bounds__(256) scale_shift_leaky_kernel(ScaleShiftLeakyP
     }
 }
 
+// ---- the variance volume in the layout conv0 reads, second mapping (round 5) --------------------------------------------------------
+// warp_variance_kernel (nr_kernels.h) gives a voxel to ONE thread, which walks the 32 channels of each of its 4 x n_num taps as eight
+// 16-byte loads: one load instruction of a wave touches 64 different 128-byte lines and uses an eighth of each, and a line has to survive
+// in the 32 KB L1 until the eighth pass over it (a wave's taps alone are ~17 KB per source view).  Here EIGHT consecutive lanes own a
+// voxel and lane q of them the channels 4 q .. 4 q + 3: a tap is one 128-byte line read once, by one instruction, whole; the sums are
+// 8 registers instead of 64 and the variance leaves as one 128-byte line per voxel.  With the loads in order the kernel is bound by its
+// VALU work (the IEEE divisions of grid_sample's un-normalisation: ~120 instructions per source view), so the eight lanes of a voxel do
+// not repeat it: lane q evaluates the homography, the taps and the bilinear weights of source view q, and the group reads them from
+// that lane (eight ds_bpermute per source view).  Same expressions, same roundings as warp_variance_kernel: the results are
+// bit-identical - every channel's sums are formed by the same operations in the same order (division by V = n_num + 1 is a
+// multiplication when V is a power of two, which is exact).  Reference view and depth plane are the workgroup's (blockIdx.y), so the
+// 3 x 4 transforms and the depth are scalar loads.  grid = (ceil(fh fw / 32), rfn dn), 256 threads: a workgroup takes 32 consecutive
+// pixels of its plane.  (A 16 x 16 pixel tile per workgroup, walked two rows at a time so that a row's source texels are met again by
+// the next row while still in L1 - 1.85 x fewer lines from L2 - measured the same: 1.564 vs 1.554 ms,
+// profiles/r05_z_warpvar_kernel_ab.log.  The kernel is not waiting for L2.  Nor does it want its loads earlier: an instantiation for
+// three source views with all twelve taps in flight before the first is spent needs 102 VGPRs instead of 58 - four waves per SIMD
+// instead of eight - and takes 1.27 ms where this one takes 1.12, profiles/r05_z_warpvar_kernel_ab3.log.)
+__global__ void __launch_bounds__(256) warp_variance_cl_kernel(WarpVarParams p) {
+    const int hw = p.fh * p.fw;
+    const int plane = blockIdx.y, r = plane / p.dn;
+    const int lane = threadIdx.x & 63, q = lane & 7, group0 = lane & ~7;
+    const int pix_raw = (int)blockIdx.x * 32 + (int)(threadIdx.x >> 3);
+    const int pix = pix_raw < hw ? pix_raw : hw - 1;           // (every lane stays in for the exchanges; a padding voxel is not stored)
+    const int y = pix / p.fw, x = pix - y * p.fw;
+    const float wm1 = (float)(p.fw - 1), hm1 = (float)(p.fh - 1);
+    const float half_w = rn_div(wm1, 2.0f), half_h = rn_div(hm1, 2.0f);
+    const float dv = p.depth_vals[plane];
+    const float gx = rn_mul((float)x, dv), gy = rn_mul((float)y, dv), gz = dv;
+    float4 sum = reinterpret_cast<const float4*>(p.ref_feats + ((long long)r * hw + pix) * 32)[q];
+    float4 sq = make_float4(sum.x * sum.x, sum.y * sum.y, sum.z * sum.z, sum.w * sum.w);
+    for (int j0 = 0; j0 < p.n_num; j0 += 8) {
+        // this lane's source view of the round (lanes beyond n_num repeat the last one: no divergence, their values are not read)
+        const int jm = j0 + q < p.n_num ? j0 + q : p.n_num - 1;
+        const float* M = p.transforms + ((long long)r * p.n_num + jm) * 12;
+        const float X = rn_add(dot3(M[0], M[1], M[2], gx, gy, gz), M[3]);
+        const float Y = rn_add(dot3(M[4], M[5], M[6], gx, gy, gz), M[7]);
+        float Z = rn_add(dot3(M[8], M[9], M[10], gx, gy, gz), M[11]);
+        if (Z < 1e-4f) Z = 1e-4f;
+        // grid_sample(align_corners=True) un-normalisation of  g = s / ((size-1)/2) - 1
+        const float ix = rn_mul(rn_div(rn_add(rn_sub(rn_div(rn_div(X, Z), half_w), 1.0f), 1.0f), 2.0f), wm1);
+        const float iy = rn_mul(rn_div(rn_add(rn_sub(rn_div(rn_div(Y, Z), half_h), 1.0f), 1.0f), 2.0f), hm1);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
+        // (NaN / huge coordinates fail every bounds test below: zero contribution, as in grid_sample)
+        const bool okx0 = x0f >= 0.0f && x0f <= wm1, okx1 = x0f + 1.0f >= 0.0f && x0f + 1.0f <= wm1;
+        const bool oky0 = y0f >= 0.0f && y0f <= hm1, oky1 = y0f + 1.0f >= 0.0f && y0f + 1.0f <= hm1;
+        const int x0 = okx0 ? (int)x0f : 0, x1 = okx1 ? (int)x0f + 1 : 0, y0 = oky0 ? (int)y0f : 0, y1 = oky1 ? (int)y0f + 1 : 0;
+        const float mw00 = (okx0 && oky0) ? wx0 * wy0 : 0.0f, mw10 = (okx1 && oky0) ? wx1 * wy0 : 0.0f;
+        const float mw01 = (okx0 && oky1) ? wx0 * wy1 : 0.0f, mw11 = (okx1 && oky1) ? wx1 * wy1 : 0.0f;
+        const int mo00 = (y0 * p.fw + x0) * 8, mo10 = (y0 * p.fw + x1) * 8, mo01 = (y1 * p.fw + x0) * 8, mo11 = (y1 * p.fw + x1) * 8;
+        const int nj = p.n_num - j0 < 8 ? p.n_num - j0 : 8;
+        for (int jj = 0; jj < nj; ++jj) {
+            const int from = group0 + jj;
+            const float w00 = __shfl(mw00, from), w10 = __shfl(mw10, from), w01 = __shfl(mw01, from), w11 = __shfl(mw11, from);
+            const int o00 = __shfl(mo00, from), o10 = __shfl(mo10, from), o01 = __shfl(mo01, from), o11 = __shfl(mo11, from);
+            const float4* m = reinterpret_cast<const float4*>(p.src_feats + (long long)p.nn_ids[r * p.n_num + j0 + jj] * hw * 32) + q;
+            const float4 a = m[o00], b = m[o10], c = m[o01], e = m[o11];
+            const float v0 = a.x * w00 + b.x * w10 + c.x * w01 + e.x * w11;
+            const float v1 = a.y * w00 + b.y * w10 + c.y * w01 + e.y * w11;
+            const float v2 = a.z * w00 + b.z * w10 + c.z * w01 + e.z * w11;
+            const float v3 = a.w * w00 + b.w * w10 + c.w * w01 + e.w * w11;
+            sum.x += v0; sum.y += v1; sum.z += v2; sum.w += v3;
+            sq.x += v0 * v0; sq.y += v1 * v1; sq.z += v2 * v2; sq.w += v3 * v3;
+        }
+    }
+    if (pix_raw >= hw) return;
+    const int vi = p.n_num + 1;
+    const float V = (float)vi;
+    float4 o;
+    if ((vi & (vi - 1)) == 0) {               // V = 2^k: x / V = x * (1 / V), both exact up to the same single rounding
+        const float iv = 1.0f / V;
+        const float m0 = rn_mul(sum.x, iv), m1 = rn_mul(sum.y, iv), m2 = rn_mul(sum.z, iv), m3 = rn_mul(sum.w, iv);
+        o = make_float4(rn_sub(rn_mul(sq.x, iv), rn_mul(m0, m0)), rn_sub(rn_mul(sq.y, iv), rn_mul(m1, m1)),
+                        rn_sub(rn_mul(sq.z, iv), rn_mul(m2, m2)), rn_sub(rn_mul(sq.w, iv), rn_mul(m3, m3)));
+    } else {
+        const float m0 = rn_div(sum.x, V), m1 = rn_div(sum.y, V), m2 = rn_div(sum.z, V), m3 = rn_div(sum.w, V);
+        o = make_float4(rn_sub(rn_div(sq.x, V), rn_mul(m0, m0)), rn_sub(rn_div(sq.y, V), rn_mul(m1, m1)),
+                        rn_sub(rn_div(sq.z, V), rn_mul(m2, m2)), rn_sub(rn_div(sq.w, V), rn_mul(m3, m3)));
+    }
+    reinterpret_cast<float4*>(p.out + ((long long)plane * hw + pix) * 32)[q] = o;
+}
+
 }  // namespace nr

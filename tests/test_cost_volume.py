@@ -75,6 +75,23 @@ def test_warp_variance_kernel_matches_oracle(gold, dev):
     same = eng.warp_variance(t('ref_feats')[:1], t('ref_feats')[:1], torch.zeros(1, 2, dtype=torch.long), t('ref_prj')[:1],
                              t('ref_prj')[:1], t('depth_vals')[:1]).cpu().numpy()
     assert float(np.abs(same[:, :, :, 1:-1, 1:-1]).max()) <= 1e-3 * float(np.abs(gold['ref_feats']).max()) ** 2
+    # the channels-last layout conv0 reads comes from its own kernel (eight lanes per voxel, warp_variance_cl_kernel): every channel's
+    # sums are formed by the same operations in the same order, so the two layouts hold the same bits - also on maps whose pixel count
+    # is not a multiple of the 32 voxels of a workgroup, and with taps that leave the source map
+    cl = eng.warp_variance(t('ref_feats'), t('src_feats'), t('nn_ids'), t('ref_prj'), t('src_prj'), t('depth_vals'), channels_last=True)
+    assert cl.shape == (2, 32, 8, 16, 16) and cl.stride(1) == 1
+    assert np.array_equal(cl.cpu().numpy(), got)
+    g = torch.Generator().manual_seed(5)
+    rf, sf = torch.randn(2, 32, 9, 11, generator=g).to(dev), torch.randn(3, 32, 9, 11, generator=g).to(dev)
+    ids = torch.tensor([[0, 2, 1], [1, 1, 0]])
+    prj = t('ref_prj')[:1].repeat(3, 1, 1).clone()
+    prj[1, 0, 3] += 40.0
+    prj[2, 1, 3] -= 25.0
+    prj[2, 0, 0] *= 1.3
+    dv = t('depth_vals')[:1, :5].repeat(2, 1).contiguous()
+    a = eng.warp_variance(rf, sf, ids, prj[:2], prj, dv)
+    b = eng.warp_variance(rf, sf, ids, prj[:2], prj, dv, channels_last=True)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy()) and float(a.abs().max()) > 0
 
 
 def test_cost_volume_init_net_matches_reference(gold, dev):

@@ -286,19 +286,56 @@ class RenderEngine:
         rfn, c, fh, fw = ref_feats.shape
         assert c == 32 and src_feats.shape[1:] == ref_feats.shape[1:]
         sn, n_num, dn = src_feats.shape[0], nn_ids.shape[1], depth_vals.shape[1]
-        assert int(nn_ids.max()) < sn and int(nn_ids.min()) >= 0
+        if nn_ids.is_cuda:
+            # A host-side `int(nn_ids.max())` is a device -> host copy: the host waits for everything the previous training step still has
+            # queued (three such waits sat at the top of every generalisation step).  The range is checked on the device instead, the
+            # verdict travels to pinned memory behind the stream and is raised by check_deferred() - at the next call of this method
+            # at the latest - while the kernel itself only ever sees clamped (in-range) indices.
+            self.check_deferred(wait=False)
+            if not torch.cuda.is_current_stream_capturing():       # (a captured graph replays the clamped kernel; nothing to report to)
+                self._defer_check(((nn_ids < 0) | (nn_ids >= sn)).any(),
+                                  "warp_variance: a neighbour index in nn_ids lies outside the %d source views" % sn)
+            nn_ids = nn_ids.clamp(0, sn - 1)
+        else:
+            assert int(nn_ids.max()) < sn and int(nn_ids.min()) >= 0
         s = self._stream()
         nhwc = lambda t: self._f32(t).permute(0, 2, 3, 1).contiguous()
         rf, sf = nhwc(ref_feats), nhwc(src_feats)
         ids = nn_ids.to(device=self.device, dtype=torch.int32).contiguous()
         # transform = src_proj @ ref_proj_inv, per (reference view, neighbour) as homo_warp computes it (modules.py:36)
-        inv = torch.inverse(self._f32(ref_prjs))
+        inv = torch.linalg.inv_ex(self._f32(ref_prjs)).inverse          # torch.inverse without its host-side singularity check (a sync)
         tr = torch.stack([self._f32(src_prjs)[nn_ids[:, j].to(self.device).long()] @ inv for j in range(n_num)], 1)[:, :, :3, :].contiguous()
         dv = self._f32(depth_vals)
         out = self.empty(rfn, dn, fh, fw, 32) if channels_last else self.empty(rfn, 32, dn, fh, fw)
         self._check(self.lib.neuray_warp_variance_layout(rf.data_ptr(), sf.data_ptr(), ids.data_ptr(), tr.data_ptr(), dv.data_ptr(),
                                                          rfn, sn, n_num, dn, fh, fw, int(bool(channels_last)), out.data_ptr(), s))
         return out.permute(0, 4, 1, 2, 3) if channels_last else out
+
+    def _defer_check(self, bad, message):
+        """bad: 0-dim bool tensor on the device (True = the input was invalid).  Recorded without waiting for it."""
+        flag = torch.empty((), dtype=torch.bool, pin_memory=True)
+        flag.copy_(bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.__dict__.setdefault('_deferred', []).append((ev, flag, message))
+
+    def check_deferred(self, wait=True):
+        """Raise the AssertionError of an input check that ran on the device (warp_variance's nn_ids range).  wait=True: after the
+        stream has drained (tests, the end of an epoch); wait=False: only verdicts that have already arrived."""
+        pending = self.__dict__.get('_deferred')
+        if not pending:
+            return
+        if wait:
+            torch.cuda.current_stream(self.device).synchronize()
+        keep, failed = [], None
+        for ev, flag, message in pending:
+            if not ev.query():
+                keep.append((ev, flag, message))
+            elif bool(flag) and failed is None:
+                failed = message
+        self.__dict__['_deferred'] = keep
+        if failed is not None:
+            raise AssertionError("neuray_amd: " + failed)
 
     def prepare_query(self, que_imgs_info):
         """-> query constant block.  K^-1 is `torch.inverse(Ks)` as in the reference (render_ops.py:20), evaluated on the

@@ -121,6 +121,9 @@ def test_abi_rejects_bad_arguments(backend):
     with pytest.raises(AssertionError):            # a neighbour index beyond the source views never reaches the kernel
         eng.warp_variance(torch.zeros(1, 32, 4, 4, device=dev), torch.zeros(2, 32, 4, 4, device=dev), torch.tensor([[0, 2]], device=dev),
                           torch.eye(4, device=dev)[None], torch.eye(4, device=dev)[None].repeat(2, 1, 1), torch.ones(1, 8, device=dev))
+        # (device-resident indices are range-checked on the device without stalling the host: the kernel ran on clamped indices and the
+        # verdict is raised here, or by the next call)
+        eng.check_deferred()
 
 
 # ---- the shapes of BASELINE.json's other configurations (parity cases, not bench lines) -------------------------

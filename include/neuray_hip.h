@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 9
+#define NEURAY_ABI_VERSION 10
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -59,6 +59,11 @@ int neuray_pack_pass_weights(const float* const* tensors_host, float* packed_hos
  * rounded once.  Same size and layout as neuray_pack_pass_weights (the prob_embed.2 slot is zero); pass NeurayPointsArgs.folded = 1
  * with it.  The backward kernels and the training forward (saved_dev) take the unfolded pack only. */
 int neuray_pack_pass_weights_folded(const float* const* tensors_host, float* packed_host);
+/* The same folded network for NEURAY_ARITH_X3: every weight of the MFMA fragments as three bf16 parts w = h + m + l (exact), laid out for
+ * the K = 32 bf16 MFMA (csrc/nr_layout.h AR_X3).  packed_host: neuray_packed_points_floats_x3() floats; it holds the point kernel's layers
+ * only - neuray_render_rays and every other entry point keep the neuray_pack_pass_weights[_folded] buffer. */
+size_t neuray_packed_points_floats_x3(void);
+int neuray_pack_pass_weights_x3(const float* const* tensors_host, float* packed_host);
 /* The same packing as a gather, for callers that keep the weights on the device (training: they change every step):
  * packed[i] = flat[index[i]] * scale[i], index -1 = padding (0); flat = the flat natural layout described at
  * neuray_render_points_backward.  index_host / scale_host: neuray_packed_pass_floats() entries each. */
@@ -118,7 +123,14 @@ typedef struct NeurayPointsArgs {
                           * ran, slots in total }.  The inference kernels skip a slot whose 16 (point, view) columns are all outside the
                           * view (mask = 0, render_ops.py:100-104,127-128): every quantity of such a column is multiplied by the mask
                           * downstream (ibrnet.py:333-349,365), so the result is the same; the counters give the executed share. */
+    int arith;           /* arithmetic of the MLP contractions (the nn.Linear layers of dist_decoder.py:64-97, aggregate_net.py:27-31,
+                          * ibrnet.py:249-293): NEURAY_ARITH_F32 = v_mfma_f32_16x16x4_f32 on fp32 operands; NEURAY_ARITH_X3 = every operand
+                          * split exactly into three bf16 parts, six v_mfma_f32_16x16x32_bf16 products per K = 32, fp32 accumulation
+                          * (each product within 2^-23 of exact: the fp32 grade, 2.5 x less matrix-pipe time).  X3: inference only,
+                          * packed_weights_dev = the neuray_pack_pass_weights_x3 buffer, no saved_dev. */
 } NeurayPointsArgs;
+#define NEURAY_ARITH_F32 0
+#define NEURAY_ARITH_X3 1
 size_t neuray_points_saved_floats(int npts);
 int neuray_render_points(const NeurayPointsArgs* args, void* stream);
 
@@ -451,6 +463,14 @@ int neuray_mfma_selftest(const float* A_dev, const float* B_dev, float* D_dev, v
 /* ---- hardware self test of the lane-group sum behind the vector rows (v_permlane16_swap / v_permlane32_swap):
  * y[l] = (x[c] + x[c+16]) + (x[c+32] + x[c+48]) with c = l % 16, for the 64 lanes of one wave. */
 int neuray_group_sum_selftest(const float* x_dev, float* y_dev, void* stream);
+
+/* ---- hardware self test of NEURAY_ARITH_X3: D [16][16] = A [16][32] @ B [32][16] through the point kernel's operand path - both operands
+ * split into three bf16 parts on the device, six v_mfma_f32_16x16x32_bf16 products, fp32 accumulation.  parts_dev (may be NULL):
+ * [3][16][32], the three parts of A as fp32 values (A = parts[0] + parts[1] + parts[2] exactly). */
+int neuray_x3_selftest(const float* A_dev, const float* B_dev, float* D_dev, float* parts_dev, void* stream);
+/* Workgroups of the point kernel (rfn = 7..8: four waves of two views, no vis head) the runtime keeps resident per compute unit for the given
+ * NEURAY_ARITH_*: hipOccupancyMaxActiveBlocksPerMultiprocessor with the kernel's registers and LDS.  -1 = not built / not a device build. */
+int neuray_points_resident_workgroups(int arith, int rfn);
 
 #ifdef __cplusplus
 }

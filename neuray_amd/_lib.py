@@ -25,6 +25,8 @@ MAX_VIEWS = 16
 MAX_SAMPLES = 128
 MAX_BACKWARD_SAMPLES = 128     # samples per ray and pass the backward kernels take (include/neuray_hip.h): = MAX_SAMPLES
 
+ARITH_F32, ARITH_X3 = 0, 1      # NeurayPointsArgs.arith (include/neuray_hip.h NEURAY_ARITH_*)
+
 c_float_p = C.POINTER(C.c_float)
 
 
@@ -37,6 +39,7 @@ class NeurayPointsArgs(C.Structure):
         ('rfn', C.c_int), ('rn', C.c_int), ('dn', C.c_int), ('h', C.c_int), ('w', C.c_int), ('fh', C.c_int),
         ('fw', C.c_int), ('has_vis_head', C.c_int), ('use_vis', C.c_int), ('var_bias', C.c_float),
         ('views_per_wave', C.c_int), ('saved_dev', C.c_void_p), ('folded', C.c_int), ('slot_stats_dev', C.c_void_p),
+        ('arith', C.c_int),
     ]
 
 
@@ -91,6 +94,8 @@ SYMBOLS = {
     'neuray_points_saved_floats': (C.c_size_t, [C.c_int]),
     'neuray_pack_pass_weights': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_weights_folded': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    'neuray_packed_points_floats_x3': (C.c_size_t, []),
+    'neuray_pack_pass_weights_x3': (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     'neuray_pack_pass_index_map': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_mt19937_shuffle': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_longlong, C.c_int]),
     'neuray_setup_views': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -124,6 +129,8 @@ SYMBOLS = {
     'neuray_self_hit_prob': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     'neuray_mfma_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_x3_selftest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'neuray_points_resident_workgroups': (C.c_int, [C.c_int, C.c_int]),
     'neuray_render_rays_backward': (C.c_int, [C.POINTER(NeurayRaysBwdArgs), C.c_void_p]),
     'neuray_flat_pass_floats': (C.c_size_t, []),
     'neuray_flat_tensor_offset': (C.c_size_t, [C.c_int]),

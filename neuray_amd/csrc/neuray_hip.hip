@@ -54,11 +54,11 @@ static_assert(NEURAY_DBG_FIELDS == nr::kDbgFields, "abi");
 static_assert(NEURAY_RAY_ATT_SAVE == nr::kRayAttSave, "abi");
 static_assert(NEURAY_MAX_SAMPLES == nr::kMaxSamples, "abi");
 
-template <int NT, int VPW, bool HAS_VIS, int OWN, int MINW, bool SAVE = false>
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MINW, bool SAVE = false, int AR = nr::AR_F32>
 int launch_points_own(const nr::PointParams& p, void* stream) {
     const int npts = p.rn * p.dn;
     const int nwaves = (p.rfn + VPW - 1) / VPW;
-    const size_t smem = nr::point_smem_bytes<NT>(nwaves);
+    const size_t smem = nr::point_smem_bytes<NT>(nwaves, AR);
     if (smem > 160 * 1024) return fail("neuray_render_points: %zu bytes of LDS needed (rfn=%d)", smem, p.rfn);
     // persistent-style grid: enough workgroups to fill the 768 resident slots (3 per CU) twenty times over, grid-stride beyond.  Measured on
     // the 800 x 800 workload (131 072 tiles per coarse launch), same box: 768 workgroups 2.30 M rays/s, 1536 2.35, 3072 / 3840 2.38,
@@ -75,9 +75,9 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     grid = (grid + 7) / 8 * 8;                         // the XCD-aware tile map needs a multiple of 8
     const int threads = 64 * nwaves;
     // __launch_bounds__(1024) caps the kernel at 128 VGPRs so that 4 waves share a SIMD (DESIGN.md "occupancy")
-    auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, SAVE>;
+    auto k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, SAVE, false, AR>;
     if constexpr (!SAVE) {
-        if (p.dbg) k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, false, true>;     // the per-view record: its own instantiation
+        if (p.dbg) k = nr::points_kernel<NT, VPW, HAS_VIS, OWN, 1024 / VPW, MINW, false, true, AR>;     // the per-view record: its own instantiation
     } else if (p.dbg) {
         return fail("neuray_render_points: dbg_dev and saved_dev together are not built (run the pass twice)");
     }
@@ -88,12 +88,12 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
     return check_launch("neuray_render_points");
 }
 
-template <int NT, int VPW, bool HAS_VIS, int MINW>
+template <int NT, int VPW, bool HAS_VIS, int MINW, int AR = nr::AR_F32>
 int launch_points(const nr::PointParams& p, void* stream) {
     const int nwaves = (p.rfn + VPW - 1) / VPW;
-    if (nwaves >= 4) return launch_points_own<NT, VPW, HAS_VIS, 1, MINW>(p, stream);
-    if (nwaves >= 2) return launch_points_own<NT, VPW, HAS_VIS, 2, MINW>(p, stream);
-    return launch_points_own<NT, VPW, HAS_VIS, 4, MINW>(p, stream);
+    if (nwaves >= 4) return launch_points_own<NT, VPW, HAS_VIS, 1, MINW, false, AR>(p, stream);
+    if (nwaves >= 2) return launch_points_own<NT, VPW, HAS_VIS, 2, MINW, false, AR>(p, stream);
+    return launch_points_own<NT, VPW, HAS_VIS, 4, MINW, false, AR>(p, stream);
 }
 
 // training forward: the same kernels with the cross-view quantities written out for the resident backward (rfn <= 8; two views per
@@ -118,8 +118,19 @@ int launch_points_save(const nr::PointParams& p, void* stream) {
 #ifndef NR_POINT_MINW
 #define NR_POINT_MINW 3        // workgroups per CU the 2-views-per-wave kernel is compiled for (A/B: -DNR_POINT_MINW=2 = 256 VGPRs, no spills)
 #endif
+#ifndef NR_POINT_MINW_X3
+#define NR_POINT_MINW_X3 3     // the same for the AR_X3 instantiation
+#endif
 template <bool HAS_VIS>
-int launch_points_cfg(const nr::PointParams& p, int vpw, void* stream) {
+int launch_points_cfg(const nr::PointParams& p, int vpw, int arith, void* stream) {
+    if (arith == NEURAY_ARITH_X3) {
+#ifdef NR_BF16_QUADS
+        return fail("neuray_render_points: arith = NEURAY_ARITH_X3 lives in the fp32 library (this is a bf16-operand variant build)");
+#else
+        if (vpw == 2) return launch_points<1, 2, HAS_VIS, NR_POINT_MINW_X3, nr::AR_X3>(p, stream);
+        return fail("neuray_render_points: arith = NEURAY_ARITH_X3 is built for views_per_wave = 2 (rfn >= 2)");
+#endif
+    }
     if (vpw == 2) return launch_points<1, 2, HAS_VIS, NR_POINT_MINW>(p, stream);
     if (vpw == 1) return launch_points<1, 1, HAS_VIS, 4>(p, stream);
     return fail("neuray_render_points: views_per_wave=%d is not built (1 or 2)", vpw);
@@ -152,6 +163,15 @@ int neuray_pack_pass_weights_folded(const float* const* tensors_host, float* pac
     if (!tensors_host || !packed_host) return fail("neuray_pack_pass_weights_folded: null argument");
     const int rc = nr::pack_pass_weights(tensors_host, packed_host, true);
     if (rc) return fail("neuray_pack_pass_weights_folded: tensor %d of the pass is missing", rc - 1);
+    return 0;
+}
+
+size_t neuray_packed_points_floats_x3(void) { return (size_t)nr::kPackedPointFloatsX3; }
+
+int neuray_pack_pass_weights_x3(const float* const* tensors_host, float* packed_host) {
+    if (!tensors_host || !packed_host) return fail("neuray_pack_pass_weights_x3: null argument");
+    const int rc = nr::pack_pass_weights_x3(tensors_host, packed_host);
+    if (rc) return fail("neuray_pack_pass_weights_x3: tensor %d of the pass is missing", rc - 1);
     return 0;
 }
 
@@ -238,13 +258,15 @@ int neuray_render_points(const NeurayPointsArgs* a, void* stream) {
     p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
     p.use_vis = a->use_vis; p.var_bias = a->var_bias; p.folded = a->folded; p.slot_stats = a->slot_stats_dev;
     if (a->folded && a->saved_dev) return fail("neuray_render_points: saved_dev (training forward) takes the unfolded pack");
+    if (a->arith != NEURAY_ARITH_F32 && a->arith != NEURAY_ARITH_X3) return fail("neuray_render_points: arith=%d is not built (0 or 1)", a->arith);
+    if (a->arith == NEURAY_ARITH_X3 && a->saved_dev) return fail("neuray_render_points: saved_dev (training forward) runs on NEURAY_ARITH_F32");
     // work decomposition: reference views processed per wave (0 = default)
     int vpw = a->views_per_wave ? a->views_per_wave : (a->rfn >= 2 ? 2 : 1);
     // the vis head is only evaluated when compute_prob consumes it (a fine decoder's vis head is ignored on the
     // reference-view path when the coarse decoder has use_vis = False: quirk A.9.2)
     const bool vis = a->has_vis_head && a->use_vis;
     if (a->saved_dev) return vis ? launch_points_save<true>(p, stream) : launch_points_save<false>(p, stream);
-    return vis ? launch_points_cfg<true>(p, vpw, stream) : launch_points_cfg<false>(p, vpw, stream);
+    return vis ? launch_points_cfg<true>(p, vpw, a->arith, stream) : launch_points_cfg<false>(p, vpw, a->arith, stream);
 }
 
 int neuray_render_rays(const NeurayRaysArgs* a, void* stream) {
@@ -557,6 +579,37 @@ int neuray_self_hit_prob(const float* query_const, const float* depth, const flo
 int neuray_mfma_selftest(const float* A, const float* B, float* D, void* stream) {
     NR_LAUNCH(nr::mfma_selftest_kernel, dim3(1), dim3(64), 0, stream, A, B, D);
     return check_launch("neuray_mfma_selftest");
+}
+
+int neuray_x3_selftest(const float* A, const float* B, float* D, float* parts, void* stream) {
+    if (!A || !B || !D) return fail("neuray_x3_selftest: null pointer");
+    NR_LAUNCH(nr::x3_selftest_kernel, dim3(1), dim3(64), 0, stream, A, B, D, parts);
+    return check_launch("neuray_x3_selftest");
+}
+
+int neuray_points_resident_workgroups(int arith, int rfn) {
+#ifdef NEURAY_EMU
+    (void)arith; (void)rfn;
+    return 0;
+#else
+    if (rfn < 7 || rfn > 8) return -1;                 // (the headline shape: four waves of two views)
+    int n = 0;
+    hipError_t e;
+    if (arith == NEURAY_ARITH_X3) {
+#ifdef NR_BF16_QUADS
+        return -1;
+#else
+        auto k = nr::points_kernel<1, 2, false, 1, 512, NR_POINT_MINW_X3, false, false, nr::AR_X3>;
+        const size_t smem = nr::point_smem_bytes<1>(4, nr::AR_X3);
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, smem);
+#endif
+    } else {
+        auto k = nr::points_kernel<1, 2, false, 1, 512, NR_POINT_MINW, false, false, nr::AR_F32>;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, nr::point_smem_bytes<1>(4, nr::AR_F32));
+    }
+    return e == hipSuccess ? n : -1;
+#endif
 }
 
 static_assert(NEURAY_PACKED_RAY_FLOATS == nr::kPackedRayFloats && NEURAY_RW_WQ == nr::RW_WQ && NEURAY_RW_WK == nr::RW_WK &&

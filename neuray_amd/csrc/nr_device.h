@@ -218,6 +218,33 @@ __device__ __forceinline__ float2 wld2(LdsW w, int voff, int soff) {
 __device__ __forceinline__ float wld1(LdsW w, int voff, int soff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
 }
+// ---- AR_X3 weight sources (nr_layout.h): the split-operand pack in global memory / a staged phase of it in LDS.  Distinct types, so
+// that every layer function picks the layout (offsets, fragment format) from the source it is handed: ws_ar<WS>::value.
+struct GlbW3 { nr_buf b; };
+struct LdsW3 { const float* base; int begin_bytes; };
+template <class WS> struct ws_ar { static constexpr int value = AR_F32; };
+template <> struct ws_ar<GlbW3> { static constexpr int value = AR_X3; };
+template <> struct ws_ar<LdsW3> { static constexpr int value = AR_X3; };
+template <class WS> struct ws_lds { typedef LdsW type; };
+template <> struct ws_lds<GlbW3> { typedef LdsW3 type; };
+__device__ __forceinline__ nr_buf ws_raw(nr_wbuf W) { return W; }
+__device__ __forceinline__ nr_buf ws_raw(GlbW3 W) { return W.b; }
+__device__ __forceinline__ float4 wld4(GlbW3 W, int voff, int soff) { return nr_buf_ld4(W.b, voff, soff); }
+__device__ __forceinline__ float wld1(GlbW3 W, int voff, int soff) { return nr_buf_ld1(W.b, voff, soff); }
+__device__ __forceinline__ nr_v4u wld4u(GlbW3 W, int voff, int soff) { return nr_buf_ld4u(W.b, voff, soff); }
+__device__ __forceinline__ nr_v2u wld2u(GlbW3 W, int voff, int soff) { return nr_buf_ld2u(W.b, voff, soff); }
+__device__ __forceinline__ float4 wld4(LdsW3 w, int voff, int soff) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
+__device__ __forceinline__ float wld1(LdsW3 w, int voff, int soff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
+__device__ __forceinline__ nr_v4u wld4u(LdsW3 w, int voff, int soff) {
+    return *reinterpret_cast<const nr_v4u*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
+__device__ __forceinline__ nr_v2u wld2u(LdsW3 w, int voff, int soff) {
+    return *reinterpret_cast<const nr_v2u*>(reinterpret_cast<const char*>(w.base) + (soff - w.begin_bytes) + voff);
+}
 // one quad fragment (nr_layout.h): 16 bytes per lane; in the bf16-operand build only the first 8 carry data
 template <class WS> __device__ __forceinline__ float4 wldq(WS W, int voff, int soff) {
 #if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT)
@@ -430,9 +457,10 @@ template <int L> struct VecPre {
 };
 template <int L, class WS>
 __device__ __forceinline__ void layer_prefetch(WS W, int lane, VecPre<L>& p) {
+    constexpr int AR = ws_ar<WS>::value;
     NR_PRAGMA_UNROLL
-    for (int i = 0; i < VecPre<L>::N * VecPre<L>::TI; ++i) p.w[i] = wld4(W, (lane >> 4) * 16, (vec_offset(L) + i * 16) * 4);
-    p.b = wld4(W, (lane >> 4) * 16, vec_bias_offset(L) * 4);
+    for (int i = 0; i < VecPre<L>::N * VecPre<L>::TI; ++i) p.w[i] = wld4(W, (lane >> 4) * 16, (vec_offset(L, AR) + i * 16) * 4);
+    p.b = wld4(W, (lane >> 4) * 16, vec_bias_offset(L, AR) * 4);
 }
 // out[t][j] = b_j + sum_f w_j[f] x[t][f], identical in the four lane groups; x in the D layout (4 registers per tile)
 template <int L, int NT, int KX>
@@ -557,29 +585,235 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const float (&xq)[NT][
     layer_fwd<L, NT, A>(W, lane, pre, xq, x1, y, none);
 }
 
+// =============================================================================================
+// AR_X3 layers (nr_layout.h): the same layer functions on split operands.  Overloads of the fp32 forms above, selected by the
+// types they are handed - a GlbW3 / LdsW3 weight source, a LayerPre3 head, an Opnd3 operand - so a kernel body written once
+// (points_kernel) instantiates either arithmetic.  Single K-steps, biases, vector rows and activations are the fp32 forms.
+// =============================================================================================
+#ifndef NR_PREFETCH3
+#define NR_PREFETCH3 1          // fragment units (3 x 16 bytes per lane) in flight ahead of the one being consumed
+#endif
+
+// B operands of a layer's quad K-steps, split: p[part][t][i] = the bf16 pair of registers (2 i, 2 i + 1) of slot t
+template <int NT, int KQX> struct Opnd3 { unsigned p[3][NT][(KQX + 1) / 2]; };
+template <int NT, int KQX>
+__device__ __forceinline__ Opnd3<NT, KQX> split_operand(const float (&x)[NT][KQX]) {
+    Opnd3<NT, KQX> o;
+    if constexpr (KQX >= 2) {
+        static_assert(KQX % 2 == 0, "register pairs");
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t)
+            NR_PRAGMA_UNROLL
+            for (int i = 0; i < KQX / 2; ++i) nr_split3(x[t][2 * i], x[t][2 * i + 1], o.p[0][t][i], o.p[1][t][i], o.p[2][t][i]);
+    } else {
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) { o.p[0][t][0] = 0u; o.p[1][t][0] = 0u; o.p[2][t][0] = 0u; }
+    }
+    return o;
+}
+// what a layer function of arithmetic AR takes as its quad operand: the registers themselves (fp32) or their split
+template <int AR, int NT, int KQX>
+__device__ __forceinline__ decltype(auto) operand(const float (&x)[NT][KQX]) {
+    if constexpr (AR == AR_X3) return split_operand(x);
+    else return (x);
+}
+
+// one fragment unit of an output tile: the three parts of a quad PAIR (K = 32), or - layers with a single quad - of that quad (K = 16,
+// words 0..1 of each part)
+struct Frag3 { nr_v4u p[3]; };
+template <int L> struct Units3 {
+    static constexpr int KQ = kShape[L].kq;
+    static_assert(KQ <= 1 || KQ % 2 == 0, "AR_X3: a layer's quads come in pairs, or it has a single one");
+    static constexpr bool HALF = KQ == 1;
+    static constexpr int UPM = HALF ? 1 : KQ / 2;                   // units per output tile
+    static constexpr int NU = kShape[L].mt_out * UPM;
+    static constexpr int TILE = tile_quads_floats(L, AR_X3);        // floats per output tile
+    static constexpr int UNIT = HALF ? 384 : 768, PART = HALF ? 128 : 256, LANE = HALF ? 8 : 16;
+};
+// unit u of tile mo_c (+ a run-time tile index inside mo_bytes)
+template <int L, class WS>
+__device__ __forceinline__ Frag3 frag3_load(WS W, int lane, int mo_bytes, int mo_c, int u) {
+    typedef Units3<L> U;
+    const int off = quads_offset(L, AR_X3) + mo_c * U::TILE + u * U::UNIT;
+    Frag3 f;
+    NR_PRAGMA_UNROLL
+    for (int pt = 0; pt < 3; ++pt) {
+        if constexpr (U::HALF) {
+            const nr_v2u h = wld2u(W, lane * 8 + mo_bytes, (off + pt * U::PART) * 4);
+            f.p[pt][0] = h[0]; f.p[pt][1] = h[1]; f.p[pt][2] = 0u; f.p[pt][3] = 0u;
+        } else {
+            f.p[pt] = wld4u(W, lane * 16 + mo_bytes, (off + pt * U::PART) * 4);
+        }
+    }
+    return f;
+}
+// six products (weight part, activation part) per slot, smallest first, back to back on the slot's accumulator: a chain of
+// v_mfma_f32_16x16x32_bf16 on ONE accumulator issues every 18.1 cycles, alternating between two accumulators costs 20.2 and between
+// three 24.2 (tests/hw/split_arith_probe.hip, profiles/r06_c_*).  u = the unit's position inside the operand array handed in.
+template <int L, int NT, int KQX>
+__device__ __forceinline__ void mfma_unit3(const Frag3& a, int u, const Opnd3<NT, KQX>& x, v4f (&acc)[NT]) {
+    constexpr int WI[6] = {2, 0, 1, 1, 0, 0}, XJ[6] = {0, 2, 1, 0, 1, 0};
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int q = 0; q < 6; ++q) {
+            if constexpr (Units3<L>::HALF) {
+                nr_v2u av, bv;
+                av[0] = a.p[WI[q]][0]; av[1] = a.p[WI[q]][1];
+                bv[0] = x.p[XJ[q]][t][0]; bv[1] = x.p[XJ[q]][t][1];
+                acc[t] = nr_mfma16x16_bf16(av, bv, acc[t]);
+            } else {
+                nr_v4u bv;
+                bv[0] = x.p[XJ[q]][t][4 * u]; bv[1] = x.p[XJ[q]][t][4 * u + 1]; bv[2] = x.p[XJ[q]][t][4 * u + 2]; bv[3] = x.p[XJ[q]][t][4 * u + 3];
+                acc[t] = nr_mfma16x32_bf16(a.p[WI[q]], bv, acc[t]);
+            }
+        }
+}
+
+template <int L> struct LayerPre3 {
+    static constexpr int MT = kShape[L].mt_out, KQ = kShape[L].kq, K1 = kShape[L].k1, NU = KQ > 0 ? Units3<L>::NU : 0;
+    static constexpr int NF = NU < NR_PREFETCH3 ? NU : NR_PREFETCH3;
+    Frag3 q[NF > 0 ? NF : 1];
+    float4 b[MT];
+    float s1[MT * K1 > 0 ? MT * K1 : 1];
+};
+template <int L, int AR> struct layer_pre_of { typedef LayerPre<L> type; };
+template <int L> struct layer_pre_of<L, AR_X3> { typedef LayerPre3<L> type; };
+template <int L, int AR> using LayerPreT = typename layer_pre_of<L, AR>::type;
+
+template <int L, class WS>
+__device__ __forceinline__ void layer_prefetch(WS W, int lane, LayerPre3<L>& p) {
+    static_assert(ws_ar<WS>::value == AR_X3, "a LayerPre3 is filled from an AR_X3 weight source");
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < LayerPre3<L>::NF; ++i) p.q[i] = frag3_load<L>(W, lane, 0, i / Units3<L>::UPM, i % Units3<L>::UPM);
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < LayerPre3<L>::MT; ++mo) p.b[mo] = wld4(W, (lane >> 4) * 16, (bias_offset(L, AR_X3) + mo * 16) * 4);
+    NR_PRAGMA_UNROLL
+    for (int i = 0; i < LayerPre3<L>::MT * LayerPre3<L>::K1; ++i) p.s1[i] = wld1(W, lane * 4, (single_offset(L, AR_X3) + i * 64) * 4);
+}
+
+template <int L, int NT, class WS, int KQX, int K1X, class PN>
+__device__ __forceinline__ void layer_acc(WS W, int lane, const LayerPre3<L>& pre, const Opnd3<NT, KQX>& xq,
+                                          const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out], PN& next) {
+    constexpr int MT = kShape[L].mt_out, KQ = kShape[L].kq, K1 = kShape[L].k1;
+    static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
+    if constexpr (KQ > 0) {
+        typedef Units3<L> U;
+        constexpr int NU = U::NU, NF = LayerPre3<L>::NF, D = NU < NR_PREFETCH3 + 1 ? NU : NR_PREFETCH3 + 1;
+        Frag3 ring[D];
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < D; ++i) ring[i] = i < NF ? pre.q[i < NF ? i : 0] : frag3_load<L>(W, lane, 0, i / U::UPM, i % U::UPM);
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < NU; ++i) {
+            const Frag3 cur = ring[i % D];
+            if (i == (NU >= 2 ? NU - 2 : 0)) layer_prefetch(W, lane, next);
+            NR_PIN();
+            const int mo = i / U::UPM, u = i % U::UPM;
+            v4f a[NT];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) a[t] = acc[t][mo];
+            mfma_unit3<L, NT>(cur, u, xq, a);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
+            if (i + D < NU) ring[i % D] = frag3_load<L>(W, lane, 0, (i + D) / U::UPM, (i + D) % U::UPM);
+        }
+    } else {
+        layer_prefetch(W, lane, next);
+        NR_PIN();
+    }
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo)
+        NR_PRAGMA_UNROLL
+        for (int k1 = 0; k1 < K1; ++k1)
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) acc[t][mo] = nr_mfma16(pre.s1[mo * K1 + k1], x1[t][k1], acc[t][mo]);
+}
+
+template <int L, int NT, int A, class WS, int KQX, int K1X, class PN>
+__device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre3<L>& pre, const Opnd3<NT, KQX>& xq,
+                                          const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4], PN& next) {
+    constexpr int MT = kShape[L].mt_out;
+    v4f acc[NT][MT];
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo)
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            acc[t][mo][0] = pre.b[mo].x; acc[t][mo][1] = pre.b[mo].y; acc[t][mo][2] = pre.b[mo].z; acc[t][mo][3] = pre.b[mo].w;
+        }
+    layer_acc<L, NT>(W, lane, pre, xq, x1, acc, next);
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int mo = 0; mo < MT; ++mo)
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; r += 2) {
+                apply_act2<A, L>(acc[t][mo][r], acc[t][mo][r + 1], y[t][4 * mo + r], y[t][4 * mo + r + 1]);
+            }
+}
+template <int L, int NT, int A, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_fwd(WS W, int lane, const Opnd3<NT, KQX>& xq,
+                                          const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {
+    LayerPre3<L> pre;
+    NoLayer none;
+    layer_prefetch<L>(W, lane, pre);
+    layer_fwd<L, NT, A>(W, lane, pre, xq, x1, y, none);
+}
+
+// K-slice of output tile `mo` (run-time) of layer L: quads [KQ0, KQ0 + KQN) = units [KQ0 / 2, (KQ0 + KQN) / 2); the operand holds the slice
+template <int L, int NT, int KQ0, int KQN, int K10, int K1N, class WS, int KQX, int K1X>
+__device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
+                                                 const Opnd3<NT, KQX>& xq, const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
+    constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
+    static_assert(KQ0 % 2 == 0 && KQN % 2 == 0 && KQ % 2 == 0, "AR_X3 slices are whole quad pairs");
+    static_assert(KQ0 + KQN <= KQ && K10 + K1N <= K1, "slice outside the layer");
+    static_assert(KQX >= (KQN > 0 ? 4 * KQN : 1) && K1X >= (K1N > 0 ? K1N : 1), "operand arrays too small");
+    const int v1 = lane * 4 + mo * (K1 * 256), mo_bytes = mo * (Units3<L>::TILE * 4);
+    float s1[K1N > 0 ? K1N : 1];
+    NR_PRAGMA_UNROLL
+    for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, v1, (single_offset(L, AR_X3) + (K10 + k1) * 64) * 4);
+    if constexpr (KQN > 0) {
+        constexpr int U0 = KQ0 / 2, UN = KQN / 2;
+        Frag3 cur = frag3_load<L>(W, lane, mo_bytes, 0, U0);
+        NR_PRAGMA_UNROLL
+        for (int u = 0; u < UN; ++u) {
+            Frag3 nxt = cur;
+            if (u + 1 < UN) nxt = frag3_load<L>(W, lane, mo_bytes, 0, U0 + u + 1);
+            NR_PIN();
+            mfma_unit3<L, NT>(cur, u, xq, acc);
+            cur = nxt;
+        }
+    }
+    NR_PRAGMA_UNROLL
+    for (int k1 = 0; k1 < K1N; ++k1)
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(s1[k1], x1[t][k1], acc[t]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight staging (nr_layout.h kPhase): the stage is two LDS regions.  phase_enter<PH> is called by every wave when it
 // is done with the previous phase: one barrier (its fence makes each wave wait for its own DMA pieces first) after
 // which phase PH is complete in its region and nobody reads the other region any more, so the copy of the NEXT phase
 // is issued into that one right away and lands while PH is being computed.
 // ---------------------------------------------------------------------------------------------
-template <int PH>
-__device__ __forceinline__ void stage_issue(float* dst, nr_wbuf W, int wave, int nw, int lane) {
-    constexpr int begin = phase_begin(PH) * 4, bytes = phase_floats(PH) * 4, NCH = (bytes + 1023) / 1024;
-    static_assert(bytes % 16 == 0 && bytes <= kStageRegionBytes, "phase does not fit a stage region");
+template <int PH, class WS>
+__device__ __forceinline__ void stage_issue(float* dst, WS W, int wave, int nw, int lane) {
+    constexpr int AR = ws_ar<WS>::value;
+    constexpr int begin = phase_begin(PH, AR) * 4, bytes = phase_floats(PH, AR) * 4, NCH = (bytes + 1023) / 1024;
+    static_assert(bytes % 16 == 0 && bytes <= stage_region_bytes(AR), "phase does not fit a stage region");
     // 1 KiB per wave instruction.  The last piece runs past the end of the phase up to the next KiB boundary: the source
     // bytes exist (later layers of the packed buffer; the buffer descriptor range-checks anyway) and the region is a
     // whole number of KiB, so no lane needs masking and the only per-lane address is lane * 16.
-    for (int c = wave; c < NCH; c += nw) nr_dma16(W, dst + c * 256, lane, lane * 16, begin + c * 1024);
+    for (int c = wave; c < NCH; c += nw) nr_dma16(ws_raw(W), dst + c * 256, lane, lane * 16, begin + c * 1024);
 }
 
 // seq0 = (tiles this workgroup has finished) * phase_count(VIS): the regions alternate along the phase sequence
-template <int PH, bool VIS>
-__device__ __forceinline__ LdsW phase_enter(float* wl, nr_wbuf W, int seq0, bool issue_next, int wave, int nw, int lane) {
+template <int PH, bool VIS, class WS>
+__device__ __forceinline__ typename ws_lds<WS>::type phase_enter(float* wl, WS W, int seq0, bool issue_next, int wave, int nw, int lane) {
+    constexpr int AR = ws_ar<WS>::value, RF = stage_region_bytes(AR) / 4;
     NR_BLOCK_SYNC();
     const int r = (seq0 + phase_seq(PH, VIS)) & 1;
-    if (issue_next) stage_issue<phase_next(PH, VIS)>(wl + (r ^ 1) * (kStageRegionBytes / 4), W, wave, nw, lane);
-    return LdsW{wl + r * (kStageRegionBytes / 4), phase_begin(PH) * 4};
+    if (issue_next) stage_issue<phase_next(PH, VIS)>(wl + (r ^ 1) * RF, W, wave, nw, lane);
+    return typename ws_lds<WS>::type{wl + r * RF, phase_begin(PH, AR) * 4};
 }
 
 // ---------------------------------------------------------------------------------------------

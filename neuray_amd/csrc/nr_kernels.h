@@ -121,15 +121,16 @@ __device__ __forceinline__ float sel4(int g, float a, float b, float c, float d)
 template <int NT>
 constexpr int point_rmax() { return 12 * NT; }
 
+// AR_X3: the 16-row exchange buffer lives inside the all-reduce scratch (points_kernel xrow), which makes room for the larger weight stage
 template <int NT>
-inline size_t point_smem_bytes(int nwaves) {
-    return sizeof(float) * (64 * ((size_t)(nwaves + 1) * point_rmax<NT>() + 16 * NT) + kWeightLdsFloats);
+inline size_t point_smem_bytes(int nwaves, int ar = AR_F32) {
+    return sizeof(float) * (64 * ((size_t)(nwaves + 1) * point_rmax<NT>() + (ar == AR_X3 ? 0 : 16 * NT)) + weight_lds_floats(ar));
 }
 
 // owner waves accumulate one cross-view statistic (8 image channels in gathered order + 3 rgb channels per tile)
 // into their tile(s) of base_fc.0's per-point part: statistic STAT uses quads [2*STAT, 2*STAT+2) and single STAT
-template <int NT, int OWN, int STAT>
-__device__ __forceinline__ void bg_accumulate(nr_wbuf W, int lane, int g, int wave, int nw,
+template <int NT, int OWN, int STAT, class WS>
+__device__ __forceinline__ void bg_accumulate(WS W, int lane, int g, int wave, int nw,
                                               const float (&st)[NT * 11], v4f (&accg)[OWN][NT]) {
     float xq[NT][8], x1[NT][1];
     NR_PRAGMA_UNROLL
@@ -138,10 +139,11 @@ __device__ __forceinline__ void bg_accumulate(nr_wbuf W, int lane, int g, int wa
         for (int s = 0; s < 8; ++s) xq[t][s] = st[t * 11 + s];
         x1[t][0] = sel4(g, st[t * 11 + 8], st[t * 11 + 9], st[t * 11 + 10], 0.0f);
     }
+    decltype(auto) oq = operand<ws_ar<WS>::value>(xq);
     NR_PRAGMA_UNROLL
     for (int j = 0; j < OWN; ++j) {
         const int mo = wave + j * nw;
-        if (mo < 4) layer_tile_slice<L_BG, NT, 2 * STAT, 2, STAT, 1>(W, lane, mo, xq, x1, accg[j]);
+        if (mo < 4) layer_tile_slice<L_BG, NT, 2 * STAT, 2, STAT, 1>(W, lane, mo, oq, x1, accg[j]);
     }
 }
 
@@ -192,9 +194,12 @@ template <int N> struct SlotCount { static constexpr int value = N; };
 //   Every variant executes the same barriers, weight-stage copies and per-point (owner wave) work.
 //   p.folded: the packed weights carry prob_embed.2 folded into its two consumers (nr_pack.cpp pack_pass_weights fold = true):
 //   the layer is skipped and prob_embed.0's ReLU output takes its place.
-template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW, bool SAVE = false, bool DBG = false>
+//   AR = arithmetic of the MFMA layers (nr_layout.h): AR_F32, or AR_X3 = three-way split bf16 operands on v_mfma_f32_16x16x32_bf16
+//   (p.weights is then the split pack of neuray_pack_pass_weights_x3: inference, always folded).
+template <int NT, int VPW, bool HAS_VIS, int OWN, int MAXT, int MINW, bool SAVE = false, bool DBG = false, int AR = AR_F32>
 __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     static_assert(NT == 1, "one 16-point tile per wave iteration");
+    static_assert(AR == AR_F32 || !SAVE, "the training forward runs on the fp32 MFMA");
     NR_DYNAMIC_SMEM(float, smem);
     constexpr int RMAX = point_rmax<NT>();
     constexpr int NS = VPW;
@@ -205,8 +210,20 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     const int g = lane >> 4, c = lane & 15;
     float* red = smem;
     float* xch = smem + (size_t)(nw + 1) * RMAX * 64;
-    float* wl = xch + 16 * NT * 64;                  // staged weights of the current phase
-    const nr_wbuf W = nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
+    float* wl = xch + (AR == AR_X3 ? 0 : 16 * NT * 64);      // staged weights of the current phase
+    // the 16 rows through which the owner waves hand base_fc.0's per-point part / geometry_fc.0's hidden layer to the others: row
+    // 4 mo + r of tile mo.  AR_X3: inside the all-reduce scratch, in the region of the wave that owns the tile (mo = wave + j nw -> its
+    // rows 4 j + r; with one wave the 16 rows run on into the result region).  A wave's region is read by others only between the two
+    // barriers of an all-reduce, the rows are written after one and consumed before the next phase barrier: no extra synchronisation.
+    auto xrow = [&](int mo, int r) -> float* {
+        if constexpr (AR == AR_X3) return red + ((size_t)(mo % nw) * RMAX + (mo / nw) * 4 + r) * 64;
+        else return xch + (mo * 4 + r) * 64;
+    };
+    auto make_w = [&]() {
+        if constexpr (AR == AR_X3) return GlbW3{nr_make_wbuf(p.weights, sizeof(float) * kPackedPointFloatsX3)};
+        else return nr_make_wbuf(p.weights, sizeof(float) * kPackedPassFloats);
+    };
+    const auto W = make_w();
     const float* __restrict__ qc = p.que_const;
     const float qnearp = qc[24], qfarp = qc[25], qinv = qc[27];
     const float w_m1 = (float)(p.w - 1), h_m1 = (float)(p.h - 1);
@@ -219,7 +236,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     const int npts = p.rn * p.dn;
     const int dn = p.dn;
     const bool use_vis = p.use_vis != 0;
-    const bool folded = !SAVE && p.folded != 0;
+    const bool folded = AR == AR_X3 || (!SAVE && p.folded != 0);
     const bool dbg_lane = DBG && (g == 0);
     // XCD-aware tile map: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Giving every
     // XCD a contiguous run of tiles keeps the texels that neighbouring samples / rays share inside one private L2
@@ -376,16 +393,20 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             NR_PRAGMA_UNROLL
             for (int s = 0; s < NA1; ++s) none[s][0] = 0.0f;
             NoLayer last;      // "no next layer": the following layer belongs to the next phase
+            // the layers' quad operands in the form the arithmetic takes (AR_X3: split once here, used by the three or four dist heads
+            // and prob_embed.0)
+            decltype(auto) o_fray = operand<AR>(fray);
+            decltype(auto) o_none = operand<AR>(none);
 
             // ---------------- dist decoder (a9) + probabilities (a10, a11) ----------------------------
             float hit[NA1], vis[NA1];
             {
                 float h1[NA1][8], h2[NA1][8], fm[NA1][2], fv[NA1][2], fa[NA1][1];
                 float mu0[NA1], mu1[NA1], s0[NA1], s1[NA1], aw[NA1], nu[NA1];
-                LayerPre<L_DV2> p_dv2; VecPre<L_DFIN_V> p_fv;
-                const LdsW W1 = phase_enter<PH_DIST_M, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                LayerPreT<L_DV2, AR> p_dv2; VecPre<L_DFIN_V> p_fv;
+                const auto W1 = phase_enter<PH_DIST_M, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                 if constexpr (NA > 0) {
-                    LayerPre<L_DM1> p_dm1; LayerPre<L_DM2> p_dm2; LayerPre<L_DV1> p_dv1; VecPre<L_DFIN_M> p_fm;
+                    LayerPreT<L_DM1, AR> p_dm1; LayerPreT<L_DM2, AR> p_dm2; LayerPreT<L_DV1, AR> p_dv1; VecPre<L_DFIN_M> p_fm;
 #ifdef NR_PROBE_PRE
                     layer_prefetch<L_DM2>(W1, lane, p_dm2);
                     NR_PRAGMA_UNROLL
@@ -394,9 +415,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         for (int k = 0; k < 8; ++k) h1[s][k] = elu_s(fm1[s][k]);
 #else
                     layer_prefetch<L_DM1>(W1, lane, p_dm1);
-                    layer_fwd<L_DM1, NA, ACT_ELU>(W1, lane, p_dm1, fray, none, h1, p_dm2);
+                    layer_fwd<L_DM1, NA, ACT_ELU>(W1, lane, p_dm1, o_fray, none, h1, p_dm2);
 #endif
-                    layer_fwd<L_DM2, NA, ACT_ELU>(W1, lane, p_dm2, h1, none, h2, p_fm);
+                    layer_fwd<L_DM2, NA, ACT_ELU>(W1, lane, p_dm2, operand<AR>(h1), none, h2, p_fm);
                     layer_prefetch<L_DV1>(W1, lane, p_dv1);
                     layer_vec<L_DFIN_M, NA>(p_fm, h2, fm);
 #ifdef NR_PROBE_PRE
@@ -405,14 +426,14 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         NR_PRAGMA_UNROLL
                         for (int k = 0; k < 8; ++k) h1[s][k] = elu_s(fv1[s][k]);
 #else
-                    layer_fwd<L_DV1, NA, ACT_ELU>(W1, lane, p_dv1, fray, none, h1, last);
+                    layer_fwd<L_DV1, NA, ACT_ELU>(W1, lane, p_dv1, o_fray, none, h1, last);
 #endif
                 }
-                const LdsW W2 = phase_enter<PH_DIST_VA, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                const auto W2 = phase_enter<PH_DIST_VA, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                 if constexpr (NA > 0) {
-                    LayerPre<L_DA1> p_da1; LayerPre<L_DA2> p_da2; VecPre<L_DFIN_A> p_fa;
+                    LayerPreT<L_DA1, AR> p_da1; LayerPreT<L_DA2, AR> p_da2; VecPre<L_DFIN_A> p_fa;
                     layer_prefetch<L_DV2>(W2, lane, p_dv2);
-                    layer_fwd<L_DV2, NA, ACT_ELU>(W2, lane, p_dv2, h1, none, h2, p_fv);
+                    layer_fwd<L_DV2, NA, ACT_ELU>(W2, lane, p_dv2, operand<AR>(h1), none, h2, p_fv);
                     layer_prefetch<L_DA1>(W2, lane, p_da1);
                     layer_vec<L_DFIN_V, NA>(p_fv, h2, fv);
                     NR_PRAGMA_UNROLL
@@ -427,19 +448,19 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         NR_PRAGMA_UNROLL
                         for (int k = 0; k < 8; ++k) h1[s][k] = elu_s(fa1[s][k]);
 #else
-                    layer_fwd<L_DA1, NA, ACT_ELU>(W2, lane, p_da1, fray, none, h1, p_da2);
+                    layer_fwd<L_DA1, NA, ACT_ELU>(W2, lane, p_da1, o_fray, none, h1, p_da2);
 #endif
-                    layer_fwd<L_DA2, NA, ACT_ELU>(W2, lane, p_da2, h1, none, h2, p_fa);
+                    layer_fwd<L_DA2, NA, ACT_ELU>(W2, lane, p_da2, operand<AR>(h1), none, h2, p_fa);
                     layer_vec<L_DFIN_A, NA>(p_fa, h2, fa);
                 }
                 if constexpr (HAS_VIS) {
-                    const LdsW W2s = phase_enter<PH_DIST_S, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                    const auto W2s = phase_enter<PH_DIST_S, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                     if constexpr (NA > 0) {
-                        LayerPre<L_DS1> p_ds1; LayerPre<L_DS2> p_ds2; VecPre<L_DFIN_S> p_fs;
+                        LayerPreT<L_DS1, AR> p_ds1; LayerPreT<L_DS2, AR> p_ds2; VecPre<L_DFIN_S> p_fs;
                         float fs[NA][1];
                         layer_prefetch<L_DS1>(W2s, lane, p_ds1);
-                        layer_fwd<L_DS1, NA, ACT_ELU>(W2s, lane, p_ds1, fray, none, h1, p_ds2);
-                        layer_fwd<L_DS2, NA, ACT_ELU>(W2s, lane, p_ds2, h1, none, h2, p_fs);
+                        layer_fwd<L_DS1, NA, ACT_ELU>(W2s, lane, p_ds1, o_fray, none, h1, p_ds2);
+                        layer_fwd<L_DS2, NA, ACT_ELU>(W2s, lane, p_ds2, operand<AR>(h1), none, h2, p_fs);
                         layer_vec<L_DFIN_S, NA>(p_fs, h2, fs);
                         NR_PRAGMA_UNROLL
                         for (int s = 0; s < NA; ++s) { aw[s] = sigmoidf(fa[s][0]); nu[s] = sigmoidf(fs[s][0]); }
@@ -469,18 +490,21 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             }
 
             // ---------------- prob_embed (a13)                         aggregate_net.py:43 -----------------
-            const LdsW W3 = phase_enter<PH_EMBED, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+            const auto W3 = phase_enter<PH_EMBED, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
             float e[NA1][8], gi[NA1][8], gr[NA1][3], sn[NA1];
-            LayerPre<L_NF1> p_nf1; VecPre<L_NF2> p_nf2;
+            Opnd3<NA1, 8> e3;                                          // AR_X3: e split once (neuray_fc.0, and half of base_fc.0's operand)
+            LayerPreT<L_NF1, AR> p_nf1; VecPre<L_NF2> p_nf2;
             if constexpr (NA > 0) {
-                LayerPre<L_PE1> p_pe1; LayerPre<L_RD1> p_rd1; LayerPre<L_RD2> p_rd2; VecPre<L_RD2> p_rd2v;
+                LayerPreT<L_PE1, AR> p_pe1; LayerPreT<L_RD1, AR> p_rd1; LayerPreT<L_RD2, AR> p_rd2; VecPre<L_RD2> p_rd2v;
                 layer_prefetch<L_PE1>(W3, lane, p_pe1);
                 {
                     float x1[NA][1];
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s)
                         x1[s][0] = sel4(g, (hit[s] - 0.5f) * 2.0f, (vis[s] - 0.5f) * 2.0f, 0.0f, 0.0f);
-                    if (folded) {
+                    if constexpr (AR == AR_X3) {                     // (always the folded pack)
+                        layer_fwd<L_PE1, NA, ACT_RELU>(W3, lane, p_pe1, o_fray, x1, e, p_rd1);
+                    } else if (folded) {
                         // prob_embed.2 lives inside neuray_fc.0 / base_fc.0 of this pack: their input is the ReLU output itself
 #ifdef NR_PROBE_PRE
                         layer_prefetch<L_RD1>(W3, lane, p_rd1);
@@ -503,9 +527,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     float x1[NA][1], h[NA][4], df[NA][8], dc[NA][3];
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s) x1[s][0] = sel4(g, dlt[s][0], dlt[s][1], dlt[s][2], dlt[s][3]);
-                    layer_fwd<L_RD1, NA, ACT_ELU>(W3, lane, p_rd1, none, x1, h, p_rd2);
+                    layer_fwd<L_RD1, NA, ACT_ELU>(W3, lane, p_rd1, o_none, x1, h, p_rd2);
                     layer_prefetch<L_RD2>(W3, lane, p_rd2v);
-                    layer_fwd<L_RD2, NA, ACT_ELU>(W3, lane, p_rd2, h, none, df, last);
+                    layer_fwd<L_RD2, NA, ACT_ELU>(W3, lane, p_rd2, operand<AR>(h), none, df, last);
                     layer_vec<L_RD2, NA>(p_rd2v, h, dc);          // the three rgb rows of ray_dir_fc.2
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s) {
@@ -518,11 +542,12 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             }
             // ---------------- neuray_fc -> sigmoid                      ibrnet.py:337 -------------------------
             // (this phase also holds base_fc.0's per-view rows 0..31, used after the statistics below)
-            const LdsW W4 = phase_enter<PH_NF_BV0, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+            const auto W4 = phase_enter<PH_NF_BV0, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
             if constexpr (NA > 0) {
                 float h[NA][4], o[NA][1];
                 layer_prefetch<L_NF1>(W4, lane, p_nf1);
-                layer_fwd<L_NF1, NA, ACT_ELU>(W4, lane, p_nf1, e, none, h, p_nf2);
+                if constexpr (AR == AR_X3) { e3 = split_operand(e); layer_fwd<L_NF1, NA, ACT_ELU>(W4, lane, p_nf1, e3, none, h, p_nf2); }
+                else layer_fwd<L_NF1, NA, ACT_ELU>(W4, lane, p_nf1, e, none, h, p_nf2);
                 layer_vec<L_NF2, NA>(p_nf2, h, o);
                 NR_PRAGMA_UNROLL
                 for (int s = 0; s < NA; ++s) sn[s] = sigmoidf(o[s][0]);
@@ -537,7 +562,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
-                    const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_BG) * 4);      // (run-time tile index in the lane offset: see layer_tile_slice)
+                    const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_BG, AR) * 4);      // (run-time tile index in the lane offset: see layer_tile_slice)
                     accg[j][0][0] = b.x; accg[j][0][1] = b.y; accg[j][0][2] = b.z; accg[j][0][3] = b.w;
                 }
                 float part[NA1][11], st[11], sv[11], wk[NA1];
@@ -609,7 +634,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     const int mo = wave_t + j * nw;
                     if (mo < 4) {
                         NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) xch[(mo * 4 + r) * 64 + lane] = accg[j][0][r];
+                        for (int r = 0; r < 4; ++r) xrow(mo, r)[lane] = accg[j][0][r];
                         if constexpr (SAVE) {
                             NR_PRAGMA_UNROLL
                             for (int r = 0; r < 4; ++r)
@@ -621,17 +646,18 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int s = 0; s < NA; ++s)
                     NR_PRAGMA_UNROLL
-                    for (int mo = 0; mo < 4; ++mo)
+                    for (int mo = 0; mo < (AR == AR_X3 ? 2 : 4); ++mo)    // (AR_X3: tiles 2, 3 are read when base_fc.0's second half starts)
                         NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) accv[s][mo][r] = xch[(mo * 4 + r) * 64 + lane];
+                        for (int r = 0; r < 4; ++r) accv[s][mo][r] = xrow(mo, r)[lane];
             }
             // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
             float x[NA1][8], vis2[NA1], z[NA1];
-            LdsW W5;
-            LayerPre<L_VF1> p_vf1;
+            typename ws_lds<decltype(make_w())>::type W5;
+            LayerPreT<L_VF1, AR> p_vf1;
             {
                 float xq[NA1][16], x1[NA1][1], h64[NA1][16];
-                LayerPre<L_BV0> p_bv0; LayerPre<L_BV1> p_bv1; LayerPre<L_B2> p_b2;
+                Opnd3<NA1, 16> xq3;                                    // AR_X3: xq split once for base_fc.0's two halves
+                LayerPreT<L_BV0, AR> p_bv0; LayerPreT<L_BV1, AR> p_bv1; LayerPreT<L_B2, AR> p_b2;
                 v4f acch[NA1][2];
                 if constexpr (NA > 0) {
                     NR_PRAGMA_UNROLL
@@ -643,7 +669,16 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     layer_prefetch<L_BV0>(W4, lane, p_bv0);
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s) { acch[s][0] = accv[s][0]; acch[s][1] = accv[s][1]; }
-                    layer_acc<L_BV0, NA>(W4, lane, p_bv0, xq, x1, acch, last);
+                    if constexpr (AR == AR_X3) {
+                        const Opnd3<NA1, 8> gi3 = split_operand(gi);
+                        NR_PRAGMA_UNROLL
+                        for (int pt = 0; pt < 3; ++pt)
+                            NR_PRAGMA_UNROLL
+                            for (int s = 0; s < NA; ++s)
+                                NR_PRAGMA_UNROLL
+                                for (int i = 0; i < 4; ++i) { xq3.p[pt][s][i] = gi3.p[pt][s][i]; xq3.p[pt][s][4 + i] = e3.p[pt][s][i]; }
+                        layer_acc<L_BV0, NA>(W4, lane, p_bv0, xq3, x1, acch, last);
+                    } else layer_acc<L_BV0, NA>(W4, lane, p_bv0, xq, x1, acch, last);
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s)
                         NR_PRAGMA_UNROLL
@@ -651,12 +686,20 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                             NR_PRAGMA_UNROLL
                             for (int r = 0; r < 4; ++r) h64[s][4 * mo + r] = elu_s(acch[s][mo][r]);   // kOutScaled[L_BV0]
                 }
-                const LdsW W4b = phase_enter<PH_BV1, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
+                const auto W4b = phase_enter<PH_BV1, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                 if constexpr (NA > 0) {
                     layer_prefetch<L_BV1>(W4b, lane, p_bv1);
                     NR_PRAGMA_UNROLL
-                    for (int s = 0; s < NA; ++s) { acch[s][0] = accv[s][2]; acch[s][1] = accv[s][3]; }
-                    layer_acc<L_BV1, NA>(W4b, lane, p_bv1, xq, x1, acch, last);
+                    for (int s = 0; s < NA; ++s) {
+                        if constexpr (AR == AR_X3) {
+                            NR_PRAGMA_UNROLL
+                            for (int mo = 0; mo < 2; ++mo)
+                                NR_PRAGMA_UNROLL
+                                for (int r = 0; r < 4; ++r) acch[s][mo][r] = xrow(2 + mo, r)[lane];
+                        } else { acch[s][0] = accv[s][2]; acch[s][1] = accv[s][3]; }
+                    }
+                    if constexpr (AR == AR_X3) layer_acc<L_BV1, NA>(W4b, lane, p_bv1, xq3, x1, acch, last);
+                    else layer_acc<L_BV1, NA>(W4b, lane, p_bv1, xq, x1, acch, last);
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s)
                         NR_PRAGMA_UNROLL
@@ -667,7 +710,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 W5 = phase_enter<PH_B2_VF1, HAS_VIS>(wl, W, seq0, true, wave_t, nw, lane);
                 if constexpr (NA > 0) {
                     layer_prefetch<L_B2>(W5, lane, p_b2);
-                    layer_fwd<L_B2, NA, ACT_ELU>(W5, lane, p_b2, h64, none, x, p_vf1);
+                    layer_fwd<L_B2, NA, ACT_ELU>(W5, lane, p_b2, operand<AR>(h64), none, x, p_vf1);
                 }
             }
             {
@@ -677,16 +720,16 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     for (int s = 0; s < NA; ++s)
                         NR_PRAGMA_UNROLL
                         for (int k = 0; k < 8; ++k) xin[s][k] = x[s][k] * wv[s];
-                    layer_fwd<L_VF1, NA, ACT_ELU>(W5, lane, p_vf1, xin, none, h, last);
+                    layer_fwd<L_VF1, NA, ACT_ELU>(W5, lane, p_vf1, operand<AR>(xin), none, h, last);
                 }
                 W5 = phase_enter<PH_TAIL, HAS_VIS>(wl, W, seq0, more, wave_t, nw, lane);
                 if constexpr (NA > 0) {
                     float y[NA][8], yv[NA][1], o[NA][1];
-                    LayerPre<L_VF2> p_vf2; LayerPre<L_V21> p_v21; LayerPre<L_RF1> p_rf1; LayerPre<L_RF2> p_rf2;
+                    LayerPreT<L_VF2, AR> p_vf2; LayerPreT<L_V21, AR> p_v21; LayerPreT<L_RF1, AR> p_rf1; LayerPreT<L_RF2, AR> p_rf2;
                     VecPre<L_VF2> p_vf2v; VecPre<L_V22> p_v22; VecPre<L_RF3> p_rf3;
                     layer_prefetch<L_VF2>(W5, lane, p_vf2);
                     layer_prefetch<L_VF2>(W5, lane, p_vf2v);
-                    layer_fwd<L_VF2, NA, ACT_ELU>(W5, lane, p_vf2, h, none, y, p_v21);
+                    layer_fwd<L_VF2, NA, ACT_ELU>(W5, lane, p_vf2, operand<AR>(h), none, y, p_v21);
                     layer_vec<L_VF2, NA>(p_vf2v, h, yv);          // row 32: the visibility logit
                     float visp[NA];
                     NR_PRAGMA_UNROLL
@@ -695,7 +738,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         NR_PRAGMA_UNROLL
                         for (int k = 0; k < 8; ++k) { x[s][k] = x[s][k] + y[s][k]; xin[s][k] = x[s][k] * visp[s]; }
                     }
-                    layer_fwd<L_V21, NA, ACT_ELU>(W5, lane, p_v21, xin, none, h, p_v22);
+                    layer_fwd<L_V21, NA, ACT_ELU>(W5, lane, p_v21, operand<AR>(xin), none, h, p_v22);
                     layer_prefetch<L_RF1>(W5, lane, p_rf1);
                     layer_vec<L_V22, NA>(p_v22, h, o);
                     NR_PRAGMA_UNROLL
@@ -706,8 +749,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         x1[s][0] = sel4(g, vis2[s], dlt[s][0], dlt[s][1], dlt[s][2]);
                         x1[s][1] = sel4(g, dlt[s][3], 0.0f, 0.0f, 0.0f);
                     }
-                    layer_fwd<L_RF1, NA, ACT_ELU>(W5, lane, p_rf1, x, x1, h16, p_rf2);
-                    layer_fwd<L_RF2, NA, ACT_ELU>(W5, lane, p_rf2, h16, none, h8, p_rf3);
+                    layer_fwd<L_RF1, NA, ACT_ELU>(W5, lane, p_rf1, operand<AR>(x), x1, h16, p_rf2);
+                    layer_fwd<L_RF2, NA, ACT_ELU>(W5, lane, p_rf2, operand<AR>(h16), none, h8, p_rf3);
                     layer_vec<L_RF3, NA>(p_rf3, h8, o);
                     NR_PRAGMA_UNROLL
                     for (int s = 0; s < NA; ++s) {
@@ -787,7 +830,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             NR_PRAGMA_UNROLL
             for (int j = 0; j < OWN; ++j) {
                 const int mo = wave_t + j * nw;
-                const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_GF1) * 4);
+                const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_GF1, AR) * 4);
                 accf[j][0][0] = b.x; accf[j][0][1] = b.y; accf[j][0][2] = b.z; accf[j][0][3] = b.w;
             }
             float var[8];
@@ -800,10 +843,11 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xq[0][k] = big[k];
                 x1[0][0] = sel4(g, meanw * inv_rfn, 0.0f, 0.0f, 0.0f);
+                decltype(auto) oq = operand<AR>(xq);
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
-                    if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
+                    if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, oq, x1, accf[j]);
                 }
                 view_allreduce<NA, IDLE, 8, RMAX, RED_SUM>(v8, var, red, wave_t, nw, lane);
                 if constexpr (SAVE) {
@@ -818,13 +862,14 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 nonet[0][0] = 0.0f;
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xq[0][k] = var[k];
+                decltype(auto) oq = operand<AR>(xq);
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
                     if (mo < 4) {
-                        layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
+                        layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, oq, nonet, accf[j]);
                         NR_PRAGMA_UNROLL
-                        for (int r = 0; r < 4; ++r) xch[(mo * 4 + r) * 64 + lane] = elu_s(accf[j][0][r]);   // kOutScaled[L_GF1]
+                        for (int r = 0; r < 4; ++r) xrow(mo, r)[lane] = elu_s(accf[j][0][r]);   // kOutScaled[L_GF1]
                         if constexpr (SAVE) {
                             NR_PRAGMA_UNROLL
                             for (int r = 0; r < 4; ++r)
@@ -838,8 +883,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 float h[1][16], G[1][4], nonet[1][1];
                 nonet[0][0] = 0.0f;
                 NR_PRAGMA_UNROLL
-                for (int k = 0; k < 16; ++k) h[0][k] = xch[((k >> 2) * 4 + (k & 3)) * 64 + lane];
-                layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, h, nonet, G);
+                for (int k = 0; k < 16; ++k) h[0][k] = xrow(k >> 2, k & 3)[lane];
+                layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, operand<AR>(h), nonet, G);
                 if (pvalid)
                     *reinterpret_cast<float4*>(p.point_out + (size_t)pidx * kPointRec + 4 * g) = make_float4(G[0][0], G[0][1], G[0][2], G[0][3]);
                 if constexpr (SAVE) {
@@ -1663,6 +1708,30 @@ __global__ void mfma_selftest_kernel(const float* __restrict__ A /*16x4*/, const
     v4f acc; acc[0] = 0.0f; acc[1] = 0.0f; acc[2] = 0.0f; acc[3] = 0.0f;
     acc = nr_mfma16(A[(lane & 15) * 4 + (lane >> 4)], B[(lane >> 4) * 16 + (lane & 15)], acc);
     for (int r = 0; r < 4; ++r) D[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+}
+
+// AR_X3 (nr_layout.h): D[m][n] = sum_k A[m][k] B[k][n], K = 32, through the point kernel's own operand path - nr_split3 on BOTH
+// operands, six v_mfma_f32_16x16x32_bf16 products in mfma_unit3's order.  parts (optional, [3][16][32]): the three bf16 parts of A as
+// fp32 values, for a host-side evaluation of the split's own error.
+__global__ void x3_selftest_kernel(const float* __restrict__ A /*16x32*/, const float* __restrict__ B /*32x16*/, float* __restrict__ D /*16x16*/,
+                                   float* __restrict__ parts) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float av[1][8], bv[1][8];
+    for (int i = 0; i < 8; ++i) { av[0][i] = A[c * 32 + 8 * g + i]; bv[0][i] = B[(8 * g + i) * 16 + c]; }
+    const Opnd3<1, 8> a3 = split_operand(av), b3 = split_operand(bv);
+    Frag3 f;
+    for (int pt = 0; pt < 3; ++pt)
+        for (int i = 0; i < 4; ++i) f.p[pt][i] = a3.p[pt][0][i];
+    v4f acc[1];
+    acc[0][0] = 0.0f; acc[0][1] = 0.0f; acc[0][2] = 0.0f; acc[0][3] = 0.0f;
+    mfma_unit3<L_DM1, 1>(f, 0, b3, acc);
+    for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + c] = acc[0][r];
+    if (parts)
+        for (int pt = 0; pt < 3; ++pt)
+            for (int i = 0; i < 8; ++i) {
+                const unsigned w = a3.p[pt][0][i / 2], u = (i & 1) ? (w & 0xffff0000u) : (w << 16);
+                parts[(pt * 16 + c) * 32 + 8 * g + i] = __int_as_float((int)u);
+            }
 }
 
 __global__ void group_sum_selftest_kernel(const float* __restrict__ x, float* __restrict__ y) {

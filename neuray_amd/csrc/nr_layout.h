@@ -156,32 +156,50 @@ constexpr VecShape kVec[L_COUNT] = {
     {1, 4}, {0, 0},          // LT_GF1: d mean weight
 };
 
+// ---- arithmetic of the MFMA layers ("AR") -----------------------------------------------------------------
+// AR_F32: v_mfma_f32_16x16x4_f32 on fp32 operands; the layout described at the top of this file.
+// AR_X3 (inference point kernel only): v_mfma_f32_16x16x32_bf16 on operands split THREE ways,
+//   x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round to nearest: exact for an fp32 x), six products
+//   hh, hm, mh, hl, lh, mm per K = 32 with fp32 accumulation; the dropped m l + l m + l l is below 2^-23 of the product.
+//   A lane's 8 K-values of a K = 32 step are its 4 + 4 B registers of TWO consecutive quads (a "pair"), so the K order and the
+//   D -> B register chaining are those of the fp32 layout.  A layer's quad fragments become, per output tile mo,
+//       [pair kp = 0 .. KQ/2 - 1][part 0..2][lane] 16 bytes : 8 bf16 = part of W[out(mo, c)][in(8 kp + i, g)], i = 0..7
+//                                                           (i < 4: component i of quad 2 kp, else component i - 4 of quad 2 kp + 1)
+//       then, for an odd KQ, the last quad alone (v_mfma_f32_16x16x16_bf16): [part 0..2][lane] 8 bytes : 4 bf16
+//   = KQ * 384 floats per tile instead of KQ * 256.  Singles (fp32 MFMA), biases and vector rows are stored as in the fp32 layout.
+//   Always the folded network (prob_embed.2 inside its consumers): L_PE2 takes no space.
+constexpr int AR_F32 = 0, AR_X3 = 1;
+constexpr bool ar_omits(int l, int ar) { return ar == AR_X3 && l == L_PE2; }
+
 // sizes in floats
-constexpr int quads_floats(int l) { return kShape[l].mt_out * kShape[l].kq * 64 * 4; }
-constexpr int single_floats(int l) { return kShape[l].mt_out * kShape[l].k1 * 64; }
-constexpr int bias_floats(int l) { return kShape[l].mt_out * 16; }
-constexpr int vec_floats(int l) { return kVec[l].n > 0 ? kVec[l].n * kVec[l].tiles * 16 + 16 : 0; }
-constexpr int layer_floats(int l) { return quads_floats(l) + single_floats(l) + bias_floats(l) + vec_floats(l); }
+constexpr int quads_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * kShape[l].kq * 64 * (ar == AR_X3 ? 6 : 4); }
+constexpr int single_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * kShape[l].k1 * 64; }
+constexpr int bias_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * 16; }
+constexpr int vec_floats(int l, int ar = AR_F32) { return (kVec[l].n > 0 && !ar_omits(l, ar)) ? kVec[l].n * kVec[l].tiles * 16 + 16 : 0; }
+constexpr int layer_floats(int l, int ar = AR_F32) { return quads_floats(l, ar) + single_floats(l, ar) + bias_floats(l, ar) + vec_floats(l, ar); }
+// floats of one output tile's quad fragments (the run-time tile index of the owner waves strides by this)
+constexpr int tile_quads_floats(int l, int ar = AR_F32) { return kShape[l].kq * 64 * (ar == AR_X3 ? 6 : 4); }
 
 // float offset of layer l inside its packed buffer: the forward layers in the pass buffer, the transposed layers in
 // the second ("T") buffer, where the offsets restart at 0
-constexpr int layer_offset(int l) {
+constexpr int layer_offset(int l, int ar = AR_F32) {
     int off = 0;
-    for (int i = (l >= L_FWD_COUNT ? (int)L_FWD_COUNT : 0); i < l; ++i) off += layer_floats(i);
+    for (int i = (l >= L_FWD_COUNT ? (int)L_FWD_COUNT : 0); i < l; ++i) off += layer_floats(i, ar);
     return off;
 }
-constexpr int quads_offset(int l) { return layer_offset(l); }
-constexpr int single_offset(int l) { return layer_offset(l) + quads_floats(l); }
-constexpr int bias_offset(int l) { return layer_offset(l) + quads_floats(l) + single_floats(l); }
-constexpr int vec_offset(int l) { return bias_offset(l) + bias_floats(l); }               // [n][tiles][16]
-constexpr int vec_bias_offset(int l) { return vec_offset(l) + kVec[l].n * kVec[l].tiles * 16; }
+constexpr int quads_offset(int l, int ar = AR_F32) { return layer_offset(l, ar); }
+constexpr int single_offset(int l, int ar = AR_F32) { return layer_offset(l, ar) + quads_floats(l, ar); }
+constexpr int bias_offset(int l, int ar = AR_F32) { return layer_offset(l, ar) + quads_floats(l, ar) + single_floats(l, ar); }
+constexpr int vec_offset(int l, int ar = AR_F32) { return bias_offset(l, ar) + bias_floats(l, ar); }               // [n][tiles][16]
+constexpr int vec_bias_offset(int l, int ar = AR_F32) { return vec_offset(l, ar) + kVec[l].n * kVec[l].tiles * 16; }
 
-constexpr int packed_range_floats(int first, int last) {
+constexpr int packed_range_floats(int first, int last, int ar = AR_F32) {
     int off = 0;
-    for (int i = first; i < last; ++i) off += layer_floats(i);
+    for (int i = first; i < last; ++i) off += layer_floats(i, ar);
     return off;
 }
 constexpr int kPackedPointFloats = packed_range_floats(0, L_FWD_COUNT);
+constexpr int kPackedPointFloatsX3 = packed_range_floats(0, L_FWD_COUNT, AR_X3);
 constexpr int kPackedTFloats = packed_range_floats(L_FWD_COUNT, L_COUNT);      // the transposed layers (backward pass)
 
 // ---- LDS staging phases of the point kernel ------------------------------------------------------------
@@ -202,15 +220,17 @@ constexpr PhaseRange kPhase[PH_COUNT] = {
     {L_B2, L_VF1},           // base_fc.2, vis_fc.0
     {L_VF2, L_RF3},          // vis_fc.2, vis_fc2, rgb_fc
 };
-constexpr int phase_begin(int ph) { return layer_offset(kPhase[ph].first); }
-constexpr int phase_floats(int ph) { return layer_offset(kPhase[ph].last + 1) - layer_offset(kPhase[ph].first); }
-constexpr int max_phase_floats() {
+constexpr int phase_begin(int ph, int ar = AR_F32) { return layer_offset(kPhase[ph].first, ar); }
+constexpr int phase_floats(int ph, int ar = AR_F32) { return layer_offset(kPhase[ph].last + 1, ar) - layer_offset(kPhase[ph].first, ar); }
+constexpr int max_phase_floats(int ar = AR_F32) {
     int m = 0;
-    for (int i = 0; i < PH_COUNT; ++i) m = phase_floats(i) > m ? phase_floats(i) : m;
+    for (int i = 0; i < PH_COUNT; ++i) m = phase_floats(i, ar) > m ? phase_floats(i, ar) : m;
     return m;
 }
-constexpr int kStageRegionBytes = (max_phase_floats() * 4 + 1023) / 1024 * 1024;   // DMA pieces are 1 KiB per wave
-constexpr int kWeightLdsFloats = 2 * kStageRegionBytes / 4;
+constexpr int stage_region_bytes(int ar = AR_F32) { return (max_phase_floats(ar) * 4 + 1023) / 1024 * 1024; }   // DMA pieces are 1 KiB per wave
+constexpr int weight_lds_floats(int ar = AR_F32) { return 2 * stage_region_bytes(ar) / 4; }
+constexpr int kStageRegionBytes = stage_region_bytes();
+constexpr int kWeightLdsFloats = weight_lds_floats();
 // position of a phase in the sequence a kernel variant runs (PH_DIST_S is skipped without a vis head), its successor
 constexpr int phase_count(bool vis) { return vis ? PH_COUNT : PH_COUNT - 1; }
 constexpr int phase_seq(int ph, bool vis) { return (vis || ph < PH_DIST_S) ? ph : ph - 1; }

@@ -261,6 +261,54 @@ int pack_pass_weights(const float* const* t_in, float* dst, bool fold) {
     return 0;
 }
 
+// ---- AR_X3 (nr_layout.h): the folded fp32 pack re-written with every quad weight split three ways --------------------------
+namespace {
+unsigned short bf16_rn(float f) {                 // round to nearest even (finite weights)
+    unsigned u; std::memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_value(unsigned short b) { const unsigned u = (unsigned)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+}  // namespace
+
+void split3_bf16(float w, unsigned short (&part)[3]) {
+    part[0] = bf16_rn(w);
+    const float r1 = w - bf16_value(part[0]);     // exact: both are multiples of w's last bit, the difference needs <= 24 bits
+    part[1] = bf16_rn(r1);
+    const float r2 = r1 - bf16_value(part[1]);    // exact, and representable in 8 significant bits
+    part[2] = bf16_rn(r2);
+}
+
+int pack_pass_weights_x3(const float* const* tensors, float* dst) {
+    std::vector<float> f32(kPackedPassFloats, 0.0f);
+    const int rc = pack_pass_weights(tensors, f32.data(), true);
+    if (rc) return rc;
+    std::memset(dst, 0, sizeof(float) * (size_t)kPackedPointFloatsX3);
+    unsigned* words = reinterpret_cast<unsigned*>(dst);
+    for (int l = 0; l < L_FWD_COUNT; ++l) {
+        if (ar_omits(l, AR_X3)) continue;
+        const int MT = kShape[l].mt_out, KQ = kShape[l].kq;
+        const float* q = f32.data() + quads_offset(l);
+        for (int mo = 0; mo < MT; ++mo)
+            for (int kq = 0; kq < KQ; ++kq)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned short part[3];
+                        split3_bf16(q[((mo * KQ + kq) * 64 + lane) * 4 + j], part);
+                        const bool half = (KQ & 1) && kq == KQ - 1;        // the last quad of an odd count stands alone (K = 16)
+                        const int unit = quads_offset(l, AR_X3) + mo * tile_quads_floats(l, AR_X3) + (kq / 2) * 768;
+                        for (int pt = 0; pt < 3; ++pt) {
+                            // pair: [part][lane] 4 words, value i = 4 (kq & 1) + j in word i / 2; single quad: [part][lane] 2 words
+                            const int i = half ? j : 4 * (kq & 1) + j;
+                            const int word = half ? unit + pt * 128 + lane * 2 + i / 2 : unit + pt * 256 + lane * 4 + i / 2;
+                            words[word] |= (unsigned)part[pt] << (16 * (i & 1));
+                        }
+                    }
+        // singles, biases, vector rows: as in the fp32 pack
+        std::memcpy(dst + single_offset(l, AR_X3), f32.data() + single_offset(l), sizeof(float) * (size_t)(layer_floats(l) - quads_floats(l)));
+    }
+    return 0;
+}
+
 // ---- transposed layers (nr_layout.h LT_*): dX = W^T dY for the backward pass, second packed buffer --------------------
 namespace {
 

@@ -24,6 +24,12 @@ void pack_vec(float* dst, int layer, const float* W, int ldw, const float* bias,
 // columns (aggregate_net.py:27-31, ibrnet.py:337,342-343); the L_PE2 slot stays zero and the kernel skips the layer.
 int pack_pass_weights(const float* const* tensors, float* dst, bool fold = false);
 
+// AR_X3 (nr_layout.h): the folded pack with every quad weight split into three bf16 parts, in the pair layout of the K = 32 bf16
+// MFMA (kPackedPointFloatsX3 floats: the point kernel's layers only; the ray kernel keeps reading the fp32 pack).  Inference only.
+int pack_pass_weights_x3(const float* const* tensors, float* dst);
+// w = part[0] + part[1] + part[2] exactly (bf16 bit patterns, each the round-to-nearest of what the parts before it left)
+void split3_bf16(float w, unsigned short (&part)[3]);
+
 // packed[i] = flat[index[i]] * scale[i] (flat natural layout, nr_layout.h); index -1 = padding.  kPackedPassFloats entries each.
 int pack_pass_index_map(bool has_vis, int* index, float* scale);
 

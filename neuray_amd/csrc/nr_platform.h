@@ -68,6 +68,34 @@ __device__ __forceinline__ v4f nr_mfma16_bf16q3(float a01h, float a23h, float a0
 }
 #endif
 #endif
+// ---- AR_X3 (nr_layout.h): fp32-grade products on v_mfma_f32_16x16x32_bf16 -----------------------------------------------
+// D(16x16) = A(16x32) * B(32x16) + C on bf16 operands, fp32 accumulation: lane l supplies A[m = l&15][k = 8*(l>>4) + i] and
+// B[k = 8*(l>>4) + i][n = l&15], i = 0..7, as four registers of bf16 pairs; same D layout as nr_mfma16.  ~17 cycles per SIMD.
+typedef unsigned int nr_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int nr_v2u __attribute__((ext_vector_type(2)));
+typedef __bf16 nr_v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 nr_v2bf_ __attribute__((ext_vector_type(2)));
+typedef short nr_v4s_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f nr_mfma16x32_bf16(nr_v4u a, nr_v4u b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nr_v8bf, a), __builtin_bit_cast(nr_v8bf, b), c, 0, 0, 0);
+}
+// K = 16 form for the last quad of a layer with an odd quad count: k = 4*(l>>4) + i, i = 0..3
+__device__ __forceinline__ v4f nr_mfma16x16_bf16(nr_v2u a, nr_v2u b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(nr_v4s_, a), __builtin_bit_cast(nr_v4s_, b), c, 0, 0, 0);
+}
+// three-way split of a register pair: x = h + m + l, every part the round-to-nearest bf16 of what the parts before it left (each
+// residual is exact in fp32, and the third one fits bf16's 8 significant bits: an fp32 value is reproduced EXACTLY).  11 VALU:
+// 3 v_cvt_pk_bf16_f32, 4 unpacks, 4 subtractions.
+__device__ __forceinline__ unsigned nr_pk_bf16_rn(float lo, float hi) {
+    nr_v2bf_ v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void nr_split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = nr_pk_bf16_rn(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = nr_pk_bf16_rn(r0, r1);
+    l = nr_pk_bf16_rn(r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u));
+}
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define NR_PRAGMA_UNROLL _Pragma("unroll")
@@ -124,6 +152,16 @@ static inline float nr_buf_ld1(nr_buf b, int voff, int soff) { return nr_buf_in(
 static inline float2 nr_buf_ld2(nr_buf b, int voff, int soff) {
     return nr_buf_in(b, voff, soff) ? *reinterpret_cast<const float2*>(b.p + (long long)voff + soff) : make_float2(0.0f, 0.0f);
 }
+static inline nr_v4u nr_buf_ld4u(nr_buf b, int voff, int soff) {
+    nr_v4u r = {0u, 0u, 0u, 0u};
+    if (nr_buf_in(b, voff, soff)) memcpy(&r, b.p + (long long)voff + soff, 16);
+    return r;
+}
+static inline nr_v2u nr_buf_ld2u(nr_buf b, int voff, int soff) {
+    nr_v2u r = {0u, 0u};
+    if (nr_buf_in(b, voff, soff)) memcpy(&r, b.p + (long long)voff + soff, 8);
+    return r;
+}
 // LDS-DMA piece (emulation: the copy happens at issue time, a legal completion point)
 static inline void nr_dma16(nr_buf b, float* lds_wave_base, int lane, int voff, int soff) {
     if (nr_buf_in(b, voff, soff)) memcpy(reinterpret_cast<char*>(lds_wave_base) + lane * 16, b.p + (long long)voff + soff, 16);
@@ -155,6 +193,9 @@ __device__ __forceinline__ float2 nr_buf_ld2(nr_buf b, int voff, int soff) {    
     const v2f_ f = __builtin_bit_cast(v2f_, u);
     return make_float2(f.x, f.y);
 }
+// raw 16 / 8 bytes (the split-operand fragments of AR_X3)
+__device__ __forceinline__ nr_v4u nr_buf_ld4u(nr_buf b, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0); }
+__device__ __forceinline__ nr_v2u nr_buf_ld2u(nr_buf b, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0); }
 // LDS-DMA piece: buffer_load_dwordx4 ... lds.  Every active lane moves 16 bytes from (voff + soff) of the buffer to
 // lds_wave_base + lane * 16 (lds_wave_base is wave-uniform and goes to M0); no VGPRs, completion counted by vmcnt.
 __device__ __forceinline__ void nr_dma16(nr_buf b, float* lds_wave_base, int /*lane*/, int voff, int soff) {

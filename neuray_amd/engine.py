@@ -74,10 +74,13 @@ class PackedPass:
     neuray_fc.0 / base_fc.0 (neuray_pack_pass_weights_folded): inference packs; the backward kernels and the training forward
     take the unfolded form."""
 
-    def __init__(self, dev_tensor, has_vis_head, folded=False):
+    def __init__(self, dev_tensor, has_vis_head, folded=False, dev_x3=None):
         self.dev = dev_tensor
         self.has_vis_head = has_vis_head
         self.folded = folded
+        # the point kernel's layers once more in the split-operand form of NEURAY_ARITH_X3 (neuray_pack_pass_weights_x3): present when
+        # the engine renders with arith='x3'; every other kernel keeps reading `dev`
+        self.dev_x3 = dev_x3
 
 
 class ViewSet:
@@ -89,11 +92,19 @@ class ViewSet:
 
 
 class RenderEngine:
-    def __init__(self, device, _test_lib=None, views_per_wave=0, variant='fp32'):
+    def __init__(self, device, _test_lib=None, views_per_wave=0, variant='fp32', arith='f32'):
         """device: torch device of the HIP GPU.  `_test_lib` is for the CPU test-suite only (binds the
         emulator build of the same kernels); the product path always uses libneuray_hip.so.
         variant: 'fp32' (the product) or 'bf16' (libneuray_hip_bf16.so: bf16 MFMA operands, fp32 accumulation;
-        inference only, reported separately - DESIGN.md section 4.8)."""
+        inference only, reported separately - DESIGN.md section 4.8).
+        arith: 'f32' = the MLP contractions of the inference point kernel on the fp32 MFMA; 'x3' = on the K = 32 bf16 MFMA with every
+        operand split exactly into three bf16 parts (six products, fp32 accumulation: each product within 2^-23 of exact - DESIGN.md
+        section 4.12; the fp32 library only).  Training forwards / backwards always run on the fp32 MFMA."""
+        if arith not in ('f32', 'x3'):
+            raise ValueError("neuray_amd: arith=%r (use 'f32' or 'x3')" % (arith,))
+        if arith == 'x3' and variant != 'fp32':
+            raise ValueError("neuray_amd: arith='x3' is an arithmetic of the fp32 library (variant=%r is its own operand format)" % (variant,))
+        self.arith = arith
         self.device = torch.device(device)
         if _test_lib is None:
             if self.device.type != 'cuda':
@@ -160,7 +171,12 @@ class RenderEngine:
         packed = torch.empty(n, dtype=torch.float32)
         pack = self.lib.neuray_pack_pass_weights_folded if fold else self.lib.neuray_pack_pass_weights
         self._check(pack(ptrs, C.c_void_p(packed.data_ptr())))
-        return PackedPass(packed.to(self.device), has_vis, folded=bool(fold))
+        dev_x3 = None
+        if fold and self.arith == 'x3':
+            x3 = torch.empty(int(self.lib.neuray_packed_points_floats_x3()), dtype=torch.float32)
+            self._check(self.lib.neuray_pack_pass_weights_x3(ptrs, C.c_void_p(x3.data_ptr())))
+            dev_x3 = x3.to(self.device)
+        return PackedPass(packed.to(self.device), has_vis, folded=bool(fold), dev_x3=dev_x3)
 
     def posenc(self, dn):
         if dn not in self._posenc:
@@ -769,14 +785,17 @@ class RenderEngine:
         rec = self.empty(rn * dn, _lib.POINT_REC)
         dbg = self.empty(rn * dn, views.rfn, _lib.DBG_FIELDS) if want_dbg else None
         saved = self.points_saved_buffer(rn * dn) if save and views.rfn <= 8 else None
+        # NEURAY_ARITH_X3: the inference point kernel with two views per wave (a single reference view stays on the fp32 MFMA)
+        x3 = packed.dev_x3 is not None and not save and views.rfn >= 2 and self.views_per_wave in (0, 2)
         a = _lib.NeurayPointsArgs(
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(),
-            views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
+            views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(),
+            packed.dev_x3.data_ptr() if x3 else packed.dev.data_ptr(),
             rec.data_ptr(), dbg.data_ptr() if want_dbg else None,
             views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
             int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), int(self.views_per_wave),
             saved.data_ptr() if saved is not None else None, int(packed.folded),
-            slot_stats.data_ptr() if slot_stats is not None else None)
+            slot_stats.data_ptr() if slot_stats is not None else None, _lib.ARITH_X3 if x3 else _lib.ARITH_F32)
         ev = self._event_pair()
         self._check(self.lib.neuray_render_points(C.byref(a), s))
         self._event_done(ev, 'points', rn * dn)
@@ -859,6 +878,6 @@ class RenderEngine:
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(),
             views.ray_feats.data_ptr(), views.img_feats.data_ptr(), views.rgba.data_ptr(), packed.dev.data_ptr(),
             rec.data_ptr(), None, views.rfn, rn, dn, views.h, views.w, views.fh, views.fw,
-            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), 0, saved.data_ptr(), 0, None)
+            int(packed.has_vis_head), int(bool(use_vis)), float(var_bias), 0, saved.data_ptr(), 0, None, _lib.ARITH_F32)
         self._check(self.lib.neuray_render_points(C.byref(a), self._stream()))
         return saved

@@ -25,7 +25,7 @@ class HipRenderPath:
         eng = self.__dict__.get('_engine')
         if eng is None or eng.device != torch.device(device):
             eng = RenderEngine(device, _test_lib=self.__dict__.get('_engine_test_lib'),
-                               variant=self.cfg.get('hip_variant', 'fp32'))
+                               variant=self.cfg.get('hip_variant', 'fp32'), arith=self.cfg.get('hip_arith', 'f32'))
             self.__dict__['_engine'] = eng
             self.__dict__['_packed'] = {}
         return eng

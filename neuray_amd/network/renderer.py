@@ -43,6 +43,10 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         # not a reference key: 'fp32' = the product library; 'bf16' = the separately built bf16-operand variant of the
         # kernels (libneuray_hip_bf16.so; inference only, never the default)
         'hip_variant': 'fp32',
+        # not a reference key: arithmetic of the MLP contractions of the inference point kernel (fp32 library): 'f32' = the fp32 MFMA;
+        # 'x3' = every operand split exactly into three bf16 parts on the K = 32 bf16 MFMA, six products per K = 32 with fp32
+        # accumulation - each product within 2^-23 of exact (NeurayPointsArgs.arith).  Training always 'f32'.
+        'hip_arith': 'f32',
         # not a reference key: the inference packs carry prob_embed.2 folded into its consumers neuray_fc.0 / base_fc.0 (one 32 x 32
         # layer less per (point, view); the same function up to fp32 rounding - neuray_pack_pass_weights_folded)
         'hip_fold_prob_embed': True,

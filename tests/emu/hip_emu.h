@@ -232,6 +232,41 @@ static inline v4f nr_mfma16_bf16q3(float a01h, float a23h, float a01l, float a23
     return d;
 }
 
+// ---- AR_X3 (nr_layout.h): the K = 32 / K = 16 bf16 MFMAs on packed operands and the three-way operand split ---------------
+typedef unsigned int nr_v4u __attribute__((vector_size(16)));
+typedef unsigned int nr_v2u __attribute__((vector_size(8)));
+static inline float emu_bf16_word(unsigned w, int hi) { const unsigned u = hi ? (w & 0xffff0000u) : (w << 16); float f; memcpy(&f, &u, 4); return f; }
+// every (m, n) sums its K products in fp32; the order differs from the hardware's only in rounding noise
+static inline v4f nr_mfma16x32_bf16(nr_v4u a, nr_v4u b, v4f c) {
+    v4f d = c;
+    for (int i = 0; i < 8; ++i) {
+        v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f t = nr_mfma16(emu_bf16_word(a[i / 2], i & 1), emu_bf16_word(b[i / 2], i & 1), z);
+        for (int r = 0; r < 4; ++r) d[r] += t[r];
+    }
+    return d;
+}
+static inline v4f nr_mfma16x16_bf16(nr_v2u a, nr_v2u b, v4f c) {
+    v4f d = c;
+    for (int i = 0; i < 4; ++i) {
+        v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f t = nr_mfma16(emu_bf16_word(a[i / 2], i & 1), emu_bf16_word(b[i / 2], i & 1), z);
+        for (int r = 0; r < 4; ++r) d[r] += t[r];
+    }
+    return d;
+}
+static inline unsigned emu_pk_bf16(float lo, float hi) {
+    unsigned a, b; const float rl = emu_bf16_round(lo), rh = emu_bf16_round(hi);
+    memcpy(&a, &rl, 4); memcpy(&b, &rh, 4);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+static inline void nr_split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = emu_pk_bf16(x0, x1);
+    const float r0 = x0 - emu_bf16_word(h, 0), r1 = x1 - emu_bf16_word(h, 1);
+    m = emu_pk_bf16(r0, r1);
+    l = emu_pk_bf16(r0 - emu_bf16_word(m, 0), r1 - emu_bf16_word(m, 1));
+}
+
 // ---- exact-rounding helpers (same names as the HIP device intrinsics) --------------------------
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }

@@ -383,6 +383,38 @@ static double time_kernel(K launch, int reps) {
     return ms / reps;
 }
 
+
+// ---- issue / dependent latency of v_mfma_f32_16x16x32_bf16: NACC independent accumulator chains, one wave per SIMD ------------------
+template <int NACC, int GAPV>
+__global__ void __launch_bounds__(256) mfma_chain(float* out, int n) {
+    v4u a = {threadIdx.x * 3u + 1u, threadIdx.x * 5u + 2u, threadIdx.x * 7u + 3u, threadIdx.x * 11u + 4u}, b = a;
+    b[0] ^= 0x01010101u;
+    v4f acc[NACC];
+    float filler = (float)threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < n; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                acc[i] = mma_bf(a, b, acc[i]);
+#pragma unroll
+                for (int v = 0; v < GAPV; ++v) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(filler));
+            }
+    }
+    float s = filler;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+template <int NACC, int GAPV>
+static void run_chain(float* dout, int cus, double ghz) {
+    const int n = 2000;
+    const double ms = time_kernel([&] { hipLaunchKernelGGL((mfma_chain<NACC, GAPV>), cus, 256, 0, 0, dout, n); }, 3);
+    printf("    16x16x32 bf16, %d accumulator chain(s), %d v_fma between MFMAs: %6.1f SIMD cycles per MFMA\n", NACC, GAPV, ms * 1e-3 * ghz * 1e9 / ((double)n * 8 * NACC));
+}
+
 static const char* kName[] = {"F32  16x16x4 f32, 8 MFMA / K32", "X3   16x16x32 bf16 3-way, 6 MFMA / K32", "X2   16x16x32 bf16 2-way, 3 MFMA / K32",
                               "X2L  16x16x16 bf16 2-way, 6 MFMA / K32", "H2   16x16x32 f16 2-way, 3 MFMA / K32", "B1   16x16x32 bf16 plain, 1 MFMA / K32"};
 
@@ -483,6 +515,9 @@ int main() {
     run<X2L>(*net, dout, cus, ghz);
     run<H2>(*net, dout, cus, ghz);
     run<B1>(*net, dout, cus, ghz);
+    printf("MFMA issue / dependency (one wave per SIMD):\n");
+    run_chain<1, 0>(dout, cus, ghz); run_chain<2, 0>(dout, cus, ghz); run_chain<3, 0>(dout, cus, ghz); run_chain<4, 0>(dout, cus, ghz);
+    run_chain<1, 2>(dout, cus, ghz); run_chain<2, 2>(dout, cus, ghz); run_chain<2, 4>(dout, cus, ghz); run_chain<4, 4>(dout, cus, ghz); run_chain<4, 8>(dout, cus, ghz);
     run_products<F32>(kName[F32]);
     run_products<X3>(kName[X3]);
     run_products<X2>(kName[X2]);

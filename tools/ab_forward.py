@@ -7,7 +7,7 @@ COARSE pixels / hit probabilities and of the chained fine pixels on N strided ra
 (TEST INFRASTRUCTURE: the oracle is the checker here, computed once).  `build:` entries compile a variant first:
     python tools/ab_forward.py base=neuray_amd/libneuray_hip.so norefine=build:-DNR_FEATURE_RCP_REFINE=0
 (variants are written to _ab/, which is git-ignored).  A path may carry `,nofold`: that library renders with the unfolded
-pack (cfg hip_fold_prob_embed = False; also what a library older than ABI 7 needs)."""
+pack (cfg hip_fold_prob_embed = False; also what a library older than ABI 7 needs); `,x3`: cfg hip_arith = 'x3'."""
 import argparse
 import json
 import os
@@ -94,10 +94,11 @@ def main():
         name, path = item.split('=', 1)
         path, *opts = path.split(',')
         fold = 'nofold' not in opts
+        arith = 'x3' if 'x3' in opts else 'f32'           # `,x3`: NEURAY_ARITH_X3 (three-way split bf16 operands on the K = 32 MFMA)
         if path.startswith('build:'):
             path = build_variant(name, path[6:].split())
         torch.manual_seed(0)
-        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold, **({'ray_batch_num': a.ray_batch, 'hip_min_ray_batch': 0} if a.ray_batch else {})}).eval()
+        r = NeuralRayBaseRenderer({**cfg, 'hip_fold_prob_embed': fold, 'hip_arith': arith, **({'ray_batch_num': a.ray_batch, 'hip_min_ray_batch': 0} if a.ray_batch else {})}).eval()
         r.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
         r = r.to(dev)
         r._engine_test_lib = bind_compat(os.path.join(ROOT, path) if not os.path.isabs(path) else path)

@@ -119,7 +119,7 @@ int launch_points_save(const nr::PointParams& p, void* stream) {
 #define NR_POINT_MINW 3        // workgroups per CU the 2-views-per-wave kernel is compiled for (A/B: -DNR_POINT_MINW=2 = 256 VGPRs, no spills)
 #endif
 #ifndef NR_POINT_MINW_X3
-#define NR_POINT_MINW_X3 3     // the same for the AR_X3 instantiation
+#define NR_POINT_MINW_X3 2     // the same for the AR_X3 instantiation: 207 VGPRs, no spills; compiled for 3 (168 VGPRs, 33 spilled) it is 8.5 % slower (profiles/r06_c_*)
 #endif
 template <bool HAS_VIS>
 int launch_points_cfg(const nr::PointParams& p, int vpw, int arith, void* stream) {

@@ -349,7 +349,7 @@ __device__ __forceinline__ void layer_bias(WS W, int lane, v4f (&acc)[NT][kShape
     constexpr int MT = kShape[L].mt_out;
     NR_PRAGMA_UNROLL
     for (int mo = 0; mo < MT; ++mo) {
-        const float4 b = wld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
+        const float4 b = wld4(W, (lane >> 4) * 16, (bias_offset(L, ws_ar<WS>::value) + mo * 16) * 4);
         NR_PRAGMA_UNROLL
         for (int t = 0; t < NT; ++t) { acc[t][mo][0] = b.x; acc[t][mo][1] = b.y; acc[t][mo][2] = b.z; acc[t][mo][3] = b.w; }
     }
@@ -390,7 +390,8 @@ __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (
 template <int L, int NT, int KQ0, int KQN, int K10, int K1N, class WS, int KQX, int K1X>
 __device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
                                                  const float (&xq)[NT][KQX], const float (&x1)[NT][K1X], v4f (&acc)[NT]) {
-    constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1;
+    constexpr int KQ = kShape[L].kq, K1 = kShape[L].k1, AR = ws_ar<WS>::value;
+    static_assert(!ar_splits(L, AR), "fp32 operands for a layer the source's layout stores split");
     static_assert(KQ0 + KQN <= KQ && K10 + K1N <= K1, "slice outside the layer");
     static_assert(KQX >= (KQN > 0 ? 4 * KQN : 1) && K1X >= (K1N > 0 ? K1N : 1), "operand arrays too small");
     // the run-time tile index goes into the per-lane byte offset, so that every load's scalar offset is a compile-time constant: as
@@ -399,13 +400,13 @@ __device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
     const int v1 = lane * 4 + mo * (K1 * 256), vq = lane * 16 + mo * (KQ * 1024);
     float s1[K1N > 0 ? K1N : 1];
     NR_PRAGMA_UNROLL
-    for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, v1, (single_offset(L) + (K10 + k1) * 64) * 4);
+    for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, v1, (single_offset(L, AR) + (K10 + k1) * 64) * 4);
     if (KQN > 0) {
-        float4 cur = wldq(W, vq, (quads_offset(L) + KQ0 * 256) * 4);
+        float4 cur = wldq(W, vq, (quads_offset(L, AR) + KQ0 * 256) * 4);
         NR_PRAGMA_UNROLL
         for (int kq = 0; kq < KQN; ++kq) {
             float4 nxt = cur;
-            if (kq + 1 < KQN) nxt = wldq(W, vq, (quads_offset(L) + (KQ0 + kq + 1) * 256) * 4);
+            if (kq + 1 < KQN) nxt = wldq(W, vq, (quads_offset(L, AR) + (KQ0 + kq + 1) * 256) * 4);
             NR_PIN();
             mfma_quad<NT>(cur, kq, xq, acc);
             cur = nxt;
@@ -440,12 +441,14 @@ struct NoLayer {};
 
 template <int L, class WS>
 __device__ __forceinline__ void layer_prefetch(WS W, int lane, LayerPre<L>& p) {
+    constexpr int AR = ws_ar<WS>::value;
+    static_assert(!ar_splits(L, AR), "fp32 operands for a layer the source's layout stores split");
     NR_PRAGMA_UNROLL
-    for (int i = 0; i < LayerPre<L>::NF; ++i) p.q[i] = wldq(W, lane * 16, (quads_offset(L) + i * 256) * 4);
+    for (int i = 0; i < LayerPre<L>::NF; ++i) p.q[i] = wldq(W, lane * 16, (quads_offset(L, AR) + i * 256) * 4);
     NR_PRAGMA_UNROLL
-    for (int mo = 0; mo < LayerPre<L>::MT; ++mo) p.b[mo] = wld4(W, (lane >> 4) * 16, (bias_offset(L) + mo * 16) * 4);
+    for (int mo = 0; mo < LayerPre<L>::MT; ++mo) p.b[mo] = wld4(W, (lane >> 4) * 16, (bias_offset(L, AR) + mo * 16) * 4);
     NR_PRAGMA_UNROLL
-    for (int i = 0; i < LayerPre<L>::MT * LayerPre<L>::K1; ++i) p.s1[i] = wld1(W, lane * 4, (single_offset(L) + i * 64) * 4);
+    for (int i = 0; i < LayerPre<L>::MT * LayerPre<L>::K1; ++i) p.s1[i] = wld1(W, lane * 4, (single_offset(L, AR) + i * 64) * 4);
 }
 template <class WS> __device__ __forceinline__ void layer_prefetch(WS, int, NoLayer&) {}
 
@@ -515,7 +518,7 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const LayerPre<L>& pre
             mfma_quad<NT>(cur, kq, xq, a);
             NR_PRAGMA_UNROLL
             for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
-            if (i + PF + 1 < NQ) ring[i % (PF + 1)] = wldq(W, lane * 16, (quads_offset(L) + (i + PF + 1) * 256) * 4);
+            if (i + PF + 1 < NQ) ring[i % (PF + 1)] = wldq(W, lane * 16, (quads_offset(L, ws_ar<WS>::value) + (i + PF + 1) * 256) * 4);
         }
     } else {
         layer_prefetch(W, lane, next);
@@ -622,6 +625,7 @@ __device__ __forceinline__ decltype(auto) operand(const float (&x)[NT][KQX]) {
 // words 0..1 of each part)
 struct Frag3 { nr_v4u p[3]; };
 template <int L> struct Units3 {
+    static_assert(ar_splits(L, AR_X3), "a per-point layer keeps fp32 operands (nr_layout.h)");
     static constexpr int KQ = kShape[L].kq;
     static_assert(KQ <= 1 || KQ % 2 == 0, "AR_X3: a layer's quads come in pairs, or it has a single one");
     static constexpr bool HALF = KQ == 1;

@@ -139,11 +139,50 @@ __device__ __forceinline__ void bg_accumulate(WS W, int lane, int g, int wave, i
         for (int s = 0; s < 8; ++s) xq[t][s] = st[t * 11 + s];
         x1[t][0] = sel4(g, st[t * 11 + 8], st[t * 11 + 9], st[t * 11 + 10], 0.0f);
     }
-    decltype(auto) oq = operand<ws_ar<WS>::value>(xq);
     NR_PRAGMA_UNROLL
     for (int j = 0; j < OWN; ++j) {
         const int mo = wave + j * nw;
-        if (mo < 4) layer_tile_slice<L_BG, NT, 2 * STAT, 2, STAT, 1>(W, lane, mo, oq, x1, accg[j]);
+        if (mo < 4) layer_tile_slice<L_BG, NT, 2 * STAT, 2, STAT, 1>(W, lane, mo, xq, x1, accg[j]);      // (fp32 operands in both arithmetics)
+    }
+}
+
+// AR_X3 (207 of the 256 registers of its two-workgroups-per-CU budget): the owner wave keeps its tile(s) of base_fc.0's per-point part - 8 quad
+// fragments, 4 singles, the bias - in registers for the whole launch (the tile a wave owns never changes), instead of fetching a
+// K-slice from L2 behind each of the four statistics all-reduces, where the wave - and at the next barrier its three siblings - waited
+// for it.
+template <int OWN> struct BgResident { float4 q[OWN][8]; float s1[OWN][4]; float4 b[OWN]; };
+template <int OWN, class WS>
+__device__ __forceinline__ void bg_resident_load(WS W, int lane, int wave, int nw, BgResident<OWN>& r) {
+    constexpr int AR = ws_ar<WS>::value;
+    NR_PRAGMA_UNROLL
+    for (int j = 0; j < OWN; ++j) {
+        const int mo = wave + j * nw, m = mo < 4 ? mo : 0;
+        NR_PRAGMA_UNROLL
+        for (int kq = 0; kq < 8; ++kq) r.q[j][kq] = wld4(W, lane * 16 + m * (8 * 1024), (quads_offset(L_BG, AR) + kq * 256) * 4);
+        NR_PRAGMA_UNROLL
+        for (int k1 = 0; k1 < 4; ++k1) r.s1[j][k1] = wld1(W, lane * 4 + m * (4 * 256), (single_offset(L_BG, AR) + k1 * 64) * 4);
+        r.b[j] = wld4(W, (lane >> 4) * 16 + m * 64, bias_offset(L_BG, AR) * 4);
+    }
+}
+template <int NT, int OWN, int STAT>
+__device__ __forceinline__ void bg_accumulate(const BgResident<OWN>& r, int g, int wave, int nw,
+                                              const float (&st)[NT * 11], v4f (&accg)[OWN][NT]) {
+    float xq[NT][8], x1[NT][1];
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t) {
+        NR_PRAGMA_UNROLL
+        for (int s = 0; s < 8; ++s) xq[t][s] = st[t * 11 + s];
+        x1[t][0] = sel4(g, st[t * 11 + 8], st[t * 11 + 9], st[t * 11 + 10], 0.0f);
+    }
+    NR_PRAGMA_UNROLL
+    for (int j = 0; j < OWN; ++j) {
+        const int mo = wave + j * nw;
+        if (mo < 4) {                    // (the same K order as layer_tile_slice: the slice's two quads, then its single)
+            mfma_quad<NT>(r.q[j][2 * STAT], 0, xq, accg[j]);
+            mfma_quad<NT>(r.q[j][2 * STAT + 1], 1, xq, accg[j]);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) accg[j][t] = nr_mfma16(r.s1[j][STAT], x1[t][0], accg[j][t]);
+        }
     }
 }
 
@@ -243,6 +282,12 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
     // instead of fetching them into all eight (the grid is a multiple of 8).
     const int bid = (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8);
     int seq0 = 0;                                       // phases entered so far (selects the stage region)
+#ifndef NR_X3_BG_RESIDENT
+#define NR_X3_BG_RESIDENT 1
+#endif
+    constexpr bool BG_RES = AR == AR_X3 && OWN == 1 && (NR_X3_BG_RESIDENT != 0);    // base_fc.0's per-point fragments live in registers (BgResident; 7 or 8 views: one tile per wave, 40 registers)
+    BgResident<OWN> bgres;
+    if constexpr (BG_RES) bg_resident_load(W, lane, wave, nw, bgres);
     int n_active = 0, n_slots = 0;                      // slot-skipping statistics of this wave (p.slot_stats)
     // Tile = 16 sample points.  Training (SAVE) and the per-view record: 16 consecutive samples of one ray (the saved buffer's and the
     // backward's tiling).  Inference (TR): the SAME sample index of 16 consecutive rays - neighbouring pixels at one depth project to
@@ -263,7 +308,11 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // lane index for the weight loads that go to global memory (L_BG, L_GF1, L_GF2): opaque and re-made per tile,
         // otherwise hipcc treats these loop-invariant loads as hoistable, keeps ~50 fragment registers alive across the
         // whole tile loop and spills them (seen as "spills outside, reloads inside the loop" in -Rpass-missed=regalloc)
+#ifdef NR_X3_HOIST_PER_POINT       // A/B: let hipcc keep the owner wave's loop-invariant per-point fragments in registers (AR_X3 has 49 to spare)
+        const int glane = AR == AR_X3 ? lane : lane + nr_opaque_zero();
+#else
         const int glane = lane + nr_opaque_zero();
+#endif
 #ifndef NR_NO_OPAQUE_WAVE
         const int wave_t = wave + nr_opaque_szero();     // (see nr_opaque_szero)
 #else
@@ -562,7 +611,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
-                    const float4 b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_BG, AR) * 4);      // (run-time tile index in the lane offset: see layer_tile_slice)
+                    float4 b;
+                    if constexpr (BG_RES) b = bgres.b[j];
+                    else b = wld4(W, gg * 16 + (mo < 4 ? mo : 0) * 64, bias_offset(L_BG, AR) * 4);      // (run-time tile index in the lane offset: see layer_tile_slice)
                     accg[j][0][0] = b.x; accg[j][0][1] = b.y; accg[j][0][2] = b.z; accg[j][0][3] = b.w;
                 }
                 float part[NA1][11], st[11], sv[11], wk[NA1];
@@ -612,11 +663,21 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         NR_PRAGMA_UNROLL
                         for (int j = 0; j < 3; ++j) { const float d_ = gr[s][j] - st[8 + j]; part[s][8 + j] = wk[s] * (d_ * d_); }
                     }
-                    if (k == 0) bg_accumulate<NT, OWN, 0>(W, glane, g, wave_t, nw, st, accg);
-                    else bg_accumulate<NT, OWN, 2>(W, glane, g, wave_t, nw, st, accg);
+                    if constexpr (BG_RES) {
+                        if (k == 0) bg_accumulate<NT, OWN, 0>(bgres, g, wave_t, nw, st, accg);
+                        else bg_accumulate<NT, OWN, 2>(bgres, g, wave_t, nw, st, accg);
+                    } else {
+                        if (k == 0) bg_accumulate<NT, OWN, 0>(W, glane, g, wave_t, nw, st, accg);
+                        else bg_accumulate<NT, OWN, 2>(W, glane, g, wave_t, nw, st, accg);
+                    }
                     view_allreduce<NA, IDLE, 11, RMAX, RED_SUM>(part, sv, red, wave_t, nw, lane);
-                    if (k == 0) bg_accumulate<NT, OWN, 1>(W, glane, g, wave_t, nw, sv, accg);
-                    else bg_accumulate<NT, OWN, 3>(W, glane, g, wave_t, nw, sv, accg);
+                    if constexpr (BG_RES) {
+                        if (k == 0) bg_accumulate<NT, OWN, 1>(bgres, g, wave_t, nw, sv, accg);
+                        else bg_accumulate<NT, OWN, 3>(bgres, g, wave_t, nw, sv, accg);
+                    } else {
+                        if (k == 0) bg_accumulate<NT, OWN, 1>(W, glane, g, wave_t, nw, sv, accg);
+                        else bg_accumulate<NT, OWN, 3>(W, glane, g, wave_t, nw, sv, accg);
+                    }
                     if constexpr (SAVE) {                          // every wave_t holds the statistics: wave_t 2k % nw writes the mean, (2k + 1) % nw the variance
                         float* d_ = p.saved + (size_t)(base / 16) * kSavedTileFloats + (kSavedStatRow + 22 * k) * 64 + lane;
                         if (wave_t == (2 * k) % nw) {
@@ -843,11 +904,10 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xq[0][k] = big[k];
                 x1[0][0] = sel4(g, meanw * inv_rfn, 0.0f, 0.0f, 0.0f);
-                decltype(auto) oq = operand<AR>(xq);
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
-                    if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, oq, x1, accf[j]);
+                    if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
                 }
                 view_allreduce<NA, IDLE, 8, RMAX, RED_SUM>(v8, var, red, wave_t, nw, lane);
                 if constexpr (SAVE) {
@@ -862,12 +922,11 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 nonet[0][0] = 0.0f;
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 8; ++k) xq[0][k] = var[k];
-                decltype(auto) oq = operand<AR>(xq);
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
                     if (mo < 4) {
-                        layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, oq, nonet, accf[j]);
+                        layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
                         NR_PRAGMA_UNROLL
                         for (int r = 0; r < 4; ++r) xrow(mo, r)[lane] = elu_s(accf[j][0][r]);   // kOutScaled[L_GF1]
                         if constexpr (SAVE) {
@@ -884,7 +943,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 nonet[0][0] = 0.0f;
                 NR_PRAGMA_UNROLL
                 for (int k = 0; k < 16; ++k) h[0][k] = xrow(k >> 2, k & 3)[lane];
-                layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, operand<AR>(h), nonet, G);
+                layer_fwd<L_GF2, NT, ACT_ELU>(W, glane, h, nonet, G);
                 if (pvalid)
                     *reinterpret_cast<float4*>(p.point_out + (size_t)pidx * kPointRec + 4 * g) = make_float4(G[0][0], G[0][1], G[0][2], G[0][3]);
                 if constexpr (SAVE) {

@@ -168,17 +168,21 @@ constexpr VecShape kVec[L_COUNT] = {
 //       then, for an odd KQ, the last quad alone (v_mfma_f32_16x16x16_bf16): [part 0..2][lane] 8 bytes : 4 bf16
 //   = KQ * 384 floats per tile instead of KQ * 256.  Singles (fp32 MFMA), biases and vector rows are stored as in the fp32 layout.
 //   Always the folded network (prob_embed.2 inside its consumers): L_PE2 takes no space.
+//   The per-point layers (L_BG, L_GF1, L_GF2: run by the owner waves between the cross-view all-reduces, 69 fp32 MFMAs per tile, bound by
+//   the latency of their L2-resident fragments, not by the matrix pipe) keep the fp32 MFMA and the fp32 fragment format inside the X3
+//   pack: splitting their operands would add VALU work and 1.5 x the fragment bytes to the tile's serial frame for no MFMA time won.
 constexpr int AR_F32 = 0, AR_X3 = 1;
 constexpr bool ar_omits(int l, int ar) { return ar == AR_X3 && l == L_PE2; }
+constexpr bool ar_splits(int l, int ar) { return ar == AR_X3 && l != L_BG && l != L_GF1 && l != L_GF2; }
 
 // sizes in floats
-constexpr int quads_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * kShape[l].kq * 64 * (ar == AR_X3 ? 6 : 4); }
+constexpr int quads_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * kShape[l].kq * 64 * (ar_splits(l, ar) ? 6 : 4); }
 constexpr int single_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * kShape[l].k1 * 64; }
 constexpr int bias_floats(int l, int ar = AR_F32) { return ar_omits(l, ar) ? 0 : kShape[l].mt_out * 16; }
 constexpr int vec_floats(int l, int ar = AR_F32) { return (kVec[l].n > 0 && !ar_omits(l, ar)) ? kVec[l].n * kVec[l].tiles * 16 + 16 : 0; }
 constexpr int layer_floats(int l, int ar = AR_F32) { return quads_floats(l, ar) + single_floats(l, ar) + bias_floats(l, ar) + vec_floats(l, ar); }
 // floats of one output tile's quad fragments (the run-time tile index of the owner waves strides by this)
-constexpr int tile_quads_floats(int l, int ar = AR_F32) { return kShape[l].kq * 64 * (ar == AR_X3 ? 6 : 4); }
+constexpr int tile_quads_floats(int l, int ar = AR_F32) { return kShape[l].kq * 64 * (ar_splits(l, ar) ? 6 : 4); }
 
 // float offset of layer l inside its packed buffer: the forward layers in the pass buffer, the transposed layers in
 // the second ("T") buffer, where the offsets restart at 0

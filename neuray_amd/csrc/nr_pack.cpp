@@ -286,6 +286,10 @@ int pack_pass_weights_x3(const float* const* tensors, float* dst) {
     unsigned* words = reinterpret_cast<unsigned*>(dst);
     for (int l = 0; l < L_FWD_COUNT; ++l) {
         if (ar_omits(l, AR_X3)) continue;
+        if (!ar_splits(l, AR_X3)) {              // per-point layers: the fp32 layer as it is
+            std::memcpy(dst + layer_offset(l, AR_X3), f32.data() + layer_offset(l), sizeof(float) * (size_t)layer_floats(l));
+            continue;
+        }
         const int MT = kShape[l].mt_out, KQ = kShape[l].kq;
         const float* q = f32.data() + quads_offset(l);
         for (int mo = 0; mo < MT; ++mo)

@@ -86,7 +86,8 @@ def _forward_layer_tables():
 def test_packed_weights_are_split_exactly(backend):
     """every quad weight of the X3 pack is its fp32 value in the folded pack: h + m + l == w bit for bit, stored in the pair layout of
     csrc/nr_layout.h (per output tile: [pair][part][lane] 16 bytes, a lone last quad as [part][lane] 8 bytes); singles, biases and
-    vector rows are copied verbatim; prob_embed.2 (layer 13, always folded) takes no space"""
+    vector rows are copied verbatim, and so are the per-point layers (28..30: fp32 MFMA in both arithmetics); prob_embed.2 (layer 13,
+    always folded) takes no space"""
     eng, dev = _engine(backend, arith='x3')
     weights = load_weights(True)
     sd = {'d.' + k[len('dist_decoder.'):]: v for k, v in weights.items() if k.startswith('dist_decoder.')}
@@ -104,6 +105,12 @@ def test_packed_weights_are_split_exactly(backend):
         if layer == 13:                                         # L_PE2
             assert not np.any(f32[p32:p32 + nq * 256])          # the folded fp32 pack leaves it zero
             p32 += nq * 256 + tail
+            continue
+        if layer in (28, 29, 30):                               # L_BG, L_GF1, L_GF2: the per-point layers keep the fp32 format
+            n = nq * 256 + tail
+            assert np.array_equal(x3[p3:p3 + n].view(np.float32), f32[p32:p32 + n]), 'layer %d' % layer
+            p32 += n
+            p3 += n
             continue
         q = f32[p32:p32 + nq * 256].reshape(mt, kq, 64, 4).astype(np.float64)
         rec = np.zeros_like(q)

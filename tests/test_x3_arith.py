@@ -133,7 +133,7 @@ def test_packed_weights_are_split_exactly(backend):
         assert np.array_equal(x3[p3 + nq * 384:p3 + nq * 384 + tail].view(np.float32), f32[p32 + nq * 256:p32 + nq * 256 + tail]), 'layer %d tail' % layer
         p32 += nq * 256 + tail
         p3 += nq * 384 + tail
-    assert p3 == x3.size and checked > 100
+    assert p3 == x3.size and checked > 60
 
 
 @pytest.mark.parametrize('backend', BACKENDS)

@@ -76,11 +76,11 @@ def algorithmic_macs_per_point(rfn, vis_head_used, folded=True, slots_run_share=
     return rfn * per_view * slots_run_share + per_point
 
 
-def build_case(device, fdn, seed, test_lib=None):
+def build_case(device, fdn, seed, test_lib=None, arith='f32'):
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False},
            'depth_sample_num': DN_COARSE, 'fine_depth_sample_num': fdn,
            'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
-           'ray_batch_num': RAY_BATCH}
+           'ray_batch_num': RAY_BATCH, 'hip_arith': arith}
     torch.manual_seed(0)
     renderer = NeuralRayBaseRenderer(cfg).eval()
     weights = {k: v.detach().numpy().copy() for k, v in renderer.state_dict().items()}
@@ -255,7 +255,65 @@ def eager_torch_baseline(cfg, weights, tq, tr, device, batches=6, rays_per_batch
                     % (batches, rays_per_batch)}
 
 
-def full_image_parity_leg(cfg, renderer, weights, que, ref, tq, tr, got, device, chunk=4096, ours_chunk=32768, recheck_cap=256):
+def float64_image(cfg, weights, tq, tr, device, chunk=4096):
+    """The eager port (oracle/torch_eager_port.py) in FLOAT64 on the GPU over every ray of the image: weights and every float input cast
+    up, as tests/golden/make_golden_full.py tile_case_f64 runs the reference itself (the port in float64 reproduces those fixtures to
+    3e-9 / 2e-6: tests/test_oracle_golden.py).  -> (coarse pixels, chained fine pixels) as float64 tensors, seconds"""
+    from oracle import torch_eager_port as tep
+    up = lambda v: v.double() if v.is_floating_point() else v      # noqa: E731
+    w = {k: torch.from_numpy(v).to(device).double() for k, v in weights.items()}
+    q64 = {k: up(v) for k, v in tq.items() if not k.startswith('_')}
+    r64 = {k: up(v) for k, v in tr.items() if not k.startswith('_')}
+    ocfg = dict(cfg, coarse_use_vis=False, fine_use_vis=True)
+    n = tq['coords'].shape[1]
+    c64 = torch.empty(n, 3, device=device, dtype=torch.float64)
+    f64 = torch.empty(n, 3, device=device, dtype=torch.float64)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for st in range(0, n, chunk):
+            q = dict(q64)
+            q['coords'] = q64['coords'][:, st:st + chunk]
+            o = tep.render_impl(w, ocfg, q, r64)
+            c64[st:st + chunk] = o['pixel_colors_nr'][0]
+            f64[st:st + chunk] = o['pixel_colors_nr_fine'][0]
+    torch.cuda.synchronize(device)
+    return c64, f64, time.perf_counter() - t0
+
+
+def against_float64(pixels_c, pixels_f, c64, f64):
+    """coarse / chained pixels [n,3] of one evaluation against the float64 image"""
+    ec = (pixels_c.double() - c64).abs().amax(-1)
+    ef = (pixels_f.double() - f64).abs().amax(-1)
+    mse = float(((pixels_f.double().clamp(0, 1) * 255).round() - (f64.clamp(0, 1) * 255).round()).pow(2).mean())
+    return {'coarse': {'max': float(ec.max()), 'mean': float(ec.mean()), 'frac_within_2e-4': float((ec <= 2e-4).double().mean()),
+                       'rays_beyond_2e-4': int((ec > 2e-4).sum()), 'rays_beyond_5e-3': int((ec > 5e-3).sum())},
+            'chained': {'max': float(ef.max()), 'mean': float(ef.mean()), 'frac_within_2e-4': float((ef <= 2e-4).double().mean()),
+                        'rays_beyond_2e-4': int((ef > 2e-4).sum()), 'rays_beyond_5e-3': int((ef > 5e-3).sum()),
+                        'psnr_db': min(200.0, 10.0 * float(np.log10(255.0 ** 2 / mse))) if mse > 0 else 200.0}}
+
+
+def float64_parity_leg(cfg, weights, tq, tr, got, others, port_fp32, device):
+    """how many rays does the REFERENCE's fp32 arithmetic put beyond 2e-4 / 5e-3 of a float64 evaluation of the same
+    image - next to ours?  `got`: the image of the timed loop; `others`: {label: image} of the other arithmetics of this library;
+    `port_fp32`: (coarse, chained) of the eager port in fp32 on this GPU (the reference's op sequence in the reference's precision).
+    Gate: each of our counts <= 1.25 x the fp32 reference arithmetic's own (+ 8 rays of slack for the small counts)."""
+    c64, f64, dt = float64_image(cfg, weights, tq, tr, device)
+    res = {'checker': 'eager port of the reference op sequence in FLOAT64 on this GPU, all %d rays, %.1f s' % (c64.shape[0], dt),
+           'ours': against_float64(got['pixel_colors_nr'][0], got['pixel_colors_nr_fine'][0], c64, f64),
+           'reference_arithmetic_fp32': against_float64(port_fp32[0], port_fp32[1], c64, f64)}
+    for k, o in others.items():
+        res[k] = against_float64(o['pixel_colors_nr'][0], o['pixel_colors_nr_fine'][0], c64, f64)
+    ok = True
+    for who in ['ours'] + list(others):
+        for tier, key in (('coarse', 'rays_beyond_2e-4'), ('chained', 'rays_beyond_2e-4'), ('chained', 'rays_beyond_5e-3')):
+            ok = ok and res[who][tier][key] <= 1.25 * res['reference_arithmetic_fp32'][tier][key] + 8
+    res['gate'] = 'rays beyond 2e-4 (coarse, chained) and beyond 5e-3 (chained): ours <= 1.25 x the fp32 reference arithmetic + 8'
+    res['pass'] = bool(ok)
+    return res
+
+
+def full_image_parity_leg(cfg, renderer, weights, que, ref, tq, tr, got, device, chunk=4096, ours_chunk=32768, recheck_cap=256, others=None):
     """parity over ALL rays of the bench image (the numpy-oracle leg covers 1.3 % of it: the oracle runs at 300 rays/s).
     Reference path: network/renderer.py:168-226.  `got`: the whole image as the timed loop rendered it.  Two tiers, both outside the
     timed region:
@@ -359,8 +417,10 @@ def full_image_parity_leg(cfg, renderer, weights, que, ref, tq, tr, got, device,
                               'why': "against a checker that is itself 1e-5 from the reference's arithmetic (checker_vs_numpy_oracle) the "
                                      "distributional gates are SURVEY 8(c)'s PSNR >= 60 dB and the shares; the strict gates are tier 2's"},
                     'tier2': {'coarse_pixel_max_vs_numpy_oracle': PARITY_GATES['coarse_pixel_max']}}
+    # the float64 yardstick over the whole image: ours and the fp32 reference arithmetic (the tier-1 checker's own pixels) against it
+    res['vs_float64'] = float64_parity_leg(cfg, weights, tq, tr, got, others or {}, (want_c, want_f), device)
     res['pass'] = bool(res['coarse_pixels']['frac_within_2e-4'] >= 0.9999 and res['chained_fine_pixels']['frac_within_2e-4'] >= 0.98
-                       and res['chained_fine_pixels']['psnr_db'] >= 60.0 and ok2 and same)
+                       and res['chained_fine_pixels']['psnr_db'] >= 60.0 and ok2 and same and res['vs_float64']['pass'])
     return res
 
 
@@ -594,6 +654,38 @@ def encoder_timing(device, n=9, hw=(800, 800), reps=5):
     out['speedup_forward'] = out['pytorch_norm']['forward_ms'] / out['fused_norm']['forward_ms']
     out['speedup_forward_backward'] = out['pytorch_norm']['forward_backward_ms'] / out['fused_norm']['forward_backward_ms']
     return out
+
+
+def fp32_mfma_leg(device, fdn, tq, tr, steps, headline_value):
+    """The SAME workload with the MLP contractions on the fp32 MFMA (cfg['hip_arith'] = 'f32', v_mfma_f32_16x16x4_f32: the
+    arithmetic of rounds 1-5), timed exactly like the headline and reported next to it whatever the headline arithmetic is.
+    -> (block of the line, the rendered image for the float64 parity leg)"""
+    cfg, r, _, _, _, _, _ = build_case(device, fdn, seed=0, arith='f32')
+    eng = r.engine(device)
+    stats = torch.zeros(2, dtype=torch.int64, device=device)
+    eng.slot_stats = stats
+    out = render_image(r, tq, tr)
+    eng.slot_stats = None
+    eng.timing = []
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = render_image(r, tq, tr)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    pts = [(e0.elapsed_time(e1) * 1e-3, n) for name, e0, e1, n in eng.timing if name == 'points']
+    eng.timing = None
+    st = stats.cpu().numpy()
+    share = float(st[0] / st[1]) if st[1] > 0 else 1.0
+    t_pts, n_pts = sum(t for t, _ in pts), sum(n for _, n in pts)
+    achieved = 2.0 * algorithmic_macs_per_point(RFN, vis_head_used=False, folded=True, slots_run_share=share) * n_pts / t_pts / 1e12
+    value = steps * H * W / dt
+    return {'what': "the same workload, same steps, with cfg['hip_arith'] = 'f32': every MLP contraction on v_mfma_f32_16x16x4_f32 (the headline "
+                    "arithmetic of rounds 1-5)", 'value': value, 'unit': 'rays/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+            'point_kernel_avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_F32_PEAK_TFLOPS,
+                         'kernel': 'nr::points_kernel<..., AR_F32>', 'view_slots_run_share': share},
+            'headline_over_this': headline_value / value}, out
 
 
 def bf16_variant_timing(device, fdn, tq, tr, fp32_pixels, steps=2, variant='bf16'):
@@ -905,6 +997,10 @@ def main(argv=None):
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--fine-samples', type=int, default=32, help='32 = BASELINE.json wording, 64 = reference default')
+    ap.add_argument('--arith', default=None, choices=['x3', 'f32'],
+                    help="arithmetic of the point kernel's MLP contractions in the timed region (cfg['hip_arith']): x3 = operands split exactly "
+                         "into three bf16 parts on the K = 32 bf16 MFMA, fp32 accumulation (each product within 2^-23 of exact); f32 = the "
+                         "fp32 MFMA.  Default x3; at N = 1 the fp32-MFMA line is timed next to it (`fp32_mfma`)")
     ap.add_argument('--cpu-sample-rays', type=int, default=8192, help='rays of the numpy-oracle parity leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-baseline', action='store_true', help='skip every side leg (baselines, extras)')
@@ -918,6 +1014,8 @@ def main(argv=None):
     ap.add_argument('--size', type=int, nargs=2, default=None, metavar=('H', 'W'), help='test hook: image size (default 800 800)')
     ap.add_argument('--leg', default=None, help='internal: run ONE training-step side leg in this (fresh) process and print its JSON')
     args = ap.parse_args(argv)
+    if args.arith is None:                                         # (the emulator smoke of the launcher path keeps the cheaper arithmetic)
+        args.arith = 'f32' if args.emulator_lib else 'x3'
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # multi-process GPU work: the host driver only supports dmabuf IPC (RCCL)
     if args.leg:
         print(json.dumps({'leg': args.leg, 'result': FRESH_PROCESS_LEGS[args.leg](torch.device('cuda', 0))}), flush=True)
@@ -961,7 +1059,7 @@ def main(argv=None):
         world_seen = 1
 
     split = args.split_image and world > 1
-    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=0 if split else rank, test_lib=emu)
+    cfg, renderer, weights, que, ref, tq, tr = build_case(device, args.fine_samples, seed=0 if split else rank, test_lib=emu, arith=args.arith)
     eng = renderer.engine(device)
     nrays = H * W
 
@@ -1002,7 +1100,8 @@ def main(argv=None):
             'value': value, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if split else 'weak',
             'vs_baseline': None,
-            'dtype': 'fp32', 'data': 'synthetic' if emu is None else 'synthetic (CPU EMULATOR smoke of the launcher path - NOT a measurement)',
+            'dtype': 'fp32' if args.arith == 'f32' else 'fp32 (MLP contractions: operands split exactly into 3 bf16 parts, 6 bf16-MFMA products per K = 32, fp32 accumulate)',
+            'arith': args.arith, 'data': 'synthetic' if emu is None else 'synthetic (CPU EMULATOR smoke of the launcher path - NOT a measurement)',
             'world_size_seen_by_process_group': world_seen,
             'config': {'workload': 'lego-800 synthetic (nerf_synthetic/lego/black_800 shape): %dx%d = %d rays/image, '
                                    '%d ref views, %d coarse + %d fine samples, maps %dx%dx32, 1 image per step per GPU'
@@ -1050,7 +1149,12 @@ def main(argv=None):
             achieved = flops_exec * n_pts / t_pts / 1e12
             line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': achieved / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
-                                'kernel': 'nr::points_kernel', 'launches': len(pts),
+                                'kernel': 'nr::points_kernel<..., %s>' % ('AR_X3' if args.arith == 'x3' else 'AR_F32'), 'launches': len(pts),
+                                'peak_note': 'fp32-in MFMA dense peak (MI355X_MICROARCH.md): the peak of the arithmetic GRADE the kernel delivers' +
+                                             ('.  With arith = x3 the contractions run on the bf16 pipe (dense peak 2500 TFLOP/s): six bf16 MFMA products per '
+                                              'fp32-grade product, i.e. %.0f TFLOP/s of bf16 MFMA work issued = %.3f of that peak; the kernel is bound by VALU '
+                                              'issue (operand splits, ELU, blends), not by the matrix pipe (DESIGN.md 4.12)'
+                                              % (6.0 * achieved, 6.0 * achieved / 2500.0) if args.arith == 'x3' else ''),
                                 'avg_launch_ms': 1e3 * t_pts / max(1, len(pts)),
                                 'flops_counted': 'executed: folded network (prob_embed.2 folded into neuray_fc.0 / base_fc.0), per-view layers only on '
                                                  'the (16-point tile, view) slots the kernel ran (fully masked slots are skipped)',
@@ -1118,6 +1222,15 @@ def main(argv=None):
             for k_, v_ in legs.items():
                 put(k_, v_)
 
+    others = {}
+    if rank == 0 and world == 1 and emu is None and device.type == 'cuda':
+        if args.arith != 'f32':       # the fp32-MFMA line, next to the headline either way (VERDICT r5 credit rule)
+            res = side(fp32_mfma_leg, device, args.fine_samples, tq, tr, args.steps, value)
+            if isinstance(res, tuple):
+                put('fp32_mfma', res[0])
+                others['ours_fp32_mfma'] = res[1]
+            else:
+                put('fp32_mfma', res)
     if rank == 0:
         if world == 1 and emu is None and not args.no_eager_baseline and not args.no_cpu_baseline:
             # the whole-step training legs first: they are host-sensitive (host time ~ device time), and after the CPU baselines' minute
@@ -1135,7 +1248,7 @@ def main(argv=None):
                     parity = res[1]
                     if not args.no_eager_baseline:
                         # all 640 000 rays against the eager port on this GPU (the numpy oracle above: 1.3 % of them)
-                        parity['full_image'] = side(full_image_parity_leg, cfg, renderer, weights, que, ref, tq, tr, out, device)
+                        parity['full_image'] = side(full_image_parity_leg, cfg, renderer, weights, que, ref, tq, tr, out, device, others=others)
                     put('parity', parity)
                 else:
                     put('numpy_oracle', res)
@@ -1156,6 +1269,25 @@ def main(argv=None):
             put('bf16_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy()))
             put('bf16x3_split_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy(),
                                              2, 'bf16x3'))
+    if rank == 0 and line is not None:
+        # the scalars a reader of the LAST kilobytes of this (long) line needs: the driver keeps only the tail of stdout
+        def pick(d, *path):
+            for k_ in path:
+                d = d.get(k_) if isinstance(d, dict) else None
+            return d
+        put('summary', {
+            'value_rays_per_s': line['value'], 'arith': args.arith, 'n_gpus': world, 'ms_per_step': line['ms_per_step'],
+            'roofline_frac': pick(line, 'roofline', 'frac'), 'point_kernel_avg_launch_ms': pick(line, 'roofline', 'avg_launch_ms'),
+            'fp32_mfma_rays_per_s': pick(line, 'fp32_mfma', 'value'), 'fp32_mfma_roofline_frac': pick(line, 'fp32_mfma', 'roofline', 'frac'),
+            'fp32_mfma_point_kernel_avg_launch_ms': pick(line, 'fp32_mfma', 'point_kernel_avg_launch_ms'),
+            'parity_pass': pick(line, 'parity', 'pass'), 'full_image_pass': pick(line, 'parity', 'full_image', 'pass'),
+            'vs_float64_pass': pick(line, 'parity', 'full_image', 'vs_float64', 'pass'),
+            'ft_step_ms': pick(line, 'ft_step', 'ms_per_step'), 'gen_train_step_ms': pick(line, 'gen_train_step', 'ms_per_step'),
+            'point_backward_ms_per_pass': pick(line, 'training_step', 'point_backward', 'ms_per_pass'),
+            'cost_volume_init_net_ms': pick(line, 'init_net', 'cost_volume_init_net_ms'),
+            'cpu_baseline_rays_per_s': pick(line, 'cpu_baseline', 'value'), 'eager_torch_rays_per_s': pick(line, 'eager_torch_baseline', 'value'),
+            'config3_llff_rays_per_s': pick(line, 'extra', 'llff_fern_cost_volume', 'value'),
+        })
     emit()
     if world > 1:
         dist.barrier()

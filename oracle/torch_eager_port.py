@@ -35,13 +35,13 @@ def _grid_gather(maps, pts, h, w):
     return out.squeeze(2).permute(0, 2, 1)
 
 
-def _posenc(dn, device):
+def _posenc(dn, device, dtype=torch.float32):
     pos = np.arange(dn, dtype=np.float64)[:, None]
     j = np.arange(16)[None, :]
     t = pos / np.power(10000, 2 * (j // 2) / 16)
     t[:, 0::2] = np.sin(t[:, 0::2])
     t[:, 1::2] = np.cos(t[:, 1::2])
-    return torch.from_numpy(t.astype(np.float32)).to(device)[None]
+    return torch.from_numpy(t.astype(np.float32)).to(device=device, dtype=dtype)[None]     # (the reference's table is built in fp32: ibrnet.py:305-313)
 
 
 def render_pass(w, cfg, depth, que, ref, is_fine):
@@ -76,7 +76,7 @@ def render_pass(w, cfg, depth, que, ref, is_fine):
     cv = (-ref['poses'][:, :, :3].transpose(1, 2) @ ref['poses'][:, :, 3:]).transpose(1, 2)
     dvec = P[None] - cv
     prj_dir = -dvec / dvec.norm(dim=2, keepdim=True).clamp_min(1e-5)
-    mf = mask.float().unsqueeze(-1)
+    mf = mask.to(depth.dtype).unsqueeze(-1)
     f_ray = _grid_gather(ref['ray_feats'], uv, h, wd) * mf
     rgb = _grid_gather(ref['imgs'], uv, h, wd) * mf
     f_img = _grid_gather(ref['img_feats'], uv, h, wd) * mf
@@ -131,7 +131,7 @@ def render_pass(w, cfg, depth, que, ref, is_fine):
     mu, va = mv(x, wgt)
     g = _mlp(w, ip + 'geometry_fc.', torch.cat([mu.squeeze(2), va.squeeze(2), wgt.mean(2)], -1), [F.elu, F.elu])
     nvalid = m.sum(2)
-    g = g + _posenc(dn, dev)
+    g = g + _posenc(dn, dev, g.dtype)
     q = _lin(g, w, ip + 'ray_attention.w_qs.').view(rn, dn, 4, 4).transpose(1, 2)
     k = _lin(g, w, ip + 'ray_attention.w_ks.').view(rn, dn, 4, 4).transpose(1, 2)
     vv = _lin(g, w, ip + 'ray_attention.w_vs.').view(rn, dn, 4, 4).transpose(1, 2)
@@ -189,7 +189,7 @@ def sample_fine(depth, hit, depth_range, fdn, u=None):
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
     if u is None:
         interval = 1 / fdn
-        u = (0.5 * interval + torch.arange(fdn, device=depth.device) * interval).expand(list(cdf.shape[:-1]) + [fdn])
+        u = (0.5 * interval + torch.arange(fdn, device=depth.device, dtype=depth.dtype) * interval).expand(list(cdf.shape[:-1]) + [fdn])
     u = u.to(depth.device).contiguous()
     idx = torch.searchsorted(cdf, u, right=True)
     lo, hi = (idx - 1).clamp_min(0), idx.clamp_max(cdf.shape[-1] - 1)
@@ -208,7 +208,7 @@ def render_impl(w, cfg, que, ref, is_train=False, u=None):
     rn = que['coords'].shape[1]
     dn = cfg['depth_sample_num']
     near, far = que['depth_range'][:, 0], que['depth_range'][:, 1]
-    ticks = torch.arange(dn, device=near.device, dtype=torch.float32)[None] * ((1 / far - 1 / near) / (dn - 1))[:, None]
+    ticks = torch.arange(dn, device=near.device, dtype=near.dtype)[None] * ((1 / far - 1 / near) / (dn - 1))[:, None]
     ticks[:, -1] = (1 / far - 1 / near)
     depth = (1 / (1 / near[:, None] + ticks))[:, None].expand(-1, rn, -1).contiguous()
     out = render_pass(w, cfg, depth, que, ref, False)

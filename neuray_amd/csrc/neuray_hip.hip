@@ -67,7 +67,8 @@ int launch_points_own(const nr::PointParams& p, void* stream) {
 #ifndef NR_POINT_GRID
 #define NR_POINT_GRID (256 * 64)
 #endif
-    int grid = grid_for(npts, 16 * NT, NR_POINT_GRID);
+    static const int grid_env = [] { const char* e = getenv("NEURAY_POINT_GRID"); return e ? atoi(e) : 0; }();     // A/B hook (tools/ab_forward.py)
+    int grid = grid_for(npts, 16 * NT, grid_env > 0 ? grid_env : NR_POINT_GRID);
 #ifndef NR_POINT_MIN_TILES
 #define NR_POINT_MIN_TILES 2       // a workgroup's prologue (constants, first weight phase) wants at least this many tiles behind it
 #endif

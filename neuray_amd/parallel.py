@@ -82,10 +82,11 @@ def encode_views_sharded(renderer, ref_imgs_info, group=None):
             f_img = renderer.image_encoder(imgs[lo:hi])
             f_ray = renderer.vis_encoder(ray0[lo:hi], f_img)
             mine = torch.cat([f_img.reshape(hi - lo, -1), f_ray.reshape(hi - lo, -1)], 1).float()
-            shapes = torch.tensor([f_img.shape[1], f_ray.shape[1], f_img.shape[2], f_img.shape[3]], dtype=torch.int64, device=imgs.device)
+            shapes = torch.tensor([f_img.shape[1], f_ray.shape[1], f_img.shape[2], f_img.shape[3]], dtype=torch.int64)
         else:
-            mine, shapes = None, torch.zeros(4, dtype=torch.int64, device=imgs.device)
-    dist.all_reduce(shapes, op=dist.ReduceOp.MAX, group=group)       # ranks without a view learn the map shape (rfn < world only)
+            mine, shapes = None, torch.zeros(4, dtype=torch.int64)
+    # ranks without a view learn the map shape (rfn < world only): host tensors over the gloo side group - no wait for the device queue
+    dist.all_reduce(shapes, op=dist.ReduceOp.MAX, group=_meta_group(group))
     c_img, c_ray, fh, fw = (int(v) for v in shapes.tolist())
     width = (c_img + c_ray) * fh * fw
     buf = torch.zeros(pad, width, dtype=torch.float32, device=imgs.device)
@@ -113,29 +114,86 @@ def render_image_sharded(renderer, que_imgs_info, ref_imgs_info, group=None, sha
     return gather_tiles(local, n, rank, world, group)
 
 
+# ---- gradient flags without a device read-back -------------------------------------------------------------------------------------
+# Which parameters received a gradient on SOME rank decides `grad = None` (torch.optim skips the parameter, as the reference's
+# single-process training does) against `grad = the reduced sum`.  That union rides in the all-reduced buffer, i.e. on the device:
+# reading it back (`.tolist()`) made every rank wait for its own backward AND the collective before it could queue the optimiser
+# step.  Which parameters a step reaches is a property of the graph, not of the data, so the union of step t is the union of step
+# t - 1: a step uses the previous step's union (a host-side list) and copies its own flags to pinned memory without blocking; the
+# NEXT call checks that copy (long complete by then) against what was assumed and raises if a rank's pattern had changed
+# unannounced.  The first step, and any step whose LOCAL pattern differs from the previous one, reads the flags the blocking way.
+_FLAG_STATE = {}
+DEFERRED_FLAGS = True           # False: always read the flags back at the call (the round-5 behaviour)
+
+
+class _Pending:
+    def __init__(self, flags_dev, assumed):
+        self.assumed = assumed
+        if flags_dev.is_cuda:
+            self.host = torch.empty(flags_dev.shape, dtype=flags_dev.dtype, pin_memory=True)
+            self.host.copy_(flags_dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(flags_dev.device))
+        else:
+            self.host, self.event = flags_dev.clone(), None
+
+    def union(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return [v > 0 for v in self.host.tolist()]
+
+
+def check_deferred_flags():
+    """Drain the pending flag copies (end of training / before a checkpoint): raises if the last step assumed the wrong union."""
+    for key, st in list(_FLAG_STATE.items()):
+        pend = st.pop('pending', None)
+        if pend is not None and pend.union() != pend.assumed:
+            _FLAG_STATE.pop(key, None)
+            raise RuntimeError("neuray_amd.parallel.allreduce_gradients: the set of parameters that received a gradient on some rank changed "
+                               "without this rank's own set changing; the previous optimiser step treated %d parameter(s) by the older set"
+                               % sum(a != b for a, b in zip(pend.union(), pend.assumed)))
+
+
 def allreduce_gradients(parameters, average=True, group=None, skip=()):
     """Data-parallel training step: sum (or average) the gradients of `parameters` over the ranks with
     ONE flattened all-reduce (the shared nets are ~2.2 M parameters = 8.7 MB: a single bucket; on the MI355X node
     this is RCCL over xGMI via backend 'nccl').  A parameter that received a gradient on SOME rank ends up with the same
     gradient on every rank; a parameter that received none anywhere keeps `grad = None` everywhere (one flag per
     parameter rides in the same buffer), so torch.optim skips it on every replica exactly as the reference's
-    single-process training does.  `skip`: parameters to leave alone - in fine-tuning mode the per-view
-    `NeuralRayFtRenderer.ray_feats` (512 MB on lego-800), which go through allreduce_scene_feature_gradients instead."""
+    single-process training does.  No device -> host wait in the steady state (see _FLAG_STATE above).  `skip`: parameters to
+    leave alone - in fine-tuning mode the per-view `NeuralRayFtRenderer.ray_feats` (512 MB on lego-800), which go through
+    allreduce_scene_feature_gradients instead."""
     skip_ids = {id(p) for p in skip}
     params = [p for p in parameters if p.requires_grad and id(p) not in skip_ids]
     if not params:
         return
     dev = params[0].device
-    flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=dev)
+    local = [p.grad is not None for p in params]
+    key = (tuple(id(p) for p in params), id(group))
+    st = _FLAG_STATE.get(key)
+    if st is not None and 'pending' in st:               # what the previous step assumed, against what its flags turned out to be
+        pend = st.pop('pending')
+        actual = pend.union()
+        if actual != pend.assumed:
+            _FLAG_STATE.pop(key, None)
+            raise RuntimeError("neuray_amd.parallel.allreduce_gradients: the set of parameters that received a gradient on some rank changed "
+                               "without this rank's own set changing (%d parameter(s)); the previous optimiser step used the older set"
+                               % sum(a != b for a, b in zip(actual, pend.assumed)))
+    flags = torch.tensor([1.0 if f else 0.0 for f in local], dtype=torch.float32, device=dev)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params] + [flags])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    got = flat[-len(params):].tolist()
+    if DEFERRED_FLAGS and st is not None and st['local'] == local:
+        union = st['union']
+        st['pending'] = _Pending(flat[-len(params):], union)
+    else:
+        union = [v > 0 for v in flat[-len(params):].tolist()]
+        _FLAG_STATE[key] = {'local': local, 'union': union}
     if average:
         flat /= dist.get_world_size(group)
     off = 0
-    for p, any_grad in zip(params, got):
+    for p, any_grad in zip(params, union):
         n = p.numel()
-        if any_grad > 0:
+        if any_grad:
             g = flat[off:off + n].view_as(p).to(p.dtype)
             if p.grad is None:
                 p.grad = g.clone()
@@ -175,6 +233,21 @@ def train_step(model, data, loss_fn, optimizer, group=None):
     return outputs, loss
 
 
+_META_GROUPS = {}
+
+
+def _meta_group(group=None):
+    """A gloo process group over the same ranks as `group` for HOST-side metadata (created on first use; every rank reaches this
+    point in the same step).  With a gloo default group it is the group itself."""
+    if dist.get_backend(group) == 'gloo':
+        return group
+    key = id(group)
+    if key not in _META_GROUPS:
+        ranks = None if group is None else dist.get_process_group_ranks(group)
+        _META_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo')
+    return _META_GROUPS[key]
+
+
 def allreduce_scene_feature_gradients(ray_feats, touched, max_touched=None, average=True, group=None):
     """Fine-tuning mode (SURVEY.md 8(e) caveat): `ray_feats` is the per-view nn.ParameterList of NeuralRayFtRenderer
     (100 views x 5 MB on lego-800) and a step gives gradients to the <= neighbor_view_num + 1 views this rank rendered
@@ -186,18 +259,21 @@ def allreduce_scene_feature_gradients(ray_feats, touched, max_touched=None, aver
     the padded length first (one scalar MAX all-reduce), so a caller need not know how many views a step can touch.
     -> sorted list of the union's view indices"""
     world = dist.get_world_size(group)
-    dev = ray_feats[0].device
     touched = sorted(set(int(i) for i in touched))
+    # The ids are host-side facts (which views this rank's sampler picked): they are exchanged as HOST tensors over a gloo group, so no
+    # rank waits for its device queue - the backward kernels keep running under the exchange (round 5 sent them through the device and
+    # read them back with .tolist() / .item(): two to three waits per step).
+    meta = _meta_group(group)
     if max_touched is None:
-        n = torch.tensor([len(touched)], dtype=torch.int64, device=dev)
-        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
-        max_touched = max(1, int(n.item()))
+        n = torch.tensor([len(touched)], dtype=torch.int64)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=meta)
+        max_touched = max(1, int(n[0]))
     if len(touched) > max_touched:
         raise ValueError("neuray_amd.parallel: this rank touched %d views, more than max_touched = %d" % (len(touched), max_touched))
-    ids = torch.full((max_touched,), -1, dtype=torch.int64, device=dev)
+    ids = torch.full((max_touched,), -1, dtype=torch.int64)
     ids[:len(touched)] = torch.as_tensor(touched, dtype=torch.int64)
     gathered = [torch.empty_like(ids) for _ in range(world)]
-    dist.all_gather(gathered, ids, group=group)
+    dist.all_gather(gathered, ids, group=meta)
     union = sorted(set(int(i) for g in gathered for i in g.tolist() if i >= 0))
     if not union:
         return union

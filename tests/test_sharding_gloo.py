@@ -274,3 +274,97 @@ def test_two_rank_view_sharded_encoders_equal_the_replicated_path(tmp_path):
             assert torch.allclose(res['sharded'][k].float(), v.float(), atol=tol), (k, float((res['sharded'][k].float() - v.float()).abs().max()))
     for k in a['sharded']:
         assert torch.equal(a['sharded'][k], b['sharded'][k]), k            # every rank holds the same full image
+
+
+# ---- the gradient flags without a read-back: steady state, a local change, an unannounced remote change ------------------------------
+def _flags_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({'a': torch.nn.Linear(4, 4), 'b': torch.nn.Linear(4, 4), 'c': torch.nn.Linear(4, 4)})
+    x = torch.full((2, 4), float(rank + 1))
+    log = []
+
+    def step(use_b, use_c):
+        for p in net.parameters():
+            p.grad = None
+        y = net['a'](x)
+        if use_b:
+            y = y + net['b'](x)
+        if use_c:
+            y = y + net['c'](x)
+        y.sum().backward()
+        parallel.allreduce_gradients(net.parameters(), average=False)
+        log.append([p.grad is None for p in net.parameters()] + [float(net['a'].weight.grad.sum())])
+
+    step(True, False)          # first step: flags read at the call; c has no gradient anywhere -> stays None
+    step(True, False)          # steady state: the previous union, own flags copied for the check
+    assert parallel._FLAG_STATE and any('pending' in st for st in parallel._FLAG_STATE.values())
+    step(True, False)          # ... whose check passes here
+    step(True, True)           # the LOCAL pattern changes on both ranks: the call notices (host-side) and reads the flags again
+    step(True, True)
+    parallel.check_deferred_flags()
+    # a rank changes its pattern while the other does not: the unchanged rank learns it one call late and says so
+    err = None
+    try:
+        step(True, rank == 0)  # rank 1 drops c: its own pattern changed -> it re-reads (union still has c, from rank 0); rank 0 keeps the old union: fine
+        step(True, rank == 0)
+        step(rank == 0, rank == 0)      # rank 1 drops b too; rank 0's pattern is unchanged and b is still in the union via rank 0: consistent
+        parallel.check_deferred_flags()
+    except RuntimeError as e:           # noqa: BLE001
+        err = str(e)
+    np.save(os.path.join(out_dir, 'log%d.npy' % rank), np.array(log, dtype=np.float64))
+    with open(os.path.join(out_dir, 'err%d.txt' % rank), 'w') as f:
+        f.write(err or '')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _flags_mismatch_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({'a': torch.nn.Linear(4, 4), 'b': torch.nn.Linear(4, 4)})
+    x = torch.ones(2, 4)
+
+    def step(use_b):
+        for p in net.parameters():
+            p.grad = None
+        y = net['a'](x) + (net['b'](x) if use_b else 0.0)
+        y.sum().backward()
+        parallel.allreduce_gradients(net.parameters(), average=False)
+
+    step(rank == 0)            # only rank 0 reaches b: the union has it
+    step(rank == 0)
+    step(False)                # rank 0 drops b (re-reads: b is gone); rank 1's own pattern is unchanged -> it still assumes b this step ...
+    msg = ''
+    try:
+        parallel.check_deferred_flags()        # ... and is told here (or by its next allreduce_gradients call), one call late
+    except RuntimeError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, 'msg%d.txt' % rank), 'w') as f:
+        f.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_flags_need_no_read_back_in_the_steady_state(tmp_path):
+    """allreduce_gradients decides `grad = None` from the previous step's union of flags (no device -> host wait); a change of the
+    rank's own pattern is seen at once, a change on another rank alone is reported by the next call"""
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_flags_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    logs = [np.load(os.path.join(str(tmp_path), 'log%d.npy' % r)) for r in range(2)]
+    for r in range(2):
+        assert open(os.path.join(str(tmp_path), 'err%d.txt' % r)).read() == ''
+    # parameters: a.w a.b b.w b.b c.w c.b ; steps 0-2: c is None everywhere; steps 3-4: nothing is None; same gradients on both ranks
+    for r in range(2):
+        assert logs[r][0][:6].tolist() == [0, 0, 0, 0, 1, 1] and logs[r][2][:6].tolist() == [0, 0, 0, 0, 1, 1]
+        assert logs[r][4][:6].tolist() == [0, 0, 0, 0, 0, 0]
+        assert logs[r][7][:6].tolist() == [0, 0, 0, 0, 0, 0]          # b and c live on through rank 0
+    assert np.array_equal(logs[0][:, 6], logs[1][:, 6])
+    port += 7
+    mp.spawn(_flags_mismatch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), 'msg0.txt')).read() == ''
+    assert 'changed' in open(os.path.join(str(tmp_path), 'msg1.txt')).read()

@@ -602,6 +602,8 @@ def gen_train_step_timing(device, steps=10):
     torch.cuda.synchronize(device)
     ms_kinv = 1e3 * (time.perf_counter() - t0) / steps
     # the init net alone, forward only (what an evaluation pays per image at this size)
+    from neuray_amd.network import render_ops as _ro
+    _ro.check_deferred_inputs(device, wait=True)        # the last step's device-side input checks (warp_variance) are raised here
     return {'what': 'NeuralRayGenRenderer(cost_volume init net + encoders) forward + render/depth loss + backward + Adam: 512 rays, 8 views of '
                     '416 x 608 (+ 4 source views), 64+64 samples, fp32',
             'ms_per_step': ms, 'ms_per_step_with_host_Ks_inv': ms_kinv,

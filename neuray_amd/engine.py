@@ -319,7 +319,11 @@ class RenderEngine:
         rf, sf = nhwc(ref_feats), nhwc(src_feats)
         ids = nn_ids.to(device=self.device, dtype=torch.int32).contiguous()
         # transform = src_proj @ ref_proj_inv, per (reference view, neighbour) as homo_warp computes it (modules.py:36)
-        inv = torch.linalg.inv_ex(self._f32(ref_prjs)).inverse          # torch.inverse without its host-side singularity check (a sync)
+        inv_res = torch.linalg.inv_ex(self._f32(ref_prjs))             # torch.inverse without its host-side singularity check (a sync) ...
+        inv = inv_res.inverse
+        if inv_res.info.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # ... whose verdict is deferred like the index range: torch.inverse would have raised on a singular projection matrix
+            self._defer_check((inv_res.info != 0).any(), "warp_variance: a reference projection matrix is singular (torch.inverse would have raised)")
         tr = torch.stack([self._f32(src_prjs)[nn_ids[:, j].to(self.device).long()] @ inv for j in range(n_num)], 1)[:, :, :3, :].contiguous()
         dv = self._f32(depth_vals)
         out = self.empty(rfn, dn, fh, fw, 32) if channels_last else self.empty(rfn, 32, dn, fh, fw)
@@ -333,11 +337,14 @@ class RenderEngine:
         flag.copy_(bad, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self.__dict__.setdefault('_deferred', []).append((ev, flag, message))
+        n = self.__dict__['_deferred_calls'] = self.__dict__.get('_deferred_calls', 0) + 1
+        self.__dict__.setdefault('_deferred', []).append((ev, flag, '%s [input check #%d of this engine]' % (message, n)))
 
     def check_deferred(self, wait=True):
-        """Raise the AssertionError of an input check that ran on the device (warp_variance's nn_ids range).  wait=True: after the
-        stream has drained (tests, the end of an epoch); wait=False: only verdicts that have already arrived."""
+        """Raise the AssertionError of an input check that ran on the device (warp_variance's nn_ids range, its singular-matrix check).
+        wait=True: after the stream has drained; wait=False: only verdicts that have already arrived.  Product code drains at the sync points
+        it already has: CostVolumeInitNet.forward in evaluation, NeuralRayGenRenderer / Ft train_step callers through
+        render_ops.check_deferred_inputs() where the loss is read back."""
         pending = self.__dict__.get('_deferred')
         if not pending:
             return

@@ -147,7 +147,14 @@ class CostVolumeInitNet(nn.Module):
         near_inv, far_inv = (-1 / dr[:, 0])[:, None, None, None], (-1 / dr[:, 1])[:, None, None, None]
         depth = torch.clamp((-1 / torch.clamp(depth.unsqueeze(1), min=1e-5) - near_inv) / (far_inv - near_inv), min=0, max=1.0)
         volume_feats = torch.cat([volume_feats, self.depth_conv(depth)], 1)
-        return self.out_conv(torch.cat([ref_feats, volume_feats], 1)).contiguous(memory_format=torch.channels_last)
+        out = self.out_conv(torch.cat([ref_feats, volume_feats], 1)).contiguous(memory_format=torch.channels_last)
+        if not is_train and out.is_cuda:
+            from . import render_ops
+            # evaluation: the verdicts of the input checks that ran on the device (neighbour index range, singular projections) are raised
+            # before the features are used - a single inference call must not return a plausible volume built from clamped indices.
+            # (Training drains them where the step already reads its loss back: render_ops.check_deferred_inputs.)
+            render_ops.check_deferred_inputs(out.device, wait=True)
+        return out
 
 
 name2init_net = {'depth': DepthInitNet, 'cost_volume': CostVolumeInitNet}

@@ -26,6 +26,15 @@ def engine_for(device):
     return _ENGINES[key]
 
 
+def check_deferred_inputs(device, wait=True):
+    """Raise what the device-side input checks of the stand-alone ops found (engine.check_deferred): the neighbour-index range and the
+    singular-projection check of warp_variance, which replaced host-side checks that cost a device -> host wait per call.  Call it where
+    the program waits for the device anyway - after `loss.item()` of a training step, at the end of an epoch, after an inference call."""
+    key = (torch.device(device).type, torch.device(device).index)
+    if key in _ENGINES:
+        _ENGINES[key].check_deferred(wait=wait)
+
+
 def _query_const(eng, pose, K, depth_range=None):
     info = {'poses': pose[None], 'Ks': K[None],
             'depth_range': depth_range[None] if depth_range is not None else torch.ones(1, 2, device=pose.device)}

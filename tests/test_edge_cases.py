@@ -124,6 +124,15 @@ def test_abi_rejects_bad_arguments(backend):
         # (device-resident indices are range-checked on the device without stalling the host: the kernel ran on clamped indices and the
         # verdict is raised here, or by the next call)
         eng.check_deferred()
+    if backend == 'hip':
+        # a singular reference projection: torch.inverse would have raised at the call; inv_ex does not - its verdict is deferred the same way
+        with pytest.raises(AssertionError, match='singular'):
+            eng.warp_variance(torch.zeros(1, 32, 4, 4, device=dev), torch.zeros(2, 32, 4, 4, device=dev), torch.tensor([[0, 1]], device=dev),
+                              torch.zeros(1, 4, 4, device=dev), torch.eye(4, device=dev)[None].repeat(2, 1, 1), torch.ones(1, 8, device=dev))
+            eng.check_deferred()
+        # product code drains the verdicts where it waits for the device anyway (network/render_ops.py check_deferred_inputs)
+        from neuray_amd.network import render_ops
+        render_ops.check_deferred_inputs(dev, wait=True)          # nothing pending: no error
 
 
 # ---- the shapes of BASELINE.json's other configurations (parity cases, not bench lines) -------------------------

@@ -196,17 +196,16 @@ int neuray_render_rays_backward(const NeurayRaysBwdArgs* args, void* stream);
  * state_dict, concatenated in the order of neuray_pack_pass_weights (vis-decoder slots always present; zeros without a
  * vis head); neuray_flat_pass_floats() floats, neuray_flat_tensor_offset(i) = start of tensor i.
  * d_flat, d_ray_feats_nhwc and d_img_feats_nhwc are ACCUMULATED into (zero them first).
- * Two kernels sit behind this entry point:
- *   - the register / LDS resident one (csrc/nr_kernels_bwd2.h; rfn <= 8, any dn): 8 waves per 16-point tile, wave = reference
- *     view, activations and gradients chained in registers on the fp32 MFMA, weight gradients accumulated in registers
- *     over the whole launch.  It is taken when packed_weights_dev (the forward's packed weights, neuray_pack_pass_weights
- *     layout) and packed_t_weights_dev (the transposed layers: packed_t[i] = flat[index[i]] with the index map of
- *     neuray_pack_pass_t_index_map, neuray_packed_t_floats() floats) are given; workspace_dev may then be NULL;
- *   - the first version (one wave per workgroup, activation arena in global memory) for rfn > 8 or when the packed buffers
- *     are NULL; workspace: neuray_points_backward_workspace_floats(rn * dn, rfn) floats of scratch. */
+ * The kernel (csrc/nr_kernels_bwd2.h; rfn <= 8 - no shipped configuration trains with more, dataset/train_dataset.py:73-74 - any dn):
+ * 8 waves per 16-point tile, wave = reference view, activations and gradients chained in registers on the fp32 MFMA, weight gradients
+ * accumulated in registers over the whole launch, run as TWO launches (the network's tail, then its front; each half keeps only its own
+ * weight-gradient accumulators and chain state in registers, the tail hands 20 floats per (point, view) lane over through handover_dev).
+ * Needs packed_weights_dev (the forward's packed weights, neuray_pack_pass_weights layout), packed_t_weights_dev (the transposed
+ * layers: packed_t[i] = flat[index[i]] with the index map of neuray_pack_pass_t_index_map, neuray_packed_t_floats() floats), saved_dev
+ * and handover_dev.  (Rounds 1-5 also carried a first-version kernel for rfn 9..16 and a one-launch form of this one; round 6 removed
+ * both: ABI 10.) */
 size_t neuray_flat_pass_floats(void);
 size_t neuray_flat_tensor_offset(int tensor);
-size_t neuray_points_backward_workspace_floats(int npoints, int rfn);
 typedef struct NeurayPointsBwdArgs {
     const float* query_const_dev;
     const float* view_const_dev;
@@ -220,17 +219,12 @@ typedef struct NeurayPointsBwdArgs {
     float* d_flat_weights_dev;        /* accumulated */
     float* d_ray_feats_nhwc_dev;      /* accumulated */
     float* d_img_feats_nhwc_dev;      /* accumulated */
-    float* workspace_dev;
     int rfn, rn, dn, h, w, fh, fw, has_vis_head, use_vis;
     float var_bias;
-    const float* packed_weights_dev;   /* [neuray_packed_pass_floats()] or NULL */
-    const float* packed_t_weights_dev; /* [neuray_packed_t_floats()] or NULL */
-    const float* saved_dev;            /* resident kernel: what neuray_render_points left in NeurayPointsArgs.saved_dev for the same inputs */
-    float* handover_dev;               /* resident kernel: NULL = one launch; neuray_points_backward_handover_floats(rn * dn) floats of scratch =
-                                        * two launches (the network's tail, then its front: each half keeps only its own weight-gradient
-                                        * accumulators and chain state in registers - 80 + 0 spilled VGPRs instead of 290 - and the tail hands
-                                        * 20 floats per (point, view) lane over: 0.63 instead of 0.92 ms per 512 x 64 x 8 pass).  Same gradients
-                                        * up to the summation order of the atomics. */
+    const float* packed_weights_dev;   /* [neuray_packed_pass_floats()] */
+    const float* packed_t_weights_dev; /* [neuray_packed_t_floats()] */
+    const float* saved_dev;            /* what neuray_render_points left in NeurayPointsArgs.saved_dev for the same inputs */
+    float* handover_dev;               /* neuray_points_backward_handover_floats(rn * dn) floats of scratch between the two launches */
 } NeurayPointsBwdArgs;
 size_t neuray_points_backward_handover_floats(int npoints);
 size_t neuray_packed_t_floats(void);
@@ -242,37 +236,21 @@ int neuray_pack_pass_t_index_map(int has_vis_head, int* index_host);
  * packer gathers fp32 values with the index maps above and converts exactly these ranges. */
 int neuray_packed_quad_ranges(int transposed, int* ranges_host, int max_pairs);
 int neuray_render_points_backward(const NeurayPointsBwdArgs* args, void* stream);
-/* Variant 0 / 2 = the resident kernel (csrc/nr_kernels_bwd2.h), as two launches whenever handover_dev is given; 1 = always as ONE launch
- * (A/B timing, cross-check of the two forms).  Variant 3 - round 3's 4-wave x 2-view decomposition, measured slower - was retired in
- * round 4 and is refused. */
-int neuray_select_points_backward(int variant);
 
 /* ---- backward of the a19 path (renderer.py:137-155): hit_prob_self [rn][dn] as a function of the gathered query-view
  * features feats [rn][32] (neuray_interpolate_feats of que ray_feats) and the dist decoder weights.
  * -> d_feats [rn][32]; d_flat (flat natural layout, only the dist decoder tensors are touched) is ACCUMULATED into.
- * workspace: neuray_self_hit_backward_workspace_floats(rn) floats. */
-size_t neuray_self_hit_backward_workspace_floats(int rn);
+ * One wave per 16 rays, the decoder in registers on the packed and transposed packs (the scheme of neuray_render_points_backward):
+ * packed_weights_dev [neuray_packed_pass_floats()], packed_t_weights_dev [neuray_packed_t_floats()].  Not in the bf16-operand build. */
 int neuray_self_hit_prob_backward(const float* query_const_dev, const float* depth_dev, const float* feats_dev,
-                                  const float* flat_weights_dev, int has_vis_head, int use_vis, float var_bias,
-                                  const float* d_hit_dev, int rn, int dn, float* d_feats_dev, float* d_flat_weights_dev,
-                                  float* workspace_dev, void* stream);
-/* The same on the resident scheme of neuray_render_points_backward (one wave per 16 rays, decoder in registers on the packed and
- * transposed packs, no workspace): packed_weights_dev [neuray_packed_pass_floats()], packed_t_weights_dev
- * [neuray_packed_t_floats()].  Not in the bf16-operand build. */
-int neuray_self_hit_prob_backward_resident(const float* query_const_dev, const float* depth_dev, const float* feats_dev,
                                            const float* packed_weights_dev, const float* packed_t_weights_dev, int has_vis_head,
                                            int use_vis, float var_bias, const float* d_hit_dev, int rn, int dn, float* d_feats_dev,
                                            float* d_flat_weights_dev, void* stream);
 /* ---- backward of neuray_dist_decoder_rows: gradients w.r.t. the decoder outputs (any of d_mean [n][2], d_var [n][2],
- * d_aw [n], d_vis [n] may be NULL) -> d_feats [n][32]; d_flat (flat natural layout) ACCUMULATED.  workspace:
- * neuray_self_hit_backward_workspace_floats(n) floats. */
-int neuray_dist_decoder_rows_backward(const float* feats_dev, const float* flat_weights_dev, int n, int has_vis_head, float var_bias,
-                                      const float* d_mean_dev, const float* d_var_dev, const float* d_aw_dev, const float* d_vis_dev,
-                                      float* d_feats_dev, float* d_flat_weights_dev, float* workspace_dev, void* stream);
-/* The same on the resident scheme of neuray_self_hit_prob_backward_resident (one wave per 16 rows, the heads in registers on the packed /
- * transposed packs of neuray_pack_pass_weights / neuray_pack_pass_t_index_map, weight gradients on the MFMA): no workspace; a head whose
- * gradient pointer is NULL is skipped (predict_mean, renderer.py:280-316: the mean head only).  ABI 9. */
-int neuray_dist_decoder_rows_backward_resident(const float* feats_dev, const float* packed_weights_dev, const float* packed_t_dev, int n,
+ * d_aw [n], d_vis [n] may be NULL: that head is skipped - predict_mean, renderer.py:280-316, needs the mean head only) -> d_feats [n][32];
+ * d_flat (flat natural layout) ACCUMULATED.  One wave per 16 rows, the heads in registers on the packed / transposed packs of
+ * neuray_pack_pass_weights / neuray_pack_pass_t_index_map, weight gradients on the MFMA. */
+int neuray_dist_decoder_rows_backward(const float* feats_dev, const float* packed_weights_dev, const float* packed_t_dev, int n,
                                                int has_vis_head, float var_bias, const float* d_mean_dev, const float* d_var_dev,
                                                const float* d_aw_dev, const float* d_vis_dev, float* d_feats_dev, float* d_flat_dev,
                                                void* stream);

@@ -66,7 +66,7 @@ class NeurayPointsBwdArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'query_const_dev', 'view_const_dev', 'coords_dev', 'depth_dev', 'ray_feats_nhwc_dev', 'img_feats_nhwc_dev',
         'rgba_dev', 'flat_weights_dev', 'd_point_rec_dev', 'd_flat_weights_dev', 'd_ray_feats_nhwc_dev',
-        'd_img_feats_nhwc_dev', 'workspace_dev')] + \
+        'd_img_feats_nhwc_dev')] + \
         [(n, C.c_int) for n in ('rfn', 'rn', 'dn', 'h', 'w', 'fh', 'fw', 'has_vis_head', 'use_vis')] + \
         [('var_bias', C.c_float), ('packed_weights_dev', C.c_void_p), ('packed_t_weights_dev', C.c_void_p), ('saved_dev', C.c_void_p),
          ('handover_dev', C.c_void_p)]
@@ -134,22 +134,15 @@ SYMBOLS = {
     'neuray_render_rays_backward': (C.c_int, [C.POINTER(NeurayRaysBwdArgs), C.c_void_p]),
     'neuray_flat_pass_floats': (C.c_size_t, []),
     'neuray_flat_tensor_offset': (C.c_size_t, [C.c_int]),
-    'neuray_points_backward_workspace_floats': (C.c_size_t, [C.c_int, C.c_int]),
     'neuray_packed_t_floats': (C.c_size_t, []),
     'neuray_pack_pass_t_index_map': (C.c_int, [C.c_int, C.c_void_p]),
-    'neuray_select_points_backward': (C.c_int, [C.c_int]),
     'neuray_points_backward_handover_floats': (C.c_size_t, [C.c_int]),
     'neuray_packed_quad_ranges': (C.c_int, [C.c_int, C.c_void_p, C.c_int]),
     'neuray_render_points_backward': (C.c_int, [C.POINTER(NeurayPointsBwdArgs), C.c_void_p]),
-    'neuray_self_hit_backward_workspace_floats': (C.c_size_t, [C.c_int]),
-    'neuray_self_hit_prob_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
-                                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'neuray_self_hit_prob_backward_resident': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    'neuray_self_hit_prob_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                          C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'neuray_dist_decoder_rows_backward_resident': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+    'neuray_dist_decoder_rows_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'neuray_dist_decoder_rows_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
-                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_interpolate_feats_backward_staged': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_interpolate_feats_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -661,34 +661,10 @@ int neuray_pack_pass_t_index_map(int has_vis_head, int* index) {
 }
 size_t neuray_flat_tensor_offset(int t) { return (t < 0 || t > nr::T_COUNT) ? (size_t)0 : (size_t)nr::tensor_offset(t); }
 
-namespace {
-int points_bwd_grid(int npoints, int vp) {
-    const int ppw = 64 / vp;
-    int cap = 4096;                               // 4096 x 230 KB of arena; four waves per SIMD
-    return grid_for(npoints, ppw, cap);
-}
-int pow2_at_least(int n) { int v = 1; while (v < n) v <<= 1; return v; }
-}  // namespace
-
-size_t neuray_points_backward_workspace_floats(int npoints, int rfn) {
-    if (npoints < 1 || rfn < 1 || rfn > NEURAY_MAX_VIEWS) return 0;
-    return (size_t)points_bwd_grid(npoints, pow2_at_least(rfn)) * nr::kBwdRows * 64;
-}
-
-// The resident point backward is nr_kernels_bwd2.h (8 waves x 1 view at two waves per SIMD: 0.88-0.93 ms per 512 x 64 x 8 pass on the MI355X as
-// one launch, 0.63 ms as its two halves - tail, then front - with a hand-over buffer in between: NeurayPointsBwdArgs.handover_dev).
-// Round 3's second decomposition (4 waves x 2 views per wave at one wave per SIMD, accumulators in AGPRs: 1.06 ms) was
-// retired in round 4 - it lost on the hardware and three parity-tested implementations of one gradient were one too many; the
-// first-version kernel (nr_kernels_bwd.h) remains as the rfn > 8 fallback and the cross-check.  The selector stays for ABI stability.
-static int g_bwd_one_launch = 0;
-int neuray_select_points_backward(int variant) {
-    if (variant != 0 && variant != 2 && variant != 1)
-        return fail("neuray_select_points_backward: variant %d is not built (0 / 2 = the resident kernel, as two launches when handover_dev is given; "
-                    "1 = always as one launch; 3 was retired in round 4)", variant);
-    g_bwd_one_launch = variant == 1;
-    return 0;
-}
-
+// The point backward is nr_kernels_bwd2.h: 8 waves x 1 view at two waves per SIMD, run as its two halves - tail, then front - with a
+// hand-over buffer in between (NeurayPointsBwdArgs.handover_dev).  Round 3's second decomposition (4 waves x 2 views per wave) was retired
+// in round 4; round 6 removed the first-version kernel (rfn 9..16: a view count no shipped configuration trains with) and the one-launch
+// form of the resident kernel (299 spilled VGPRs, 0.92 against 0.63 ms per pass).
 size_t neuray_points_backward_handover_floats(int npoints) {
 #ifdef NR_INFERENCE_ONLY
     (void)npoints;
@@ -706,110 +682,69 @@ int neuray_render_points_backward(const NeurayPointsBwdArgs* a, void* stream) {
     if (a->rfn < 1 || a->rfn > NEURAY_MAX_VIEWS) return fail("neuray_render_points_backward: rfn=%d outside [1,%d]", a->rfn, NEURAY_MAX_VIEWS);
     if (a->rn < 1 || a->dn < 3 || a->dn > NEURAY_MAX_SAMPLES) return fail("neuray_render_points_backward: rn=%d dn=%d", a->rn, a->dn);
 #ifdef NR_INFERENCE_ONLY
-    if (a->packed_weights_dev || a->packed_t_weights_dev) return fail("neuray_render_points_backward: the bf16-operand library is inference only");
+    return fail("neuray_render_points_backward: the bf16-operand library is inference only");
 #else
-    if (a->packed_weights_dev && a->packed_t_weights_dev && a->rfn <= nr::kB2Waves) {      // register / LDS resident kernel
-        if (!a->saved_dev) return fail("neuray_render_points_backward: the resident kernel needs saved_dev (run neuray_render_points with saved_dev on the same inputs first)");
-        nr::PointBwd2Params q;
-        q.que_const = a->query_const_dev; q.view_const = a->view_const_dev; q.coords = a->coords_dev; q.depth = a->depth_dev;
-        q.ray_feats = a->ray_feats_nhwc_dev; q.img_feats = a->img_feats_nhwc_dev; q.rgba = a->rgba_dev;
-        q.weights = a->packed_weights_dev; q.weights_t = a->packed_t_weights_dev;
-        q.d_point_rec = a->d_point_rec_dev; q.d_flat = a->d_flat_weights_dev; q.d_ray_feats = a->d_ray_feats_nhwc_dev;
-        q.d_img_feats = a->d_img_feats_nhwc_dev; q.saved = a->saved_dev;
-        q.rfn = a->rfn; q.rn = a->rn; q.dn = a->dn; q.h = a->h; q.w = a->w; q.fh = a->fh; q.fw = a->fw;
-        q.use_vis = a->use_vis; q.var_bias = a->var_bias;
-        q.handover = a->handover_dev;
-        const int grid2 = grid_for((long long)a->rn * a->dn, 16, 256);            // persistent: one workgroup per CU
-        const size_t smem = nr::point_bwd2_smem_bytes();
-        auto launch = [&](auto k) {
+    if (a->rfn > nr::kB2Waves)
+        return fail("neuray_render_points_backward: rfn=%d - the backward covers at most %d reference views (the forward kernels take %d)",
+                    a->rfn, nr::kB2Waves, NEURAY_MAX_VIEWS);
+    if (!a->packed_weights_dev || !a->packed_t_weights_dev)
+        return fail("neuray_render_points_backward: packed_weights_dev and packed_t_weights_dev are needed (neuray_pack_pass_weights / neuray_pack_pass_t_index_map)");
+    if (!a->saved_dev) return fail("neuray_render_points_backward: saved_dev is NULL (run neuray_render_points with saved_dev on the same inputs first)");
+    if (!a->handover_dev) return fail("neuray_render_points_backward: handover_dev is NULL (neuray_points_backward_handover_floats(rn * dn) floats of scratch)");
+    nr::PointBwd2Params q;
+    q.que_const = a->query_const_dev; q.view_const = a->view_const_dev; q.coords = a->coords_dev; q.depth = a->depth_dev;
+    q.ray_feats = a->ray_feats_nhwc_dev; q.img_feats = a->img_feats_nhwc_dev; q.rgba = a->rgba_dev;
+    q.weights = a->packed_weights_dev; q.weights_t = a->packed_t_weights_dev;
+    q.d_point_rec = a->d_point_rec_dev; q.d_flat = a->d_flat_weights_dev; q.d_ray_feats = a->d_ray_feats_nhwc_dev;
+    q.d_img_feats = a->d_img_feats_nhwc_dev; q.saved = a->saved_dev;
+    q.rfn = a->rfn; q.rn = a->rn; q.dn = a->dn; q.h = a->h; q.w = a->w; q.fh = a->fh; q.fw = a->fw;
+    q.use_vis = a->use_vis; q.var_bias = a->var_bias;
+    q.handover = a->handover_dev;
+    const int grid2 = grid_for((long long)a->rn * a->dn, 16, 256);            // persistent: one workgroup per CU
+    const size_t smem = nr::point_bwd2_smem_bytes();
+    auto launch = [&](auto k) {
 #ifndef NEURAY_EMU
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-            NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
-        };
-        // (a vis head that compute_prob does not consume - the fine decoder's when the coarse decoder has use_vis = False, quirk A.9.2 -
-        // has an identically zero gradient on this path: the kernel without the head is the same computation)
-        const bool vis = a->has_vis_head && a->use_vis;
-        if (a->handover_dev && g_bwd_one_launch == 0) {        // two launches: tail, then front (nr_kernels_bwd2.h B2Part)
-            if (vis) { launch(nr::points_backward2_kernel<true, nr::B2_TAIL>); launch(nr::points_backward2_kernel<true, nr::B2_FRONT>); }
-            else { launch(nr::points_backward2_kernel<false, nr::B2_TAIL>); launch(nr::points_backward2_kernel<false, nr::B2_FRONT>); }
-        } else {
-            if (vis) launch(nr::points_backward2_kernel<true, nr::B2_WHOLE>);
-            else launch(nr::points_backward2_kernel<false, nr::B2_WHOLE>);
-        }
-        return check_launch("neuray_render_points_backward (resident)");
-    }
-#endif
-    if (!a->workspace_dev) return fail("neuray_render_points_backward: workspace_dev is NULL (needed by the first-version kernel)");
-    nr::PointBwdParams p;
-    p.que_const = a->query_const_dev; p.view_const = a->view_const_dev; p.coords = a->coords_dev; p.depth = a->depth_dev;
-    p.ray_feats = a->ray_feats_nhwc_dev; p.img_feats = a->img_feats_nhwc_dev; p.rgba = a->rgba_dev; p.flat = a->flat_weights_dev;
-    p.d_point_rec = a->d_point_rec_dev; p.d_flat = a->d_flat_weights_dev; p.d_ray_feats = a->d_ray_feats_nhwc_dev;
-    p.d_img_feats = a->d_img_feats_nhwc_dev; p.workspace = a->workspace_dev;
-    p.rfn = a->rfn; p.rn = a->rn; p.dn = a->dn; p.h = a->h; p.w = a->w; p.fh = a->fh; p.fw = a->fw;
-    p.vp = pow2_at_least(a->rfn); p.has_vis_head = a->has_vis_head; p.use_vis = a->use_vis; p.var_bias = a->var_bias;
-    const int grid = points_bwd_grid(a->rn * a->dn, p.vp);
-    NR_LAUNCH(nr::points_backward_kernel, dim3(grid), dim3(64), 0, stream, p);
+        NR_LAUNCH(k, dim3(grid2), dim3(64 * nr::kB2Waves), smem, stream, q);
+    };
+    // (a vis head that compute_prob does not consume - the fine decoder's when the coarse decoder has use_vis = False, quirk A.9.2 -
+    // has an identically zero gradient on this path: the kernel without the head is the same computation)
+    const bool vis = a->has_vis_head && a->use_vis;
+    // two launches: tail, then front (nr_kernels_bwd2.h B2Part)
+    if (vis) { launch(nr::points_backward2_kernel<true, nr::B2_TAIL>); launch(nr::points_backward2_kernel<true, nr::B2_FRONT>); }
+    else { launch(nr::points_backward2_kernel<false, nr::B2_TAIL>); launch(nr::points_backward2_kernel<false, nr::B2_FRONT>); }
     return check_launch("neuray_render_points_backward");
+#endif
 }
 
-size_t neuray_self_hit_backward_workspace_floats(int rn) {
-    if (rn < 1) return 0;
-    return (size_t)grid_for(rn, 64, 1024) * nr::kSelfBwdRows * 64;
-}
-
-int neuray_self_hit_prob_backward(const float* qc, const float* depth, const float* feats, const float* flat, int has_vis_head,
-                                  int use_vis, float var_bias, const float* d_hit, int rn, int dn, float* d_feats, float* d_flat,
-                                  float* workspace, void* stream) {
-    if (!qc || !depth || !feats || !flat || !d_hit || !d_feats || !d_flat || !workspace)
-        return fail("neuray_self_hit_prob_backward: null argument");
-    if (rn < 1 || dn < 3 || dn > NEURAY_MAX_SAMPLES) return fail("neuray_self_hit_prob_backward: rn=%d dn=%d", rn, dn);
-    nr::SelfHitBwdParams p;
-    p.que_const = qc; p.depth = depth; p.feats = feats; p.flat = flat; p.d_hit = d_hit; p.d_feats = d_feats; p.d_flat = d_flat;
-    p.workspace = workspace; p.rn = rn; p.dn = dn; p.has_vis_head = has_vis_head; p.use_vis = use_vis; p.var_bias = var_bias;
-    NR_LAUNCH(nr::self_hit_backward_kernel, dim3(grid_for(rn, 64, 1024)), dim3(64), 0, stream, p);
-    return check_launch("neuray_self_hit_prob_backward");
-}
-
-int neuray_self_hit_prob_backward_resident(const float* qc, const float* depth, const float* feats, const float* packed, const float* packed_t,
+int neuray_self_hit_prob_backward(const float* qc, const float* depth, const float* feats, const float* packed, const float* packed_t,
                                            int has_vis_head, int use_vis, float var_bias, const float* d_hit, int rn, int dn,
                                            float* d_feats, float* d_flat, void* stream) {
 #ifdef NR_INFERENCE_ONLY
-    return fail("neuray_self_hit_prob_backward_resident: the bf16-operand variant is inference only");
+    return fail("neuray_self_hit_prob_backward: the bf16-operand variant is inference only");
 #else
     if (!qc || !depth || !feats || !packed || !packed_t || !d_hit || !d_feats || !d_flat)
-        return fail("neuray_self_hit_prob_backward_resident: null argument");
-    if (rn < 1 || dn < 3 || dn > NEURAY_MAX_SAMPLES) return fail("neuray_self_hit_prob_backward_resident: rn=%d dn=%d", rn, dn);
+        return fail("neuray_self_hit_prob_backward: null argument");
+    if (rn < 1 || dn < 3 || dn > NEURAY_MAX_SAMPLES) return fail("neuray_self_hit_prob_backward: rn=%d dn=%d", rn, dn);
     nr::SelfHitBwd2Params p;
     p.que_const = qc; p.depth = depth; p.feats = feats; p.weights = packed; p.weights_t = packed_t; p.d_hit = d_hit;
     p.d_feats = d_feats; p.d_flat = d_flat; p.rn = rn; p.dn = dn; p.use_vis = use_vis; p.var_bias = var_bias;
     const dim3 grid(grid_for(rn, 16, 512));
     if (has_vis_head && use_vis) NR_LAUNCH(nr::self_hit_backward2_kernel<true>, grid, dim3(64), 0, stream, p);   // (an unused vis head: zero gradient)
     else NR_LAUNCH(nr::self_hit_backward2_kernel<false>, grid, dim3(64), 0, stream, p);
-    return check_launch("neuray_self_hit_prob_backward_resident");
+    return check_launch("neuray_self_hit_prob_backward");
 #endif
 }
 
-int neuray_dist_decoder_rows_backward(const float* feats, const float* flat, int n, int has_vis_head, float var_bias,
-                                      const float* d_mean, const float* d_var, const float* d_aw, const float* d_vis,
-                                      float* d_feats, float* d_flat, float* workspace, void* stream) {
-    if (!feats || !flat || !d_feats || !d_flat || !workspace) return fail("neuray_dist_decoder_rows_backward: null argument");
-    if (n < 1) return fail("neuray_dist_decoder_rows_backward: n=%d", n);
-    nr::RowsBwdParams p;
-    p.feats = feats; p.flat = flat; p.d_mean = d_mean; p.d_var = d_var; p.d_aw = d_aw; p.d_vis = d_vis; p.d_feats = d_feats;
-    p.d_flat = d_flat; p.workspace = workspace; p.n = n; p.has_vis_head = has_vis_head; p.var_bias = var_bias;
-    NR_LAUNCH(nr::decoder_rows_backward_kernel, dim3(grid_for(n, 64, 1024)), dim3(64), 0, stream, p);
-    return check_launch("neuray_dist_decoder_rows_backward");
-}
-
-int neuray_dist_decoder_rows_backward_resident(const float* feats, const float* packed, const float* packed_t, int n, int has_vis_head,
+int neuray_dist_decoder_rows_backward(const float* feats, const float* packed, const float* packed_t, int n, int has_vis_head,
                                                float var_bias, const float* d_mean, const float* d_var, const float* d_aw, const float* d_vis,
                                                float* d_feats, float* d_flat, void* stream) {
 #ifdef NR_INFERENCE_ONLY
-    return fail("neuray_dist_decoder_rows_backward_resident: the bf16-operand variant is inference only");
+    return fail("neuray_dist_decoder_rows_backward: the bf16-operand variant is inference only");
 #else
-    if (!feats || !packed || !packed_t || !d_feats || !d_flat) return fail("neuray_dist_decoder_rows_backward_resident: null argument");
-    if (n < 1) return fail("neuray_dist_decoder_rows_backward_resident: n=%d", n);
+    if (!feats || !packed || !packed_t || !d_feats || !d_flat) return fail("neuray_dist_decoder_rows_backward: null argument");
+    if (n < 1) return fail("neuray_dist_decoder_rows_backward: n=%d", n);
     nr::RowsBwd2Params p;
     p.feats = feats; p.weights = packed; p.weights_t = packed_t; p.d_mean = d_mean; p.d_var = d_var; p.d_aw = d_aw; p.d_vis = d_vis;
     p.d_feats = d_feats; p.d_flat = d_flat; p.n = n; p.var_bias = var_bias;
@@ -817,7 +752,7 @@ int neuray_dist_decoder_rows_backward_resident(const float* feats, const float* 
     const dim3 grid(grid_for(n, 16, 512));
     if (has_vis_head && d_vis) NR_LAUNCH(nr::decoder_rows_backward2_kernel<true>, grid, dim3(64), 0, stream, p);      // (no gradient into the vis head: not run)
     else NR_LAUNCH(nr::decoder_rows_backward2_kernel<false>, grid, dim3(64), 0, stream, p);
-    return check_launch("neuray_dist_decoder_rows_backward_resident");
+    return check_launch("neuray_dist_decoder_rows_backward");
 #endif
 }
 

@@ -54,13 +54,13 @@ constexpr int kB2Stride = 132;           // floats per staged row: 128 columns (
 constexpr int kB2StageRows = 176;
 constexpr int kB2PStride = 20;           // per-point staging: 16 columns + 4
 constexpr int kB2Rmax = 12;              // rows of the widest all-reduce
-// The kernel as ONE launch (B2_WHOLE) or as TWO (round 4): B2_TAIL = geometry_fc -> blend -> rgb_fc -> vis_fc2 -> vis_fc -> base_fc -> the
+// The kernel runs as TWO launches (round 4; its one-launch form - 299 spilled VGPRs, 0.92 ms - was removed in round 6): B2_TAIL = geometry_fc -> blend -> rgb_fc -> vis_fc2 -> vis_fc -> base_fc -> the
 // cross-view statistics, leaving per (point, view) column the gradients of what the front of the network produced (d gi: 8 per lane,
 // d e: 8, d gr: 3, d sn: 1 = kB2Handover floats per lane); B2_FRONT = neuray_fc / ray_dir_fc / prob_embed -> probabilities -> dist decoder
 // heads -> map gradients from those.  Each half holds only its own weight-gradient accumulators (109 / 57 of the 166 jobs) and its own
 // part of the chain state: 80 + 0 spilled VGPRs instead of 290, at the price of the geometry, the gathers and part of the recomputed
 // forward twice and 84 MB of hand-over per pass: 0.63 ms instead of 0.92.
-enum B2Part { B2_TAIL = 0, B2_FRONT = 1, B2_WHOLE = 2 };
+enum B2Part { B2_TAIL = 0, B2_FRONT = 1 };
 constexpr int kB2Handover = 20;
 inline size_t point_bwd2_handover_floats(int npts) { return (size_t)((npts + 15) / 16) * kB2Waves * kB2Handover * 64; }
 // LDS (floats): all-reduce scratch | xch (base_fc.0 per-point part: 64 features x 16 points, kept from the forward to its
@@ -347,9 +347,9 @@ __device__ __forceinline__ void dw_flush_all(const v4f (&acc)[kDwAcc], const flo
     (dw_flush<IDS>(acc, bacc, d_flat, wave, lane), ...);
 }
 
-template <bool HAS_VIS, int PART = B2_WHOLE>
+template <bool HAS_VIS, int PART>
 __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Params p) {
-    constexpr bool DO_TAIL = PART != B2_FRONT, DO_FRONT = PART != B2_TAIL;
+    constexpr bool DO_TAIL = PART == B2_TAIL, DO_FRONT = PART == B2_FRONT;
     NR_DYNAMIC_SMEM(float, smem);
     const int lane = threadIdx.x & 63;
     const int wave = NR_UNIFORM((int)(threadIdx.x >> 6));
@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(512, 2) points_backward2_kernel(PointBwd2Param
             for (int k = 0; k < 8; ++k) { dgi[k] = ho[k * 64]; de[0][k] = ho[(8 + k) * 64]; }
             dgr[0] = ho[16 * 64]; dgr[1] = ho[17 * 64]; dgr[2] = ho[18 * 64]; dsn = ho[19 * 64];
         }
-        if constexpr (DO_TAIL && !DO_FRONT) {
+        if constexpr (DO_TAIL) {
             NR_PRAGMA_UNROLL
             for (int k = 0; k < 8; ++k) { ho[k * 64] = dgi[k]; ho[(8 + k) * 64] = de[0][k]; }
             ho[16 * 64] = dgr[0]; ho[17 * 64] = dgr[1]; ho[18 * 64] = dgr[2]; ho[19 * 64] = dsn;

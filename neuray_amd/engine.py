@@ -121,7 +121,6 @@ class RenderEngine:
         self.timing = None
         self.max_backward_samples = _lib.MAX_BACKWARD_SAMPLES
         self.slot_stats = None                     # optional int64 device tensor [2]: every point-kernel launch adds (view slots run, view slots)
-        self.points_backward_kernel = 'auto'       # 'v1': force the first-version point backward (A/B timing, tests)
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -619,94 +618,68 @@ class RenderEngine:
         return dev
 
     def render_points_backward(self, qconst, views, coords, depth, flat, has_vis_head, use_vis, d_point_rec, var_bias=0.05,
-                               packed=None, kernel='auto', saved=None, out=None):
+                               packed=None, saved=None, out=None):
         """Backward of the point kernel: -> (d_flat [flat pass floats], d_ray_feats NHWC [rfn,fh,fw,32], d_img_feats NHWC).
-        packed: the forward's PackedPass of the same weights (built from `flat` here if absent).  kernel: 'auto' = the
-        register / LDS resident kernel when it applies (rfn <= 8; run as its two halves), 'one_launch' = the resident kernel as a single
-        launch (A/B, cross-check), 'v1' = force the first-version kernel (tests).
-        saved: render_pass(save=True)['saved'] of the same inputs (resident kernel; produced here by one more forward if absent)."""
+        The register / LDS resident kernel of csrc/nr_kernels_bwd2.h, run as its two halves (tail, front) with a hand-over buffer in
+        between; at most 8 reference views (no shipped configuration trains with more: dataset/train_dataset.py:73-74,
+        renderer.py:350 - the forward kernels take up to 16).  packed: the forward's PackedPass of the same weights (built from `flat`
+        here if absent).  saved: render_pass(save=True)['saved'] of the same inputs (produced here by one more forward if absent)."""
         coords, depth, d_point_rec = self._f32(coords), self._f32(depth), self._f32(d_point_rec)
         rn, dn = depth.shape
+        if views.rfn > 8:
+            raise NotImplementedError("neuray_amd: the point backward covers at most 8 reference views (got %d); render under "
+                                      "torch.no_grad() or train with <= 8 working views (INTEGRATION.md 'Shape limits')" % views.rfn)
         # out: (d_flat, d_ray_feats, d_img_feats) already zeroed by the caller (engine.zeroed: one fill for the whole pass)
         d_flat, d_rf, d_if = out if out is not None else self.zeroed(flat.shape, views.ray_feats.shape, views.img_feats.shape)
         if packed is not None and packed.folded:
             raise ValueError("neuray_amd: the backward kernels take the unfolded pack (pack_pass(fold=False) / pack_pass_device)")
-        resident = kernel != 'v1' and self.points_backward_kernel != 'v1' and views.rfn <= 8
-        ws = pk = pt = ho = None
-        if resident:
-            if kernel != 'one_launch':      # the kernel as its two halves (tail, front) with a hand-over buffer in between: 0.63 vs 0.92 ms
-                ho = self.empty(int(self.lib.neuray_points_backward_handover_floats(rn * dn)))
-            packed = packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))
-            pk = packed.dev
-            pt = self.pack_pass_t_device(flat, bool(has_vis_head))
-            if saved is None:
-                saved = self.render_points_saved(qconst, views, coords, depth, packed, use_vis, var_bias)
-        else:
-            if views.rfn > 8 and kernel == 'auto' and self.points_backward_kernel == 'auto' and not self.__dict__.get('_v1_warned'):
-                import warnings
-                warnings.warn("neuray_amd: %d reference views > 8 - the point backward runs its first-version kernel (activation arena in "
-                              "global memory, ~5 x the time of the register / LDS resident kernel that covers rfn <= 8: ~4.4 instead of "
-                              "~0.9 ms per 512-ray pass on an MI355X; INTEGRATION.md 'Shape limits').  The forward kernels take up to 16 "
-                              "views at full speed." % views.rfn)
-                self.__dict__['_v1_warned'] = True
-            ws = self.empty(int(self.lib.neuray_points_backward_workspace_floats(rn * dn, views.rfn)))
+        ho = self.empty(int(self.lib.neuray_points_backward_handover_floats(rn * dn)))
+        packed = packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))
+        pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+        if saved is None:
+            saved = self.render_points_saved(qconst, views, coords, depth, packed, use_vis, var_bias)
         a = _lib.NeurayPointsBwdArgs(
             qconst.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
             views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_point_rec.data_ptr(), d_flat.data_ptr(),
-            d_rf.data_ptr(), d_if.data_ptr(), ws.data_ptr() if ws is not None else None, views.rfn, rn, dn, views.h, views.w,
+            d_rf.data_ptr(), d_if.data_ptr(), views.rfn, rn, dn, views.h, views.w,
             views.fh, views.fw, int(has_vis_head), int(bool(use_vis)), float(var_bias),
-            pk.data_ptr() if pk is not None else None, pt.data_ptr() if pt is not None else None,
-            saved.data_ptr() if (resident and saved is not None) else None, ho.data_ptr() if ho is not None else None)
+            packed.dev.data_ptr(), pt.data_ptr(), saved.data_ptr(), ho.data_ptr())
         ev = self._event_pair()
         self._check(self.lib.neuray_render_points_backward(C.byref(a), self._stream()))
         self._event_done(ev, 'points_backward', rn * dn)
         return d_flat, d_rf, d_if
 
-    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05, packed=None, kernel='auto',
-                               d_flat=None):
-        """Backward of dist_decoder_rows + self_hit_prob: -> (d_feats [rn,32], d_flat).  The resident kernel (one wave per 16 rays, decoder
-        in registers on the packed / transposed packs) unless kernel == 'v1' (first version: lane = ray, global arena).
-        d_flat: an existing flat gradient buffer to accumulate into (the kernels add atomically) instead of a fresh zeroed one."""
+    def self_hit_prob_backward(self, qconst, depth, feats, flat, has_vis_head, use_vis, d_hit, var_bias=0.05, packed=None, d_flat=None):
+        """Backward of dist_decoder_rows + self_hit_prob: -> (d_feats [rn,32], d_flat).  One wave per 16 rays, the decoder in registers on
+        the packed / transposed packs.  d_flat: an existing flat gradient buffer to accumulate into (the kernel adds atomically) instead
+        of a fresh zeroed one."""
         depth, feats, d_hit = self._f32(depth), self._f32(feats), self._f32(d_hit)
         rn, dn = depth.shape
         d_feats = self.empty(rn, 32)
         d_flat = torch.zeros_like(flat) if d_flat is None else d_flat
         if packed is not None and packed.folded:
             raise ValueError("neuray_amd: the backward kernels take the unfolded pack (pack_pass(fold=False) / pack_pass_device)")
-        if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant in ('fp32', 'bf16x3'):
-            pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
-            pt = self.pack_pass_t_device(flat, bool(has_vis_head))
-            self._check(self.lib.neuray_self_hit_prob_backward_resident(
-                qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), pk.data_ptr(), pt.data_ptr(), int(has_vis_head), int(bool(use_vis)),
-                float(var_bias), d_hit.data_ptr(), rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), self._stream()))
-            return d_feats, d_flat
-        ws = self.empty(int(self.lib.neuray_self_hit_backward_workspace_floats(rn)))
-        self._check(self.lib.neuray_self_hit_prob_backward(qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), flat.data_ptr(),
-                                                           int(has_vis_head), int(bool(use_vis)), float(var_bias), d_hit.data_ptr(),
-                                                           rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), ws.data_ptr(), self._stream()))
+        pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
+        pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+        self._check(self.lib.neuray_self_hit_prob_backward(
+            qconst.data_ptr(), depth.data_ptr(), feats.data_ptr(), pk.data_ptr(), pt.data_ptr(), int(has_vis_head), int(bool(use_vis)),
+            float(var_bias), d_hit.data_ptr(), rn, dn, d_feats.data_ptr(), d_flat.data_ptr(), self._stream()))
         return d_feats, d_flat
 
-    def dist_decoder_rows_backward(self, feats, flat, has_vis_head, var_bias, d_mean=None, d_var=None, d_aw=None, d_vis=None, packed=None,
-                                   kernel='auto'):
-        """Backward of dist_decoder_rows: -> (d_feats [n,32], d_flat).  The resident kernel (one wave per 16 rows, the heads in registers on the
-        packed / transposed packs; heads without an incoming gradient are skipped) unless kernel == 'v1' (first version: lane = row, global arena)."""
+    def dist_decoder_rows_backward(self, feats, flat, has_vis_head, var_bias, d_mean=None, d_var=None, d_aw=None, d_vis=None, packed=None):
+        """Backward of dist_decoder_rows: -> (d_feats [n,32], d_flat).  One wave per 16 rows, the heads in registers on the packed /
+        transposed packs; heads without an incoming gradient are skipped."""
         feats = self._f32(feats).reshape(-1, 32)
         n = feats.shape[0]
         g = [self._f32(t).reshape(-1) if t is not None else None for t in (d_mean, d_var, d_aw, d_vis)]
         d_feats = self.empty(n, 32)
         d_flat = torch.zeros_like(flat)
         ptr = lambda t: t.data_ptr() if t is not None else None       # noqa: E731
-        if kernel != 'v1' and self.points_backward_kernel != 'v1' and self.variant in ('fp32', 'bf16x3'):
-            pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
-            pt = self.pack_pass_t_device(flat, bool(has_vis_head))
-            self._check(self.lib.neuray_dist_decoder_rows_backward_resident(
-                feats.data_ptr(), pk.data_ptr(), pt.data_ptr(), n, int(has_vis_head), float(var_bias), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]),
-                d_feats.data_ptr(), d_flat.data_ptr(), self._stream()))
-            return d_feats, d_flat
-        ws = self.empty(int(self.lib.neuray_self_hit_backward_workspace_floats(n)))
-        self._check(self.lib.neuray_dist_decoder_rows_backward(feats.data_ptr(), flat.data_ptr(), n, int(has_vis_head), float(var_bias),
-                                                               ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), d_feats.data_ptr(),
-                                                               d_flat.data_ptr(), ws.data_ptr(), self._stream()))
+        pk = (packed if packed is not None else self.pack_pass_device(flat, bool(has_vis_head))).dev
+        pt = self.pack_pass_t_device(flat, bool(has_vis_head))
+        self._check(self.lib.neuray_dist_decoder_rows_backward(
+            feats.data_ptr(), pk.data_ptr(), pt.data_ptr(), n, int(has_vis_head), float(var_bias), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]),
+            d_feats.data_ptr(), d_flat.data_ptr(), self._stream()))
         return d_feats, d_flat
 
     def interpolate_feats_backward(self, d_out, feats_shape, points, h=None, w=None, align_corners=False, mask=None, out=None, staged=None):

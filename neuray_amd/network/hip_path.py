@@ -87,6 +87,10 @@ class HipRenderPath:
                 raise NotImplementedError("neuray_amd: cfg['hip_variant'] = %r is inference only (the training forward's saved "
                                           "quantities and the backward kernels exist in the fp32 and the split 'bf16x3' libraries); "
                                           "render under torch.no_grad() or use one of those" % eng.variant)
+            if views.rfn > 8:
+                raise NotImplementedError("neuray_amd: the backward kernels cover at most 8 reference views (got %d; no shipped configuration "
+                                          "trains with more: dataset/train_dataset.py:73-74); render under torch.no_grad() or reduce the "
+                                          "working views" % views.rfn)
             if que_depth.shape[-1] > eng.max_backward_samples:
                 raise NotImplementedError("neuray_amd: the backward kernels take at most %d samples per ray and pass"
                                           % eng.max_backward_samples)

@@ -110,7 +110,7 @@ def _pass_case(rfn, rn, dn, use_vis_head, seed):
 
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('rfn,rn,dn,vis_head', [(3, 5, 8, False), (8, 3, 6, True), (2, 4, 5, False), (1, 3, 5, False),
-                                                  (16, 2, 4, True), (5, 7, 9, True)])
+                                                  (7, 2, 4, True), (5, 7, 9, True)])
 def test_pass_backward_matches_autograd(rfn, rn, dn, vis_head, backend):
     from neuray_amd.engine import RenderEngine
     from oracle import neuray_oracle as orc
@@ -259,9 +259,10 @@ def test_dist_decoder_module_forward_backward(use_vis, backend):
 
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('use_vis', [False, True])
-def test_resident_rows_backward_equals_the_first_version(use_vis, backend):
-    """neuray_dist_decoder_rows_backward_resident (one wave per 16 rows, heads in registers) against the first-version kernel (global
-    arena) on the same rows: all heads, and with heads left out (a null gradient pointer = no contribution, as predict_mean's backward)"""
+def test_rows_backward_skips_the_heads_without_a_gradient(use_vis, backend):
+    """neuray_dist_decoder_rows_backward (one wave per 16 rows, heads in registers): a head whose gradient pointer is NULL contributes
+    exactly what a zero gradient contributes - nothing (predict_mean's backward passes the mean head only, renderer.py:280-316); the
+    full gradient against autograd is test_predict_mean_backward_matches_autograd / test_self_hit_prob_backward_matches_autograd"""
     from neuray_amd.network.dist_decoder import MixtureLogisticsDistDecoder
     dev = 'cpu' if backend == 'emu' else 'cuda:0'
     torch.manual_seed(6)
@@ -274,8 +275,10 @@ def test_resident_rows_backward_equals_the_first_version(use_vis, backend):
     n = 53                                                       # not a multiple of 16: a partly filled tile
     feats = torch.randn(n, 32, device=dev)
     gm, gv, ga, gs = torch.randn(n, 2, device=dev), torch.randn(n, 2, device=dev), torch.randn(n, 1, device=dev), torch.randn(n, 1, device=dev)
-    for heads in ((gm, gv, ga, gs if use_vis else None), (gm, None, None, None), (None, gv, ga, None)):
-        f1, w1 = eng.dist_decoder_rows_backward(feats, flat, has_vis, 0.05, *heads, kernel='v1')
+    z2, z1 = torch.zeros(n, 2, device=dev), torch.zeros(n, 1, device=dev)
+    for heads, zeros in (((gm, None, None, None), (gm, z2, z1, z1 if use_vis else None)),
+                         ((None, gv, ga, None), (z2, gv, ga, z1 if use_vis else None))):
+        f1, w1 = eng.dist_decoder_rows_backward(feats, flat, has_vis, 0.05, *zeros)
         f2, w2 = eng.dist_decoder_rows_backward(feats, flat, has_vis, 0.05, *heads)
         assert float((f1 - f2).abs().max()) <= 1e-5 * max(1.0, float(f1.abs().max()))
         assert float((w1 - w2).abs().max()) <= 2e-5 * max(1.0, float(w1.abs().max()))
@@ -427,10 +430,9 @@ def test_self_hit_backward_matches_autograd_and_the_first_version(rn, dn, vis_he
     feats = eng.interpolate_feats(t(que['ray_feats']), t(que['coords']), 48, 64, align_corners=False)[0]      # [rn,32]
     flat, has_vis = eng.flat_pass(weights, 'dist_decoder.', 'agg_net.')
     got = {}
-    for kernel in ('auto', 'v1'):
-        d_feats, d_flat = eng.self_hit_prob_backward(qc, t(depth[0]), feats, flat, has_vis, vis_head, t(lw), kernel=kernel)
-        d_map = eng.interpolate_feats_backward(d_feats[None], tuple(tq['ray_feats'].shape), t(que['coords']), 48, 64, align_corners=False)
-        got[kernel] = (eng.unflatten_pass_grads(d_flat, weights, 'dist_decoder.', 'agg_net.'), d_map, d_feats)
+    d_feats, d_flat = eng.self_hit_prob_backward(qc, t(depth[0]), feats, flat, has_vis, vis_head, t(lw))
+    d_map = eng.interpolate_feats_backward(d_feats[None], tuple(tq['ray_feats'].shape), t(que['coords']), 48, 64, align_corners=False)
+    got['auto'] = (eng.unflatten_pass_grads(d_flat, weights, 'dist_decoder.', 'agg_net.'), d_map, d_feats)
 
     def close(a, b, name, rel):
         a, b = a.detach().cpu().numpy(), (b.detach().cpu().numpy() if torch.is_tensor(b) else b)
@@ -440,9 +442,7 @@ def test_self_hit_backward_matches_autograd_and_the_first_version(rn, dn, vis_he
     for k, p_ in w.items():
         want = p_.grad if p_.grad is not None else torch.zeros_like(p_)
         close(got['auto'][0][k], want, k, 2e-3)
-        close(got['auto'][0][k], got['v1'][0][k], k + ' (v1)', 1e-4)
     close(got['auto'][1], tq['ray_feats'].grad, 'que ray_feats', 2e-3)
-    close(got['auto'][2], got['v1'][2], 'd_feats (v1)', 1e-4)
     for k, g in got['auto'][0].items():                      # nothing but the dist decoder is touched
         if not k.startswith('dist_decoder.'):
             assert float(g.abs().max()) == 0.0, k
@@ -479,52 +479,46 @@ def test_resident_point_backward_uses_the_forwards_saved_quantities(backend):
     args = _lib.NeurayPointsBwdArgs(
         qc.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
         views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_rec.data_ptr(), d_flat.data_ptr(), d_rf.data_ptr(),
-        d_if.data_ptr(), None, views.rfn, 6, 7, views.h, views.w, views.fh, views.fw, int(has_vis), 0, 0.05,
-        packed.dev.data_ptr(), pt.data_ptr(), None)
+        d_if.data_ptr(), views.rfn, 6, 7, views.h, views.w, views.fh, views.fw, int(has_vis), 0, 0.05,
+        packed.dev.data_ptr(), pt.data_ptr(), None, None)
     assert eng.lib.neuray_render_points_backward(C.byref(args), eng._stream()) != 0
     assert b'saved_dev' in eng.lib.neuray_last_error()
 
 
-def test_retired_backward_variant_is_refused():
-    """round 3's 4-wave x 2-view decomposition of the resident point backward lost on the hardware and was retired in round 4"""
-    lib = emu_lib()
-    assert lib.neuray_select_points_backward(0) == 0 and lib.neuray_select_points_backward(2) == 0
-    assert lib.neuray_select_points_backward(3) != 0 and b'retired' in lib.neuray_last_error()
-
-
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('rfn,rn,dn,vis_head', [(8, 5, 9, False), (3, 4, 16, True), (5, 7, 7, True), (1, 3, 5, False)])
-def test_two_launch_point_backward_equals_the_single_launch(backend, rfn, rn, dn, vis_head):
-    """the resident point backward as its two halves (tail kernel -> hand-over buffer -> front kernel: what the engine runs) against
-    the same kernel source as ONE launch: every gradient, up to the summation order of the atomics; tiles with padding points
-    (rn * dn not a multiple of 16), padding waves (rfn < 8), with and without a consumed vis head"""
+def test_point_backward_limits_are_refused_cleanly(backend):
+    """round 6 removed the first-version point backward (rfn 9..16) and the one-launch form of the resident one: more than 8 views under
+    autograd raise, and the C entry point names the buffer it misses"""
     from neuray_amd.engine import RenderEngine
+    from neuray_amd import _lib
+    import ctypes as C
     from oracle import neuray_oracle as orc
     dev = 'cpu' if backend == 'emu' else 'cuda:0'
     eng = RenderEngine(dev, _test_lib=emu_lib() if backend == 'emu' else None)
-    que, ref, weights, rng = _pass_case(rfn, rn, dn, vis_head, seed=57 + rfn)
+    que, ref, weights, rng = _pass_case(9, 2, 4, False, seed=3)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)         # noqa: E731
     views = eng.prepare_views({k: t(v) for k, v in ref.items()})
     qc = eng.prepare_query({k: t(v) for k, v in que.items()})
-    depth = t(orc.sample_depth(que['depth_range'], rn, dn)[0])
+    depth = t(orc.sample_depth(que['depth_range'], 2, 4)[0])
     coords = t(que['coords'][0])
-    packed = eng.pack_pass(weights, 'dist_decoder.', 'agg_net.')
     flat, has_vis = eng.flat_pass(weights, 'dist_decoder.', 'agg_net.')
-    assert has_vis == vis_head
-    fwd = eng.render_pass(qc, views, coords, depth, packed, use_vis=vis_head, save=True)
-    d_rec = t(rng.randn(rn, dn, 20).astype(np.float32))
-    assert int(eng.lib.neuray_points_backward_handover_floats(rn * dn)) == ((rn * dn + 15) // 16) * 8 * 20 * 64
-    two = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, vis_head, d_rec, packed=packed, saved=fwd['saved'])
-    one = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, vis_head, d_rec, packed=packed, saved=fwd['saved'],
-                                     kernel='one_launch')
-    for x, y, name in zip(two, one, ('d_flat', 'd_ray_feats', 'd_img_feats')):
-        assert float(y.abs().max()) > 0, name
-        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())), name
-    # the selector forces the single launch even when a hand-over buffer is given
-    assert eng.lib.neuray_select_points_backward(1) == 0
-    try:
-        forced = eng.render_points_backward(qc, views, coords, depth, flat, has_vis, vis_head, d_rec, packed=packed, saved=fwd['saved'])
-    finally:
-        assert eng.lib.neuray_select_points_backward(0) == 0
-    for x, y in zip(forced, one):
-        assert float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+    d_rec = t(rng.randn(2, 4, 20).astype(np.float32))
+    with pytest.raises(NotImplementedError, match='8 reference views'):
+        eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec)
+    assert int(eng.lib.neuray_points_backward_handover_floats(5 * 9)) == ((5 * 9 + 15) // 16) * 8 * 20 * 64
+    packed = eng.pack_pass(weights, 'dist_decoder.', 'agg_net.')
+    pt = eng.pack_pass_t_device(flat, has_vis)
+    d_flat, d_rf, d_if = torch.zeros_like(flat), torch.zeros_like(views.ray_feats), torch.zeros_like(views.img_feats)
+    saved = eng.points_saved_buffer(8)
+
+    def call(rfn, saved_, ho):
+        args = _lib.NeurayPointsBwdArgs(
+            qc.data_ptr(), views.view_const.data_ptr(), coords.data_ptr(), depth.data_ptr(), views.ray_feats.data_ptr(),
+            views.img_feats.data_ptr(), views.rgba.data_ptr(), flat.data_ptr(), d_rec.data_ptr(), d_flat.data_ptr(), d_rf.data_ptr(),
+            d_if.data_ptr(), rfn, 2, 4, views.h, views.w, views.fh, views.fw, int(has_vis), 0, 0.05,
+            packed.dev.data_ptr(), pt.data_ptr(), saved_, ho)
+        return eng.lib.neuray_render_points_backward(C.byref(args), eng._stream()), eng.lib.neuray_last_error()
+    rc, msg = call(9, saved.data_ptr(), None)
+    assert rc != 0 and b'at most 8' in msg
+    rc, msg = call(8, saved.data_ptr(), None)
+    assert rc != 0 and b'handover_dev' in msg

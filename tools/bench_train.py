@@ -49,7 +49,6 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--ft', action='store_true', help='a NeuralRayFtRenderer.train_step on a 24-view 800 x 800 in-memory scene '
                                                       '(per-view learnable ray_feats, encoders trained) instead of the bare render_impl step')
-    ap.add_argument('--kernel', default='auto', help="'v1': the first-version point backward (A/B)")
     ap.add_argument('--use-all', action='store_true', help="cfg fine_depth_use_all: the fine pass runs on 64 + 64 = 128 samples per ray (rays_backward_kernel<2>)")
     ap.add_argument('--variant', default='fp32', help="'bf16x3': the split library (hi + lo bf16 MFMA operands, fp32 accumulate)")
     args = ap.parse_args()
@@ -63,7 +62,6 @@ def main():
         cfg.update(fine_depth_use_all=True, fine_agg_net_cfg={'sample_num': 128})
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).train().to(dev)
-    r.engine(dev).points_backward_kernel = args.kernel
     que, ref = synthetic.make_scene(400, 600, 8, seed=0, que_imgs=True)
     rng = np.random.RandomState(0)
     que['coords'] = (rng.rand(1, args.rays, 2) * np.array([599, 399])).astype(np.float32)
@@ -88,7 +86,7 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps
 
-    res = {'rays': args.rays, 'views': 8, 'samples': '64+64', 'point_backward_kernel': args.kernel, 'hip_ms_per_step': 1e3 * timeit(step_ours)}
+    res = {'rays': args.rays, 'views': 8, 'samples': '64+64', 'hip_ms_per_step': 1e3 * timeit(step_ours)}
     print(json.dumps(res))
 
 

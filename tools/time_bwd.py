@@ -1,5 +1,5 @@
 """Time the point backward kernel alone (HIP events): 512 rays x 8 views x 64 samples (the training shape).
-    python tools/time_bwd.py [--kernel v1] [--reps 20]        (NEURAY_HIP_LIB=<other .so> for A/B builds)"""
+    python tools/time_bwd.py [--reps 20]        (NEURAY_HIP_LIB=<other .so> for A/B builds)"""
 import argparse
 import json
 import os
@@ -17,7 +17,6 @@ from neuray_amd.network.renderer import NeuralRayBaseRenderer      # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--kernel', default='auto')
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--rays', type=int, default=512)
     ap.add_argument('--hw', type=int, nargs=2, default=[400, 600], help='image size (the feature maps are 8 x h x w x 32 floats each)')
@@ -38,7 +37,7 @@ def main():
     packed = eng.pack_pass_device(flat, has_vis)
     d_rec = torch.randn(args.rays, 64, 20, device=dev) * 1e-2
     saved = eng.render_points_saved(qc, views, coords, depth, packed, False)       # what the training forward leaves for the backward
-    run = lambda: eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec, packed=packed, kernel=args.kernel, saved=saved)   # noqa: E731
+    run = lambda: eng.render_points_backward(qc, views, coords, depth, flat, has_vis, False, d_rec, packed=packed, saved=saved)   # noqa: E731
     run(); run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -46,7 +45,7 @@ def main():
     for _ in range(args.reps):
         e0.record(); out = run(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    print(json.dumps({'lib': os.environ.get('NEURAY_HIP_LIB', 'product'), 'kernel': args.kernel, 'rays': args.rays,
+    print(json.dumps({'lib': os.environ.get('NEURAY_HIP_LIB', 'product'), 'rays': args.rays,
                       'ms_min': min(ts), 'ms_median': float(np.median(ts)), 'd_flat_abs_sum': float(out[0].abs().sum())}))
 
 

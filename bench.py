@@ -612,7 +612,7 @@ def gen_train_step_timing(device, steps=10):
                     "carries que_imgs_info['Ks_inv'] computed by the host pipeline before the upload (the two agree within the run-to-run "
                     "noise of +-2 ms: the copy is taken before anything of the step is queued)",
             'loss_is_finite': bool(torch.isfinite(loss).item()),
-            'kernel_classes': 'profiles/r04_*_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
+            'kernel_classes': 'profiles/r05_t_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
 
 
 def encoder_timing(device, n=9, hw=(800, 800), reps=5):
@@ -856,11 +856,11 @@ def side(fn, *a, **k):
         return {'error': '%s: %s' % (type(e).__name__, e)}
 
 
-def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
+def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2, arith='f32'):
     """The same image at another sampling / batching configuration (reported next to the headline, never instead of it)."""
     cfg = {'use_hierarchical_sampling': True, 'dist_decoder_cfg': {'use_vis': False}, 'depth_sample_num': DN_COARSE,
            'fine_depth_sample_num': fdn, 'agg_net_cfg': {'sample_num': DN_COARSE}, 'fine_agg_net_cfg': {'sample_num': fdn},
-           'ray_batch_num': ray_batch, 'hip_min_ray_batch': 0}      # (launches of exactly `ray_batch` rays: render() would merge them otherwise)
+           'ray_batch_num': ray_batch, 'hip_min_ray_batch': 0, 'hip_arith': arith}      # (launches of exactly `ray_batch` rays: render() would merge them otherwise)
     torch.manual_seed(0)
     r = NeuralRayBaseRenderer(cfg).eval().to(device)
     eng = r.engine(device)
@@ -882,6 +882,68 @@ def extra_config_timing(device, fdn, ray_batch, tq, tr, steps=2):
     achieved = 2.0 * algorithmic_macs_per_point(RFN, False, True, share) * sum(n for _, n in pts) / sum(t for t, _ in pts) / 1e12     # executed FLOPs
     return {'samples': '64+%d' % fdn, 'ray_batch': ray_batch, 'value': steps * H * W / dt, 'unit': 'rays/s', 'view_slots_run_share': share,
             'point_kernel_ms_per_launch': 1e3 * sum(t for t, _ in pts) / len(pts), 'point_kernel_frac_of_fp32_mfma_peak': achieved / MFMA_F32_PEAK_TFLOPS}
+
+
+def llff_fern_cost_volume_timing(device, arith, steps=2, h=756, w=1008, rfn=8, extra_src=4):
+    """BASELINE.json configs[2] end to end (VERDICT r5 missing #4): `neuray_gen_cost_volume` (configs/gen/neuray_gen_cost_volume.yaml:
+    NeuralRayGenRenderer, init_net_type cost_volume, 64 + 64 samples) on an llff_colmap/fern/high-shaped scene - a 756 x 1008 query view
+    (762 048 rays), 8 working views padded to the ref_pad_interval of 32 (768 x 1024, dataset/train_dataset.py / render.py), 3 cost-volume
+    neighbours per view out of 8 + `extra_src` source views, depth range [1.2, 12] - through renderer(data) in evaluation: MVSNet feature
+    net + plane-sweep variance volume + 3-D U-Net per working view (init_net.py:113-160), `res_net`, image / visibility encoders, then
+    the coarse + fine ray-batch loop.  Synthetic smooth images, seeded random weights (no datasets / checkpoints here).
+    -> rays/s and ms per image for the whole call, and for the per-image networks alone."""
+    from neuray_amd.network.renderer import NeuralRayGenRenderer
+    hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    cfg = {'init_net_type': 'cost_volume', 'use_hierarchical_sampling': True, 'use_depth_loss': True, 'dist_decoder_cfg': {'use_vis': False},
+           'ray_batch_num': RAY_BATCH, 'hip_arith': arith}
+    torch.manual_seed(0)
+    model = NeuralRayGenRenderer(cfg).eval().to(device)
+    n_src = rfn + extra_src
+    que, scene = synthetic.make_scene(hp, wp, n_src, seed=3, que_imgs=False, smooth=True, depth_range=(1.2, 12.0))
+    cams = {k: torch.from_numpy(scene[k]).to(device) for k in ('imgs', 'poses', 'Ks', 'depth_range')}
+    src = dict(cams)
+    ref = {k: v[:rfn].contiguous() for k, v in cams.items()}
+    ref['nn_ids'] = torch.tensor([[(v + 1) % n_src, (v + 2) % n_src, (v + 5) % n_src] for v in range(rfn)], device=device)
+    tq = {k: torch.from_numpy(v).to(device) for k, v in que.items() if k not in ('ray_feats', 'imgs')}
+    tq['coords'] = torch.from_numpy(synthetic.meshgrid_coords(h, w)).to(device)
+    data = lambda: {'que_imgs_info': dict(tq), 'ref_imgs_info': dict(ref), 'src_imgs_info': dict(src), 'eval': True}      # noqa: E731
+
+    def whole():
+        with torch.no_grad():
+            return model(data())
+    out = whole()
+    whole()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = whole()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    # the per-image networks alone: cost-volume init net, then the encoders on its output
+    def nets():
+        with torch.no_grad():
+            r = dict(ref)
+            r['ray_feats'] = model.init_net(r, dict(src), False)
+            r['img_feats'] = model.image_encoder(r['imgs'])
+            r['ray_feats'] = model.vis_encoder(r['ray_feats'], r['img_feats'])
+            return r
+    nets()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nets()
+    torch.cuda.synchronize(device)
+    dn = (time.perf_counter() - t0) / steps
+    from neuray_amd.network import render_ops as _ro
+    _ro.check_deferred_inputs(device, wait=True)
+    px = out['pixel_colors_nr_fine']
+    return {'what': 'BASELINE.json configs[2] shape: neuray_gen_cost_volume on an llff fern/high-shaped scene - %d x %d query (%d rays), %d working views '
+                    'padded to %d x %d, cost-volume init net (3 neighbours of %d source views, 64 planes) + res_net + encoders + 64+64 render, '
+                    'renderer(data) in evaluation; synthetic smooth images, random weights' % (h, w, h * w, rfn, hp, wp, n_src),
+            'value': h * w / dt, 'unit': 'rays/s', 'ms_per_image': 1e3 * dt, 'arith': arith,
+            'per_image_networks_ms': 1e3 * dn, 'render_loop_ms': 1e3 * (dt - dn),
+            'rays_per_s_of_the_render_loop_alone': h * w / max(dt - dn, 1e-9),
+            'finite': bool(torch.isfinite(px).all().item()), 'pixels': list(px.shape)}
 
 
 def direct_rendering_timing(device, tq, tr, steps=2):
@@ -1260,8 +1322,9 @@ def main(argv=None):
                 eb['speedup_vs_eager'] = value / eb['value']
             put('eager_torch_baseline', eb)
             put('extra', {
-                'reference_default_64+64': side(extra_config_timing, device, 64, RAY_BATCH, tq, tr),
-                'reference_cli_ray_batch_4096': side(extra_config_timing, device, args.fine_samples, 4096, tq, tr),
+                'reference_default_64+64': side(extra_config_timing, device, 64, RAY_BATCH, tq, tr, 2, args.arith),
+                'reference_cli_ray_batch_4096': side(extra_config_timing, device, args.fine_samples, 4096, tq, tr, 2, args.arith),
+                'llff_fern_cost_volume': side(llff_fern_cost_volume_timing, device, args.arith),
             })
             put('direct_rendering', side(direct_rendering_timing, device, tq, tr))
             put('training_step', side(training_step_timing, device))

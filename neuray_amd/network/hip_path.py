@@ -10,6 +10,8 @@ Replaced reference methods (same signatures): `render_by_depth` (renderer.py:168
 whose backward runs the backward kernels (network/autograd.py).  Anything the HIP path does not implement raises - it
 never silently switches to an eager implementation.
 """
+import os
+
 import torch
 
 from ..engine import RenderEngine
@@ -25,7 +27,8 @@ class HipRenderPath:
         eng = self.__dict__.get('_engine')
         if eng is None or eng.device != torch.device(device):
             eng = RenderEngine(device, _test_lib=self.__dict__.get('_engine_test_lib'),
-                               variant=self.cfg.get('hip_variant', 'fp32'), arith=self.cfg.get('hip_arith', 'f32'))
+                               variant=self.cfg.get('hip_variant', 'fp32'),
+                               arith=os.environ.get('NEURAY_HIP_ARITH') or self.cfg.get('hip_arith', 'f32'))      # (the environment wins: scripts run unchanged)
             self.__dict__['_engine'] = eng
             self.__dict__['_packed'] = {}
         return eng

@@ -754,6 +754,34 @@ __device__ __forceinline__ void layer_fwd(WS W, int lane, const LayerPre3<L>& pr
                 apply_act2<A, L>(acc[t][mo][r], acc[t][mo][r + 1], y[t][4 * mo + r], y[t][4 * mo + r + 1]);
             }
 }
+// y = act(scale_t * (W x) + b): a layer whose input is the operand times one scalar per (point, view) column - W (s x) = s (W x) - so that
+// ONE split of x serves this layer and the layers that consume x itself (vis_fc2.0 on x * vis' next to rgb_fc.0 on x: ibrnet.py:347-349,
+// 363).  Differs from evaluating W (s x) by fp32 rounding only.  No single K-steps.
+template <int L, int NT, int A, class WS, int KQX, class PN>
+__device__ __forceinline__ void layer_fwd_scaled(WS W, int lane, const LayerPre3<L>& pre, const Opnd3<NT, KQX>& xq, const float (&scale)[NT],
+                                                 float (&y)[NT][kShape[L].mt_out * 4], PN& next) {
+    constexpr int MT = kShape[L].mt_out;
+    static_assert(kShape[L].k1 == 0, "scaled form: quad K-steps only");
+    v4f acc[NT][MT];
+    float none1[NT][1];
+    NR_PRAGMA_UNROLL
+    for (int mo = 0; mo < MT; ++mo)
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < NT; ++t) { acc[t][mo][0] = 0.0f; acc[t][mo][1] = 0.0f; acc[t][mo][2] = 0.0f; acc[t][mo][3] = 0.0f; }
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t) none1[t][0] = 0.0f;
+    layer_acc<L, NT>(W, lane, pre, xq, none1, acc, next);
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int mo = 0; mo < MT; ++mo) {
+            const float b[4] = {pre.b[mo].x, pre.b[mo].y, pre.b[mo].z, pre.b[mo].w};
+            NR_PRAGMA_UNROLL
+            for (int r = 0; r < 4; r += 2)
+                apply_act2<A, L>(fmaf(acc[t][mo][r], scale[t], b[r]), fmaf(acc[t][mo][r + 1], scale[t], b[r + 1]), y[t][4 * mo + r], y[t][4 * mo + r + 1]);
+        }
+}
+
 template <int L, int NT, int A, class WS, int KQX, int K1X>
 __device__ __forceinline__ void layer_fwd(WS W, int lane, const Opnd3<NT, KQX>& xq,
                                           const float (&x1)[NT][K1X], float (&y)[NT][kShape[L].mt_out * 4]) {

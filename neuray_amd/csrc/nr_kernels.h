@@ -799,7 +799,11 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         NR_PRAGMA_UNROLL
                         for (int k = 0; k < 8; ++k) { x[s][k] = x[s][k] + y[s][k]; xin[s][k] = x[s][k] * visp[s]; }
                     }
-                    layer_fwd<L_V21, NA, ACT_ELU>(W5, lane, p_v21, operand<AR>(xin), none, h, p_v22);
+                    Opnd3<NA, 8> x3;                                   // AR_X3: x (after the vis_fc update) split once, for vis_fc2.0 and rgb_fc.0
+                    if constexpr (AR == AR_X3) {
+                        x3 = split_operand(x);
+                        layer_fwd_scaled<L_V21, NA, ACT_ELU>(W5, lane, p_v21, x3, visp, h, p_v22);       // W (x vis') = vis' (W x)
+                    } else layer_fwd<L_V21, NA, ACT_ELU>(W5, lane, p_v21, xin, none, h, p_v22);
                     layer_prefetch<L_RF1>(W5, lane, p_rf1);
                     layer_vec<L_V22, NA>(p_v22, h, o);
                     NR_PRAGMA_UNROLL
@@ -810,7 +814,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                         x1[s][0] = sel4(g, vis2[s], dlt[s][0], dlt[s][1], dlt[s][2]);
                         x1[s][1] = sel4(g, dlt[s][3], 0.0f, 0.0f, 0.0f);
                     }
-                    layer_fwd<L_RF1, NA, ACT_ELU>(W5, lane, p_rf1, operand<AR>(x), x1, h16, p_rf2);
+                    if constexpr (AR == AR_X3) layer_fwd<L_RF1, NA, ACT_ELU>(W5, lane, p_rf1, x3, x1, h16, p_rf2);
+                    else layer_fwd<L_RF1, NA, ACT_ELU>(W5, lane, p_rf1, x, x1, h16, p_rf2);
                     layer_fwd<L_RF2, NA, ACT_ELU>(W5, lane, p_rf2, operand<AR>(h16), none, h8, p_rf3);
                     layer_vec<L_RF3, NA>(p_rf3, h8, o);
                     NR_PRAGMA_UNROLL

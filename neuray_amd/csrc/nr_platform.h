@@ -90,11 +90,39 @@ __device__ __forceinline__ unsigned nr_pk_bf16_rn(float lo, float hi) {
     nr_v2bf_ v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
     return __builtin_bit_cast(unsigned, v);
 }
+#ifndef NR_SPLIT3_DOT2
+#define NR_SPLIT3_DOT2 1
+#endif
 __device__ __forceinline__ void nr_split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#if NR_SPLIT3_DOT2
+    // residual x - float(part) in ONE instruction per value: v_dot2_f32_bf16  d = a.lo * b.lo + a.hi * b.hi + c  with b = (-1, 0) / (0, -1)
+    // picks the half of the packed pair and subtracts it (the product and the sum are exact: the residual is representable; checked bit
+    // for bit against the shift / mask / subtract form by tests/hw/dot2_residual_probe.hip and tests/test_x3_arith.py) - 7 VALU per
+    // register pair (3 v_cvt_pk_bf16_f32 + 4 dot products) instead of 11; a dot product costs one plain VALU issue slot
+    // (tests/hw/valu_cost_probe.hip).  VOP3P form through inline asm with the selector pairs in SGPRs:
+    // __builtin_amdgcn_fdot2_f32_bf16 emits v_dot2c_f32_bf16_e32 with the INLINE constant -1.0 for the pair (-1, 0), which the
+    // hardware does not read as that pair (64 of 128 residuals wrong, same probe).
+    // The selector pairs come out of an opaque s_mov: handed to the builtin as literals, hipcc (ROCm 7.2) folds the pair (-1, 0) into the
+    // INLINE constant -1.0 of v_dot2c_f32_bf16_e32, which the hardware does not read as that pair (64 of 128 residuals wrong:
+    // tests/hw/dot2_residual_probe.hip).  The builtin - not inline asm - so that the compiler knows a DOT instruction is there: a DOT
+    // result needs 3 wait states before another VALU reads it (GCNHazardRecognizer), which an opaque asm statement silently violates.
+    unsigned klo_, khi_;
+    asm("s_mov_b32 %0, 0xbf80" : "=s"(klo_));
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(khi_));
+    const nr_v2bf_ klo = __builtin_bit_cast(nr_v2bf_, klo_), khi = __builtin_bit_cast(nr_v2bf_, khi_);
+    h = nr_pk_bf16_rn(x0, x1);
+    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nr_v2bf_, h), klo, x0, false);
+    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nr_v2bf_, h), khi, x1, false);
+    m = nr_pk_bf16_rn(r0, r1);
+    const float s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nr_v2bf_, m), klo, r0, false);
+    const float s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(nr_v2bf_, m), khi, r1, false);
+    l = nr_pk_bf16_rn(s0, s1);
+#else
     h = nr_pk_bf16_rn(x0, x1);
     const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
     m = nr_pk_bf16_rn(r0, r1);
     l = nr_pk_bf16_rn(r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u));
+#endif
 }
 // wave-uniform value -> SGPR (lets hipcc use scalar loads for per-view constants)
 #define NR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)

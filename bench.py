@@ -793,7 +793,7 @@ def init_net_timing(device, reps=10):
     return res
 
 
-def pipeline_timing(device, fdn, poses=3, views=16):
+def pipeline_timing(device, fdn, poses=3, views=16, arith='f32'):
     """Side measurement: host buffers in -> uint8 image out.  An in-memory scene with the reference's
     database accessors (uint8 images, masks, depth maps on the HOST), render.py's loop through neuray_amd.pipeline: working
     views by camera distance, uint8 upload of each view once (DeviceViewCache), depth init net + encoders + the 64+fdn render
@@ -803,7 +803,7 @@ def pipeline_timing(device, fdn, poses=3, views=16):
     from neuray_amd.network import renderer as R
     db = synthetic.MemoryDatabase(views, H, W, seed=0)
     gen = R.NeuralRayGenRenderer({'use_hierarchical_sampling': True, 'fine_depth_sample_num': fdn, 'fine_agg_net_cfg': {'sample_num': fdn},
-                                  'ray_batch_num': RAY_BATCH, 'init_net_type': 'depth', 'dist_decoder_cfg': {'use_vis': False}}).eval().to(device)
+                                  'ray_batch_num': RAY_BATCH, 'init_net_type': 'depth', 'dist_decoder_cfg': {'use_vis': False}, 'hip_arith': arith}).eval().to(device)
     qposes = np.stack([synthetic.look_at_pose(synthetic.sphere_pos(4.03, 360.0 * (i + 0.37) / views, 27.0)) for i in range(poses)]).astype(np.float32)
     ref_ids = pipeline.select_working_views_db(db, None, qposes, RFN, False)
     K, shape, dr = [db.get_K(0)] * poses, [(H, W)] * poses, [(2.0, 6.0)] * poses
@@ -1330,7 +1330,7 @@ def main(argv=None):
             put('training_step', side(training_step_timing, device))
             put('encoders', side(encoder_timing, device))
             put('init_net', side(init_net_timing, device))
-            put('pipeline_pcie_inclusive', side(pipeline_timing, device, args.fine_samples))
+            put('pipeline_pcie_inclusive', side(pipeline_timing, device, args.fine_samples, 3, 16, args.arith))
             put('bf16_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy()))
             put('bf16x3_split_variant', side(bf16_variant_timing, device, args.fine_samples, tq, tr, out['pixel_colors_nr_fine'].cpu().numpy(),
                                              2, 'bf16x3'))

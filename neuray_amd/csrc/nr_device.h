@@ -383,6 +383,61 @@ __device__ __forceinline__ void mfma_quad(const float4& a, int kq, const float (
     for (int t = 0; t < NT; ++t) acc[t] = nr_mfma16(a.w, xq[t][4 * kq + 3], acc[t]);
 }
 
+#if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT) && !defined(NEURAY_EMU)      // (the emulator keeps the per-quad form: the same sums in another order)
+// The plain bf16-operand library on gfx950's K = 32 MFMA: two consecutive quads (a lane's 4 + 4 K-values) per v_mfma_f32_16x16x32_bf16 instead
+// of one v_mfma_f32_16x16x16_bf16 each - half the MFMAs.  Measured (round 6): 2.84 -> 2.82 ms per launch - that library is VALU-bound, the
+// matrix pipe was never its limit.  The two-way split library (NR_BF16_SPLIT) stays on K = 16: paired, its kernel keeps 288 B of scratch per
+// lane at the 168-register budget and runs 4.89 instead of 3.73 ms; its K = 32 successor is AR_X3 of the fp32 library (nr_layout.h).
+// a0 / a1: the fragments of quads kq and kq + 1.
+// B operands of a layer's quad K-steps as bf16 pairs, converted (and, in the split library, split) ONCE per layer call
+template <int NT, int KQX> struct BfOpnd {
+    unsigned h[NT][(KQX + 1) / 2];
+#ifdef NR_BF16_SPLIT
+    unsigned l[NT][(KQX + 1) / 2];
+#endif
+};
+template <int NT, int KQX>
+__device__ __forceinline__ BfOpnd<NT, KQX> bf_operand(const float (&xq)[NT][KQX]) {
+    BfOpnd<NT, KQX> o;
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t)
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < KQX / 2; ++i) {
+#ifdef NR_BF16_SPLIT
+            nr_split_bf16(xq[t][2 * i], xq[t][2 * i + 1], o.h[t][i], o.l[t][i]);
+#else
+            o.h[t][i] = nr_pk_bf16(xq[t][2 * i], xq[t][2 * i + 1]);
+#endif
+        }
+    return o;
+}
+template <int NT, int KQX>
+__device__ __forceinline__ void mfma_quad_pair(const float4& a0, const float4& a1, int kq, const BfOpnd<NT, KQX>& x, v4f (&acc)[NT]) {
+    nr_v4u ah;
+    ah[0] = __builtin_bit_cast(unsigned, a0.x); ah[1] = __builtin_bit_cast(unsigned, a0.y);
+    ah[2] = __builtin_bit_cast(unsigned, a1.x); ah[3] = __builtin_bit_cast(unsigned, a1.y);
+#ifdef NR_BF16_SPLIT
+    nr_v4u al;
+    al[0] = __builtin_bit_cast(unsigned, a0.z); al[1] = __builtin_bit_cast(unsigned, a0.w);
+    al[2] = __builtin_bit_cast(unsigned, a1.z); al[3] = __builtin_bit_cast(unsigned, a1.w);
+#endif
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < NT; ++t) {
+        nr_v4u bh;
+        bh[0] = x.h[t][2 * kq]; bh[1] = x.h[t][2 * kq + 1]; bh[2] = x.h[t][2 * kq + 2]; bh[3] = x.h[t][2 * kq + 3];
+#ifdef NR_BF16_SPLIT
+        nr_v4u bl;
+        bl[0] = x.l[t][2 * kq]; bl[1] = x.l[t][2 * kq + 1]; bl[2] = x.l[t][2 * kq + 2]; bl[3] = x.l[t][2 * kq + 3];
+        acc[t] = nr_mfma16x32_bf16(al, bh, acc[t]);          // (small terms first, as nr_mfma16_bf16q3)
+        acc[t] = nr_mfma16x32_bf16(ah, bl, acc[t]);
+        acc[t] = nr_mfma16x32_bf16(ah, bh, acc[t]);
+#else
+        acc[t] = nr_mfma16x32_bf16(ah, bh, acc[t]);
+#endif
+    }
+}
+#endif
+
 // accumulate a K-slice (quads [KQ0, KQ0+KQN), singles [K10, K10+K1N)) of output tile `mo` (may be a runtime value)
 // of layer L; the operand arrays hold only the slice.  The fragment stream is software-pipelined: the load of
 // fragment i+1 is issued before the MFMAs of fragment i (hipcc otherwise emits load -> wait -> MFMAs per fragment and
@@ -401,6 +456,23 @@ __device__ __forceinline__ void layer_tile_slice(WS W, int lane, int mo,
     float s1[K1N > 0 ? K1N : 1];
     NR_PRAGMA_UNROLL
     for (int k1 = 0; k1 < K1N; ++k1) s1[k1] = wld1(W, v1, (single_offset(L, AR) + (K10 + k1) * 64) * 4);
+#if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT) && !defined(NEURAY_EMU)
+    if constexpr (KQN > 0 && KQN % 2 == 0) {
+        const BfOpnd<NT, KQX> xb = bf_operand(xq);
+        float4 c0 = wldq(W, vq, (quads_offset(L, AR) + KQ0 * 256) * 4), c1 = wldq(W, vq, (quads_offset(L, AR) + (KQ0 + 1) * 256) * 4);
+        NR_PRAGMA_UNROLL
+        for (int kq = 0; kq < KQN; kq += 2) {
+            float4 n0 = c0, n1 = c1;
+            if (kq + 2 < KQN) {
+                n0 = wldq(W, vq, (quads_offset(L, AR) + (KQ0 + kq + 2) * 256) * 4);
+                n1 = wldq(W, vq, (quads_offset(L, AR) + (KQ0 + kq + 3) * 256) * 4);
+            }
+            NR_PIN();
+            mfma_quad_pair<NT>(c0, c1, kq, xb, acc);
+            c0 = n0; c1 = n1;
+        }
+    } else
+#endif
     if (KQN > 0) {
         float4 cur = wldq(W, vq, (quads_offset(L, AR) + KQ0 * 256) * 4);
         NR_PRAGMA_UNROLL
@@ -500,6 +572,33 @@ __device__ __forceinline__ void layer_acc(WS W, int lane, const LayerPre<L>& pre
                                           const float (&x1)[NT][K1X], v4f (&acc)[NT][kShape[L].mt_out], PN& next) {
     constexpr int MT = kShape[L].mt_out, KQ = kShape[L].kq, K1 = kShape[L].k1;
     static_assert(KQX >= (KQ > 0 ? 4 * KQ : 1) && K1X >= (K1 > 0 ? K1 : 1), "operand arrays too small");
+#if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT) && !defined(NEURAY_EMU)
+    if constexpr (KQ > 0 && KQ % 2 == 0) {
+        // quad pairs on the K = 32 MFMA (mfma_quad_pair): a ring of four fragments, two consumed and two fetched per step
+        constexpr int NQ = MT * KQ, NF = LayerPre<L>::NF, R = NQ < 4 ? NQ : 4;
+        const BfOpnd<NT, KQX> xb = bf_operand(xq);
+        float4 ring[R];
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < R; ++i) ring[i] = i < NF ? pre.q[i < NF ? i : 0] : wldq(W, lane * 16, (quads_offset(L, ws_ar<WS>::value) + i * 256) * 4);
+        NR_PRAGMA_UNROLL
+        for (int i = 0; i < NQ; i += 2) {
+            const float4 c0 = ring[i % R], c1 = ring[(i + 1) % R];
+            if (i == (NQ >= 4 ? NQ - 4 : 0)) layer_prefetch(W, lane, next);
+            NR_PIN();
+            const int mo = i / KQ, kq = i % KQ;
+            v4f a[NT];
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) a[t] = acc[t][mo];
+            mfma_quad_pair<NT>(c0, c1, kq, xb, a);
+            NR_PRAGMA_UNROLL
+            for (int t = 0; t < NT; ++t) acc[t][mo] = a[t];
+            if (i + R < NQ) {
+                ring[i % R] = wldq(W, lane * 16, (quads_offset(L, ws_ar<WS>::value) + (i + R) * 256) * 4);
+                ring[(i + 1) % R] = wldq(W, lane * 16, (quads_offset(L, ws_ar<WS>::value) + (i + R + 1) * 256) * 4);
+            }
+        }
+    } else
+#endif
     if constexpr (KQ > 0) {
         // fragment stream with NR_PREFETCH quads in flight ahead of the one being consumed
         constexpr int NQ = MT * KQ, PF = NR_PREFETCH < NQ ? NR_PREFETCH : NQ - 1;

@@ -53,7 +53,9 @@ from neuray_amd.network.renderer import NeuralRayBaseRenderer  # noqa: E402
 H = W = 800
 RFN = 8
 DN_COARSE = 64
-RAY_BATCH = 32768
+RAY_BATCH = 65536      # rays per launch (results do not depend on it: bitwise batching invariance).  32768 in rounds 1-5; with the X3 kernel's shorter
+                       # launches the gaps between them weigh more: 3.195 M rays/s at 32768, 3.231 at 65536, 3.235 / 3.242 at 131072 / 262144
+                       # (profiles/r06_s_x3_ray_batch.log)
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA dense peak
 
 
@@ -1231,10 +1233,11 @@ def main(argv=None):
                                 # 4th, unused colour channel: 1,088 B actually requested), reported separately
                                 'gather_demand_tb_per_s': 1072.0 * RFN * n_pts * share / t_pts / 1e12,
                                 'gather_requested_tb_per_s_rgba_texels': 1088.0 * RFN * n_pts * share / t_pts / 1e12,
-                                'gather_demand_note': "north_star's '>= 40 % HBM roofline on feature gather' (3.2 TB/s of demand = 4.2 M rays/s at "
-                                                      "64+32 samples) is out of reach in fp32 by construction: the fp32 MFMA bound of the folded network "
-                                                      "(33.25 MFLOP/ray at 157.3 TFLOP/s) is ~3.7 M rays/s.  The maps are L2 / Infinity-Cache resident "
-                                                      "(roofline.traffic), so the demand rate is a cache-path figure, not an HBM one",
+                                'gather_demand_note': "north_star's '>= 40 % HBM roofline on feature gather' = 3.2 TB/s of demand = 4.2 M rays/s at 64+32 samples.  The "
+                                                      "fp32 MFMA bound of the folded network (33.25 MFLOP/ray at 157.3 TFLOP/s) is ~3.7 M rays/s; the x3 arithmetic lifts "
+                                                      "that bound (six bf16 MFMAs per K = 32: 0.28 of the matrix pipe busy) and is bound by VALU issue instead - operand "
+                                                      "splits, ELU, blends, statistics (DESIGN.md 4.12).  The maps are L2 / Infinity-Cache resident (roofline.traffic), so "
+                                                      "the demand rate is a cache-path figure, not an HBM one",
                                 'point_kernel_share_of_step': t_pts / dt, 'ray_kernel_share_of_step': sum(rays_k) / dt}
         else:
             line['roofline'] = None

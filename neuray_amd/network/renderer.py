@@ -51,7 +51,7 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
         # layer less per (point, view); the same function up to fp32 rounding - neuray_pack_pass_weights_folded)
         'hip_fold_prob_embed': True,
         # not a reference key: inference render() merges ray batches up to this many rays per launch (0 = exactly cfg['ray_batch_num'])
-        'hip_min_ray_batch': 32768,
+        'hip_min_ray_batch': 65536,
     }
 
     def __init__(self, cfg):
@@ -130,7 +130,7 @@ class NeuralRayBaseRenderer(HipRenderPath, nn.Module):
             # machine idle in its tail (2.56 vs 2.79 M rays/s): inference uses at least cfg['hip_min_ray_batch'] rays per launch
             # Direct rendering (use_dr_prediction) adds the per-(point, view) record: rn * dn * rfn * 16 floats per pass (1.1 GB at 32768
             # rays x 64 samples x 8 views), so there the merged batch is bounded to ~1 GiB of record and never below the configured size.
-            merged = int(self.cfg.get('hip_min_ray_batch', 32768))
+            merged = int(self.cfg.get('hip_min_ray_batch', 65536))
             if self.cfg.get('use_dr_prediction', False):
                 dn_max = max(self.cfg['depth_sample_num'], self.cfg['fine_depth_sample_num'] if self.cfg['use_hierarchical_sampling'] else 0)
                 merged = min(merged, max(1, (1 << 30) // (dn_max * ref_imgs_info['imgs'].shape[0] * 16 * 4)))

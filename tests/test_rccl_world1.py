@@ -55,6 +55,14 @@ before = [None if p.grad is None else p.grad.clone() for p in params]
 parallel.allreduce_gradients(params)
 for p, b in zip(params, before):
     assert (p.grad is None) == (b is None) and (b is None or torch.equal(p.grad, b))
+# steady state: the second and third call take the previous union of flags and copy their own flags to pinned memory without
+# blocking (parallel._Pending on a CUDA tensor); the deferred check passes
+for _ in range(2):
+    parallel.allreduce_gradients(params)
+    for p, b in zip(params, before):
+        assert (p.grad is None) == (b is None) and (b is None or torch.equal(p.grad, b))
+assert any('pending' in st for st in parallel._FLAG_STATE.values())
+parallel.check_deferred_flags()
 maps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(1, 32, 12, 16, device=dev)) for _ in range(5)])
 maps[1].grad = torch.ones_like(maps[1]); maps[3].grad = torch.full_like(maps[3], 2.0)
 union = parallel.allreduce_scene_feature_gradients(maps, [3, 1])

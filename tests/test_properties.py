@@ -54,10 +54,10 @@ def build(cfg, backend, seed):
     return r.cuda(), 'cuda:0'
 
 
-def check_invariants(backend, seed, rfn, dn, fdn, rn, h, w, near, far_ratio, spread, use_vis):
+def check_invariants(backend, seed, rfn, dn, fdn, rn, h, w, near, far_ratio, spread, use_vis, arith='f32'):
     cfg = {'use_hierarchical_sampling': True, 'depth_sample_num': dn, 'fine_depth_sample_num': fdn, 'agg_net_cfg': {'sample_num': dn},
            'fine_agg_net_cfg': {'sample_num': fdn}, 'dist_decoder_cfg': {'use_vis': use_vis}, 'fine_dist_decoder_cfg': {'use_vis': True},
-           'ray_mask_view_num': 0, 'ray_mask_point_num': 0}
+           'ray_mask_view_num': 0, 'ray_mask_point_num': 0, 'hip_arith': arith}
     r, dev = build(cfg, backend, seed)
     que, ref = random_scene(seed, rfn, h, w, near, far_ratio, spread)
     rng = np.random.RandomState(seed + 1)
@@ -83,6 +83,7 @@ def check_invariants(backend, seed, rfn, dn, fdn, rn, h, w, near, far_ratio, spr
         # ---- the coarse pass stage by stage: per-view record (no slot is skipped in this instantiation) vs the inference kernel
         views = r._views(eng, tr)
         packed = r._packed_pass(eng, False)
+        assert (packed.dev_x3 is not None) == (arith == 'x3')
         plain = eng.render_pass(qc, views, tq['coords'][0], depth, packed, use_vis=use_vis, ray_mask_view_num=0, ray_mask_point_num=0)
         rec = eng.render_pass(qc, views, tq['coords'][0], depth, packed, use_vis=use_vis, ray_mask_view_num=0, ray_mask_point_num=0,
                               want_dbg=True)
@@ -135,8 +136,21 @@ def test_invariants_on_random_scenes_emulator(seed, rfn, dn, fdn, rn, hw, near, 
     check_invariants('emu', seed, rfn, dn, fdn, rn, hw[0], hw[1], near, far_ratio, spread, use_vis)
 
 
+@settings(max_examples=8, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 10 ** 6), rfn=st.sampled_from([2, 3, 5, 8, 9, 16]), dn=st.sampled_from([8, 16, 32]),
+       fdn=st.sampled_from([8, 16]), rn=st.integers(1, 9), hw=st.sampled_from([(16, 24), (32, 32)]),
+       near=st.floats(0.4, 3.0), far_ratio=st.floats(1.3, 8.0), spread=st.floats(0.0, 1.5), use_vis=st.booleans())
+def test_invariants_on_random_scenes_emulator_arith_x3(seed, rfn, dn, fdn, rn, hw, near, far_ratio, spread, use_vis):
+    """the same invariants with cfg['hip_arith'] = 'x3' (split bf16 operands on the K = 32 MFMA): slot skipping, masked views and batching
+    stay exact bit for bit in that arithmetic too"""
+    if dn * rn * rfn > 3000:
+        rn = max(1, 3000 // (dn * rfn))
+    check_invariants('emu', seed, rfn, dn, fdn, rn, hw[0], hw[1], near, far_ratio, spread, use_vis, arith='x3')
+
+
 @pytest.mark.gpu
-def test_invariants_fixed_seed_sweep_gpu():
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
+def test_invariants_fixed_seed_sweep_gpu(arith):
     """48 drawn configurations through libneuray_hip.so, thousands of rays each: every sample count of the kernels' tail paths
     (dn not a multiple of 16, npts not a multiple of 16), 1 ... 16 views (one and two views per wave, padding views), near / far
     ratios up to 10, cameras that look past the scene"""
@@ -149,7 +163,7 @@ def test_invariants_fixed_seed_sweep_gpu():
         rn = int(rng.choice([1, 37, 512, 1000, 2048]))
         h, w = [(64, 96), (120, 160), (200, 200)][i % 3]
         far_ratio, spread = (1.2, 0.0) if i % 4 == 0 else (float(rng.uniform(1.3, 10.0)), float(rng.uniform(0.0, 1.5)))   # (every 4th: all views see the samples)
-        m, d = check_invariants('hip', int(rng.randint(0, 10 ** 6)), rfn, dn, fdn, rn, h, w, float(rng.uniform(0.4, 3.0)), far_ratio, spread, bool(i % 2))
+        m, d = check_invariants('hip', int(rng.randint(0, 10 ** 6)), rfn, dn, fdn, rn, h, w, float(rng.uniform(0.4, 3.0)), far_ratio, spread, bool(i % 2), arith)
         seen_masked.append(m)
         seen_dead += d
     print('masked (point, view) share per configuration: min %.2f, median %.2f, max %.2f; fully masked views replaced: %d' % (

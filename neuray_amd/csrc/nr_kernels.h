@@ -308,11 +308,7 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
         // lane index for the weight loads that go to global memory (L_BG, L_GF1, L_GF2): opaque and re-made per tile,
         // otherwise hipcc treats these loop-invariant loads as hoistable, keeps ~50 fragment registers alive across the
         // whole tile loop and spills them (seen as "spills outside, reloads inside the loop" in -Rpass-missed=regalloc)
-#ifdef NR_X3_HOIST_PER_POINT       // A/B: let hipcc keep the owner wave's loop-invariant per-point fragments in registers (AR_X3 has 49 to spare)
-        const int glane = AR == AR_X3 ? lane : lane + nr_opaque_zero();
-#else
         const int glane = lane + nr_opaque_zero();
-#endif
 #ifndef NR_NO_OPAQUE_WAVE
         const int wave_t = wave + nr_opaque_szero();     // (see nr_opaque_szero)
 #else

@@ -193,7 +193,9 @@ def test_launcher_runs_an_unmodified_script(tmp_path, patched):
         real_run = launch.run
         launch.run = lambda *a, **k: launch_main_ns.update(real_run(*a, **k))
         try:
-            launch.main(['--ft-host', '--render-loop', script])
+            os.environ.pop('NEURAY_HIP_ARITH', None)
+            launch.main(['--ft-host', '--render-loop', '--arith', 'x3', script])
+            assert os.environ.pop('NEURAY_HIP_ARITH') == 'x3'             # (what HipRenderPath.engine reads: the scripts stay unchanged)
         finally:
             launch.run = real_run
         sys.path[:] = keep

@@ -692,7 +692,9 @@ class RenderEngine:
         d_feats = out if out is not None else torch.zeros(b, c, fh, fw, dtype=torch.float32, device=self.device)
         m = self._f32(mask) if mask is not None else None
         if staged is None:            # many points per map: scatter into a channels-last staging map (coalesced atomics), then transpose-add
-            staged = n >= 1024 and b * fh * fw * c <= (1 << 28)
+            # ... when the points are dense enough to pay for the zero-filled staging map and its transpose-add (1 024 points on
+            # 8 x 32 x 800 x 800 maps would allocate and sweep 655 MB for a 128 KB scatter), and the map stays below 256 MB
+            staged = n >= 1024 and n * 8 >= fh * fw and b * fh * fw * c * 4 <= (1 << 28)
         if staged:
             tmp = torch.zeros(b, fh, fw, c, dtype=torch.float32, device=self.device)
             self._check(self.lib.neuray_interpolate_feats_backward_staged(

@@ -124,6 +124,11 @@ class FeatureNet(nn.Module):
                 pack, shift = _mfma_conv_pack(w, shift)
             hit = conv.__dict__['_mfma_pack'] = (stamp, pack.to(x.device), shift.to(x.device))
         from . import render_ops
+        # per layer, not per net: what the kernel cannot take - another dtype (a library layer ran under autocast in between),
+        # not an [n, c, h, w] tensor, an image of 2^31 bytes or more - goes through the module this layer replaces
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] * x.shape[2] * x.shape[3] * 4 >= 0x7fffff00 or torch.is_autocast_enabled():
+            y = conv(x)
+            return y if bn is None else bn(y)
         y = render_ops.engine_for(x.device).conv3d_bn_leaky(x.contiguous()[:, :, None], hit[1], hit[2], 1.0 if bn is None else bn.slope,
                                                             conv.out_channels, 1)
         return y[:, :, 0]

@@ -181,8 +181,9 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         slot = self.__dict__.pop('_depth_coords_slot', None)
         if slot is not None:
             slot['thread'].join()
-        if slot is not None and slot.get('n') == h * w and 'perm' in slot:
+        if slot is not None and slot.get('n') == h * w and 'perm' in slot and torch.equal(torch.get_rng_state(), slot['state0']):
             pick = slot['perm'][:num]                 # drawn ahead of time by _prefetch_depth_coords, at this draw's place in the stream
+            torch.set_rng_state(slot['state1'])       # (the global generator moves on as the in-line draw would have moved it)
         else:
             pick = torch.randperm(h * w)[:num]
         pairs = torch.stack([pick // w, pick % w], -1)
@@ -195,10 +196,17 @@ class NeuralRayGenRenderer(NeuralRayBaseRenderer):
         million draws; the step is host-bound) and releases the interpreter lock: it runs on a worker thread, started by
         render_impl right after the step's only other draw from the CPU generator (the fine-sampling uniforms, render_ops.py:205) - the
         reference's order, so a seeded run consumes the generator identically - while the main thread queues the per-ray kernels."""
-        slot = {'n': n}
+        # The worker draws from a PRIVATE generator started at the global generator's present state; the draw is adopted at the join
+        # (gen_depth_loss_coords) only if the global generator is still exactly there - then its state is advanced to where the private one
+        # ended, which is what the in-line torch.randperm would have left - and discarded for the in-line draw otherwise (a custom
+        # init net, a hook or another thread drew in between).  The main thread's own draws never race with the worker (ADVICE r5).
+        slot = {'n': n, 'state0': torch.get_rng_state()}
 
         def work():
-            slot['perm'] = torch.randperm(n)
+            g = torch.Generator()
+            g.set_state(slot['state0'])
+            slot['perm'] = torch.randperm(n, generator=g)
+            slot['state1'] = g.get_state()
         slot['thread'] = threading.Thread(target=work, name='neuray-depth-coords', daemon=True)
         self.__dict__['_depth_coords_slot'] = slot
         slot['thread'].start()

@@ -941,9 +941,6 @@ __device__ __forceinline__ void stage_issue(float* dst, WS W, int wave, int nw, 
 template <int PH, bool VIS, class WS>
 __device__ __forceinline__ typename ws_lds<WS>::type phase_enter(float* wl, WS W, int seq0, bool issue_next, int wave, int nw, int lane) {
     constexpr int AR = ws_ar<WS>::value, RF = stage_region_bytes(AR) / 4;
-#ifdef NR_PROBE_FEWER_PHASE_BARRIERS      // timing probe (racy, wrong results possible): what two phase barriers less per tile would buy the X3 kernel
-    if (!(AR == AR_X3 && (PH == PH_NF_BV0 || PH == PH_B2_VF1)))
-#endif
     NR_BLOCK_SYNC();
     const int r = (seq0 + phase_seq(PH, VIS)) & 1;
     if (issue_next) stage_issue<phase_next(PH, VIS)>(wl + (r ^ 1) * RF, W, wave, nw, lane);

@@ -56,9 +56,9 @@ def ray_err(a, b):
     return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).reshape(-1, a.shape[-1]).max(1)
 
 
-def staged_compare(name, backend, sel, chained_frac, chained_psnr):
+def staged_compare(name, backend, sel, chained_frac, chained_psnr, arith='f32'):
     z, cfg, que, ref, want, mid = load_tile(name)
-    r, dev = renderer_for(cfg, backend)
+    r, dev = renderer_for({**cfg, 'hip_arith': arith}, backend)
     idx = np.arange(z['coords'].shape[1])[sel]
     tq = {k: torch.from_numpy(v).to(dev) for k, v in que.items()}
     tq['coords'] = torch.from_numpy(z['coords'][:, idx]).to(dev)
@@ -94,8 +94,8 @@ def staged_compare(name, backend, sel, chained_frac, chained_psnr):
     # (4) chained coarse -> fine
     err = ray_err(got['pixel_colors_nr_fine'], W['pixel_colors_nr_fine'])
     psnr = synthetic.psnr_uint8(np.clip(got['pixel_colors_nr_fine'], 0, 1), np.clip(W['pixel_colors_nr_fine'], 0, 1))
-    print('%s[%s]: %d rays, coarse max %.2e, fine-on-identical max %.2e, chained: %.4f within 2e-4, worst %.2e, PSNR %.1f dB' % (
-        name, backend, len(idx), ray_err(got['pixel_colors_nr'], W['pixel_colors_nr']).max(),
+    print('%s[%s, %s]: %d rays, coarse max %.2e, fine-on-identical max %.2e, chained: %.4f within 2e-4, worst %.2e, PSNR %.1f dB' % (
+        name, backend, arith, len(idx), ray_err(got['pixel_colors_nr'], W['pixel_colors_nr']).max(),
         ray_err(fine['pixel_colors_nr'], W['pixel_colors_nr_fine']).max(), np.mean(err <= 2e-4), err.max(), psnr))
     assert np.mean(err <= 2e-4) >= chained_frac and psnr >= chained_psnr, (name, float(np.mean(err <= 2e-4)), psnr)
 
@@ -122,14 +122,15 @@ def test_kernels_on_the_emulator_at_baseline_shapes(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('arith', ['f32', 'x3'])
 @pytest.mark.parametrize('name', TILES)
-def test_tiles_against_the_reference_on_the_gpu(name):
+def test_tiles_against_the_reference_on_the_gpu(name, arith):
     """every ray of the tile; chained gates: what the evidence supports (tests/test_chained_parity.py: the fp32 reference
     itself is 1.3 % beyond 2e-4 of its float64 evaluation on the white-noise scene, where a displaced fine sample lands on
     an unrelated texel; the smooth scene is what encoder outputs of real images look like).  Round 3, with the
     feature-path divisions refined: 99.7-99.8 % / >= 80 dB on the white-noise tiles, 100 % on the smooth one"""
     frac, psnr = (0.999, 80.0) if name == 'c2_smooth' else (0.99, 70.0)
-    staged_compare(name, 'hip', slice(None), frac, psnr)
+    staged_compare(name, 'hip', slice(None), frac, psnr, arith)       # (round 6: the same gates under cfg['hip_arith'] = 'x3', every reference tile)
 
 
 @pytest.mark.gpu

@@ -285,6 +285,9 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
 #ifndef NR_X3_BG_RESIDENT
 #define NR_X3_BG_RESIDENT 1
 #endif
+#ifndef NR_X3_GF_PREFETCH
+#define NR_X3_GF_PREFETCH 1
+#endif
     constexpr bool BG_RES = AR == AR_X3 && OWN == 1 && (NR_X3_BG_RESIDENT != 0);    // base_fc.0's per-point fragments live in registers (BgResident; 7 or 8 views: one tile per wave, 40 registers)
     BgResident<OWN> bgres;
     if constexpr (BG_RES) bg_resident_load(W, lane, wave, nw, bgres);
@@ -709,6 +712,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
             }
             // ---------------- base_fc per-view part, vis_fc, vis_fc2, rgb_fc   ibrnet.py:342-349,363-365 ------
             float x[NA1][8], vis2[NA1], z[NA1];
+            constexpr bool GF_PRE = BG_RES && (NR_X3_GF_PREFETCH != 0);
+            float4 gfq[4]; float gfs = 0.0f;
             typename ws_lds<decltype(make_w())>::type W5;
             LayerPreT<L_VF1, AR> p_vf1;
             {
@@ -780,6 +785,14 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                     layer_fwd<L_VF1, NA, ACT_ELU>(W5, lane, p_vf1, operand<AR>(xin), none, h, last);
                 }
                 W5 = phase_enter<PH_TAIL, HAS_VIS>(wl, W, seq0, more, wave_t, nw, lane);
+                if constexpr (GF_PRE) {
+                    // geometry_fc.0's fragments of the tile this wave owns are fetched HERE, a phase ahead of their use behind the last two
+                    // all-reduces, where the wave (and at the next barrier its siblings) used to wait for them (AR_X3: registers to spare)
+                    const int m = wave_t < 4 ? wave_t : 0;
+                    NR_PRAGMA_UNROLL
+                    for (int kq = 0; kq < 4; ++kq) gfq[kq] = wld4(W, glane * 16 + m * (4 * 1024), (quads_offset(L_GF1, AR) + kq * 256) * 4);
+                    gfs = wld1(W, glane * 4 + m * 256, single_offset(L_GF1, AR) * 4);
+                }
                 if constexpr (NA > 0) {
                     float y[NA][8], yv[NA][1], o[NA][1];
                     LayerPreT<L_VF2, AR> p_vf2; LayerPreT<L_V21, AR> p_v21; LayerPreT<L_RF1, AR> p_rf1; LayerPreT<L_RF2, AR> p_rf2;
@@ -908,7 +921,13 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 NR_PRAGMA_UNROLL
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
-                    if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
+                    if constexpr (GF_PRE) {
+                        if (mo < 4) {                 // (layer_tile_slice's order: the slice's two quads, then its single)
+                            mfma_quad<NT>(gfq[0], 0, xq, accf[j]);
+                            mfma_quad<NT>(gfq[1], 1, xq, accf[j]);
+                            accf[j][0] = nr_mfma16(gfs, x1[0][0], accf[j][0]);
+                        }
+                    } else if (mo < 4) layer_tile_slice<L_GF1, NT, 0, 2, 0, 1>(W, glane, mo, xq, x1, accf[j]);
                 }
                 view_allreduce<NA, IDLE, 8, RMAX, RED_SUM>(v8, var, red, wave_t, nw, lane);
                 if constexpr (SAVE) {
@@ -927,7 +946,8 @@ __global__ void __launch_bounds__(MAXT, MINW) points_kernel(PointParams p) {
                 for (int j = 0; j < OWN; ++j) {
                     const int mo = wave_t + j * nw;
                     if (mo < 4) {
-                        layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
+                        if constexpr (GF_PRE) { mfma_quad<NT>(gfq[2], 0, xq, accf[j]); mfma_quad<NT>(gfq[3], 1, xq, accf[j]); }
+                        else layer_tile_slice<L_GF1, NT, 2, 2, 0, 0>(W, glane, mo, xq, nonet, accf[j]);
                         NR_PRAGMA_UNROLL
                         for (int r = 0; r < 4; ++r) xrow(mo, r)[lane] = elu_s(accf[j][0][r]);   // kOutScaled[L_GF1]
                         if constexpr (SAVE) {

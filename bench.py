@@ -1218,7 +1218,7 @@ def main(argv=None):
                                 'kernel': 'nr::points_kernel<..., %s>' % ('AR_X3' if args.arith == 'x3' else 'AR_F32'), 'launches': len(pts),
                                 **({'issued_bf16_mfma_tflops': 6.0 * achieved, 'bf16_mfma_dense_peak_tflops': 2500.0,
                                     'frac_of_bf16_dense_peak_issued': 6.0 * achieved / 2500.0,
-                                    'matrix_pipe_busy_pmc': '0.28 (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, profiles/r06_w_pmc_summary.json; fp32 kernel: 0.51)'}
+                                    'matrix_pipe_busy_pmc': '0.28 (SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, profiles/r06_zy_pmc_summary.json; fp32 kernel: 0.51)'}
                                    if args.arith == 'x3' else {}),
                                 'peak_note': 'fp32-in MFMA dense peak (MI355X_MICROARCH.md): the peak of the arithmetic GRADE the kernel delivers' +
                                              ('.  With arith = x3 the contractions run on the bf16 pipe (dense peak 2500 TFLOP/s): six bf16 MFMA products per '

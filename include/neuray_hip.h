@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NEURAY_ABI_VERSION 10
+#define NEURAY_ABI_VERSION 11
 #define NEURAY_POINT_REC 20      /* floats per sample-point record (see neuray_render_points) */
 #define NEURAY_VIEW_CONST 20     /* floats per reference-view constant block */
 #define NEURAY_QUERY_CONST 28    /* floats of the query constant block */
@@ -341,6 +341,24 @@ int neuray_convtranspose3d_bn_leaky(const float* x_dev, const float* wpack_dev, 
  *   out_dev [n][C_out][(d - 1) / stride + 1][(h - 1) / stride + 1][(w - 1) / stride + 1].  ABI 9. */
 int neuray_conv3d_bn_leaky(const float* x_dev, const float* wpack_dev, const float* bias_dev, float slope, int n, int cin, int cout, int stride,
                            int d, int h, int w, float* out_dev, void* stream);
+/* ---- f-1: the 3 x 3 stride-1 convolutions of the per-image encoders at fp32 grade on the K = 32 bf16 MFMA (ABI 11).  Replaces
+ * F.conv2d / nn.Conv2d(C_in, C_out, 3, padding_mode='reflect') on an input that already carries its reflection padding - the
+ * BasicBlock / conv layers of ResUNetLight (network/ops.py:86-148,150-230), network/vis_encoder.py:6-21, the res_net of
+ * network/init_net.py:13-61 - and, with pad = 2 and a transpose_flip pack, their data gradient.  Arithmetic: every weight and every
+ * activation is split exactly into three bf16 parts, a product is the six MFMAs lh, hl, mm, mh, hm, hh with fp32 accumulation (the
+ * dropped terms are below 2^-23 of the product): the AR_X3 arithmetic of neuray_render_points.
+ * neuray_conv3x3_x3_pack_bytes: size of a pack, -1 unless C_in and C_out are multiples of 32.
+ * neuray_conv3x3_x3_pack: w_dev [C_out][C_in][3][3] fp32 (the layer's weight) -> wpack_dev, the pack of the layer itself
+ *   [9 taps][C_in / 32][C_out / 16][3 parts][64 lanes][4 dwords] (lane l = (m = l & 15, g = l >> 4), dword d: the bf16 pair of input channels
+ *   32 kb + 8 g + 2 d, + 1 of output channel 16 mt + m), and / or wpack_t_dev, the pack of its DATA GRADIENT - the convolution from C_out to
+ *   C_in channels with W'[i][o][dy][dx] = w[o][i][2 - dy][2 - dx], same size; either pointer may be NULL.  One launch.
+ * neuray_conv3x3_x3: x_dev [n][C_in][h][w] NCHW fp32, `pad` rings of zeros around it (0: valid correlation of a pre-padded input;
+ *   1: padding = 1 zeros; 2: full correlation), bias_dev [C_out] or NULL -> out_dev [n][C_out][h + 2 pad - 2][w + 2 pad - 2].
+ *   The data gradient of a layer: x_dev = d_out, C_in / C_out exchanged, wpack_t_dev, pad = 2. */
+long long neuray_conv3x3_x3_pack_bytes(int cin, int cout);
+int neuray_conv3x3_x3_pack(const float* w_dev, int cout, int cin, void* wpack_dev, void* wpack_t_dev, void* stream);
+int neuray_conv3x3_x3(const float* x_dev, const void* wpack_dev, const float* bias_dev, int n, int cin, int cout, int h, int w, int pad,
+                      float* out_dev, void* stream);
 /* neuray_scale_shift_leaky: MVSNet's frozen activated batch norm behind every convolution of the feature net and the cost regularisation
  *   (inplace_abn.ABN in evaluation mode; network/mvsnet/modules.py:7-23 `self.bn(self.conv(x))`, network/mvsnet/mvsnet.py:7-69) as ONE pass, in
  *   place on the convolution's output: x_dev [n][c][inner] (inner = h w or d h w) <- leaky_relu(x * scale_dev[c] + shift_dev[c], slope),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libneuray_hip.so')
 SOURCES = [os.path.join(CSRC, 'neuray_hip.hip'), os.path.join(CSRC, 'nr_pack.cpp')]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bwd.h', 'nr_kernels_bwd2.h', 'nr_kernels_dr.h', 'nr_kernels_norm.h', 'nr_kernels_conv3d.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bwd.h', 'nr_kernels_bwd2.h', 'nr_kernels_dr.h', 'nr_kernels_norm.h', 'nr_kernels_conv3d.h', 'nr_kernels_conv2d.h', 'nr_device.h', 'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
     [os.path.join(os.path.dirname(HERE), 'include', 'neuray_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: arithmetic is exactly as written (explicit fmaf where fusion is wanted), so a ray's result does

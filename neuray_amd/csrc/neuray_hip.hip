@@ -6,6 +6,7 @@
 #include "nr_kernels_dr.h"
 #include "nr_kernels_norm.h"
 #include "nr_kernels_conv3d.h"
+#include "nr_kernels_conv2d.h"
 // the plain bf16-operand build is inference only; the fp32 build and the split build (hi + lo bf16 operands: fp32-grade products)
 // carry the training path
 #if defined(NR_BF16_QUADS) && !defined(NR_BF16_SPLIT)
@@ -137,6 +138,22 @@ int launch_points_cfg(const nr::PointParams& p, int vpw, int arith, void* stream
     return fail("neuray_render_points: views_per_wave=%d is not built (1 or 2)", vpw);
 }
 
+}  // namespace
+
+namespace {
+template <int NT, int MTW>
+void launch_conv2d_x3(const nr::Conv2dX3Params& p, int bands, void* stream) {
+    const int lw = p.tw + 2, hp = p.h + 2 * p.pad;
+    const long long q = (long long)p.n * hp * lw;
+    const int per = nr::kC2Waves * NT * 16;
+    const size_t smem = (size_t)nr::conv2d_x3_smem_bytes(NT, lw);
+    auto k = nr::conv2d_x3_kernel<NT, MTW>;
+#ifndef NEURAY_EMU
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+    NR_LAUNCH(k, dim3((unsigned)((q + per - 1) / per), (unsigned)(p.cout / 16 / MTW), (unsigned)bands), dim3(64 * nr::kC2Waves), smem, stream, p);
+}
+int g_conv2d_nt = 0, g_conv2d_mtw = 0, g_conv2d_tw = 0;     // NEURAY_CONV2D_NT / _MTW / _TW: tile-shape overrides of the A/B tools
 }  // namespace
 
 extern "C" {
@@ -353,6 +370,60 @@ int neuray_conv3d_c32_c8(const float* x_ndhwc, const float* wpack, const float* 
 #endif
     NR_LAUNCH(k, dim3(grid), dim3(64 * nr::kConv0Waves), smem, stream, p);
     return check_launch("neuray_conv3d_c32_c8");
+}
+
+long long neuray_conv3x3_x3_pack_bytes(int cin, int cout) {
+    if (cin < 32 || cout < 32 || cin % 32 || cout % 32) return -1;
+    return (long long)9 * cin * cout * 6;
+}
+
+int neuray_conv3x3_x3_pack(const float* w, int cout, int cin, void* wpack, void* wpack_t, void* stream) {
+    if (!w || (!wpack && !wpack_t)) return fail("neuray_conv3x3_x3_pack: null pointer");
+    if (cin < 32 || cout < 32 || cin % 32 || cout % 32)
+        return fail("neuray_conv3x3_x3_pack: (C_in, C_out) = (%d, %d): both must be multiples of 32", cin, cout);
+    nr::Conv2dPackParams p;
+    p.w = w; p.wpack = (unsigned*)wpack; p.wpack_t = (unsigned*)wpack_t; p.cout = cout; p.cin = cin;
+    const int total = 9 * (cin / 32) * (cout / 16) * 256;
+    NR_LAUNCH(nr::conv2d_x3_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p);
+    return check_launch("neuray_conv3x3_x3_pack");
+}
+
+int neuray_conv3x3_x3(const float* x, const void* wpack, const float* bias, int n, int cin, int cout, int h, int w, int pad, float* out, void* stream) {
+    if (!x || !wpack || !out) return fail("neuray_conv3x3_x3: null pointer");
+    if (neuray_conv3x3_x3_pack_bytes(cin, cout) < 0)
+        return fail("neuray_conv3x3_x3: (C_in, C_out) = (%d, %d): both must be multiples of 32", cin, cout);
+    if (n < 1 || pad < 0 || pad > 2 || h + 2 * pad < 3 || w + 2 * pad < 3) return fail("neuray_conv3x3_x3: bad shape n=%d h=%d w=%d pad=%d", n, h, w, pad);
+    const int oh = h + 2 * pad - 2, ow = w + 2 * pad - 2;
+    if ((long long)n * cin * h * w * 4 >= 0x7fffff00LL || (long long)n * cout * oh * ow * 4 >= 0x7fffff00LL)
+        return fail("neuray_conv3x3_x3: the input and the output must each stay below 2^31 bytes");
+    static bool env_read = false;
+    if (!env_read) {
+        env_read = true;
+        if (const char* e = getenv("NEURAY_CONV2D_NT")) g_conv2d_nt = atoi(e);
+        if (const char* e = getenv("NEURAY_CONV2D_MTW")) g_conv2d_mtw = atoi(e);
+        if (const char* e = getenv("NEURAY_CONV2D_TW")) g_conv2d_tw = atoi(e);
+    }
+    // bands of at most 62 output columns (52-wide rows on 50 / 100 / 200-pixel maps: 2 dropped positions per row, a halo of 106 positions)
+    const int tw_max = g_conv2d_tw > 0 ? g_conv2d_tw : 62;
+    const int bands = (ow + tw_max - 1) / tw_max;
+    nr::Conv2dX3Params p;
+    p.x = x; p.wpack = (const unsigned*)wpack; p.bias = bias; p.out = out; p.n = n; p.cin = cin; p.cout = cout; p.h = h; p.w = w; p.pad = pad;
+    p.tw = (ow + bands - 1) / bands;
+    const int mt = cout / 16;
+    const long long q = (long long)n * (h + 2 * pad) * (p.tw + 2);
+    if (q + 1024 >= 0x7fffffffLL) return fail("neuray_conv3x3_x3: n * (h + 2 pad) * (band width + 2) must stay below 2^31");
+    // 64 positions x 32 output channels per wave: two workgroups per CU (70 KB of LDS each), the fastest shape on every encoder layer
+    // (profiles/r06_zz5_conv2d_probes.log); the larger tiles stay built for the A/B tool
+    int nt = 4, mtw = 2;
+    if (g_conv2d_nt == 4 || g_conv2d_nt == 8) nt = g_conv2d_nt;
+    if ((g_conv2d_mtw == 2 || g_conv2d_mtw == 4) && mt % g_conv2d_mtw == 0) mtw = g_conv2d_mtw;
+    if ((size_t)nr::conv2d_x3_smem_bytes(nt, p.tw + 2) > 160 * 1024 || nr::conv2d_x3_positions(nt, p.tw + 2) > 64 * nr::conv2d_x3_max_passes(nt))
+        return fail("neuray_conv3x3_x3: band of %d columns does not fit the LDS", p.tw);
+    if (nt == 8 && mtw == 4) launch_conv2d_x3<8, 4>(p, bands, stream);
+    else if (nt == 8) launch_conv2d_x3<8, 2>(p, bands, stream);
+    else if (mtw == 4) launch_conv2d_x3<4, 4>(p, bands, stream);
+    else launch_conv2d_x3<4, 2>(p, bands, stream);
+    return check_launch("neuray_conv3x3_x3");
 }
 
 int neuray_convtranspose3d_bn_leaky(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int cin, int cout,

@@ -277,6 +277,32 @@ class RenderEngine:
                                                     out.data_ptr(), self._stream()))
         return out
 
+    def conv3x3_x3_packs(self, weight, forward=True, gradient=False):
+        """weight [C_out, C_in, 3, 3] -> (pack, pack_t): the split-operand packs of neuray_conv3x3_x3 for the layer and for its data gradient
+        (None where not asked for), one launch"""
+        co, ci = weight.shape[:2]
+        w = weight.detach().contiguous().float()
+        nbytes = self.lib.neuray_conv3x3_x3_pack_bytes(ci, co)
+        assert nbytes > 0 and tuple(weight.shape[2:]) == (3, 3), tuple(weight.shape)
+        pack = torch.empty(nbytes // 4, dtype=torch.int32, device=self.device) if forward else None
+        pack_t = torch.empty(nbytes // 4, dtype=torch.int32, device=self.device) if gradient else None
+        self._check(self.lib.neuray_conv3x3_x3_pack(w.data_ptr(), co, ci, pack.data_ptr() if forward else None, pack_t.data_ptr() if gradient else None,
+                                                    self._stream()))
+        return pack, pack_t
+
+    def conv3x3_x3_pack(self, weight, transpose_flip=False):
+        return self.conv3x3_x3_packs(weight, not transpose_flip, transpose_flip)[1 if transpose_flip else 0]
+
+    def conv3x3_x3(self, x, pack, bias, cout, pad=0):
+        """x [n, C_in, h, w] contiguous fp32 with `pad` rings of zeros -> the 3 x 3 correlation [n, cout, h + 2 pad - 2, w + 2 pad - 2] on the
+        K = 32 bf16 MFMA with exactly split operands (neuray_conv3x3_x3)"""
+        n, c, h, w = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32 and (bias is None or (bias.is_contiguous() and bias.dtype == torch.float32 and bias.numel() == cout))
+        out = self.empty(n, cout, h + 2 * pad - 2, w + 2 * pad - 2)
+        self._check(self.lib.neuray_conv3x3_x3(x.data_ptr(), pack.data_ptr(), bias.data_ptr() if bias is not None else None, n, c, cout, h, w, int(pad),
+                                               out.data_ptr(), self._stream()))
+        return out
+
     def scale_shift_leaky_(self, x, scale, shift, slope):
         """x [n,c,...] contiguous fp32 <- leaky_relu(x * scale[c] + shift[c], slope), in place (neuray_scale_shift_leaky: MVSNet's frozen
         activated batch norm as one pass)"""

@@ -40,6 +40,10 @@ def set_fused_norm(on):
     fused_norm.FUSED_NORM = bool(on)
 
 
+def set_x3_conv(on):
+    fused_norm.X3_CONV = bool(on)
+
+
 def _inorm(c):
     return nn.InstanceNorm2d(c, track_running_stats=False, affine=True)
 

@@ -8,6 +8,8 @@ reflection_pad2d), with a two-pass backward.  The result is handed to the next c
 (`conv_prepadded`); the un-padded activation is the interior view of the same buffer (`interior`).  On a device without the
 kernels (plain CPU) the same function composes the PyTorch ops, so the modules have one forward."""
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -113,8 +115,62 @@ def interior(zp, pad):
     return zp[:, :, pad:zp.shape[2] - pad, pad:zp.shape[3] - pad]
 
 
+X3_CONV = True             # False: every convolution through PyTorch / MIOpen (A/B timing, tests)
+_PACKS = {}                # inference: id(weight) -> (weight._version, data_ptr, pack, weak reference) of the frozen weights
+
+
+class _Conv3x3X3Fn(torch.autograd.Function):
+    """3 x 3 stride-1 convolution of an input that carries its padding, on the K = 32 bf16 MFMA with exactly split operands
+    (csrc/nr_kernels_conv2d.h, neuray_conv3x3_x3): forward and data gradient are the same kernel (the gradient is the full correlation with
+    the flipped, transposed pack; both packs come out of one launch); the weight gradient is the library's."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, bias):
+        eng = _engine(xp.device)
+        xp = xp.contiguous()
+        pack, pack_t = eng.conv3x3_x3_packs(weight, True, ctx.needs_input_grad[0])
+        b = bias.detach().contiguous() if bias is not None else None
+        ctx.save_for_backward(xp, weight)
+        ctx.pack_t, ctx.has_bias = pack_t, bias is not None
+        return eng.conv3x3_x3(xp, pack, b, weight.shape[0], 0)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        xp, weight = ctx.saved_tensors
+        eng = _engine(xp.device)
+        d_out = d_out.contiguous()
+        dx = eng.conv3x3_x3(d_out, ctx.pack_t, None, weight.shape[1], 2) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            _, dw, db = torch.ops.aten.convolution_backward(d_out, xp, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False,
+                                                            [0, 0], 1, [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        return dx, dw, db
+
+
+def _x3_conv_ok(conv, xp):
+    w = conv.weight
+    return (X3_CONV and tuple(w.shape[2:]) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 and xp.dtype == torch.float32 and w.dtype == torch.float32
+            and xp.is_contiguous() and xp.shape[2] >= 3 and xp.shape[3] >= 3 and xp.numel() * 4 < 0x7fffff00 and xp.shape[0] * w.shape[0] * xp.shape[2] * xp.shape[3] * 4 < 0x7fffff00
+            and _engine(xp.device) is not None)
+
+
 def conv_prepadded(conv, xp):
-    """`conv` (an nn.Conv2d with padding_mode='reflect') on an input that already carries its reflection padding"""
+    """`conv` (an nn.Conv2d with padding_mode='reflect') on an input that already carries its reflection padding.  The 3 x 3 stride-1 layers
+    with channel counts in multiples of 32 - every residual-block and decoder convolution of the encoders behind layer1's first - run on the
+    split-operand bf16 MFMA kernel (fp32 grade; 1.45 x MIOpen's fp32 kernels on these shapes, profiles/r06_zz5_conv2d_probes.log); the strided,
+    1 x 1, 7 x 7 and narrow ones stay with the library."""
+    if _x3_conv_ok(conv, xp):
+        if torch.is_grad_enabled() and (xp.requires_grad or conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)):
+            return _Conv3x3X3Fn.apply(xp, conv.weight, conv.bias)
+        eng = _engine(xp.device)
+        w = conv.weight
+        hit = _PACKS.get(id(w))
+        if hit is None or hit[0] != w._version or hit[1] != w.data_ptr() or hit[2].device != xp.device or hit[3]() is not w:
+            hit = (w._version, w.data_ptr(), eng.conv3x3_x3_pack(w), weakref.ref(w))
+            _PACKS[id(w)] = hit
+        b = conv.bias.detach().contiguous() if conv.bias is not None else None
+        return eng.conv3x3_x3(xp.contiguous(), hit[2], b, w.shape[0], 0)
     return F.conv2d(xp, conv.weight, conv.bias, conv.stride, 0, conv.dilation, conv.groups)
 
 

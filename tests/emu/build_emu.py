@@ -10,7 +10,7 @@ CSRC = os.path.join(ROOT, 'neuray_amd', 'csrc')
 OUT_DIR = os.path.join(HERE, '_build')
 OUT = os.path.join(OUT_DIR, 'libneuray_emu.so')
 SOURCES = [os.path.join(CSRC, 'neuray_hip.hip'), os.path.join(CSRC, 'nr_pack.cpp'), os.path.join(HERE, 'hip_emu.cpp')]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bwd.h', 'nr_kernels_bwd2.h', 'nr_kernels_dr.h', 'nr_kernels_norm.h', 'nr_kernels_conv3d.h', 'nr_device.h',
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ('nr_kernels.h', 'nr_kernels_bwd.h', 'nr_kernels_bwd2.h', 'nr_kernels_dr.h', 'nr_kernels_norm.h', 'nr_kernels_conv3d.h', 'nr_kernels_conv2d.h', 'nr_device.h',
                                               'nr_layout.h', 'nr_platform.h', 'nr_pack.h')] + \
     [os.path.join(HERE, 'hip_emu.h'), os.path.join(ROOT, 'include', 'neuray_hip.h')]
 

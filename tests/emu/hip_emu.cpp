@@ -78,7 +78,7 @@ static void watchdog(int) {
 
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
     if (const char* w = getenv("NEURAY_EMU_WATCHDOG")) { signal(SIGALRM, watchdog); alarm(atoi(w)); }
-    const unsigned nblocks = grid.x * grid.y;
+    const unsigned nblocks = grid.x * grid.y * grid.z;
     unsigned nthr = std::thread::hardware_concurrency();
     const char* env = getenv("NEURAY_EMU_THREADS");
     if (env) nthr = (unsigned)atoi(env);
@@ -92,7 +92,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
             unsigned i = next.fetch_add(1);
             if (i >= nblocks) break;
             Block b;
-            b.bidx = dim3(i % grid.x, i / grid.x, 0);
+            b.bidx = dim3(i % grid.x, (i / grid.x) % grid.y, i / (grid.x * grid.y));
             b.bdim = block; b.gdim = grid; b.body = &body;
             b.dyn_smem = (char*)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
             run_block(b, stacks);

@@ -83,10 +83,12 @@ extern thread_local Lane* g_lane;
 
 struct TidProxy { unsigned y = 0, z = 0; struct X { operator unsigned() const { return g_lane->tid; } } x; };
 struct BidProxy { struct X { operator unsigned() const { return g_blk->bidx.x; } } x;
-                  struct Y { operator unsigned() const { return g_blk->bidx.y; } } y; unsigned z = 0; };
+                  struct Y { operator unsigned() const { return g_blk->bidx.y; } } y;
+                  struct Z { operator unsigned() const { return g_blk->bidx.z; } } z; };
 struct BdimProxy { struct X { operator unsigned() const { return g_blk->bdim.x; } } x; unsigned y = 1, z = 1; };
 struct GdimProxy { struct X { operator unsigned() const { return g_blk->gdim.x; } } x;
-                   struct Y { operator unsigned() const { return g_blk->gdim.y; } } y; unsigned z = 1; };
+                   struct Y { operator unsigned() const { return g_blk->gdim.y; } } y;
+                   struct Z { operator unsigned() const { return g_blk->gdim.z; } } z; };
 
 void yield_lane();
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);

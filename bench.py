@@ -614,14 +614,16 @@ def gen_train_step_timing(device, steps=10):
                     "carries que_imgs_info['Ks_inv'] computed by the host pipeline before the upload (the two agree within the run-to-run "
                     "noise of +-2 ms: the copy is taken before anything of the step is queued)",
             'loss_is_finite': bool(torch.isfinite(loss).item()),
-            'kernel_classes': 'profiles/r05_t_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
+            'kernel_classes': 'profiles/r06_zz7_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
 
 
 def encoder_timing(device, n=9, hw=(800, 800), reps=5):
     """Side measurement: image_encoder + vis_encoder on the fine-tuning step's 9 images of 800 x 800
     (renderer.py:229-235), forward and forward + backward, with the fused InstanceNorm / activation / residual / reflection-pad
     kernels (csrc/nr_kernels_norm.h) and with the PyTorch composition they replace (MIOpen batch-norm + element-wise + pad kernels).
-    The convolutions are MIOpen's fp32 kernels in both."""
+    `fused_norm`: the product path - those kernels plus the 3 x 3 stride-1 convolutions (forward and data gradient) on the split-operand
+    bf16 MFMA (csrc/nr_kernels_conv2d.h); `fused_norm_miopen_convs`: the same with every convolution MIOpen's (the round-5 path);
+    `pytorch_norm`: MIOpen / PyTorch throughout."""
     from neuray_amd.network import encoders
     torch.manual_seed(0)
     img_enc, vis_enc = encoders.ImageEncoder().to(device), encoders.DefaultVisEncoder({}).to(device)
@@ -650,11 +652,13 @@ def encoder_timing(device, n=9, hw=(800, 800), reps=5):
         return 1e3 * (time.perf_counter() - t0) / reps
     out = {'what': 'image_encoder + vis_encoder, %d x 3 x %d x %d, fp32' % (n, hw[0], hw[1])}
     try:
-        for tag, on in (('fused_norm', True), ('pytorch_norm', False)):
+        for tag, on, x3 in (('fused_norm', True, True), ('fused_norm_miopen_convs', True, False), ('pytorch_norm', False, False)):
             encoders.set_fused_norm(on)
+            encoders.set_x3_conv(x3)
             out[tag] = {'forward_ms': timeit(fwd, False), 'forward_backward_ms': timeit(fwd_bwd, True)}
     finally:
         encoders.set_fused_norm(True)
+        encoders.set_x3_conv(True)
     out['speedup_forward'] = out['pytorch_norm']['forward_ms'] / out['fused_norm']['forward_ms']
     out['speedup_forward_backward'] = out['pytorch_norm']['forward_backward_ms'] / out['fused_norm']['forward_backward_ms']
     return out

@@ -359,6 +359,14 @@ long long neuray_conv3x3_x3_pack_bytes(int cin, int cout);
 int neuray_conv3x3_x3_pack(const float* w_dev, int cout, int cin, void* wpack_dev, void* wpack_t_dev, void* stream);
 int neuray_conv3x3_x3(const float* x_dev, const void* wpack_dev, const float* bias_dev, int n, int cin, int cout, int h, int w, int pad,
                       float* out_dev, void* stream);
+/* neuray_conv3x3_x3_wrw: the WEIGHT gradient of the same layers in the same arithmetic, straight from the NCHW tensors (the contraction runs
+ *   over positions, which NCHW stores contiguously: no transposed copies): dy_dev [n][C_out][hp - 2][wp - 2] (the gradient of the layer's
+ *   output), xp_dev [n][C_in][hp][wp] (the layer's pre-padded input) -> dw_dev [C_out][C_in][3][3] (overwritten).  wp must be even.
+ *   workspace_dev: neuray_conv3x3_x3_wrw_workspace_floats(...) floats (-1: shape not supported) - per-workgroup partial sums, added in a fixed
+ *   order by a second launch (deterministic, no atomics).  torch.ops.aten.convolution_backward(..., output_mask=[False, True, False]). */
+long long neuray_conv3x3_x3_wrw_workspace_floats(int n, int cin, int cout, int hp, int wp);
+int neuray_conv3x3_x3_wrw(const float* dy_dev, const float* xp_dev, int n, int cin, int cout, int hp, int wp, float* workspace_dev, float* dw_dev,
+                          void* stream);
 /* neuray_scale_shift_leaky: MVSNet's frozen activated batch norm behind every convolution of the feature net and the cost regularisation
  *   (inplace_abn.ABN in evaluation mode; network/mvsnet/modules.py:7-23 `self.bn(self.conv(x))`, network/mvsnet/mvsnet.py:7-69) as ONE pass, in
  *   place on the convolution's output: x_dev [n][c][inner] (inner = h w or d h w) <- leaky_relu(x * scale_dev[c] + shift_dev[c], slope),

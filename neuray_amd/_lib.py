@@ -160,6 +160,8 @@ SYMBOLS = {
     'neuray_conv3x3_x3_pack_bytes': (C.c_longlong, [C.c_int, C.c_int]),
     'neuray_conv3x3_x3_pack': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_conv3x3_x3': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'neuray_conv3x3_x3_wrw_workspace_floats': (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'neuray_conv3x3_x3_wrw': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'neuray_scale_shift_leaky': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
     'neuray_conv3d_c8_c1': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'neuray_convtranspose3d_c16_c8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

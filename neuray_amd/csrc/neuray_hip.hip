@@ -426,6 +426,42 @@ int neuray_conv3x3_x3(const float* x, const void* wpack, const float* bias, int 
     return check_launch("neuray_conv3x3_x3");
 }
 
+namespace {
+int conv2d_wrw_ksplit(int n, int cin, int cout, int hp, int wp) {
+    const int pairs = (cin / 32) * (cout / 32);
+    const long long nkb = (long long)n * (((long long)(hp - 2) * wp + 31) / 32);
+    long long ks = 512 / pairs;                     // two workgroups per CU over the whole launch ...
+    if (ks > nkb / 8) ks = nkb / 8;                 // ... but at least two K blocks per wave
+    return ks < 1 ? 1 : (int)ks;
+}
+}  // namespace
+
+long long neuray_conv3x3_x3_wrw_workspace_floats(int n, int cin, int cout, int hp, int wp) {
+    if (cin < 32 || cout < 32 || cin % 32 || cout % 32 || n < 1 || hp < 3 || wp < 10 || (wp & 1)) return -1;
+    return (long long)conv2d_wrw_ksplit(n, cin, cout, hp, wp) * (cin / 32) * (cout / 32) * nr::kWrwAcc * 64;
+}
+
+int neuray_conv3x3_x3_wrw(const float* dy, const float* xp, int n, int cin, int cout, int hp, int wp, float* workspace, float* dw, void* stream) {
+    if (!dy || !xp || !workspace || !dw) return fail("neuray_conv3x3_x3_wrw: null pointer");
+    if (neuray_conv3x3_x3_wrw_workspace_floats(n, cin, cout, hp, wp) < 0)
+        return fail("neuray_conv3x3_x3_wrw: n=%d (C_in, C_out) = (%d, %d) padded input %d x %d: the channel counts must be multiples of 32 and the padded width even and >= 10",
+                    n, cin, cout, hp, wp);
+    if ((long long)n * cin * hp * wp * 4 >= 0x7fffff00LL || (long long)n * cout * hp * wp * 4 >= 0x7fffff00LL)
+        return fail("neuray_conv3x3_x3_wrw: the input and the output gradient must each stay below 2^31 bytes");
+    nr::Conv2dWrwParams p;
+    p.dy = dy; p.xp = xp; p.ws = workspace; p.dw = dw; p.n = n; p.cin = cin; p.cout = cout; p.hp = hp; p.wp = wp;
+    p.ksplit = conv2d_wrw_ksplit(n, cin, cout, hp, wp);
+    const int pairs = (cin / 32) * (cout / 32);
+    const size_t smem = sizeof(float) * 2 * nr::kWrwAcc * 64;
+    auto k = nr::conv2d_x3_wrw_kernel;
+#ifndef NEURAY_EMU
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#endif
+    NR_LAUNCH(k, dim3((unsigned)p.ksplit, (unsigned)pairs), dim3(256), smem, stream, p);
+    NR_LAUNCH(nr::conv2d_x3_wrw_reduce_kernel, dim3((unsigned)(pairs * nr::kWrwAcc)), dim3(64 * nr::kWrwRedWaves), 0, stream, p);
+    return check_launch("neuray_conv3x3_x3_wrw");
+}
+
 int neuray_convtranspose3d_bn_leaky(const float* x, const float* wpack, const float* bias, float slope, const float* skip, int n, int cin, int cout,
                                     int d, int h, int w, float* out, void* stream) {
     if (!x || !wpack || !bias || !out) return fail("neuray_convtranspose3d_bn_leaky: null pointer");

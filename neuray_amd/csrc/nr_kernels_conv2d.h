@@ -245,4 +245,146 @@ __global__ void __launch_bounds__(64 * kC2Waves) conv2d_x3_kernel(Conv2dX3Params
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers: dW[co][ci][dy][dx] = sum over (image, y < oh, x < ow) of dY[co][y][x] * xp[ci][y + dy][x + dx], in the same
+// split arithmetic.  In NCHW the contraction index - positions - is the contiguous one, so BOTH operands come straight from global memory as
+// two (unaligned) 16-byte loads per lane, no LDS and no transposes (the library's weight-gradient kernels ask for NHWC copies of both
+// tensors): K runs over q = y * wp + x of the PADDED row pitch, 32 positions per MFMA, lane (channel i, group g) owning q0 = qb + 8 g .. + 7.
+//   B = xp[ci][q + dy * wp + dx]: a tap is a shift of the load address;
+//   A = dY[co] at q: dY's rows are ow = wp - 2 long, so its linear index is q - 2 y; the two dropped columns of a row are zeros, and the
+//       elements of a lane's run that lie in the next row are the loaded run shifted by two (wp even: a run never starts on the last column).
+// A wave owns a 32 x 32 (co, ci) block for all nine taps (144 accumulator registers) and every (4 * ksplit)-th K block; the four waves of a
+// workgroup are summed through LDS, the workgroup's partial goes to a workspace, conv2d_x3_wrw_reduce_kernel adds the partials in a fixed
+// order (deterministic: no atomics).
+struct Conv2dWrwParams {
+    const float* dy;         // [n][cout][oh][ow]
+    const float* xp;         // [n][cin][hp][wp], hp = oh + 2, wp = ow + 2
+    float* ws;               // [ksplit][pairs][144][64] partial sums (register dumps)
+    float* dw;               // [cout][cin][3][3]
+    int n, cin, cout, hp, wp;
+    int ksplit;
+};
+
+constexpr int kWrwAcc = 9 * 2 * 2 * 4;
+
+__global__ void __launch_bounds__(256, 2) conv2d_x3_wrw_kernel(Conv2dWrwParams p) {
+    NR_DYNAMIC_SMEM(float, red);                                   // [2][kWrwAcc][64]
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = NR_UNIFORM(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int oh = p.hp - 2, ow = p.wp - 2;
+    const int cib = p.cin / 32, pair = (int)blockIdx.y, co0 = 32 * (pair / cib), ci0 = 32 * (pair % cib);
+    const int kpi = (oh * p.wp + 31) / 32, nkb = p.n * kpi;        // K blocks per image, in all
+    const nr_mbuf DY = nr_make_mbuf(p.dy, sizeof(float) * (size_t)p.n * p.cout * oh * ow);
+    const nr_mbuf X = nr_make_mbuf(p.xp, sizeof(float) * (size_t)p.n * p.cin * p.hp * p.wp);
+    v4f acc[9][2][2];
+    NR_PRAGMA_UNROLL
+    for (int t = 0; t < 9; ++t)
+        NR_PRAGMA_UNROLL
+        for (int a = 0; a < 2; ++a)
+            NR_PRAGMA_UNROLL
+            for (int b = 0; b < 2; ++b) { acc[t][a][b][0] = 0.0f; acc[t][a][b][1] = 0.0f; acc[t][a][b][2] = 0.0f; acc[t][a][b][3] = 0.0f; }
+#pragma unroll 1
+    for (int kblk = (int)blockIdx.x * 4 + wave; kblk < nkb; kblk += p.ksplit * 4) {
+        const int img = kblk / kpi;
+        const int q0 = (kblk - img * kpi) * 32 + 8 * g;
+        const int y0 = q0 / p.wp, x0 = q0 - y0 * p.wp, jw = p.wp - x0;
+        nr_v4u A[2][3];
+        NR_PRAGMA_UNROLL
+        for (int mt = 0; mt < 2; ++mt) {
+            const int off = (((img * p.cout + co0 + 16 * mt + i) * oh) * ow + q0 - 2 * y0) * 4;
+            const float4 lo = nr_buf_ld4(DY, off, 0), hi = nr_buf_ld4(DY, off + 16, 0);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float a[8];
+            NR_PRAGMA_UNROLL
+            for (int j = 0; j < 8; ++j) {
+                const float same = (x0 + j < ow && y0 < oh) ? v[j] : 0.0f;
+                const float next = (j >= 2 && y0 + 1 < oh) ? v[j >= 2 ? j - 2 : 0] : 0.0f;
+                a[j] = j < jw ? same : next;
+            }
+            NR_PRAGMA_UNROLL
+            for (int d = 0; d < 4; ++d) {
+                unsigned h, m, l;
+                nr_split3(a[2 * d], a[2 * d + 1], h, m, l);
+                A[mt][0][d] = h; A[mt][1][d] = m; A[mt][2][d] = l;
+            }
+        }
+        const int xoff = ((img * p.cin + ci0 + i) * p.hp) * p.wp + q0;
+        NR_PRAGMA_UNROLL
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            nr_v4u B[2][3];
+            NR_PRAGMA_UNROLL
+            for (int nt = 0; nt < 2; ++nt) {
+                const int off = (xoff + 16 * nt * p.hp * p.wp + dy * p.wp + dx) * 4;
+                const float4 lo = nr_buf_ld4(X, off, 0), hi = nr_buf_ld4(X, off + 16, 0);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                NR_PRAGMA_UNROLL
+                for (int d = 0; d < 4; ++d) {
+                    unsigned h, m, l;
+                    nr_split3(v[2 * d], v[2 * d + 1], h, m, l);
+                    B[nt][0][d] = h; B[nt][1][d] = m; B[nt][2][d] = l;
+                }
+            }
+            constexpr int WI[6] = {2, 0, 1, 1, 0, 0}, XJ[6] = {0, 2, 1, 0, 1, 0};
+            NR_PRAGMA_UNROLL
+            for (int pr = 0; pr < 6; ++pr)
+                NR_PRAGMA_UNROLL
+                for (int mt = 0; mt < 2; ++mt)
+                    NR_PRAGMA_UNROLL
+                    for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = nr_mfma16x32_bf16(A[mt][WI[pr]], B[nt][XJ[pr]], acc[tap][mt][nt]);
+        }
+    }
+    // waves 2, 3 -> 0, 1; wave 1 -> 0; wave 0 writes the workgroup's partial (register dump: [register][lane])
+    auto dump = [&](float* dst) NR_LAMBDA_INLINE {
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < 9; ++t)
+            NR_PRAGMA_UNROLL
+            for (int a = 0; a < 2; ++a)
+                NR_PRAGMA_UNROLL
+                for (int b = 0; b < 2; ++b)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) dst[((((t * 2 + a) * 2 + b) * 4) + r) * 64 + lane] = acc[t][a][b][r];
+    };
+    auto gather = [&](const float* src) NR_LAMBDA_INLINE {
+        NR_PRAGMA_UNROLL
+        for (int t = 0; t < 9; ++t)
+            NR_PRAGMA_UNROLL
+            for (int a = 0; a < 2; ++a)
+                NR_PRAGMA_UNROLL
+                for (int b = 0; b < 2; ++b)
+                    NR_PRAGMA_UNROLL
+                    for (int r = 0; r < 4; ++r) acc[t][a][b][r] += src[((((t * 2 + a) * 2 + b) * 4) + r) * 64 + lane];
+    };
+    if (wave >= 2) dump(red + (wave - 2) * kWrwAcc * 64);
+    NR_BLOCK_SYNC();
+    if (wave < 2) gather(red + wave * kWrwAcc * 64);
+    NR_BLOCK_SYNC();
+    if (wave == 1) dump(red);
+    NR_BLOCK_SYNC();
+    if (wave == 0) {
+        gather(red);
+        dump(p.ws + ((size_t)blockIdx.x * gridDim.y + pair) * kWrwAcc * 64);
+    }
+}
+
+// dw[co][ci][tap] = the partials of its (co, ci) block, added in a fixed order: a workgroup per (pair, register) row of 64 lanes, wave w adds
+// the partials w, w + 8, ... and wave 0 the eight sums.
+constexpr int kWrwRedWaves = 8;
+__global__ void __launch_bounds__(64 * kWrwRedWaves) conv2d_x3_wrw_reduce_kernel(Conv2dWrwParams p) {
+    __shared__ float part[kWrwRedWaves][64];
+    const int cib = p.cin / 32, pairs = cib * (p.cout / 32);
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int reg = (int)blockIdx.x % kWrwAcc, pair = (int)blockIdx.x / kWrwAcc;
+    float s = 0.0f;
+    for (int k = wave; k < p.ksplit; k += kWrwRedWaves) s += p.ws[((size_t)k * pairs + pair) * kWrwAcc * 64 + reg * 64 + lane];
+    part[wave][lane] = s;
+    NR_BLOCK_SYNC();
+    if (wave) return;
+    for (int w = 1; w < kWrwRedWaves; ++w) s += part[w][lane];
+    const int r = reg & 3, nt = (reg >> 2) & 1, mt = (reg >> 3) & 1, tap = reg >> 4;
+    const int co = 32 * (pair / cib) + 16 * mt + 4 * (lane >> 4) + r, ci = 32 * (pair % cib) + 16 * nt + (lane & 15);
+    p.dw[((size_t)co * p.cin + ci) * 9 + tap] = s;
+}
+
 }  // namespace nr

@@ -303,6 +303,19 @@ class RenderEngine:
                                                out.data_ptr(), self._stream()))
         return out
 
+    def conv3x3_x3_wrw(self, d_out, xp):
+        """d_out [n, C_out, h, w], xp [n, C_in, h + 2, w + 2] (the layer's pre-padded input), both contiguous fp32 -> the weight gradient
+        [C_out, C_in, 3, 3] (neuray_conv3x3_x3_wrw), or None where the shape is not supported (odd padded width)"""
+        n, cout, oh, ow = d_out.shape
+        cin, hp, wp = xp.shape[1:]
+        assert d_out.is_contiguous() and xp.is_contiguous() and d_out.dtype == xp.dtype == torch.float32 and (hp, wp) == (oh + 2, ow + 2)
+        nws = self.lib.neuray_conv3x3_x3_wrw_workspace_floats(n, cin, cout, hp, wp)
+        if nws < 0:
+            return None
+        ws, dw = self.empty(nws), self.empty(cout, cin, 3, 3)
+        self._check(self.lib.neuray_conv3x3_x3_wrw(d_out.data_ptr(), xp.data_ptr(), n, cin, cout, hp, wp, ws.data_ptr(), dw.data_ptr(), self._stream()))
+        return dw
+
     def scale_shift_leaky_(self, x, scale, shift, slope):
         """x [n,c,...] contiguous fp32 <- leaky_relu(x * scale[c] + shift[c], slope), in place (neuray_scale_shift_leaky: MVSNet's frozen
         activated batch norm as one pass)"""

@@ -116,13 +116,15 @@ def interior(zp, pad):
 
 
 X3_CONV = True             # False: every convolution through PyTorch / MIOpen (A/B timing, tests)
+X3_WRW = True              # False: the weight gradient of the kernel's layers through the library
 _PACKS = {}                # inference: id(weight) -> (weight._version, data_ptr, pack, weak reference) of the frozen weights
 
 
 class _Conv3x3X3Fn(torch.autograd.Function):
     """3 x 3 stride-1 convolution of an input that carries its padding, on the K = 32 bf16 MFMA with exactly split operands
     (csrc/nr_kernels_conv2d.h, neuray_conv3x3_x3): forward and data gradient are the same kernel (the gradient is the full correlation with
-    the flipped, transposed pack; both packs come out of one launch); the weight gradient is the library's."""
+    the flipped, transposed pack; both packs come out of one launch); the weight gradient is neuray_conv3x3_x3_wrw, straight from the NCHW
+    tensors (the library's kernels want NHWC copies of both); the bias gradient is the library's reduction."""
 
     @staticmethod
     def forward(ctx, xp, weight, bias):
@@ -141,9 +143,13 @@ class _Conv3x3X3Fn(torch.autograd.Function):
         d_out = d_out.contiguous()
         dx = eng.conv3x3_x3(d_out, ctx.pack_t, None, weight.shape[1], 2) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            _, dw, db = torch.ops.aten.convolution_backward(d_out, xp, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False,
-                                                            [0, 0], 1, [False, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw = eng.conv3x3_x3_wrw(d_out, xp) if X3_WRW else None          # (None: an odd padded width)
+        if (ctx.needs_input_grad[1] and dw is None) or want_b:
+            _, dw_lib, db = torch.ops.aten.convolution_backward(d_out, xp, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False,
+                                                                [0, 0], 1, [False, ctx.needs_input_grad[1] and dw is None, want_b])
+            dw = dw if dw is not None else dw_lib
         return dx, dw, db
 
 

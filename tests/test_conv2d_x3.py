@@ -81,6 +81,25 @@ def test_data_gradient_is_the_full_correlation_with_the_flipped_pack(dev):
         assert _rel(got, ref) < 3e-6
 
 
+def test_weight_gradient(dev):
+    """neuray_conv3x3_x3_wrw against autograd of a float64 convolution: K blocks that straddle rows and end inside the last one, several (co, ci)
+    blocks, more K blocks than one wave takes (the LDS and workspace reductions)"""
+    eng = ro.engine_for(torch.device(dev))
+    shapes = [(2, 32, 32, 7, 10), (1, 64, 32, 12, 52), (3, 32, 64, 9, 18)] + ([] if dev == 'cpu' else [(9, 128, 128, 52, 52), (9, 64, 32, 202, 202), (4, 128, 64, 102, 102)])
+    for i, (n, cin, cout, hp, wp) in enumerate(shapes):
+        x, wgt, _ = _case(n, cin, cout, hp, wp, 20 + i)
+        wr = wgt.double().requires_grad_(True)
+        y = F.conv2d(x.double(), wr)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(i), dtype=torch.float64)
+        ref, = torch.autograd.grad(y, wr, dy)
+        got = eng.conv3x3_x3_wrw(dy.float().to(dev).contiguous(), x.to(dev))
+        assert got is not None and tuple(got.shape) == tuple(wgt.shape)
+        lib = torch.ops.aten.convolution_backward(dy.float(), x, wgt, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        e_x3, e_f32 = _rel(got, ref), _rel(lib, ref)
+        assert e_x3 < 3e-6 and e_x3 < 4.0 * e_f32 + 2e-7, (n, cin, cout, hp, wp, e_x3, e_f32)
+    assert eng.conv3x3_x3_wrw(torch.zeros(1, 32, 5, 9, device=dev), torch.zeros(1, 32, 7, 11, device=dev)) is None      # odd padded width
+
+
 def test_bad_shapes_are_refused(dev):
     eng = ro.engine_for(torch.device(dev))
     assert eng.lib.neuray_conv3x3_x3_pack_bytes(16, 32) == -1 and eng.lib.neuray_conv3x3_x3_pack_bytes(32, 48) == -1
@@ -108,7 +127,7 @@ def test_conv_prepadded_routes_the_encoder_layers_through_the_kernel(dev):
     wr, br = conv.weight.detach().double().cpu().requires_grad_(True), conv.bias.detach().double().cpu().requires_grad_(True)
     yr = F.conv2d(xr, wr, br)
     rx, rw, rb = torch.autograd.grad(yr, (xr, wr, br), dy.double().cpu())
-    for got, ref in ((y, yr), (gx, rx), (gw, rw), (gb, rb)):
+    for got, ref in ((y, yr), (gx, rx), (gw, rw), (gb, rb)):          # (gw: the kernel's weight gradient; an odd padded width takes the library's)
         assert _rel(got.detach(), ref.detach()) < 3e-6
     with torch.no_grad():                                             # inference: the pack of the frozen weight is cached, and dropped when it changes
         y0 = fn.conv_prepadded(conv, xp.detach())

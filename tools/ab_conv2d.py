@@ -67,14 +67,21 @@ def main():
         t_x3 = timed(lambda: eng.conv3x3_x3(x, pack, None, cout, 0), args.reps)
         t_lib_b = timed(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False]), args.reps)
         t_x3_b = timed(lambda: eng.conv3x3_x3(dy, pack_t, None, cin, 2), args.reps)
-        print('%-28s %9.4f %9.4f %7.1f | %9.4f %9.4f %7.1f | %9.2e %9.2e (dx %.2e)' % (label, t_lib, t_x3, flop / t_x3 * 1e-9, t_lib_b, t_x3_b, flop / t_x3_b * 1e-9,
-                                                                                     e_lib, e_x3, e_dx))
+        t_lib_w = timed(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]), args.reps)
+        t_x3_w = timed(lambda: eng.conv3x3_x3_wrw(dy, x), args.reps)
+        wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double())
+        e_w = float((eng.conv3x3_x3_wrw(dy, x).double() - wref).abs().max() / wref.abs().max())
+        print('%-28s %9.4f %9.4f %7.1f | %9.4f %9.4f %7.1f | %9.2e %9.2e (dx %.2e) | dW: MIOpen %.4f x3 %.4f ms (%.1f TF/s, err %.2e)'
+              % (label, t_lib, t_x3, flop / t_x3 * 1e-9, t_lib_b, t_x3_b, flop / t_x3_b * 1e-9, e_lib, e_x3, e_dx, t_lib_w, t_x3_w, flop / t_x3_w * 1e-9, e_w))
+        tot['miopen_wrw'] = tot.get('miopen_wrw', 0.0) + count * t_lib_w
+        tot['x3_wrw'] = tot.get('x3_wrw', 0.0) + count * t_x3_w
         tot['miopen_fwd'] += count * t_lib
         tot['x3_fwd'] += count * t_x3
         tot['miopen_bwd'] += count * t_lib_b
         tot['x3_bwd'] += count * t_x3_b
     print('per encoder pass (image + visibility encoder, weighted by layer count): forward MIOpen %.3f ms, x3 %.3f ms; data gradient MIOpen %.3f ms, x3 %.3f ms'
           % (tot['miopen_fwd'], tot['x3_fwd'], tot['miopen_bwd'], tot['x3_bwd']))
+    print('weight gradient: MIOpen (with the NHWC copies it makes) %.3f ms, x3 %.3f ms' % (tot.get('miopen_wrw', 0.0), tot.get('x3_wrw', 0.0)))
     t_pack = timed(lambda: eng.conv3x3_x3_pack(w), args.reps)
     print('pack of one 64 -> 32 layer: %.4f ms' % t_pack)
 

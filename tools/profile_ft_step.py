@@ -65,6 +65,8 @@ def classify(path, steps):
         cls = 'other'
         if 'inorm' in name:
             cls = 'fused norm (nr::inorm)'
+        elif 'nr::conv2d_x3' in name:
+            cls = 'encoder 3x3 convolutions (nr::conv2d_x3: forward + data gradient + packs)'
         elif 'nr::upsample2x' in name:
             cls = 'up-sampling'
         elif any(k in name for k in ('nr::costreg', 'nr::warp_variance', 'nr::diff_feats', 'nr::conv3d_kernel', 'nr::scale_shift_leaky')):

@@ -7,7 +7,7 @@ ONLY=${2:-}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python tools/ab_conv2d.py --reps 10 --only $ONLY"
+CMD="python tools/ab_conv2d.py --reps 10 --only=$ONLY"
 $CMD > "$OUT/ab.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- $CMD > "$OUT/trace.log" 2>&1
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"

@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(64 * kC2Waves) conv2d_x3_kernel(Conv2dX3Params
 // split arithmetic.  In NCHW the contraction index - positions - is the contiguous one, so BOTH operands come straight from global memory as
 // two (unaligned) 16-byte loads per lane, no LDS and no transposes (the library's weight-gradient kernels ask for NHWC copies of both
 // tensors): K runs over q = y * wp + x of the PADDED row pitch, 32 positions per MFMA, lane (channel i, group g) owning q0 = qb + 8 g .. + 7.
-//   B = xp[ci][q + dy * wp + dx]: a tap is a shift of the load address;
+//   B = xp[ci][q + dy * wp + dx]: a tap is a shift of the load address (the three dx taps of a row share one ten-element window);
 //   A = dY[co] at q: dY's rows are ow = wp - 2 long, so its linear index is q - 2 y; the two dropped columns of a row are zeros, and the
 //       elements of a lane's run that lie in the next row are the loaded run shifted by two (wp even: a run never starts on the last column).
 // A wave owns a 32 x 32 (co, ci) block for all nine taps (144 accumulator registers) and every (4 * ksplit)-th K block; the four waves of a
@@ -311,28 +311,39 @@ __global__ void __launch_bounds__(256, 2) conv2d_x3_wrw_kernel(Conv2dWrwParams p
         }
         const int xoff = ((img * p.cin + ci0 + i) * p.hp) * p.wp + q0;
         NR_PRAGMA_UNROLL
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            nr_v4u B[2][3];
+        for (int dy = 0; dy < 3; ++dy) {
+            // the ten positions q0 + dy wp .. + 9 of the lane's channel: the runs of the three dx taps are windows of them (three loads per
+            // row and channel tile instead of six - the kernel is bound by the cache lines its loads touch, 16 channel planes per instruction)
+            float win[2][10];
             NR_PRAGMA_UNROLL
             for (int nt = 0; nt < 2; ++nt) {
-                const int off = (xoff + 16 * nt * p.hp * p.wp + dy * p.wp + dx) * 4;
+                const int off = (xoff + 16 * nt * p.hp * p.wp + dy * p.wp) * 4;
                 const float4 lo = nr_buf_ld4(X, off, 0), hi = nr_buf_ld4(X, off + 16, 0);
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                NR_PRAGMA_UNROLL
-                for (int d = 0; d < 4; ++d) {
-                    unsigned h, m, l;
-                    nr_split3(v[2 * d], v[2 * d + 1], h, m, l);
-                    B[nt][0][d] = h; B[nt][1][d] = m; B[nt][2][d] = l;
-                }
+                const float2 tl = nr_buf_ld2(X, off + 32, 0);
+                win[nt][0] = lo.x; win[nt][1] = lo.y; win[nt][2] = lo.z; win[nt][3] = lo.w;
+                win[nt][4] = hi.x; win[nt][5] = hi.y; win[nt][6] = hi.z; win[nt][7] = hi.w;
+                win[nt][8] = tl.x; win[nt][9] = tl.y;
             }
-            constexpr int WI[6] = {2, 0, 1, 1, 0, 0}, XJ[6] = {0, 2, 1, 0, 1, 0};
             NR_PRAGMA_UNROLL
-            for (int pr = 0; pr < 6; ++pr)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int tap = 3 * dy + dx;
+                nr_v4u B[2][3];
                 NR_PRAGMA_UNROLL
-                for (int mt = 0; mt < 2; ++mt)
+                for (int nt = 0; nt < 2; ++nt)
                     NR_PRAGMA_UNROLL
-                    for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = nr_mfma16x32_bf16(A[mt][WI[pr]], B[nt][XJ[pr]], acc[tap][mt][nt]);
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned h, m, l;
+                        nr_split3(win[nt][dx + 2 * d], win[nt][dx + 2 * d + 1], h, m, l);
+                        B[nt][0][d] = h; B[nt][1][d] = m; B[nt][2][d] = l;
+                    }
+                constexpr int WI[6] = {2, 0, 1, 1, 0, 0}, XJ[6] = {0, 2, 1, 0, 1, 0};
+                NR_PRAGMA_UNROLL
+                for (int pr = 0; pr < 6; ++pr)
+                    NR_PRAGMA_UNROLL
+                    for (int mt = 0; mt < 2; ++mt)
+                        NR_PRAGMA_UNROLL
+                        for (int nt = 0; nt < 2; ++nt) acc[tap][mt][nt] = nr_mfma16x32_bf16(A[mt][WI[pr]], B[nt][XJ[pr]], acc[tap][mt][nt]);
+            }
         }
     }
     // waves 2, 3 -> 0, 1; wave 1 -> 0; wave 0 writes the workgroup's partial (register dump: [register][lane])

@@ -143,13 +143,14 @@ class _Conv3x3X3Fn(torch.autograd.Function):
         d_out = d_out.contiguous()
         dx = eng.conv3x3_x3(d_out, ctx.pack_t, None, weight.shape[1], 2) if ctx.needs_input_grad[0] else None
         dw = db = None
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = eng.conv3x3_x3_wrw(d_out, xp) if X3_WRW else None          # (None: an odd padded width)
-        if (ctx.needs_input_grad[1] and dw is None) or want_b:
-            _, dw_lib, db = torch.ops.aten.convolution_backward(d_out, xp, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False,
-                                                                [0, 0], 1, [False, ctx.needs_input_grad[1] and dw is None, want_b])
-            dw = dw if dw is not None else dw_lib
+            if dw is None:
+                dw = torch.ops.aten.convolution_backward(d_out, xp, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # rows first: a reduction over the contiguous axis runs at memory speed, the generic (0, 2, 3) reduction of the library's bias
+            # gradient at a fifth of it (75 us per layer at 9 x 800 x 800)
+            db = d_out.flatten(2).sum(2).sum(0)
         return dx, dw, db
 
 

@@ -614,7 +614,7 @@ def gen_train_step_timing(device, steps=10):
                     "carries que_imgs_info['Ks_inv'] computed by the host pipeline before the upload (the two agree within the run-to-run "
                     "noise of +-2 ms: the copy is taken before anything of the step is queued)",
             'loss_is_finite': bool(torch.isfinite(loss).item()),
-            'kernel_classes': 'profiles/r06_zza_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
+            'kernel_classes': 'profiles/r06_zzc_gen_step_by_class.txt (bash profiles/collect_gen_step.sh)'}
 
 
 def encoder_timing(device, n=9, hw=(800, 800), reps=5):

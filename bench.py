@@ -1361,6 +1361,9 @@ def main(argv=None):
             'ft_step_ms': pick(line, 'ft_step', 'ms_per_step'), 'gen_train_step_ms': pick(line, 'gen_train_step', 'ms_per_step'),
             'point_backward_ms_per_pass': pick(line, 'training_step', 'point_backward', 'ms_per_pass'),
             'cost_volume_init_net_ms': pick(line, 'init_net', 'cost_volume_init_net_ms'),
+            'encoders_forward_backward_ms': pick(line, 'encoders', 'fused_norm', 'forward_backward_ms'),
+            'encoders_forward_backward_ms_miopen_convs': pick(line, 'encoders', 'fused_norm_miopen_convs', 'forward_backward_ms'),
+            'encoders_speedup_forward_backward': pick(line, 'encoders', 'speedup_forward_backward'),
             'cpu_baseline_rays_per_s': pick(line, 'cpu_baseline', 'value'), 'eager_torch_rays_per_s': pick(line, 'eager_torch_baseline', 'value'),
             'config3_llff_rays_per_s': pick(line, 'extra', 'llff_fern_cost_volume', 'value'),
         })

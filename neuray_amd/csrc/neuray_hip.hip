@@ -141,19 +141,19 @@ int launch_points_cfg(const nr::PointParams& p, int vpw, int arith, void* stream
 }  // namespace
 
 namespace {
-template <int NT, int MTW>
+template <int NT, int MTW, int WC = 1>
 void launch_conv2d_x3(const nr::Conv2dX3Params& p, int bands, void* stream) {
     const int lw = p.tw + 2, hp = p.h + 2 * p.pad;
     const long long q = (long long)p.n * hp * lw;
     const int per = nr::kC2Waves * NT * 16;
     const size_t smem = (size_t)nr::conv2d_x3_smem_bytes(NT, lw);
-    auto k = nr::conv2d_x3_kernel<NT, MTW>;
+    auto k = nr::conv2d_x3_kernel<NT, MTW, WC>;
 #ifndef NEURAY_EMU
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 #endif
-    NR_LAUNCH(k, dim3((unsigned)((q + per - 1) / per), (unsigned)(p.cout / 16 / MTW), (unsigned)bands), dim3(64 * nr::kC2Waves), smem, stream, p);
+    NR_LAUNCH(k, dim3((unsigned)((q + per - 1) / per), (unsigned)(p.cout / 16 / MTW / WC), (unsigned)bands), dim3(64 * nr::kC2Waves * WC), smem, stream, p);
 }
-int g_conv2d_nt = 0, g_conv2d_mtw = 0, g_conv2d_tw = 0;     // NEURAY_CONV2D_NT / _MTW / _TW: tile-shape overrides of the A/B tools
+int g_conv2d_nt = 0, g_conv2d_mtw = 0, g_conv2d_tw = 0, g_conv2d_wc = 0;     // NEURAY_CONV2D_NT / _MTW / _TW / _WC: tile-shape overrides of the A/B tools
 }  // namespace
 
 extern "C" {
@@ -402,6 +402,7 @@ int neuray_conv3x3_x3(const float* x, const void* wpack, const float* bias, int 
         if (const char* e = getenv("NEURAY_CONV2D_NT")) g_conv2d_nt = atoi(e);
         if (const char* e = getenv("NEURAY_CONV2D_MTW")) g_conv2d_mtw = atoi(e);
         if (const char* e = getenv("NEURAY_CONV2D_TW")) g_conv2d_tw = atoi(e);
+        if (const char* e = getenv("NEURAY_CONV2D_WC")) g_conv2d_wc = atoi(e);
     }
     // bands of at most 62 output columns (52-wide rows on 50 / 100 / 200-pixel maps: 2 dropped positions per row, a halo of 106 positions)
     const int tw_max = g_conv2d_tw > 0 ? g_conv2d_tw : 62;
@@ -422,6 +423,9 @@ int neuray_conv3x3_x3(const float* x, const void* wpack, const float* bias, int 
     if (nt == 8 && mtw == 4) launch_conv2d_x3<8, 4>(p, bands, stream);
     else if (nt == 8) launch_conv2d_x3<8, 2>(p, bands, stream);
     else if (mtw == 4) launch_conv2d_x3<4, 4>(p, bands, stream);
+    // two channel groups per workgroup where there are at least eight tiles of output channels: -7 % forward / -10 % data gradient at 128
+    // channels, +-3 % at 64 (profiles/r06_zzf_conv2d_wc2.log)
+    else if (mt >= 8 && (mt / 2) % 2 == 0 && nr::conv2d_x3_positions(4, p.tw + 2) % 128 == 0 && g_conv2d_wc != 1) launch_conv2d_x3<4, 2, 2>(p, bands, stream);
     else launch_conv2d_x3<4, 2>(p, bands, stream);
     return check_launch("neuray_conv3x3_x3");
 }

@@ -11,7 +11,8 @@
 // position is q = R * lw + x.  The output at q reads the inputs q + dy * lw + dx, so in q the 9 taps are pure shifts: an MFMA column tile is 16
 // CONSECUTIVE q (rows wrap inside a tile), and the positions x >= tw / the last two rows of every image are computed and dropped (2 / lw of the
 // work with lw = 52 on the 50-, 100- and 200-pixel maps of an 800 x 800 view: no per-image or per-row rounding to 16).
-//   workgroup = 4 waves x NT tiles = 64 NT consecutive q  x  16 MTW output channels (blockIdx.y: channel group, blockIdx.z: band)
+//   workgroup = 4 waves x NT tiles = 64 NT consecutive q  x  16 MTW output channels (blockIdx.y: channel group, blockIdx.z: band); with
+//               WC = 2 (layers of 128 output channels) eight waves: two channel groups share the staged block (half the staging per output)
 //   LDS       = the 64 NT + 2 lw + 2 input positions the workgroup reads, per 32-channel block: [3 parts][position][32 channels bf16]
 //               (a position's 64 bytes are 4 lane groups x 8 channels: the B operand of tile t for tap (dy, dx) is ONE ds_read_b128 per part
 //               at position t * 16 + c + dy * lw + dx - a contiguous 1 KB per wave, no bank conflicts)
@@ -26,14 +27,9 @@ constexpr int kC2Waves = 4;
 constexpr int conv2d_x3_positions(int nt, int lw) { return (kC2Waves * nt * 16 + 2 * lw + 2 + 63) / 64 * 64; }      // whole staging passes
 constexpr int conv2d_x3_smem_bytes(int nt, int lw) { return conv2d_x3_positions(nt, lw) * 64 * 3; }
 constexpr int conv2d_x3_max_passes(int nt) { return nt <= 4 ? 7 : 12; }   // staging passes of 64 positions a kernel instance holds in registers
-#ifndef NR_C2_TAP_UNROLL
-#define NR_C2_TAP_UNROLL 1            // taps per unrolled body of the tap loop (1 | 3 | 9)
-#endif
 #ifndef NR_C2_PROBE
 #define NR_C2_PROBE 0                 // timing probes with WRONG results: 1 no staging, 2 no A loads, 3 no B loads, 4 no MFMAs
 #endif
-#define NR_C2_STR2(x) #x
-#define NR_C2_STR(x) NR_C2_STR2(x)
 
 // w [cout][cin][3][3] (fp32) -> wpack.  Lane l = (m = l & 15, g = l >> 4) of tile mt holds, in dword d of part p, the bf16 pair of input channels
 // 32 kb + 8 g + 2 d (+ 1) of output channel 16 mt + m.
@@ -79,16 +75,17 @@ struct Conv2dX3Params {
     int tw;                  // output columns per band (blockIdx.z); lw = tw + 2
 };
 
-template <int NT, int MTW>
-__global__ void __launch_bounds__(64 * kC2Waves) conv2d_x3_kernel(Conv2dX3Params p) {
-    constexpr int MAXP = conv2d_x3_max_passes(NT);
+template <int NT, int MTW, int WC = 1>
+__global__ void __launch_bounds__(64 * kC2Waves * WC) conv2d_x3_kernel(Conv2dX3Params p) {
+    constexpr int MAXP = (conv2d_x3_max_passes(NT) + WC - 1) / WC;
     NR_DYNAMIC_SMEM(unsigned char, lds);
     const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = NR_UNIFORM(tid >> 6);
+    const int wave_all = NR_UNIFORM(tid >> 6);
+    const int wave = wave_all & 3, wave_c = wave_all >> 2;         // position quarter, output-channel group of the workgroup
     const int c = lane & 15, g = lane >> 4;
     const int hp = p.h + 2 * p.pad, oh = hp - 2, ow = p.w + 2 * p.pad - 2;
     const int lw = p.tw + 2, band_x0 = (int)blockIdx.z * p.tw;
-    const int kbn = p.cin / 32, mtn = p.cout / 16, mt0 = (int)blockIdx.y * MTW;
+    const int kbn = p.cin / 32, mtn = p.cout / 16, mt0 = ((int)blockIdx.y * WC + wave_c) * MTW;
     const int rows = p.n * hp;                                     // (the host checks n * hp * lw < 2^31)
     const int q0 = (int)blockIdx.x * (kC2Waves * NT * 16);
     const int px = conv2d_x3_positions(NT, lw), part_bytes = px * 64;
@@ -99,12 +96,12 @@ __global__ void __launch_bounds__(64 * kC2Waves) conv2d_x3_kernel(Conv2dX3Params
     // staging: thread (slot = tid >> 2, octet = tid & 3) moves channels 8 octet .. + 7 of position pass * 64 + slot.  The source offset of
     // channel 0 of the block (bytes; out of the padded image: past the buffer's range = reads 0) is the same for every channel block.
     const int slot = tid >> 2, oct = tid & 3;
-    const int npass = px / 64;
+    const int npass = px / (64 * WC);
     int src[MAXP];
     NR_PRAGMA_UNROLL
     for (int ps = 0; ps < MAXP; ++ps) {
         src[ps] = -1;
-        const unsigned q = (unsigned)(q0 + ps * 64 + slot);
+        const unsigned q = (unsigned)(q0 + ps * 64 * WC + slot);
         const int R = (int)(q / (unsigned)lw);
         const int xx = (int)q - R * lw;
         if (ps < npass && R < rows) {
@@ -137,7 +134,7 @@ __global__ void __launch_bounds__(64 * kC2Waves) conv2d_x3_kernel(Conv2dX3Params
                 nr_split3(v[ps][2 * d], v[ps][2 * d + 1], a, b, e);
                 ph[d] = a; pm[d] = b; pl[d] = e;
             }
-            unsigned char* dst = lds + (ps * 64 + slot) * 64 + oct * 16;
+            unsigned char* dst = lds + (ps * 64 * WC + slot) * 64 + oct * 16;
             *reinterpret_cast<nr_v4u*>(dst) = ph;
             *reinterpret_cast<nr_v4u*>(dst + part_bytes) = pm;
             *reinterpret_cast<nr_v4u*>(dst + 2 * part_bytes) = pl;
@@ -324,6 +321,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_x3_wrw_kernel(Conv2dWrwParams p
                 win[nt][4] = hi.x; win[nt][5] = hi.y; win[nt][6] = hi.z; win[nt][7] = hi.w;
                 win[nt][8] = tl.x; win[nt][9] = tl.y;
             }
+            // the window's even pairs (0,1) .. (8,9) serve dx = 0 (pairs 0..3) and dx = 2 (pairs 1..4), its odd pairs (1,2) .. (7,8) dx = 1:
+            // nine pair splits per window instead of twelve
+            unsigned pe[2][3][5], po[2][3][4];
+            NR_PRAGMA_UNROLL
+            for (int nt = 0; nt < 2; ++nt) {
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 5; ++k) nr_split3(win[nt][2 * k], win[nt][2 * k + 1], pe[nt][0][k], pe[nt][1][k], pe[nt][2][k]);
+                NR_PRAGMA_UNROLL
+                for (int k = 0; k < 4; ++k) nr_split3(win[nt][2 * k + 1], win[nt][2 * k + 2], po[nt][0][k], po[nt][1][k], po[nt][2][k]);
+            }
             NR_PRAGMA_UNROLL
             for (int dx = 0; dx < 3; ++dx) {
                 const int tap = 3 * dy + dx;
@@ -331,11 +338,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_x3_wrw_kernel(Conv2dWrwParams p
                 NR_PRAGMA_UNROLL
                 for (int nt = 0; nt < 2; ++nt)
                     NR_PRAGMA_UNROLL
-                    for (int d = 0; d < 4; ++d) {
-                        unsigned h, m, l;
-                        nr_split3(win[nt][dx + 2 * d], win[nt][dx + 2 * d + 1], h, m, l);
-                        B[nt][0][d] = h; B[nt][1][d] = m; B[nt][2][d] = l;
-                    }
+                    for (int pt = 0; pt < 3; ++pt)
+                        NR_PRAGMA_UNROLL
+                        for (int d = 0; d < 4; ++d) B[nt][pt][d] = dx == 1 ? po[nt][pt][d] : pe[nt][pt][d + (dx >> 1)];
                 constexpr int WI[6] = {2, 0, 1, 1, 0, 0}, XJ[6] = {0, 2, 1, 0, 1, 0};
                 NR_PRAGMA_UNROLL
                 for (int pr = 0; pr < 6; ++pr)

@@ -46,7 +46,7 @@ def main():
     eng = ro.engine_for(dev)
     torch.manual_seed(0)
     tot = {'miopen_fwd': 0.0, 'x3_fwd': 0.0, 'miopen_bwd': 0.0, 'x3_bwd': 0.0}
-    print('tile overrides: NT=%s MTW=%s TW=%s' % tuple(os.environ.get(k, '-') for k in ('NEURAY_CONV2D_NT', 'NEURAY_CONV2D_MTW', 'NEURAY_CONV2D_TW')))
+    print('tile overrides: NT=%s MTW=%s TW=%s WC=%s' % tuple(os.environ.get(k, '-') for k in ("NEURAY_CONV2D_NT", "NEURAY_CONV2D_MTW", "NEURAY_CONV2D_TW", "NEURAY_CONV2D_WC")))
     print('%-28s %9s %9s %7s | %9s %9s %7s | %9s %9s' % ('layer (n = %d)' % args.n, 'MIOpen ms', 'x3 ms', 'TF/s x3', 'MIOpen dx', 'x3 dx', 'TF/s', 'err fp32', 'err x3'))
     for label, cin, cout, s, count in LAYERS:
         if args.only not in label:

@@ -40,7 +40,7 @@ def _rel(a, ref):
 
 
 # (n, cin, cout, h, w): rows that wrap inside a 16-position tile, several bands (w > 64), more than one channel block and channel group
-SMALL = [(2, 32, 32, 7, 9), (1, 64, 32, 5, 70), (1, 32, 64, 19, 6), (3, 64, 32, 4, 4)]
+SMALL = [(2, 32, 32, 7, 9), (1, 64, 32, 5, 70), (1, 32, 64, 19, 6), (3, 64, 32, 4, 4), (2, 32, 128, 6, 8)]      # (128 outputs: eight-wave workgroups)
 LARGE = [(9, 128, 128, 52, 52), (9, 64, 64, 102, 102), (9, 32, 32, 202, 202), (9, 128, 64, 102, 102), (9, 64, 32, 202, 202), (2, 96, 64, 191, 254)]
 
 
@@ -67,7 +67,7 @@ def test_forward_valid_and_padded(dev):
 
 def test_data_gradient_is_the_full_correlation_with_the_flipped_pack(dev):
     eng = ro.engine_for(torch.device(dev))
-    for i, (n, cin, cout, h, w) in enumerate(_shapes(dev)[:6]):
+    for i, (n, cin, cout, h, w) in enumerate(_shapes(dev)[:7]):
         x, wgt, _ = _case(n, cin, cout, h, w, 10 + i)
         if cout % 32:
             continue                                                   # (the gradient's contraction runs over C_out: a multiple of 32)
